@@ -1,0 +1,193 @@
+"""CPU oracle for the PUNetG score network (TEST INFRASTRUCTURE -- see oracle/__init__.py).
+
+A functional forward pass driven by a PyTorch ``state_dict`` with the reference's
+key names, restating
+  diffsci/models/nets/punetg.py:356-416          (forward / encode / decode / bottom_forward)
+  diffsci/models/nets/commonlayers.py:809-836    (ResnetBlockC.forward)
+  diffsci/models/nets/commonlayers.py:372-384    (GroupRMSNorm.forward)
+  diffsci/models/nets/commonlayers.py:185-190    (GaussianFourierProjection.forward)
+  diffsci/models/nets/commonlayers.py:516-549    (ResnetTimeBlock)
+  diffsci/models/nets/commonlayers.py:81,145     (DownSampler / UpSampler forward)
+  diffsci/models/nets/attention.py:54-90         (TwoDimensionalAttention, nn.MultiheadAttention, 1 head)
+for the default configuration family (2-D, "default" convolutions, GroupLN +
+GroupRMS norms, bias=True, dropout 0).  Convolution / GroupNorm / attention
+arithmetic is torch's, as in the reference.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+def default_config(**over):
+    """PUNetGConfig defaults, punetg_config.py:8-38 (only the fields this oracle reads)."""
+    cfg = dict(input_channels=1, output_channels=1, model_channels=64,
+               channel_expansion=[2, 4],
+               number_resnet_downward_block=2, number_resnet_upward_block=2,
+               number_resnet_attn_block=2, number_resnet_before_attn_block=2,
+               number_resnet_after_attn_block=2, attn_residual=False)
+    cfg.update(over)
+    return cfg
+
+
+def fourier_features(t, W):
+    """commonlayers.py:185-190: [sin(2*pi*t*W), cos(2*pi*t*W)]."""
+    proj = 2 * math.pi * t[..., None] * W
+    return torch.cat([torch.sin(proj), torch.cos(proj)], dim=-1)
+
+
+def group_rms_norm(x, weight, bias, eps=1e-5):
+    """commonlayers.py:372-384 with num_groups == num_channels (per-(b,c) RMS over H*W)."""
+    B, C = x.shape[:2]
+    xg = x.view(B, C, 1, *x.shape[2:])
+    dims = tuple(range(2, xg.dim()))
+    xg = xg / (torch.sqrt(xg.pow(2).mean(dim=dims, keepdim=True) + eps))
+    x = xg.view(B, C, *xg.shape[3:])
+    w = weight.view(1, C, *([1] * (x.dim() - 2)))
+    b = bias.view(1, C, *([1] * (x.dim() - 2)))
+    return x * w + b
+
+
+def time_shift(sd, prefix, te):
+    """ResnetTimeBlock: Linear-SiLU-Linear-SiLU-Linear, commonlayers.py:516-522,546-549."""
+    h = F.linear(te, sd[prefix + "net.0.weight"], sd[prefix + "net.0.bias"])
+    h = F.silu(h)
+    h = F.linear(h, sd[prefix + "net.2.weight"], sd[prefix + "net.2.bias"])
+    h = F.silu(h)
+    h = F.linear(h, sd[prefix + "net.4.weight"], sd[prefix + "net.4.bias"])
+    return h.view(*h.shape, 1, 1)
+
+
+def resnet_block(sd, prefix, x, te):
+    """ResnetBlockC.forward, commonlayers.py:824-833."""
+    C = x.shape[1]
+    h = F.group_norm(x, C, sd[prefix + "gnorm1.weight"], sd[prefix + "gnorm1.bias"], 1e-5)
+    y = F.conv2d(F.silu(h), sd[prefix + "conv1.weight"], sd[prefix + "conv1.bias"], padding="same")
+    y = y + time_shift(sd, prefix + "timeblock.", te)
+    h = group_rms_norm(y, sd[prefix + "gnorm2.weight"], sd[prefix + "gnorm2.bias"])
+    y = F.conv2d(F.silu(h), sd[prefix + "conv2.weight"], sd[prefix + "conv2.bias"], padding="same")
+    return y + x
+
+
+def attention_2d(sd, prefix, x, attn_residual=False):
+    """TwoDimensionalAttention (attention.py:67-90) around nn.MultiheadAttention(E, 1 head)."""
+    B, C, Hh, Ww = x.shape
+    xr = x.permute(0, 2, 3, 1).reshape(B, Hh * Ww, C)   # 'b c w h -> b (w h) c'
+    out, _ = F.multi_head_attention_forward(
+        xr.transpose(0, 1), xr.transpose(0, 1), xr.transpose(0, 1),
+        C, 1,
+        sd[prefix + "mhattn.in_proj_weight"], sd[prefix + "mhattn.in_proj_bias"],
+        None, None, False, 0.0,
+        sd[prefix + "mhattn.out_proj.weight"], sd[prefix + "mhattn.out_proj.bias"],
+        training=False, need_weights=False)
+    out = out.transpose(0, 1).reshape(B, Hh, Ww, C).permute(0, 3, 1, 2)
+    return x + out if attn_residual else out
+
+
+def punetg_forward(sd, cfg, x, t, ye=None):
+    """PUNetG.forward, punetg.py:389-416.  ``ye`` is the already-embedded condition
+    (conditional_embedding(y), shape [B or 1, model_channels]) or None."""
+    nlev = len(cfg["channel_expansion"])
+    x = F.conv2d(x, sd["convin.weight"], sd["convin.bias"], padding="same")
+    te = fourier_features(t, sd["time_projection.W"])
+    if ye is not None:
+        te = te + ye
+    skips = []
+    for lv in range(nlev):                                           # encode, punetg.py:356-365
+        for r in range(cfg["number_resnet_downward_block"]):
+            x = resnet_block(sd, f"downward_blocks.{lv}.{r}.", x, te)
+        skips.append(x)
+        x = F.conv2d(F.max_pool2d(x, 2), sd[f"downsamplers.{lv}.conv.weight"],
+                     sd[f"downsamplers.{lv}.conv.bias"], padding="same")
+    for r in range(cfg["number_resnet_before_attn_block"]):         # bottom, punetg.py:378-387
+        x = resnet_block(sd, f"before_block.{r}.", x, te)
+    xa = x
+    nattn = cfg["number_resnet_attn_block"]
+    for r in range(nattn):                                           # punetg.py:344-354
+        xa = resnet_block(sd, f"attn_resnet_block.{r}.", xa, te)
+        if r < nattn - 1:
+            xa = attention_2d(sd, f"attn_block.{r}.", xa, cfg["attn_residual"])
+    x = x + xa
+    for r in range(cfg["number_resnet_after_attn_block"]):
+        x = resnet_block(sd, f"after_block.{r}.", x, te)
+    for lv in range(nlev):                                           # decode, punetg.py:367-376
+        x = F.interpolate(x, scale_factor=2.0, mode="nearest")
+        x = F.conv2d(x, sd[f"upsamplers.{lv}.conv.weight"],
+                     sd[f"upsamplers.{lv}.conv.bias"], padding="same")
+        x = x + skips.pop()
+        for r in range(cfg["number_resnet_upward_block"]):
+            x = resnet_block(sd, f"upward_blocks.{lv}.{r}.", x, te)
+    return F.conv2d(x, sd["convout.weight"], sd["convout.bias"], padding="same")
+
+
+def make_net(sd, cfg, embed=None):
+    """Return net(x, c_noise[, y]) with the reference model protocol (karrasmodule.py:706-716).
+    embed: optional callable y -> [*, model_channels] (conditional_embedding)."""
+    def net(x, t, y=None):
+        ye = None
+        if y is not None:
+            ye = y if embed is None else embed(y)
+        return punetg_forward(sd, cfg, x, t, ye)
+    return net
+
+
+def random_state_dict(cfg, seed=0, dtype=torch.float32):
+    """Synthetic weights with the reference's default initialisers:
+    Conv/Linear U(+-1/sqrt(fan_in)) for weight and bias, norm w=1 b=0, Fourier W~N(0,30^2),
+    MultiheadAttention xavier-uniform in_proj and zero biases.  Used by bench/smoke only;
+    parity fixtures carry the reference's own state_dict."""
+    g = torch.Generator().manual_seed(seed)
+    mc = cfg["model_channels"]
+    mult = [1] + list(cfg["channel_expansion"])
+    sd = {}
+
+    def uni(shape, bound):
+        return (torch.rand(shape, generator=g, dtype=torch.float64) * 2 - 1).mul(bound).to(dtype)
+
+    def conv(name, co, ci, k=3):
+        b = 1.0 / math.sqrt(ci * k * k)
+        sd[name + ".weight"] = uni((co, ci, k, k), b)
+        sd[name + ".bias"] = uni((co,), b)
+
+    def lin(name, co, ci):
+        b = 1.0 / math.sqrt(ci)
+        sd[name + ".weight"] = uni((co, ci), b)
+        sd[name + ".bias"] = uni((co,), b)
+
+    def res(prefix, C):
+        for n in ("gnorm1", "gnorm2"):
+            sd[prefix + n + ".weight"] = torch.ones(C, dtype=dtype)
+            sd[prefix + n + ".bias"] = torch.zeros(C, dtype=dtype)
+        conv(prefix + "conv1", C, C)
+        conv(prefix + "conv2", C, C)
+        lin(prefix + "timeblock.net.0", 4 * mc, mc)
+        lin(prefix + "timeblock.net.2", 4 * mc, 4 * mc)
+        lin(prefix + "timeblock.net.4", C, 4 * mc)
+
+    sd["time_projection.W"] = (torch.randn(mc // 2, generator=g, dtype=torch.float64) * 30.0).to(dtype)
+    conv("convin", mc, cfg["input_channels"])
+    conv("convout", cfg["output_channels"], mc)
+    nlev = len(cfg["channel_expansion"])
+    for lv in range(nlev):
+        for r in range(cfg["number_resnet_downward_block"]):
+            res(f"downward_blocks.{lv}.{r}.", mult[lv] * mc)
+        conv(f"downsamplers.{lv}.conv", mult[lv + 1] * mc, mult[lv] * mc)
+    Cb = mult[-1] * mc
+    for r in range(cfg["number_resnet_before_attn_block"]):
+        res(f"before_block.{r}.", Cb)
+    for r in range(cfg["number_resnet_attn_block"]):
+        res(f"attn_resnet_block.{r}.", Cb)
+    for r in range(cfg["number_resnet_attn_block"] - 1):
+        bound = math.sqrt(6.0 / (3 * Cb + Cb))
+        sd[f"attn_block.{r}.mhattn.in_proj_weight"] = uni((3 * Cb, Cb), bound)
+        sd[f"attn_block.{r}.mhattn.in_proj_bias"] = torch.zeros(3 * Cb, dtype=dtype)
+        sd[f"attn_block.{r}.mhattn.out_proj.weight"] = uni((Cb, Cb), 1.0 / math.sqrt(Cb))
+        sd[f"attn_block.{r}.mhattn.out_proj.bias"] = torch.zeros(Cb, dtype=dtype)
+    for r in range(cfg["number_resnet_after_attn_block"]):
+        res(f"after_block.{r}.", Cb)
+    rmult = list(reversed(mult))
+    for lv in range(nlev):
+        conv(f"upsamplers.{lv}.conv", rmult[lv + 1] * mc, rmult[lv] * mc)
+        for r in range(cfg["number_resnet_upward_block"]):
+            res(f"upward_blocks.{lv}.{r}.", rmult[lv + 1] * mc)
+    return sd

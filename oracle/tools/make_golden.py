@@ -1,0 +1,217 @@
+"""Generate tests/golden/*.npz by running the REAL reference (imported from /root/reference).
+
+Container-only (the reference does not exist on the GPU box).  Run:
+    python oracle/tools/make_golden.py
+The fixtures are data only: inputs, state_dicts and the reference's outputs.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import refshim  # noqa: E402
+
+refshim.install()
+import diffsci.models as M  # noqa: E402
+import diffsci.data  # noqa: E402
+
+OUT = os.path.join(HERE, "..", "..", "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+torch.set_num_threads(8)
+
+
+def npz(name, **arrs):
+    conv = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        conv[k] = np.asarray(v)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **conv)
+    print(f"{name}: {os.path.getsize(path)/1024:.1f} KiB")
+
+
+def sd_arrays(sd, prefix="sd/"):
+    return {prefix + k: v for k, v in sd.items()}
+
+
+class RandnRecorder:
+    """Record every torch.randn_like draw (the integrators' only RNG use)."""
+    def __init__(self):
+        self.draws = []
+        self._orig = torch.randn_like
+
+    def __enter__(self):
+        def rec(x, *a, **k):
+            e = self._orig(x, *a, **k)
+            self.draws.append(e.clone())
+            return e
+        torch.randn_like = rec
+        return self
+
+    def __exit__(self, *a):
+        torch.randn_like = self._orig
+
+
+# ---------------------------------------------------------------- 1. schedule tables
+def schedule():
+    s = M.EDMScheduler()
+    arrs = {"cpu_capability": np.array(torch.backends.cpu.get_cpu_capability())}
+    for n in (2, 5, 10, 18, 50, 100, 256):
+        arrs[f"steps_{n}"] = s.create_steps(n + 1)
+    tq = torch.tensor([80.0, 57.5, 10.0, 1.0, 0.3, 0.01, 0.002])
+    for n in (19, 51):
+        arrs[f"step_from_time_{n}"] = s.step_from_time(tq, n)
+    arrs["step_from_time_t"] = tq
+    p = M.EDMPreconditioner()
+    for B in (1, 4, 64):
+        for n in (18, 50):
+            t = s.create_steps(n + 1)[:-1]
+            rows = []
+            for ti in t:
+                sig = ti * torch.ones(B)
+                rows.append(torch.stack([p.skip_scaling(sig)[0], p.output_scaling(sig)[0],
+                                         p.input_scaling(sig)[0], p.noise_conditioner(sig)[0],
+                                         p.skip_scaling(sig)[-1], p.output_scaling(sig)[-1],
+                                         p.input_scaling(sig)[-1], p.noise_conditioner(sig)[-1]]))
+            arrs[f"precond_B{B}_N{n}"] = torch.stack(rows)
+    npz("schedule", **arrs)
+
+
+# ---------------------------------------------------------------- 2. toy / analytic + MLP (config 1)
+def toy():
+    torch.manual_seed(0)
+    ds = diffsci.data.ZeroDataset(num_samples=8, shape=[2])
+    gs = diffsci.data.ZeroMeanGaussianDataset(num_samples=8, shape=[2], scale=0.7)
+    sch = M.EDMScheduler()
+    x = torch.randn(8, 2)
+    arrs = {"x": x}
+    for nm, d in (("zero", ds), ("gauss", gs)):
+        for integ in ("heun", "euler"):
+            sch.set_temporary_integrator(integ)
+            arrs[f"{nm}_{integ}_N18"] = sch.propagate_backward(x * 80.0, d.gradlogprob, 18, record_history=True)
+            sch.unset_temporary_integrator()
+    npz("toy_analytic", **arrs)
+
+    torch.manual_seed(0)
+    model = M.MLPUncond(2, [20])
+    config = M.KarrasModuleConfig.from_edm()
+    module = M.KarrasModule(model, config)
+    torch.manual_seed(1)
+    wn = torch.randn(8, 2)
+    arrs = dict(sd_arrays(model.state_dict()), white_noise=wn)
+    for integ in ("heun", "euler"):
+        arrs[f"hist_{integ}_N18_f32"] = module.propagate_white_noise(wn, nsteps=18, record_history=True, integrator=integ)
+    with RandnRecorder() as rec:
+        arrs["hist_karras_N18_f32"] = module.propagate_white_noise(wn, nsteps=18, record_history=True, integrator="karras")
+    arrs["eps_karras_N18"] = torch.stack(rec.draws)
+    config.noisescheduler.langevin_const = 0.7
+    with RandnRecorder() as rec:
+        # EM lives in scheduler.stochastic_integrator; route through propagate_backward(stochastic=True)
+        y = None
+
+        def rhs(xx, sigma):
+            return module.get_score(xx, sigma, y, 1.0)
+        with torch.inference_mode():
+            arrs["hist_em_N18_f32"] = config.noisescheduler.propagate_backward(
+                wn * 80.0, rhs, 18, record_history=True, stochastic=True)
+    arrs["eps_em_N18"] = torch.stack(rec.draws)
+    arrs["em_langevin_const"] = np.array(0.7)
+    config.noisescheduler.langevin_const = 1.0
+    module.double()
+    arrs["hist_heun_N18_f64"] = module.propagate_white_noise(wn.double(), nsteps=18, record_history=True, integrator="heun")
+    npz("mlp_cfg1", **arrs)
+
+
+# ---------------------------------------------------------------- 3. PUNetG layers + forward + trajectories
+def punetg():
+    torch.manual_seed(0)
+    cfg = M.nets.PUNetGConfig(model_channels=8)
+    net = M.nets.PUNetG(cfg).eval()
+    # make norm affines non-trivial so the fixtures exercise them
+    with torch.no_grad():
+        for k, v in net.state_dict().items():
+            if "gnorm" in k:
+                v.add_(0.25 * torch.randn_like(v))
+            if k.endswith("in_proj_bias") or k.endswith("out_proj.bias"):
+                v.add_(0.1 * torch.randn_like(v))
+    sd = net.state_dict()
+    torch.manual_seed(2)
+    x = torch.randn(2, 1, 32, 32)
+    t = torch.tensor([0.3, -1.7])
+    arrs = dict(sd_arrays(sd), x=x, t=t)
+    with torch.inference_mode():
+        arrs["out_f32"] = net(x, t)
+        # layer-level goldens
+        h = net.convin(x)
+        te = net.time_projection(t)
+        arrs["convin"] = h
+        arrs["te"] = te
+        blk = net.downward_blocks[0][0]
+        arrs["gn1_silu"] = blk.act(blk.gnorm1(h))
+        arrs["timeshift"] = blk.timeblock(te)
+        y1 = blk.conv1(blk.act(blk.gnorm1(h))) + blk.timeblock(te)
+        arrs["conv1_shift"] = y1
+        arrs["rms_silu"] = blk.act(blk.gnorm2(y1))
+        r = blk(h, te)
+        arrs["resblock"] = r
+        arrs["down"] = net.downsamplers[0](r)
+        hb = torch.randn(2, 32, 8, 8)
+        arrs["attn_in"] = hb
+        arrs["attn_out"] = net.attn_block[0](hb)
+        arrs["up"] = net.upsamplers[0](hb)
+    net64 = M.nets.PUNetG(cfg).double()
+    net64.load_state_dict({k: v.double() for k, v in sd.items()})
+    net64.eval()
+    with torch.inference_mode():
+        arrs["out_f64"] = net64(x.double(), t.double())
+    npz("punetg8_forward", **arrs)
+
+    # trajectories through KarrasModule
+    config = M.KarrasModuleConfig.from_edm()
+    module = M.KarrasModule(net, config).eval()
+    torch.manual_seed(3)
+    wn = torch.randn(2, 1, 32, 32)
+    arrs = dict(white_noise=wn)   # state_dict shared with punetg8_forward
+    arrs["hist_heun_N6_f32"] = module.propagate_white_noise(wn, nsteps=6, record_history=True)
+    arrs["out_heun_N18_f32"] = module.propagate_white_noise(wn, nsteps=18)
+    arrs["hist_euler_N6_f32"] = module.propagate_white_noise(wn, nsteps=6, record_history=True, integrator="euler")
+    with RandnRecorder() as rec:
+        arrs["hist_karras_N6_f32"] = module.propagate_white_noise(wn, nsteps=6, record_history=True, integrator="karras")
+    arrs["eps_karras_N6"] = torch.stack(rec.draws)
+    with RandnRecorder() as rec:
+        def rhs(xx, sigma):
+            return module.get_score(xx, sigma, None, 1.0)
+        with torch.inference_mode():
+            arrs["hist_em_N6_f32"] = config.noisescheduler.propagate_backward(
+                wn * 80.0, rhs, 6, record_history=True, stochastic=True)
+    arrs["eps_em_N6"] = torch.stack(rec.draws)
+    # sample(): CPU-generator noise + minibatching (karrasmodule.py:817-838)
+    torch.manual_seed(5)
+    arrs["sample_seed5_n3_mb2_N4"] = module.sample(3, [1, 32, 32], nsteps=4, maximum_batch_size=2)
+    mod64 = M.KarrasModule(net64, M.KarrasModuleConfig.from_edm()).eval()
+    arrs["hist_heun_N6_f64"] = mod64.propagate_white_noise(wn.double(), nsteps=6, record_history=True)
+    arrs["out_heun_N18_f64"] = mod64.propagate_white_noise(wn.double(), nsteps=18)
+    npz("punetg8_traj", **arrs)
+
+    # classifier-free guidance with a conditional embedding (config 5 shape of the path)
+    torch.manual_seed(4)
+    emb = torch.nn.Embedding(4, 8)
+    cnet = M.nets.PUNetG(cfg, conditional_embedding=emb).eval()
+    cnet.load_state_dict({**sd, "conditional_embedding.weight": emb.weight.detach()})
+    cmod = M.KarrasModule(cnet, M.KarrasModuleConfig.from_edm(), conditional=True).eval()
+    y = torch.tensor(2)
+    arrs = {"emb_weight": emb.weight.detach(), "y": y, "white_noise": wn}
+    arrs["hist_cfg_g2_N4_f32"] = cmod.propagate_white_noise(wn, y=y, guidance=2.0, nsteps=4, record_history=True)
+    arrs["out_cond_g1_N4_f32"] = cmod.propagate_white_noise(wn, y=y, guidance=1.0, nsteps=4)
+    arrs["out_cond_g0_N4_f32"] = cmod.propagate_white_noise(wn, y=y, guidance=0.0, nsteps=4)
+    npz("punetg8_cfg", **arrs)
+
+
+if __name__ == "__main__":
+    schedule()
+    toy()
+    punetg()

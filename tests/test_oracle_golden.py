@@ -1,0 +1,186 @@
+"""Pin the CPU oracle (oracle/) against golden vectors produced by the real reference.
+
+These tests are the oracle's licence: bit-for-bit agreement (fp32 and fp64) with
+outputs of /root/reference generated in the build container.  They run on CPU.
+"""
+import pytest
+import torch
+
+from oracle import karras_ref as K
+from oracle import mlp_ref, punetg_ref
+from tests.golden_util import load, rel_l2
+
+torch.set_num_threads(8)
+
+SAME_ISA = None
+
+
+def _same_isa():
+    v, _ = load("schedule")
+    return v["cpu_capability"] == torch.backends.cpu.get_cpu_capability()
+
+
+def assert_exact_or_ulp(got, want, what):
+    """Bit-exact on the ISA the fixtures were made on; <= 2 ulp elsewhere (torch's CPU
+    pow/log/sin kernels are ISA-dependent in the last place)."""
+    if _same_isa():
+        assert torch.equal(got, want), f"{what}: not bit-exact (max abs {float((got-want).abs().max())})"
+    else:
+        torch.testing.assert_close(got, want, rtol=3e-7, atol=0)
+
+
+def assert_exact_or_rel(got, want, what, rel):
+    """Network-sized tensors: bit-exact on the fixtures' ISA, rel-L2 bound elsewhere."""
+    if _same_isa():
+        assert torch.equal(got, want), f"{what}: not bit-exact (rel-L2 {rel_l2(got, want):.3e})"
+    else:
+        assert rel_l2(got, want) < rel, what
+
+
+@pytest.mark.parametrize("n", [2, 5, 10, 18, 50, 100, 256])
+def test_sigma_grid(n):
+    v, _ = load("schedule")
+    assert_exact_or_ulp(K.edm_sigma_grid(n + 1), v[f"steps_{n}"], f"sigma grid n={n}")
+
+
+def test_sigma_grid_shape_and_ends():
+    g = K.edm_sigma_grid(51)
+    assert g.shape == (51,) and g.dtype == torch.float32
+    # (80**(1/7))**7 is NOT 80 in fp32 -- the reference's grid starts 1 ulp-ish above it
+    assert abs(g[0].item() - 80.0) < 1e-4 and g[-1].item() == 0.0
+    assert abs(g[-2].item() - 0.002) < 1e-8
+    assert (torch.diff(g) < 0).all()
+
+
+@pytest.mark.parametrize("n", [19, 51])
+def test_step_from_time_integer_path(n):
+    v, _ = load("schedule")
+    got = K.edm_step_from_time(v["step_from_time_t"], n)
+    assert got.dtype == torch.int32
+    assert torch.equal(got, v[f"step_from_time_{n}"])
+
+
+@pytest.mark.parametrize("B", [1, 4, 64])
+@pytest.mark.parametrize("n", [18, 50])
+def test_precond_scalars(B, n):
+    v, _ = load("schedule")
+    grid = v[f"steps_{n}"][:-1]
+    want = v[f"precond_B{B}_N{n}"]
+    for i, ti in enumerate(grid):
+        sig = ti * torch.ones(B)
+        cs, co, ci, cn = K.edm_precond(sig)
+        got = torch.stack([cs[0], co[0], ci[0], cn[0], cs[-1], co[-1], ci[-1], cn[-1]])
+        assert_exact_or_ulp(got, want[i], f"precond row {i}")
+
+
+@pytest.mark.parametrize("target", ["zero", "gauss"])
+@pytest.mark.parametrize("integ", ["heun", "euler"])
+def test_analytic_trajectories(target, integ):
+    v, _ = load("toy_analytic")
+    fn = K.point_target_score(0.0) if target == "zero" else K.gaussian_target_score(0.7)
+    hist = K.propagate_backward(v["x"] * 80.0, fn, 18, integrator=integ, record_history=True)
+    assert_exact_or_ulp(hist, v[f"{target}_{integ}_N18"], f"{target}/{integ}")
+
+
+def test_reference_own_known_answer():
+    """tests/test_karras_on_toy_dataset.py:18-27 of the reference: point mass at 0 -> samples ~ 0."""
+    torch.manual_seed(0)
+    x = torch.randn(100, 1)
+    hist = K.propagate_backward(x, K.point_target_score(0.0), 100, record_history=True)
+    assert hist.shape == (101, 100, 1)
+    assert torch.isclose(hist[0], x).all()
+    assert torch.isclose(hist[-1], torch.tensor(0.0), rtol=1e-2, atol=1e-2).all()
+
+
+def test_heun_closed_form_gain():
+    """N(0,s^2) target => x_N = x_0 * prod g_i."""
+    grid = K.edm_sigma_grid(19)
+    x = torch.tensor([[1.0], [-2.5]], dtype=torch.float64) * 80.0
+    out = K.propagate_backward(x, K.gaussian_target_score(0.7), 18, sigma_grid=grid)
+    g = K.heun_gain_product(grid, 0.7)
+    torch.testing.assert_close(out, x * g, rtol=1e-12, atol=0)
+
+
+def test_mlp_cfg1_trajectories():
+    v, sd = load("mlp_cfg1")
+    net = mlp_ref.make_net(sd)
+    for integ in ("heun", "euler"):
+        hist = K.propagate_white_noise(net, v["white_noise"], 18, integrator=integ, record_history=True)
+        assert_exact_or_ulp(hist, v[f"hist_{integ}_N18_f32"], f"mlp {integ}")
+    hist = K.propagate_white_noise(net, v["white_noise"], 18, integrator="karras",
+                                   record_history=True, eps=v["eps_karras_N18"])
+    assert_exact_or_ulp(hist, v["hist_karras_N18_f32"], "mlp karras")
+    hist = K.propagate_white_noise(net, v["white_noise"], 18, integrator="euler-maruyama",
+                                   record_history=True, eps=v["eps_em_N18"],
+                                   langevin_const=float(v["em_langevin_const"]))
+    assert_exact_or_ulp(hist, v["hist_em_N18_f32"], "mlp euler-maruyama")
+    sd64 = {k: t.double() for k, t in sd.items()}
+    hist = K.propagate_white_noise(mlp_ref.make_net(sd64), v["white_noise"].double(), 18,
+                                   record_history=True)
+    assert_exact_or_ulp(hist, v["hist_heun_N18_f64"], "mlp heun fp64")
+
+
+def test_punetg_layers_and_forward():
+    v, sd = load("punetg8_forward")
+    cfg = punetg_ref.default_config(model_channels=8)
+    import torch.nn.functional as F
+    with torch.inference_mode():
+        x, t = v["x"], v["t"]
+        h = F.conv2d(x, sd["convin.weight"], sd["convin.bias"], padding="same")
+        assert_exact_or_ulp(h, v["convin"], "convin")
+        te = punetg_ref.fourier_features(t, sd["time_projection.W"])
+        assert_exact_or_ulp(te, v["te"], "fourier")
+        p = "downward_blocks.0.0."
+        g1 = F.silu(F.group_norm(h, 8, sd[p + "gnorm1.weight"], sd[p + "gnorm1.bias"], 1e-5))
+        assert_exact_or_ulp(g1, v["gn1_silu"], "gn1+silu")
+        assert_exact_or_ulp(punetg_ref.time_shift(sd, p + "timeblock.", te), v["timeshift"], "timeshift")
+        r = punetg_ref.resnet_block(sd, p, h, te)
+        assert_exact_or_ulp(r, v["resblock"], "resblock")
+        rs = F.silu(punetg_ref.group_rms_norm(v["conv1_shift"], sd[p + "gnorm2.weight"], sd[p + "gnorm2.bias"]))
+        assert_exact_or_ulp(rs, v["rms_silu"], "rms+silu")
+        a = punetg_ref.attention_2d(sd, "attn_block.0.", v["attn_in"])
+        assert_exact_or_rel(a, v["attn_out"], "attn_out", 2e-6)
+        out = punetg_ref.punetg_forward(sd, cfg, x, t)
+        assert_exact_or_rel(out, v["out_f32"], "out_f32", 2e-6)
+        sd64 = {k: w.double() for k, w in sd.items()}
+        out64 = punetg_ref.punetg_forward(sd64, cfg, x.double(), t.double())
+        assert_exact_or_rel(out64, v["out_f64"], "out_f64", 1e-14)
+
+
+def test_punetg_trajectories():
+    v, _ = load("punetg8_traj")
+    _, sd = load("punetg8_forward")
+    cfg = punetg_ref.default_config(model_channels=8)
+    net = punetg_ref.make_net(sd, cfg)
+    wn = v["white_noise"]
+    h = K.propagate_white_noise(net, wn, 6, record_history=True)
+    assert_exact_or_rel(h, v["hist_heun_N6_f32"], "hist_heun_N6_f32", 2e-6)
+    h = K.propagate_white_noise(net, wn, 6, integrator="euler", record_history=True)
+    assert_exact_or_rel(h, v["hist_euler_N6_f32"], "hist_euler_N6_f32", 2e-6)
+    h = K.propagate_white_noise(net, wn, 6, integrator="karras", record_history=True, eps=v["eps_karras_N6"])
+    assert_exact_or_rel(h, v["hist_karras_N6_f32"], "hist_karras_N6_f32", 2e-6)
+    h = K.propagate_white_noise(net, wn, 6, integrator="euler-maruyama", record_history=True, eps=v["eps_em_N6"])
+    assert_exact_or_rel(h, v["hist_em_N6_f32"], "hist_em_N6_f32", 2e-6)
+    o = K.propagate_white_noise(net, wn, 18)
+    assert_exact_or_rel(o, v["out_heun_N18_f32"], "out_heun_N18_f32", 5e-6)
+    sd64 = {k: w.double() for k, w in sd.items()}
+    net64 = punetg_ref.make_net(sd64, cfg)
+    h = K.propagate_white_noise(net64, wn.double(), 6, record_history=True)
+    assert_exact_or_rel(h, v["hist_heun_N6_f64"], "hist_heun_N6_f64", 1e-13)
+    o = K.propagate_white_noise(net64, wn.double(), 18)
+    assert_exact_or_rel(o, v["out_heun_N18_f64"], "out_heun_N18_f64", 1e-13)
+
+
+def test_punetg_cfg_guidance():
+    v, _ = load("punetg8_cfg")
+    _, sd = load("punetg8_forward")
+    cfg = punetg_ref.default_config(model_channels=8)
+    W = v["emb_weight"]
+    net = punetg_ref.make_net(sd, cfg, embed=lambda y: W[y])
+    wn, y = v["white_noise"], v["y"]
+    h = K.propagate_white_noise(net, wn, 4, y=y, guidance=2.0, conditional=True, record_history=True)
+    assert_exact_or_rel(h, v["hist_cfg_g2_N4_f32"], "hist_cfg_g2_N4_f32", 2e-6)
+    o = K.propagate_white_noise(net, wn, 4, y=y, guidance=1.0, conditional=True)
+    assert_exact_or_rel(o, v["out_cond_g1_N4_f32"], "out_cond_g1_N4_f32", 2e-6)
+    o = K.propagate_white_noise(net, wn, 4, y=y, guidance=0.0, conditional=True)
+    assert_exact_or_rel(o, v["out_cond_g0_N4_f32"], "out_cond_g0_N4_f32", 2e-6)
