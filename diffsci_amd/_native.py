@@ -1,0 +1,93 @@
+"""ctypes binding of libdiffsci_hip.so (the C ABI in include/diffsci_hip.h).
+
+There is deliberately no fallback: if the library cannot be loaded, every compute entry
+point of diffsci_amd raises.  Build it with ``python build.py`` (hipcc, gfx950).
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_lib", "libdiffsci_hip.so")
+
+DS_IN_NETWORK, DS_IN_SCORE, DS_IN_DRIFT = 0, 1, 2
+DS_LOAD_PLAIN, DS_LOAD_MAXPOOL2, DS_LOAD_UPSAMPLE2 = 0, 1, 2
+
+
+class EvalCoef(Structure):
+    """struct ds_eval_coef."""
+    _fields_ = [("c_out", c_float), ("c_skip", c_float), ("sigma_sq", c_float),
+                ("neg_mult", c_float), ("neg_lang", c_float), ("guidance", c_float),
+                ("one_minus_guidance", c_float), ("input_kind", c_int), ("stochastic", c_int)]
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+_P = c_void_p
+_PROTOS = {
+    "ds_version": (c_int, []),
+    "ds_last_error": (c_char_p, []),
+    "ds_device_info": (c_int, [POINTER(c_int), POINTER(c_int), ctypes.c_char_p, c_int]),
+    "ds_karras_scale": (c_int, [_P, _P, c_float, c_size_t, _P]),
+    "ds_karras_drift": (c_int, [_P, _P, _P, _P, POINTER(EvalCoef), c_size_t, _P]),
+    "ds_karras_score": (c_int, [_P, _P, _P, _P, POINTER(EvalCoef), c_size_t, _P]),
+    "ds_karras_euler": (c_int, [_P, _P, _P, _P, _P, POINTER(EvalCoef), c_float, c_float,
+                                _P, c_float, c_float, c_size_t, _P]),
+    "ds_karras_heun": (c_int, [_P, _P, _P, _P, _P, POINTER(EvalCoef), _P, _P, POINTER(EvalCoef),
+                               c_float, c_float, c_size_t, _P]),
+    "ds_karras_churn": (c_int, [_P, _P, _P, _P, c_float, c_float, c_size_t, _P]),
+    "ds_karras_denoiser": (c_int, [_P, _P, _P, _P, c_float, c_float, _P, _P, c_int, c_size_t, _P]),
+    "ds_inorm_silu": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_float, c_int, _P]),
+    "ds_conv2d_packed_floats": (c_size_t, [c_int, c_int, c_int]),
+    "ds_conv2d_pack_weights": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
+    "ds_conv2d": (c_int, [_P, _P, _P, _P, _P, c_int, _P, _P, c_int, c_int, c_int, c_int, c_int,
+                          c_int, c_int, _P]),
+    "ds_attention": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
+    "ds_linear": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "ds_fourier_features": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P]),
+    "ds_add": (c_int, [_P, _P, _P, c_size_t, _P]),
+    "ds_graph_begin_capture": (c_int, [_P]),
+    "ds_graph_end_capture": (c_int, [_P, POINTER(_P), POINTER(c_int)]),
+    "ds_graph_launch": (c_int, [_P, _P]),
+    "ds_graph_destroy": (c_int, [_P]),
+}
+
+_lib = None
+
+
+def exported_symbols():
+    """Names this binding expects; tests compare them with include/diffsci_hip.h."""
+    return sorted(_PROTOS)
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeLibraryError(
+            f"{LIB_PATH} is missing: diffsci_amd has no CPU or PyTorch fallback. "
+            "Run `python build.py` (needs hipcc; cross-compiles for gfx950 without a GPU).")
+    try:
+        L = ctypes.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover
+        raise NativeLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in _PROTOS.items():
+        try:
+            fn = getattr(L, name)
+        except AttributeError as e:
+            raise NativeLibraryError(f"{LIB_PATH} does not export {name}; rebuild with build.py") from e
+        fn.restype = res
+        fn.argtypes = args
+    if L.ds_version() != 1:
+        raise NativeLibraryError(f"ABI version {L.ds_version()} != 1; rebuild with build.py")
+    _lib = L
+    return L
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().ds_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"{what} failed (status {rc}): {msg}")

@@ -1,0 +1,230 @@
+// Per-(sample, channel) instance normalisation fused with SiLU -- the two norms of
+// ResnetBlockC (commonlayers.py:824, 829): GroupNorm(C, C) and GroupRMSNorm(C, C).
+//
+// HBM-bound: 8 bytes per element (one read, one write).  A plane (H*W floats, contiguous in
+// NCHW) is held entirely in registers between the statistics pass and the apply pass:
+//   - planes of <= 1024 floats: one 64-lane wave per plane, reductions by DPP/shuffle only;
+//   - planes up to 64 Ki floats: one workgroup per plane (256 or 1024 threads, <= 16 float4 per
+//     lane), wave shuffles + one LDS exchange per statistic;
+//   - anything else (H*W not a multiple of 4, or larger): a two-read fallback.
+// Statistics are two-pass in registers (mean, then centred second moment), fp32.
+#include "ds_common.h"
+
+namespace {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+__device__ __forceinline__ float silu(float v) { return v / (1.0f + __expf(-v)); }
+
+// exact-ish exp: use expf (ocml, <= 1 ulp) rather than the fast intrinsic
+__device__ __forceinline__ float silu_precise(float v) { return v / (1.0f + expf(-v)); }
+
+template <int KIND>
+__device__ __forceinline__ float apply_one(float v, float mean, float scale_or_denom, float w, float b) {
+  float y;
+  if (KIND == 0) {
+    y = (v - mean) * scale_or_denom * w + b;   // scale_or_denom = rstd
+  } else {
+    y = v / scale_or_denom * w + b;            // scale_or_denom = sqrt(mean(x^2)+eps), commonlayers.py:377-383
+  }
+  return silu_precise(y);
+}
+
+// ---- one wave per plane ---------------------------------------------------------------
+template <int KIND, int VPT>
+__global__ __launch_bounds__(256) void k_inorm_wave(float* out, const float* x, const float* __restrict__ w,
+                                                    const float* __restrict__ b, int planes, int C, int hw4,
+                                                    float inv_hw, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int plane = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (plane >= planes) return;
+  const float4* src = reinterpret_cast<const float4*>(x) + (size_t)plane * hw4;
+  float4 v[VPT];
+#pragma unroll
+  for (int i = 0; i < VPT; ++i) {
+    int idx = lane + 64 * i;
+    v[i] = idx < hw4 ? src[idx] : make_float4(0, 0, 0, 0);
+  }
+  float mean = 0.f, sod;
+  if (KIND == 0) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    mean = wave_sum(s) * inv_hw;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+      if (lane + 64 * i < hw4) {
+        float a0 = v[i].x - mean, a1 = v[i].y - mean, a2 = v[i].z - mean, a3 = v[i].w - mean;
+        q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+      }
+    }
+    float var = wave_sum(q) * inv_hw;
+    sod = 1.0f / sqrtf(var + eps);
+  } else {
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) q += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+    sod = sqrtf(wave_sum(q) * inv_hw + eps);
+  }
+  const int c = plane % C;
+  const float wc = w ? w[c] : 1.0f, bc = b ? b[c] : 0.0f;
+  float4* dst = reinterpret_cast<float4*>(out) + (size_t)plane * hw4;
+#pragma unroll
+  for (int i = 0; i < VPT; ++i) {
+    int idx = lane + 64 * i;
+    if (idx < hw4) {
+      float4 o;
+      o.x = apply_one<KIND>(v[i].x, mean, sod, wc, bc);
+      o.y = apply_one<KIND>(v[i].y, mean, sod, wc, bc);
+      o.z = apply_one<KIND>(v[i].z, mean, sod, wc, bc);
+      o.w = apply_one<KIND>(v[i].w, mean, sod, wc, bc);
+      dst[idx] = o;
+    }
+  }
+}
+
+// ---- one workgroup per plane ----------------------------------------------------------
+template <int THREADS>
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  const int wid = threadIdx.x >> 6;
+  __syncthreads();  // protect red[] reuse
+  if ((threadIdx.x & 63) == 0) red[wid] = v;
+  __syncthreads();
+  float t = 0.f;
+#pragma unroll
+  for (int i = 0; i < THREADS / 64; ++i) t += red[i];
+  return t;
+}
+
+template <int KIND, int THREADS, int VPT>
+__global__ __launch_bounds__(THREADS) void k_inorm_block(float* out, const float* x, const float* __restrict__ w,
+                                                         const float* __restrict__ b, int C, int hw4, float inv_hw,
+                                                         float eps) {
+  __shared__ float red[THREADS / 64];
+  const int plane = blockIdx.x;
+  const float4* src = reinterpret_cast<const float4*>(x) + (size_t)plane * hw4;
+  float4 v[VPT];
+#pragma unroll
+  for (int i = 0; i < VPT; ++i) {
+    int idx = threadIdx.x + THREADS * i;
+    v[i] = idx < hw4 ? src[idx] : make_float4(0, 0, 0, 0);
+  }
+  float mean = 0.f, sod;
+  if (KIND == 0) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    mean = block_sum<THREADS>(s, red) * inv_hw;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+      if (threadIdx.x + THREADS * i < hw4) {
+        float a0 = v[i].x - mean, a1 = v[i].y - mean, a2 = v[i].z - mean, a3 = v[i].w - mean;
+        q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+      }
+    }
+    float var = block_sum<THREADS>(q, red) * inv_hw;
+    sod = 1.0f / sqrtf(var + eps);
+  } else {
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) q += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+    sod = sqrtf(block_sum<THREADS>(q, red) * inv_hw + eps);
+  }
+  const int c = plane % C;
+  const float wc = w ? w[c] : 1.0f, bc = b ? b[c] : 0.0f;
+  float4* dst = reinterpret_cast<float4*>(out) + (size_t)plane * hw4;
+#pragma unroll
+  for (int i = 0; i < VPT; ++i) {
+    int idx = threadIdx.x + THREADS * i;
+    if (idx < hw4) {
+      float4 o;
+      o.x = apply_one<KIND>(v[i].x, mean, sod, wc, bc);
+      o.y = apply_one<KIND>(v[i].y, mean, sod, wc, bc);
+      o.z = apply_one<KIND>(v[i].z, mean, sod, wc, bc);
+      o.w = apply_one<KIND>(v[i].w, mean, sod, wc, bc);
+      dst[idx] = o;
+    }
+  }
+}
+
+// ---- fallback: any plane size, data re-read from memory -------------------------------
+template <int KIND>
+__global__ __launch_bounds__(256) void k_inorm_generic(float* out, const float* x, const float* __restrict__ w,
+                                                       const float* __restrict__ b, int C, int hw, float inv_hw,
+                                                       float eps) {
+  __shared__ float red[4];
+  const int plane = blockIdx.x;
+  const float* src = x + (size_t)plane * hw;
+  float mean = 0.f, sod;
+  if (KIND == 0) {
+    float s = 0.f;
+    for (int i = threadIdx.x; i < hw; i += 256) s += src[i];
+    mean = block_sum<256>(s, red) * inv_hw;
+    float q = 0.f;
+    for (int i = threadIdx.x; i < hw; i += 256) {
+      float a = src[i] - mean;
+      q += a * a;
+    }
+    sod = 1.0f / sqrtf(block_sum<256>(q, red) * inv_hw + eps);
+  } else {
+    float q = 0.f;
+    for (int i = threadIdx.x; i < hw; i += 256) q += src[i] * src[i];
+    sod = sqrtf(block_sum<256>(q, red) * inv_hw + eps);
+  }
+  const int c = plane % C;
+  const float wc = w ? w[c] : 1.0f, bc = b ? b[c] : 0.0f;
+  float* dst = out + (size_t)plane * hw;
+  // out may alias x: each element is read (above and here) only by the thread that writes it
+  // after the statistics are complete (block_sum ends with a barrier-ordered LDS read).
+  __syncthreads();
+  for (int i = threadIdx.x; i < hw; i += 256) dst[i] = apply_one<KIND>(src[i], mean, sod, wc, bc);
+}
+
+template <int KIND>
+int launch_inorm(float* out, const float* x, const float* w, const float* b, int B, int C, int HW, float eps,
+                 hipStream_t s) {
+  const int planes = B * C;
+  const float inv = 1.0f / (float)HW;
+  const bool vec = (HW % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) & 15u) == 0;
+  const int hw4 = HW / 4;
+  if (vec && hw4 <= 256) {
+    dim3 g((planes + 3) / 4), t(256);
+    if (hw4 <= 64) hipLaunchKernelGGL((k_inorm_wave<KIND, 1>), g, t, 0, s, out, x, w, b, planes, C, hw4, inv, eps);
+    else if (hw4 <= 128) hipLaunchKernelGGL((k_inorm_wave<KIND, 2>), g, t, 0, s, out, x, w, b, planes, C, hw4, inv, eps);
+    else hipLaunchKernelGGL((k_inorm_wave<KIND, 4>), g, t, 0, s, out, x, w, b, planes, C, hw4, inv, eps);
+  } else if (vec && hw4 <= 4096) {
+    dim3 g(planes), t(256);
+    if (hw4 <= 512) hipLaunchKernelGGL((k_inorm_block<KIND, 256, 2>), g, t, 0, s, out, x, w, b, C, hw4, inv, eps);
+    else if (hw4 <= 1024) hipLaunchKernelGGL((k_inorm_block<KIND, 256, 4>), g, t, 0, s, out, x, w, b, C, hw4, inv, eps);
+    else if (hw4 <= 2048) hipLaunchKernelGGL((k_inorm_block<KIND, 256, 8>), g, t, 0, s, out, x, w, b, C, hw4, inv, eps);
+    else hipLaunchKernelGGL((k_inorm_block<KIND, 256, 16>), g, t, 0, s, out, x, w, b, C, hw4, inv, eps);
+  } else if (vec && hw4 <= 16384) {
+    dim3 g(planes), t(1024);
+    if (hw4 <= 8192) hipLaunchKernelGGL((k_inorm_block<KIND, 1024, 8>), g, t, 0, s, out, x, w, b, C, hw4, inv, eps);
+    else hipLaunchKernelGGL((k_inorm_block<KIND, 1024, 16>), g, t, 0, s, out, x, w, b, C, hw4, inv, eps);
+  } else {
+    hipLaunchKernelGGL((k_inorm_generic<KIND>), dim3(planes), dim3(256), 0, s, out, x, w, b, C, HW, inv, eps);
+  }
+  DS_CHECK_LAUNCH("ds_inorm_silu");
+  return DS_OK;
+}
+
+}  // namespace
+
+extern "C" int ds_inorm_silu(float* out, const float* x, const float* w, const float* b, int B, int C, int HW,
+                             float eps, int kind, void* stream) {
+  DS_REQUIRE(out && x, DS_ERR_NULL, "ds_inorm_silu: NULL pointer");
+  DS_REQUIRE(B >= 0 && C > 0 && HW > 0, DS_ERR_SHAPE, "ds_inorm_silu: bad shape B=%d C=%d HW=%d", B, C, HW);
+  DS_REQUIRE(kind == 0 || kind == 1, DS_ERR_UNSUPPORTED, "ds_inorm_silu: kind must be 0 (GroupLN) or 1 (GroupRMS)");
+  DS_REQUIRE((long long)B * C < (1ll << 31), DS_ERR_SHAPE, "ds_inorm_silu: too many planes");
+  if (B == 0) return DS_OK;
+  hipStream_t s = ds::as_stream(stream);
+  return kind == 0 ? launch_inorm<0>(out, x, w, b, B, C, HW, eps, s) : launch_inorm<1>(out, x, w, b, B, C, HW, eps, s);
+}

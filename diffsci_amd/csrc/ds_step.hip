@@ -1,0 +1,334 @@
+// Karras stepper kernels: HBM-bound elementwise passes over the state tensor.
+//
+// Arithmetic is written in the reference's own operation order (one rounding per op, no FMA
+// contraction: the file is compiled with -ffp-contract=off) so that, given the same network
+// outputs, every result is bit-identical to the reference's torch fp32 path:
+//   D     = c_out*F + c_skip*x                      karrasmodule.py:717-718
+//   score = (D - x)/sigma^2                         karrasmodule.py:733
+//   d     = (-(sigma*sigma'))*score [+ -(lambda*score)]   schedulers.py:267-274
+//   Euler: x + dt*d ; Heun: x + (0.5*(d1+d2))*dt    integrators.py:35,46,53
+// Layout: flat fp32; 16 B per lane per access (float4), grid-stride, <= 2048 workgroups.
+#include "ds_common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+
+__device__ __forceinline__ float score_of(float x, float f, float fu, bool has_u, const ds_eval_coef& k) {
+  float F = f;
+  if (has_u) F = k.one_minus_guidance * fu + k.guidance * f;
+  float so = k.c_out * F;
+  float D = so + k.c_skip * x;
+  return (D - x) / k.sigma_sq;
+}
+
+__device__ __forceinline__ float drift(float x, float f, float fu, bool has_u, const ds_eval_coef& k) {
+  if (k.input_kind == DS_IN_DRIFT) return f;
+  float score = (k.input_kind == DS_IN_SCORE) ? f : score_of(x, f, fu, has_u, k);
+  float d = k.neg_mult * score;
+  if (k.stochastic) d = d + k.neg_lang * score;
+  return d;
+}
+
+inline int grid_for(size_t n4) {
+  size_t g = (n4 + kThreads - 1) / kThreads;
+  if (g > 2048) g = 2048;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+__global__ __launch_bounds__(kThreads) void k_scale(float* __restrict__ out, const float* __restrict__ x, float s,
+                                                    size_t n4, size_t n) {
+  size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x;
+  size_t stride = (size_t)gridDim.x * kThreads;
+  for (; i < n4; i += stride) {
+    float4 v = reinterpret_cast<const float4*>(x)[i];
+    v.x = s * v.x; v.y = s * v.y; v.z = s * v.z; v.w = s * v.w;
+    reinterpret_cast<float4*>(out)[i] = v;
+  }
+  // tail (n not a multiple of 4)
+  size_t t = n4 * 4 + (size_t)blockIdx.x * kThreads + threadIdx.x;
+  if (t < n) out[t] = s * x[t];
+}
+
+template <bool HAS_U, bool HAS_EPS>
+__device__ __forceinline__ void euler_one(float x, float f, float fu, float e, const ds_eval_coef& k, float dt,
+                                          float noise_coef, float sq, float c_in_next, float& xo, float& xi) {
+  float d = drift(x, f, fu, HAS_U, k);
+  float r = x + dt * d;
+  if (HAS_EPS) r = r + (noise_coef * e) * sq;
+  xo = r;
+  xi = c_in_next * r;
+}
+
+template <bool HAS_U, bool HAS_EPS>
+__global__ __launch_bounds__(kThreads) void k_euler(float* x_out, float* xin_out, const float* x,
+                                                    const float* __restrict__ f, const float* __restrict__ fu,
+                                                    const float* __restrict__ eps, ds_eval_coef k, float dt,
+                                                    float c_in_next, float noise_coef, float sq, size_t n4, size_t n) {
+  size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x;
+  size_t stride = (size_t)gridDim.x * kThreads;
+  for (; i < n4; i += stride) {
+    float4 vx = reinterpret_cast<const float4*>(x)[i];
+    float4 vf = reinterpret_cast<const float4*>(f)[i];
+    float4 vu = make_float4(0, 0, 0, 0), ve = make_float4(0, 0, 0, 0);
+    if (HAS_U) vu = reinterpret_cast<const float4*>(fu)[i];
+    if (HAS_EPS) ve = reinterpret_cast<const float4*>(eps)[i];
+    float4 o, q;
+    euler_one<HAS_U, HAS_EPS>(vx.x, vf.x, vu.x, ve.x, k, dt, noise_coef, sq, c_in_next, o.x, q.x);
+    euler_one<HAS_U, HAS_EPS>(vx.y, vf.y, vu.y, ve.y, k, dt, noise_coef, sq, c_in_next, o.y, q.y);
+    euler_one<HAS_U, HAS_EPS>(vx.z, vf.z, vu.z, ve.z, k, dt, noise_coef, sq, c_in_next, o.z, q.z);
+    euler_one<HAS_U, HAS_EPS>(vx.w, vf.w, vu.w, ve.w, k, dt, noise_coef, sq, c_in_next, o.w, q.w);
+    if (x_out) reinterpret_cast<float4*>(x_out)[i] = o;
+    if (xin_out) reinterpret_cast<float4*>(xin_out)[i] = q;
+  }
+  size_t t = n4 * 4 + (size_t)blockIdx.x * kThreads + threadIdx.x;
+  if (t < n) {
+    float o, q;
+    euler_one<HAS_U, HAS_EPS>(x[t], f[t], HAS_U ? fu[t] : 0.f, HAS_EPS ? eps[t] : 0.f, k, dt, noise_coef, sq,
+                              c_in_next, o, q);
+    if (x_out) x_out[t] = o;
+    if (xin_out) xin_out[t] = q;
+  }
+}
+
+template <bool HAS_U>
+__device__ __forceinline__ void heun_one(float x, float f1, float f1u, float f2, float f2u, const ds_eval_coef& k1,
+                                         const ds_eval_coef& k2, float dt, float c_in_next, float& xo, float& xi) {
+  float d1 = drift(x, f1, f1u, HAS_U, k1);
+  float xe = x + dt * d1;
+  float d2 = drift(xe, f2, f2u, HAS_U, k2);
+  float r = x + (0.5f * (d1 + d2)) * dt;
+  xo = r;
+  xi = c_in_next * r;
+}
+
+template <bool HAS_U>
+__global__ __launch_bounds__(kThreads) void k_heun(float* x_out, float* xin_out, const float* x,
+                                                   const float* __restrict__ f1, const float* __restrict__ f1u,
+                                                   const float* __restrict__ f2, const float* __restrict__ f2u,
+                                                   ds_eval_coef k1, ds_eval_coef k2, float dt, float c_in_next,
+                                                   size_t n4, size_t n) {
+  size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x;
+  size_t stride = (size_t)gridDim.x * kThreads;
+  for (; i < n4; i += stride) {
+    float4 vx = reinterpret_cast<const float4*>(x)[i];
+    float4 a = reinterpret_cast<const float4*>(f1)[i];
+    float4 b = reinterpret_cast<const float4*>(f2)[i];
+    float4 au = make_float4(0, 0, 0, 0), bu = make_float4(0, 0, 0, 0);
+    if (HAS_U) {
+      au = reinterpret_cast<const float4*>(f1u)[i];
+      bu = reinterpret_cast<const float4*>(f2u)[i];
+    }
+    float4 o, q;
+    heun_one<HAS_U>(vx.x, a.x, au.x, b.x, bu.x, k1, k2, dt, c_in_next, o.x, q.x);
+    heun_one<HAS_U>(vx.y, a.y, au.y, b.y, bu.y, k1, k2, dt, c_in_next, o.y, q.y);
+    heun_one<HAS_U>(vx.z, a.z, au.z, b.z, bu.z, k1, k2, dt, c_in_next, o.z, q.z);
+    heun_one<HAS_U>(vx.w, a.w, au.w, b.w, bu.w, k1, k2, dt, c_in_next, o.w, q.w);
+    reinterpret_cast<float4*>(x_out)[i] = o;
+    if (xin_out) reinterpret_cast<float4*>(xin_out)[i] = q;
+  }
+  size_t t = n4 * 4 + (size_t)blockIdx.x * kThreads + threadIdx.x;
+  if (t < n) {
+    float o, q;
+    heun_one<HAS_U>(x[t], f1[t], HAS_U ? f1u[t] : 0.f, f2[t], HAS_U ? f2u[t] : 0.f, k1, k2, dt, c_in_next, o, q);
+    x_out[t] = o;
+    if (xin_out) xin_out[t] = q;
+  }
+}
+
+template <bool HAS_U, bool SCORE_ONLY>
+__global__ __launch_bounds__(kThreads) void k_drift(float* out, const float* x, const float* __restrict__ f,
+                                                    const float* __restrict__ fu, ds_eval_coef k, size_t n) {
+  size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x;
+  size_t stride = (size_t)gridDim.x * kThreads;
+  for (; i < n; i += stride) {
+    float xv = x ? x[i] : 0.f;
+    float fuv = HAS_U ? fu[i] : 0.f;
+    out[i] = SCORE_ONLY ? score_of(xv, f[i], fuv, HAS_U, k) : drift(xv, f[i], fuv, HAS_U, k);
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void k_churn(float* xhat, float* xin_out, const float* x,
+                                                    const float* __restrict__ eps, float coef, float c_in, size_t n4,
+                                                    size_t n) {
+  size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x;
+  size_t stride = (size_t)gridDim.x * kThreads;
+  for (; i < n4; i += stride) {
+    float4 vx = reinterpret_cast<const float4*>(x)[i];
+    float4 ve = reinterpret_cast<const float4*>(eps)[i];
+    float4 o, q;
+    o.x = vx.x + coef * ve.x; o.y = vx.y + coef * ve.y; o.z = vx.z + coef * ve.z; o.w = vx.w + coef * ve.w;
+    q.x = c_in * o.x; q.y = c_in * o.y; q.z = c_in * o.z; q.w = c_in * o.w;
+    reinterpret_cast<float4*>(xhat)[i] = o;
+    if (xin_out) reinterpret_cast<float4*>(xin_out)[i] = q;
+  }
+  size_t t = n4 * 4 + (size_t)blockIdx.x * kThreads + threadIdx.x;
+  if (t < n) {
+    float o = x[t] + coef * eps[t];
+    xhat[t] = o;
+    if (xin_out) xin_out[t] = c_in * o;
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void k_denoiser(float* out, const float* __restrict__ x,
+                                                       const float* __restrict__ f, const float* __restrict__ fu,
+                                                       float g, float omg, const float* __restrict__ c_out,
+                                                       const float* __restrict__ c_skip, size_t nps, size_t total) {
+  size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x;
+  size_t stride = (size_t)gridDim.x * kThreads;
+  for (; i < total; i += stride) {
+    size_t b = i / nps;
+    float F = f[i];
+    if (fu) F = omg * fu[i] + g * F;
+    float so = c_out[b] * F;
+    out[i] = so + c_skip[b] * x[i];
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void k_add(float* out, const float* __restrict__ a,
+                                                  const float* __restrict__ b, size_t n4, size_t n) {
+  size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x;
+  size_t stride = (size_t)gridDim.x * kThreads;
+  for (; i < n4; i += stride) {
+    float4 va = reinterpret_cast<const float4*>(a)[i];
+    float4 vb = reinterpret_cast<const float4*>(b)[i];
+    va.x += vb.x; va.y += vb.y; va.z += vb.z; va.w += vb.w;
+    reinterpret_cast<float4*>(out)[i] = va;
+  }
+  size_t t = n4 * 4 + (size_t)blockIdx.x * kThreads + threadIdx.x;
+  if (t < n) out[t] = a[t] + b[t];
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+}  // namespace
+
+#define DS_ALIGN_OK(p) ((p) == nullptr || aligned16(p))
+
+extern "C" {
+
+int ds_karras_scale(float* out, const float* x, float s, size_t n, void* stream) {
+  DS_REQUIRE(out && x, DS_ERR_NULL, "ds_karras_scale: NULL pointer");
+  DS_REQUIRE(aligned16(out) && aligned16(x), DS_ERR_SHAPE, "ds_karras_scale: pointers must be 16-byte aligned");
+  if (n == 0) return DS_OK;
+  size_t n4 = n / 4;
+  hipLaunchKernelGGL(k_scale, dim3(grid_for(n4 ? n4 : 1)), dim3(kThreads), 0, ds::as_stream(stream), out, x, s, n4, n);
+  DS_CHECK_LAUNCH("ds_karras_scale");
+  return DS_OK;
+}
+
+int ds_karras_euler(float* x_out, float* xin_out, const float* x, const float* f, const float* fu,
+                    const ds_eval_coef* k, float dt, float c_in_next, const float* eps, float noise_coef,
+                    float sqrt_abs_dt, size_t n, void* stream) {
+  DS_REQUIRE(x && f && k, DS_ERR_NULL, "ds_karras_euler: NULL pointer");
+  DS_REQUIRE(x_out || xin_out, DS_ERR_NULL, "ds_karras_euler: no output requested");
+  DS_REQUIRE(DS_ALIGN_OK(x_out) && DS_ALIGN_OK(xin_out) && aligned16(x) && aligned16(f) && DS_ALIGN_OK(fu) &&
+                 DS_ALIGN_OK(eps),
+             DS_ERR_SHAPE, "ds_karras_euler: pointers must be 16-byte aligned");
+  DS_REQUIRE(!(k->input_kind != 0 && fu), DS_ERR_SHAPE, "ds_karras_euler: guidance blend needs network outputs");
+  if (n == 0) return DS_OK;
+  size_t n4 = n / 4;
+  dim3 g(grid_for(n4 ? n4 : 1)), b(kThreads);
+  hipStream_t s = ds::as_stream(stream);
+#define L(U, E) \
+  hipLaunchKernelGGL((k_euler<U, E>), g, b, 0, s, x_out, xin_out, x, f, fu, eps, *k, dt, c_in_next, noise_coef, sqrt_abs_dt, n4, n)
+  if (fu && eps) L(true, true);
+  else if (fu) L(true, false);
+  else if (eps) L(false, true);
+  else L(false, false);
+#undef L
+  DS_CHECK_LAUNCH("ds_karras_euler");
+  return DS_OK;
+}
+
+int ds_karras_heun(float* x_out, float* xin_out, const float* x, const float* f1, const float* f1u,
+                   const ds_eval_coef* k1, const float* f2, const float* f2u, const ds_eval_coef* k2, float dt,
+                   float c_in_next, size_t n, void* stream) {
+  DS_REQUIRE(x_out && x && f1 && f2 && k1 && k2, DS_ERR_NULL, "ds_karras_heun: NULL pointer");
+  DS_REQUIRE((f1u == nullptr) == (f2u == nullptr), DS_ERR_SHAPE,
+             "ds_karras_heun: f1u and f2u must both be given or both be NULL");
+  DS_REQUIRE(aligned16(x_out) && DS_ALIGN_OK(xin_out) && aligned16(x) && aligned16(f1) && aligned16(f2) &&
+                 DS_ALIGN_OK(f1u) && DS_ALIGN_OK(f2u),
+             DS_ERR_SHAPE, "ds_karras_heun: pointers must be 16-byte aligned");
+  DS_REQUIRE(!((k1->input_kind != 0 || k2->input_kind != 0) && f1u), DS_ERR_SHAPE,
+             "ds_karras_heun: guidance blend needs network outputs");
+  if (n == 0) return DS_OK;
+  size_t n4 = n / 4;
+  dim3 g(grid_for(n4 ? n4 : 1)), b(kThreads);
+  hipStream_t s = ds::as_stream(stream);
+  if (f1u)
+    hipLaunchKernelGGL((k_heun<true>), g, b, 0, s, x_out, xin_out, x, f1, f1u, f2, f2u, *k1, *k2, dt, c_in_next, n4, n);
+  else
+    hipLaunchKernelGGL((k_heun<false>), g, b, 0, s, x_out, xin_out, x, f1, f1u, f2, f2u, *k1, *k2, dt, c_in_next, n4, n);
+  DS_CHECK_LAUNCH("ds_karras_heun");
+  return DS_OK;
+}
+
+static int launch_drift(float* out, const float* x, const float* f, const float* fu, const ds_eval_coef* k,
+                        size_t n, void* stream, bool score_only, const char* who) {
+  DS_REQUIRE(out && f && k, DS_ERR_NULL, "%s: NULL pointer", who);
+  DS_REQUIRE(x || k->input_kind != DS_IN_NETWORK, DS_ERR_NULL, "%s: x is required for network outputs", who);
+  DS_REQUIRE(!(k->input_kind != 0 && fu), DS_ERR_SHAPE, "%s: guidance blend needs network outputs", who);
+  DS_REQUIRE(!(score_only && k->input_kind != DS_IN_NETWORK), DS_ERR_SHAPE, "%s: input is not a network output", who);
+  if (n == 0) return DS_OK;
+  dim3 g(grid_for((n + 3) / 4)), b(kThreads);
+  hipStream_t s = ds::as_stream(stream);
+  if (fu) {
+    if (score_only) hipLaunchKernelGGL((k_drift<true, true>), g, b, 0, s, out, x, f, fu, *k, n);
+    else hipLaunchKernelGGL((k_drift<true, false>), g, b, 0, s, out, x, f, fu, *k, n);
+  } else {
+    if (score_only) hipLaunchKernelGGL((k_drift<false, true>), g, b, 0, s, out, x, f, fu, *k, n);
+    else hipLaunchKernelGGL((k_drift<false, false>), g, b, 0, s, out, x, f, fu, *k, n);
+  }
+  DS_CHECK_LAUNCH(who);
+  return DS_OK;
+}
+
+int ds_karras_drift(float* d_out, const float* x, const float* f, const float* fu, const ds_eval_coef* k, size_t n,
+                    void* stream) {
+  return launch_drift(d_out, x, f, fu, k, n, stream, false, "ds_karras_drift");
+}
+
+int ds_karras_score(float* s_out, const float* x, const float* f, const float* fu, const ds_eval_coef* k, size_t n,
+                    void* stream) {
+  return launch_drift(s_out, x, f, fu, k, n, stream, true, "ds_karras_score");
+}
+
+int ds_karras_churn(float* xhat_out, float* xin_out, const float* x, const float* eps, float coef, float c_in,
+                    size_t n, void* stream) {
+  DS_REQUIRE(xhat_out && x && eps, DS_ERR_NULL, "ds_karras_churn: NULL pointer");
+  DS_REQUIRE(aligned16(xhat_out) && DS_ALIGN_OK(xin_out) && aligned16(x) && aligned16(eps), DS_ERR_SHAPE,
+             "ds_karras_churn: pointers must be 16-byte aligned");
+  if (n == 0) return DS_OK;
+  size_t n4 = n / 4;
+  hipLaunchKernelGGL(k_churn, dim3(grid_for(n4 ? n4 : 1)), dim3(kThreads), 0, ds::as_stream(stream), xhat_out,
+                     xin_out, x, eps, coef, c_in, n4, n);
+  DS_CHECK_LAUNCH("ds_karras_churn");
+  return DS_OK;
+}
+
+int ds_karras_denoiser(float* out, const float* x, const float* f, const float* fu, float guidance,
+                       float one_minus_guidance,
+                       const float* c_out, const float* c_skip, int B, size_t n_per_sample, void* stream) {
+  DS_REQUIRE(out && x && f && c_out && c_skip, DS_ERR_NULL, "ds_karras_denoiser: NULL pointer");
+  DS_REQUIRE(B >= 0, DS_ERR_SHAPE, "ds_karras_denoiser: B < 0");
+  size_t total = (size_t)B * n_per_sample;
+  if (total == 0) return DS_OK;
+  hipLaunchKernelGGL(k_denoiser, dim3(grid_for((total + 3) / 4)), dim3(kThreads), 0, ds::as_stream(stream), out, x, f,
+                     fu, guidance, one_minus_guidance, c_out, c_skip, n_per_sample, total);
+  DS_CHECK_LAUNCH("ds_karras_denoiser");
+  return DS_OK;
+}
+
+int ds_add(float* out, const float* a, const float* b, size_t n, void* stream) {
+  DS_REQUIRE(out && a && b, DS_ERR_NULL, "ds_add: NULL pointer");
+  DS_REQUIRE(aligned16(out) && aligned16(a) && aligned16(b), DS_ERR_SHAPE, "ds_add: pointers must be 16-byte aligned");
+  if (n == 0) return DS_OK;
+  size_t n4 = n / 4;
+  hipLaunchKernelGGL(k_add, dim3(grid_for(n4 ? n4 : 1)), dim3(kThreads), 0, ds::as_stream(stream), out, a, b, n4, n);
+  DS_CHECK_LAUNCH("ds_add");
+  return DS_OK;
+}
+
+}  // extern "C"

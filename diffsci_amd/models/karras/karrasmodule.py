@@ -1,0 +1,294 @@
+"""KarrasModuleConfig / KarrasModule: the sampling surface of the reference
+(diffsci/models/karras/karrasmodule.py:29-401, 431-455, 673-931, 1192-1234) on the HIP stepper.
+
+Kept: ``KarrasModuleConfig.from_edm`` (+ the plain constructor), ``KarrasModule(model, config,
+conditional=...)`` with ``sample``, ``propagate_white_noise``, ``propagate_toward_sample``,
+``propagate_partial_toward_sample``, ``get_denoiser``, ``get_score``, ``encode`` / ``decode``
+(non-latent: identity up to ``norm``), ``device``, ``.to()`` / ``.eval()``, and the model protocol
+``model(c_in*x, c_noise[, y])``.  Training (loss_fn, training_step, optimisers), latent
+autoencoders and EDM batch-norm are outside this path and raise if requested.
+
+For a HIP-native score network (``PUNetG``) the whole N-step loop -- ~85 launches per network
+evaluation -- is captured once per (batch shape, nsteps, integrator, guidance) into a hipGraph
+and replayed; an arbitrary ``model`` runs eagerly through the same step kernels."""
+from typing import Any
+
+import torch
+
+from ... import ops
+from ..._native import DS_IN_NETWORK
+from . import integrators, noisesamplers, preconditioners, schedulers
+from .engine import Loop, ModuleSource
+from .steptable import build_step_table
+
+
+def get_minibatch_sizes(n: int, b: int) -> list[int]:
+    """diffsci/utils.py:5-11."""
+    return [b] * (n // b) + ([n % b] if n % b else [])
+
+
+def dict_map(func, d):
+    return {k: dict_map(func, v) for k, v in d.items()} if isinstance(d, dict) else func(d)
+
+
+def dict_unsqueeze(d, dim):
+    """diffsci/torchutils.py:75-77."""
+    return dict_map(lambda x: torch.unsqueeze(x, dim), d)
+
+
+def dict_to(d, device):
+    """diffsci/torchutils.py:85-87."""
+    return dict_map(lambda x: x.to(device), d)
+
+
+class KarrasModuleConfig(object):
+    def __init__(self, preconditioner, noisesampler, noisescheduler, loss_metric="huber",
+                 tag: str = "custom", has_edm_batch_norm: bool = False,
+                 dynamic_loss_weight: int | None = None, extra_args: None | dict[str, Any] = None,
+                 **legacy):
+        if has_edm_batch_norm:
+            raise NotImplementedError("has_edm_batch_norm is outside the HIP sampling path")
+        self.preconditioner = preconditioner
+        self.noisesampler = noisesampler
+        self.noisescheduler = noisescheduler
+        self.loss_metric = loss_metric
+        self.tag = tag
+        self.has_edm_batch_norm = has_edm_batch_norm
+        self.dynamic_loss_weight = dynamic_loss_weight
+        self.extra_args = dict() if extra_args is None else extra_args
+        for k, v in legacy.items():          # autoregressive_loss_*, spatial_shape, focus_radius
+            setattr(self, k, v)
+
+    @classmethod
+    def from_edm(cls, sigma_data: float = 0.5, prior_mean: float = -1.2, prior_std: float = 1.2,
+                 has_edm_batch_norm: bool = False, dynamic_loss_weight: int | None = None,
+                 loss_metric="huber", **kwargs):
+        """karrasmodule.py:96-175."""
+        extra_args = dict(sigma_data=sigma_data, prior_mean=prior_mean, prior_std=prior_std,
+                          loss_metric=loss_metric, **kwargs)
+        return cls(preconditioner=preconditioners.EDMPreconditioner(sigma_data=sigma_data),
+                   noisesampler=noisesamplers.EDMNoiseSampler(sigma_data=sigma_data, prior_mean=prior_mean,
+                                                              prior_std=prior_std),
+                   noisescheduler=schedulers.EDMScheduler(),
+                   loss_metric=loss_metric, tag="edm", has_edm_batch_norm=has_edm_batch_norm,
+                   dynamic_loss_weight=dynamic_loss_weight, extra_args=extra_args, **kwargs)
+
+    @classmethod
+    def from_vp(cls, *a, **k):
+        raise NotImplementedError("VP parameterisation is the next scope row (SURVEY 8f-2)")
+
+    @classmethod
+    def from_ve(cls, *a, **k):
+        raise NotImplementedError("VE parameterisation is the next scope row (SURVEY 8f-2)")
+
+    def export_description(self) -> dict[str, Any]:
+        return dict(tag=self.tag, extra_args=self.extra_args)
+
+
+class _Plan:
+    """A captured N-step run: static buffers + hipGraph."""
+
+    def __init__(self, loop, graph):
+        self.loop, self.graph = loop, graph
+
+
+class KarrasModule(torch.nn.Module):
+    def __init__(self, model: torch.nn.Module, config: KarrasModuleConfig, conditional: bool = False,
+                 masked: bool = False, autoencoder: None | torch.nn.Module = None,
+                 autoencoder_conditional: bool = False, encode_y: bool = False,
+                 decode_original_y: bool = False):
+        super().__init__()
+        if autoencoder is not None or encode_y or decode_original_y:
+            raise NotImplementedError("latent (autoencoder) models are outside the HIP sampling path")
+        self.model = model
+        self.config = config
+        self.conditional = conditional
+        self.masked = masked
+        self.autoencoder = None
+        self.autoencoder_conditional = autoencoder_conditional
+        self.encode_y = False
+        self.decode_original_y = False
+        self.norm = 1.0
+        self.use_graph = True          # capture the loop as a hipGraph for HIP-native networks
+        self._plans = {}
+
+    # ---------------------------------------------------------------- bookkeeping
+    @property
+    def device(self):
+        try:
+            return next(self.parameters()).device
+        except StopIteration:
+            return torch.device("cpu")
+
+    @property
+    def latent_model(self):
+        return False
+
+    def _apply(self, fn, *a, **k):
+        self._plans = {}
+        return super()._apply(fn, *a, **k)
+
+    # ---------------------------------------------------------------- denoiser / score (public API)
+    def _coefs(self, sigma):
+        """Per-sample preconditioner values on the host, in the reference's fp32 op order."""
+        s = sigma.detach().to("cpu", torch.float32).reshape(-1)
+        p = self.config.preconditioner
+        return p.skip_scaling(s), p.output_scaling(s), p.input_scaling(s), p.noise_conditioner(s)
+
+    def _run_model(self, x, sigma, y, guidance):
+        """scaled_input = c_in*x; F = model(scaled_input, c_noise[, y]) (karrasmodule.py:690-716)."""
+        ops.require_device(x, "x")
+        x = x.contiguous()
+        c_skip, c_out, c_in, c_noise = self._coefs(sigma)
+        if c_in.numel() not in (1, x.shape[0]):
+            raise ValueError("sigma must have one entry per sample")
+        c_skip, c_out, c_in, c_noise = (c.expand(x.shape[0]).contiguous() for c in (c_skip, c_out, c_in, c_noise))
+        xin = torch.empty_like(x)
+        if bool((c_in == c_in[0]).all()):
+            ops.scale(x, float(c_in[0]), out=xin)
+        else:
+            for b in range(x.shape[0]):
+                ops.scale(x[b], float(c_in[b]), out=xin[b])
+        cn = c_noise.to(x.device)
+        fu = None
+        if self.conditional and guidance != 0.0:
+            f = self.model(xin, cn, y)
+            if guidance != 1.0:
+                fu = self.model(xin, cn)
+        else:
+            f = self.model(xin, cn)
+        return x, f.contiguous(), (None if fu is None else fu.contiguous()), c_skip, c_out, cn
+
+    def get_denoiser(self, x, sigma, y=None, guidance: float = 1.0):
+        """karrasmodule.py:673-719.  sigma: [B] (values may differ per sample)."""
+        x, f, fu, c_skip, c_out, cn = self._run_model(x, sigma, y, guidance)
+        D = ops.denoiser(x, f, c_out.to(x.device), c_skip.to(x.device), fu=fu, guidance=guidance)
+        return D, cn
+
+    def get_score(self, x, sigma, y=None, guidance: float = 1.0):
+        """(D - x)/sigma^2, karrasmodule.py:721-733 -- fused with the denoiser in one pass."""
+        from ..._native import EvalCoef
+        x, f, fu, c_skip, c_out, _ = self._run_model(x, sigma, y, guidance)
+        s2 = (sigma.detach().to("cpu", torch.float32).reshape(-1) ** 2).expand(x.shape[0])
+        out = torch.empty_like(x)
+
+        def coef(b):
+            return EvalCoef(c_out=float(c_out[b]), c_skip=float(c_skip[b]), sigma_sq=float(s2[b]), neg_mult=0.0,
+                            neg_lang=0.0, guidance=float(guidance), one_minus_guidance=float(1 - guidance),
+                            input_kind=DS_IN_NETWORK, stochastic=0)
+        if bool((s2 == s2[0]).all()):
+            ops.score(x, f, coef(0), fu=fu, out=out)
+        else:
+            for b in range(x.shape[0]):
+                ops.score(x[b], f[b], coef(b), fu=None if fu is None else fu[b], out=out[b])
+        return out
+
+    # ---------------------------------------------------------------- sampling
+    def sample(self, nsamples: int, shape: list[int], y=None, guidance: float = 1.0, nsteps: int = 100,
+               record_history: bool = False, maximum_batch_size: None | int = None,
+               integrator=None, move_to_cpu: bool = False, is_latent_shape: bool = False,
+               squeeze_memory_efficiency: bool = False, return_in_latent_space: bool = False):
+        """karrasmodule.py:801-865: CPU-generator white noise, optional minibatching."""
+        with torch.inference_mode():
+            if maximum_batch_size is not None:
+                result = [self.sample(b, shape, y, guidance, nsteps, record_history, maximum_batch_size=None,
+                                      integrator=integrator, move_to_cpu=move_to_cpu)
+                          for b in get_minibatch_sizes(nsamples, maximum_batch_size)]
+                return torch.cat(result, dim=1 if record_history else 0)
+            white_noise = torch.randn(*([nsamples] + list(shape))).to(self.device)
+            if y is not None:
+                y = dict_to(y, self.device)
+            return self.propagate_white_noise(white_noise, y, guidance, nsteps, record_history,
+                                              integrator=integrator, move_to_cpu=move_to_cpu)
+
+    def propagate_white_noise(self, x, y=None, guidance: float = 1.0, nsteps: int = 100,
+                              record_history: bool = False, integrator=None, original_y=None,
+                              move_to_cpu: bool = False, latent_shape: bool = False,
+                              squeeze_memory_efficiency: bool = False, return_in_latent_space: bool = False,
+                              eps=None):
+        """karrasmodule.py:867-905: x*maximum_scale, the N-step loop, decode."""
+        with torch.inference_mode():
+            result = self.propagate_toward_sample(x, y, guidance, nsteps, record_history,
+                                                  integrator=integrator, eps=eps,
+                                                  _scale=self.config.noisescheduler.maximum_scale)
+            result = self.decode(result, y, record_history)
+        if move_to_cpu:
+            result = result.detach().cpu()
+        return result
+
+    def propagate_toward_sample(self, x, y=None, guidance: float = 1.0, nsteps: int = 100,
+                                record_history: bool = False, integrator=None, eps=None, _scale=None):
+        """karrasmodule.py:907-931.  eps (extension): injected per-step noise [nsteps, *x.shape]."""
+        return self._propagate(x, y, guidance, nsteps, record_history, integrator, eps, _scale, 0, None)
+
+    def propagate_partial_toward_sample(self, x, initial_step: int, final_step: int = None, y=None,
+                                        nsteps: int = 100, record_history: bool = False,
+                                        guidance: float = 1.0, integrator=None, eps=None):
+        """karrasmodule.py:933-976."""
+        final_step = nsteps if final_step is None else final_step
+        return self._propagate(x, y, guidance, nsteps, record_history, integrator, eps, None,
+                               initial_step, final_step)
+
+    def _propagate(self, x, y, guidance, nsteps, record_history, integrator, eps, scale, i0, i1):
+        ops.require_device(x, "x")
+        sch = self.config.noisescheduler
+        if y is not None:
+            y = dict_unsqueeze(y, 0)                                     # karrasmodule.py:916-917
+        if integrator is not None:
+            sch.set_temporary_integrator(integrator)
+        try:
+            integ = sch.integrator
+            if not schedulers._is_builtin(integ):
+                def rhs(xx, sigma):
+                    return self.get_score(xx, sigma, y, guidance)
+                xs = x if scale is None else ops.scale(x.contiguous(), scale)
+                return sch._propagate_custom(xs, rhs, integ, nsteps, record_history, True, i0, i1)
+            table = build_step_table(sch, integ, nsteps, backward=True, initial_step=i0, final_step=i1,
+                                     preconditioner=self.config.preconditioner)
+        finally:
+            if integrator is not None:
+                sch.unset_temporary_integrator()
+        src = ModuleSource(self, y, guidance, x.shape[0], x)
+        if src.planned and self.use_graph:
+            return self._run_planned(table, src, x, y, guidance, nsteps, record_history, integ, eps, scale,
+                                     i0, i1)
+        loop = Loop(table, src, x, record_history)
+        loop.load(x, scale)
+        loop.set_noise(eps)
+        loop.launch()
+        return loop.result()
+
+    def _run_planned(self, table, src, x, y, guidance, nsteps, record_history, integ, eps, scale, i0, i1):
+        sch = self.config.noisescheduler
+        ykey = None if y is None else repr(dict_map(lambda t: (tuple(t.shape), t.flatten()[:8].tolist()), y))
+        key = (tuple(x.shape), str(x.device), nsteps, i0, i1, record_history, table.kind,
+               tuple(sorted(vars(integ).items(), key=str)) if table.kind == "karras" else None,
+               float(guidance), ykey, float(sch.langevin_const), repr(sch.langevin_interval),
+               tuple(float(v) for v in table.t.tolist()),
+               tuple((p.data_ptr(), p._version) for p in self.model.parameters()))
+        plan = self._plans.get(key)
+        if plan is None:
+            loop = Loop(table, src, x, record_history)
+            loop.load(x, scale)
+            loop.set_noise(eps)
+            loop.launch()                      # eager pass: allocates the workspace, validates shapes
+            torch.cuda.current_stream().synchronize()
+            with ops.Graph() as g:
+                loop.launch()
+            plan = _Plan(loop, g)
+            if len(self._plans) >= 4:
+                self._plans.pop(next(iter(self._plans)))
+            self._plans[key] = plan
+        plan.loop.load(x, scale)
+        plan.loop.set_noise(eps)
+        plan.graph.launch()
+        return plan.loop.result().clone()
+
+    # ---------------------------------------------------------------- encode / decode (non-latent)
+    def encode(self, x, y=None, record_history=False):
+        """karrasmodule.py:1192-1214 for a non-latent module."""
+        return x / self.norm
+
+    def decode(self, x, y=None, record_history=False):
+        """karrasmodule.py:1216-1234 for a non-latent module: x*norm (norm = 1.0 -> identity)."""
+        return x if self.norm == 1.0 else ops.scale(x.contiguous(), self.norm)

@@ -1,0 +1,3 @@
+from .punetg_config import PUNetGConfig  # noqa: F401
+from .punetg import PUNetG, PUNetGCond  # noqa: F401
+from .mlp import MLPUncond  # noqa: F401

@@ -1,0 +1,328 @@
+"""PUNetG score network on HIP kernels.
+
+Same constructor, forward protocol ``net(x, t=None, y=None)`` and state_dict key names as the
+reference (diffsci/models/nets/punetg.py:80-106,356-416), so reference checkpoints load with
+``load_state_dict``.  The torch.nn layers created here are *parameter containers only* -- they
+give the reference's key names and default initialisers -- and are never called: every tensor
+operation of the forward pass is a launch into libdiffsci_hip.so:
+
+  convin / convout / conv1+time-shift / conv2+residual   ds_conv2d (fp32 MFMA implicit GEMM)
+  DownSampler (max-pool -> conv), UpSampler (nearest -> conv) + skip add   ds_conv2d load modes
+  GroupNorm(C,C)+SiLU, GroupRMSNorm(C,C)+SiLU              ds_inorm_silu
+  GaussianFourierProjection, ResnetTimeBlock MLPs          ds_fourier_features, ds_linear
+  TwoDimensionalAttention (nn.MultiheadAttention, 1 head)  ds_conv2d (1x1 projections) + ds_attention
+  x + xa (punetg.py:385)                                    folded into the preceding conv epilogue
+"""
+from typing import Any
+
+import torch
+
+from ... import ops
+from ..._native import DS_LOAD_MAXPOOL2, DS_LOAD_PLAIN, DS_LOAD_UPSAMPLE2
+from .punetg_config import PUNetGConfig
+
+
+class _AffineHolder(torch.nn.Module):
+    """weight/bias container for GroupRMSNorm (commonlayers.py:332-361)."""
+
+    def __init__(self, C):
+        super().__init__()
+        self.weight = torch.nn.Parameter(torch.ones(C))
+        self.bias = torch.nn.Parameter(torch.zeros(C))
+
+
+class _TimeBlock(torch.nn.Module):
+    """ResnetTimeBlock parameters: net.{0,2,4} Linear (commonlayers.py:516-522)."""
+
+    def __init__(self, embed, out):
+        super().__init__()
+        self.net = torch.nn.Sequential(
+            torch.nn.Linear(embed, 4 * embed), torch.nn.Identity(),
+            torch.nn.Linear(4 * embed, 4 * embed), torch.nn.Identity(),
+            torch.nn.Linear(4 * embed, out))
+
+
+class _ResBlock(torch.nn.Module):
+    """ResnetBlockC parameters (commonlayers.py:766-807)."""
+
+    def __init__(self, C, embed):
+        super().__init__()
+        self.gnorm1 = torch.nn.GroupNorm(C, C)
+        self.gnorm2 = _AffineHolder(C)
+        self.conv1 = torch.nn.Conv2d(C, C, 3, padding="same")
+        self.conv2 = torch.nn.Conv2d(C, C, 3, padding="same")
+        self.timeblock = _TimeBlock(embed, C)
+
+
+class _Sampler(torch.nn.Module):
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.conv = torch.nn.Conv2d(cin, cout, 3, padding="same")
+
+
+class _Attn(torch.nn.Module):
+    def __init__(self, C):
+        super().__init__()
+        self.mhattn = torch.nn.MultiheadAttention(C, num_heads=1, batch_first=True)
+
+
+class _Fourier(torch.nn.Module):
+    def __init__(self, embed_dim, scale):
+        super().__init__()
+        self.register_buffer("W", torch.randn(embed_dim // 2) * scale)
+
+
+class _Workspace:
+    """Shape-keyed pool of device buffers.  A forward pass takes and gives buffers in a fixed
+    order, so after the first pass no allocation happens -- a requirement for hipGraph capture."""
+
+    def __init__(self):
+        self.free = {}
+        self.frozen = False
+        self.bytes = 0
+
+    def take(self, shape, device):
+        key = (tuple(shape), str(device))
+        lst = self.free.get(key)
+        if lst:
+            return lst.pop()
+        if self.frozen:
+            raise RuntimeError(f"workspace is frozen (graph captured) but a new buffer {shape} was requested")
+        t = torch.empty(shape, dtype=torch.float32, device=device)
+        self.bytes += t.numel() * 4
+        return t
+
+    def give(self, t):
+        self.free.setdefault((tuple(t.shape), str(t.device)), []).append(t)
+
+
+class PUNetG(torch.nn.Module):
+    def __init__(self,
+                 config: PUNetGConfig,
+                 conditional_embedding: torch.nn.Module | None = None,
+                 extra_residual: torch.nn.Module | None = None):
+        super().__init__()
+        why = config.unsupported_reason()
+        if why:
+            raise NotImplementedError(why)
+        if extra_residual is not None:
+            raise NotImplementedError("extra_residual is not implemented on the HIP path")
+        self.config = config
+        mc = config.model_channels
+        mult = config.extended_channel_expansion
+        self.time_projection = _Fourier(mc, config.time_projection_scale)
+        self.conditional_embedding = conditional_embedding
+        self.convin = torch.nn.Conv2d(config.input_channels, mc, 3, padding="same")
+        self.convout = torch.nn.Conv2d(mc, config.output_channels, 3, padding="same")
+
+        def blocks(m, n):
+            return torch.nn.ModuleList([_ResBlock(m * mc, mc) for _ in range(n)])
+
+        self.downward_blocks = torch.nn.ModuleList(
+            [blocks(mult[i], config.number_resnet_downward_block) for i in range(len(mult) - 1)])
+        self.downsamplers = torch.nn.ModuleList(
+            [_Sampler(mult[i] * mc, mult[i + 1] * mc) for i in range(len(mult) - 1)])
+        rmult = list(reversed(mult))
+        self.upward_blocks = torch.nn.ModuleList(
+            [blocks(rmult[i + 1], config.number_resnet_upward_block) for i in range(len(mult) - 1)])
+        self.upsamplers = torch.nn.ModuleList(
+            [_Sampler(rmult[i] * mc, rmult[i + 1] * mc) for i in range(len(mult) - 1)])
+        self.before_block = blocks(mult[-1], config.number_resnet_before_attn_block)
+        self.after_block = blocks(mult[-1], config.number_resnet_after_attn_block)
+        self.attn_resnet_block = blocks(mult[-1], config.number_resnet_attn_block)
+        self.attn_block = torch.nn.ModuleList(
+            [_Attn(mult[-1] * mc) for _ in range(config.number_resnet_attn_block - 1)])
+        self._packed = None
+        self._packed_sig = None
+        self._ws = _Workspace()
+
+    # ------------------------------------------------------------------ reference surface
+    def export_description(self) -> dict[str, Any]:
+        cemb = self.conditional_embedding
+        cemb_args = cemb.export_description() if getattr(cemb, "export_description", None) else None
+        return dict(config=self.config.export_description(),
+                    conditional_embedding_args=cemb_args,
+                    has_conditional_embedding=cemb is not None)
+
+    def set_conditional_embedding(self, conditional_embedding: torch.nn.Module | None = None):
+        self.conditional_embedding = conditional_embedding
+
+    def forward(self, x, t=None, y=None):
+        """punetg.py:389-416.  x [B, Cin, H, W]; t [B] noise conditioning; y optional condition."""
+        ops.require_device(x, "x")
+        B = x.shape[0]
+        if t is None:
+            te = torch.zeros(B, self.config.model_channels, device=x.device)
+        else:
+            te = self.embed_time(t.reshape(-1).to(x), self.embed_condition(y))
+        shifts = self.time_shifts(te)
+        return self.forward_with_shifts(x.contiguous(), shifts, row=None)
+
+    # ------------------------------------------------------------------ conditioning
+    def embed_condition(self, y):
+        """ye of punetg.py:400-410 (conditional_embedding is a user module, run as given)."""
+        if y is None:
+            return None
+        ye = y if self.conditional_embedding is None else self.conditional_embedding(y)
+        if ye.ndim != 2:
+            raise NotImplementedError("spatial conditional embeddings (ye.ndim > 2) are not implemented")
+        return ye.to(torch.float32).contiguous()
+
+    def embed_time(self, t, ye=None):
+        """te = GaussianFourierProjection(t) [+ ye]  (punetg.py:396-410)."""
+        if ye is not None and ye.shape[0] not in (1, t.numel()):
+            raise ValueError("conditional embedding batch must be 1 or match t")
+        return ops.fourier_features(t.contiguous(), self.time_projection.W, add=ye)
+
+    def time_shifts(self, te):
+        """Per-block ResnetTimeBlock(te): list of [M, C_block] tensors in block order."""
+        out = []
+        for blk in self._resblocks():
+            n = blk.timeblock.net
+            h = ops.linear(te, n[0].weight, n[0].bias, act=1)
+            h = ops.linear(h, n[2].weight, n[2].bias, act=1)
+            out.append(ops.linear(h, n[4].weight, n[4].bias, act=0))
+        return out
+
+    def _resblocks(self):
+        for lv in self.downward_blocks:
+            yield from lv
+        yield from self.before_block
+        yield from self.attn_resnet_block
+        yield from self.after_block
+        for lv in self.upward_blocks:
+            yield from lv
+
+    # ------------------------------------------------------------------ weights
+    def _conv_modules(self):
+        yield self.convin
+        yield self.convout
+        for blk in self._resblocks():
+            yield blk.conv1
+            yield blk.conv2
+        for s in list(self.downsamplers) + list(self.upsamplers):
+            yield s.conv
+
+    def packed_weights(self):
+        """MFMA-operand repack of every conv / projection weight, cached per parameter version."""
+        mods = list(self._conv_modules())
+        sig = tuple((m.weight.data_ptr(), m.weight._version) for m in mods) + tuple(
+            (a.mhattn.in_proj_weight.data_ptr(), a.mhattn.in_proj_weight._version) for a in self.attn_block)
+        if self._packed is not None and sig == self._packed_sig:
+            return self._packed
+        pk = {}
+        with torch.no_grad():
+            for m in mods:
+                pk[id(m)] = ops.pack_conv_weight(m.weight.detach())
+            for a in self.attn_block:
+                E = a.mhattn.embed_dim
+                pk[(id(a), "in")] = ops.pack_conv_weight(a.mhattn.in_proj_weight.detach().reshape(3 * E, E, 1, 1))
+                pk[(id(a), "out")] = ops.pack_conv_weight(a.mhattn.out_proj.weight.detach().reshape(E, E, 1, 1))
+        self._packed, self._packed_sig = pk, sig
+        return pk
+
+    # ------------------------------------------------------------------ the network
+    def _conv(self, m, x, pk, **kw):
+        return ops.conv2d(x, pk[id(m)], m.out_channels, m.kernel_size[0], bias=m.bias, **kw)
+
+    def _res(self, blk, x, shift, pk, ws, res2=None):
+        """ResnetBlockC.forward (commonlayers.py:824-833); returns a fresh buffer, x untouched."""
+        a = ops.inorm_silu(x, blk.gnorm1.weight, blk.gnorm1.bias, kind=0, eps=blk.gnorm1.eps,
+                           out=ws.take(x.shape, x.device))
+        y = self._conv(blk.conv1, a, pk, shift=shift, out=ws.take(x.shape, x.device))
+        ops.inorm_silu(y, blk.gnorm2.weight, blk.gnorm2.bias, kind=1, eps=1e-5, out=a)
+        self._conv(blk.conv2, a, pk, res1=x, res2=res2, out=y)
+        ws.give(a)
+        return y
+
+    def forward_with_shifts(self, x, shifts, row=None, out=None):
+        """UNet body given the per-block time shifts.  shifts[k] is [M, C_k]; row selects one row
+        shared by the whole batch (sampling: sigma is a per-step constant), row=None means one row
+        per sample (M == B)."""
+        pk = self.packed_weights()
+        ws = self._ws
+        cfg = self.config
+        B = x.shape[0]
+        it = iter(range(len(shifts)))
+
+        def sh():
+            s = shifts[next(it)]
+            if row is not None:
+                return s[row:row + 1]
+            if s.shape[0] not in (1, B):
+                raise ValueError("time embedding batch does not match x")
+            return s
+
+        h = self._conv(self.convin, x, pk, out=ws.take((B, cfg.model_channels) + tuple(x.shape[2:]), x.device))
+        skips = []
+        for lv, blocks in enumerate(self.downward_blocks):                      # punetg.py:356-365
+            for blk in blocks:
+                h2 = self._res(blk, h, sh(), pk, ws)
+                ws.give(h)
+                h = h2
+            skips.append(h)
+            ds = self.downsamplers[lv].conv
+            h = self._conv(ds, h, pk, load_mode=DS_LOAD_MAXPOOL2,
+                           out=ws.take((B, ds.out_channels, h.shape[2] // 2, h.shape[3] // 2), x.device))
+        for blk in self.before_block:                                             # punetg.py:378-387
+            h2 = self._res(blk, h, sh(), pk, ws)
+            ws.give(h)
+            h = h2
+        xa = h
+        nattn = len(self.attn_resnet_block)
+        for i, blk in enumerate(self.attn_resnet_block):
+            last = i == nattn - 1
+            # x + xa is folded into the last residual block's epilogue when no attention follows it
+            xa2 = self._res(blk, xa, sh(), pk, ws, res2=h if (last and i >= len(self.attn_block)) else None)
+            if xa is not h:
+                ws.give(xa)
+            xa = xa2
+            if i < len(self.attn_block):
+                xa2 = self._attention(self.attn_block[i], xa, pk, ws, res2=h if last else None)
+                ws.give(xa)
+                xa = xa2
+        if nattn == 0:
+            xa = ops.add(h, h, out=ws.take(h.shape, x.device))
+        ws.give(h)
+        h = xa
+        for blk in self.after_block:
+            h2 = self._res(blk, h, sh(), pk, ws)
+            ws.give(h)
+            h = h2
+        for lv, blocks in enumerate(self.upward_blocks):                         # punetg.py:367-376
+            us = self.upsamplers[lv].conv
+            skip = skips.pop()
+            h2 = self._conv(us, h, pk, load_mode=DS_LOAD_UPSAMPLE2, res1=skip, out=ws.take(skip.shape, x.device))
+            ws.give(h)
+            ws.give(skip)
+            h = h2
+            for blk in blocks:
+                h2 = self._res(blk, h, sh(), pk, ws)
+                ws.give(h)
+                h = h2
+        y = self._conv(self.convout, h, pk, out=out)
+        ws.give(h)
+        return y
+
+    def _attention(self, att, x, pk, ws, res2=None):
+        """TwoDimensionalAttention.forward (attention.py:67-72,82-90), channel-major throughout."""
+        B, E, Hh, Ww = x.shape
+        L = Hh * Ww
+        m = att.mhattn
+        qkv = ops.conv2d(x, pk[(id(att), "in")], 3 * E, 1, bias=m.in_proj_bias,
+                         out=ws.take((B, 3 * E, Hh, Ww), x.device))
+        o = ops.attention(qkv.view(B, 3 * E, L), E, out=ws.take((B, E, L), x.device))
+        res1 = x if self.config.attn_residual else None
+        y = ops.conv2d(o.view(B, E, Hh, Ww), pk[(id(att), "out")], E, 1, bias=m.out_proj.bias,
+                       res1=res1, res2=res2, out=ws.take(x.shape, x.device))
+        ws.give(qkv)
+        ws.give(o)
+        return y
+
+
+class PUNetGCond(PUNetG):
+    def __init__(self, *a, **k):
+        raise NotImplementedError(
+            "PUNetGCond (channel-concatenated conditioning, punetg.py:719-735) is outside the HIP "
+            "path's scope; use PUNetG(config, conditional_embedding=...) as the reference's CFG "
+            "path requires (PUNetGCond cannot run the unconditional branch).")

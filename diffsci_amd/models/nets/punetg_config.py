@@ -1,0 +1,73 @@
+"""PUNetGConfig -- same constructor arguments, defaults and (de)serialisation as the reference
+(diffsci/models/nets/punetg_config.py:8-122).  Options outside the HIP path's coverage are
+accepted here and rejected with a clear error when the network is built."""
+from typing import Any
+import pathlib
+
+import yaml
+
+_FIELDS = dict(
+    input_channels=1, output_channels=1, dimension=2, model_channels=64,
+    channel_expansion=(2, 4),
+    number_resnet_downward_block=2, number_resnet_upward_block=2,
+    number_resnet_attn_block=2, number_resnet_before_attn_block=2,
+    number_resnet_after_attn_block=2,
+    kernel_size=3, in_out_kernel_size=3, in_embedding=False,
+    time_projection_scale=30.0, input_projection_scale=1.0,
+    transition_scale_factor=2, transition_kernel_size=3,
+    dropout=0.0, cond_dropout=0.0, cond_drop=0.0, cond_drop_learnable=True,
+    first_resblock_norm="GroupLN", second_resblock_norm="GroupRMS", affine_norm=True,
+    convolution_type="default", num_groups=1, attn_residual=False, attn_type="default",
+    bias=True)
+
+
+class PUNetGConfig(object):
+    def __init__(self, **kwargs):
+        unknown = set(kwargs) - set(_FIELDS)
+        if unknown:
+            raise TypeError(f"PUNetGConfig got unexpected arguments {sorted(unknown)}")
+        for k, default in _FIELDS.items():
+            v = kwargs.get(k, default)
+            if k == "channel_expansion":
+                v = list(v)
+            setattr(self, k, v)
+
+    @property
+    def extended_channel_expansion(self):
+        return [1] + list(self.channel_expansion)
+
+    @property
+    def magnitude_preserving(self):
+        return self.convolution_type == "mp"
+
+    def export_description(self) -> dict[str, Any]:
+        return {k: getattr(self, k) for k in _FIELDS}
+
+    @classmethod
+    def from_description(cls, description: dict):
+        return cls(**description)
+
+    @classmethod
+    def from_config_file(cls, config_file: pathlib.Path | str):
+        with open(config_file, "r") as f:
+            return cls.from_description(yaml.safe_load(f))
+
+    def unsupported_reason(self):
+        """None if the HIP path implements this configuration, else why not."""
+        checks = [
+            (self.dimension == 2, "only 2-D fields (dimension=2)"),
+            (self.convolution_type == "default", "only convolution_type='default' (circular / mp are a later scope row)"),
+            (self.first_resblock_norm == "GroupLN" and self.second_resblock_norm == "GroupRMS",
+             "only first_resblock_norm='GroupLN' with second_resblock_norm='GroupRMS'"),
+            (self.affine_norm, "affine_norm=True"),
+            (self.kernel_size == 3 and self.in_out_kernel_size == 3 and self.transition_kernel_size == 3,
+             "3x3 kernels"),
+            (self.transition_scale_factor == 2, "transition_scale_factor=2"),
+            (not self.in_embedding, "in_embedding=False"),
+            (self.bias, "bias=True"),
+            (self.attn_type == "default", "attn_type='default'"),
+            (self.dropout == 0.0 and self.cond_dropout == 0.0, "dropout=0 (sampling path)"),
+            (not self.cond_drop, "cond_drop=0 (sampling path)"),
+        ]
+        bad = [msg for ok, msg in checks if not ok]
+        return None if not bad else "diffsci_amd PUNetG supports: " + "; ".join(bad)

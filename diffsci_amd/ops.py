@@ -1,0 +1,235 @@
+"""Tensor-level wrappers over the C ABI: shape / dtype / device checks on the host, then a raw
+pointer + stream call.  PyTorch is used only as the owner of device memory and of the stream."""
+import ctypes
+
+import torch
+
+from . import _native as N
+from ._native import EvalCoef  # noqa: F401  (re-export)
+
+
+def require_device(t, what="tensor"):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{what} must be a torch.Tensor")
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"{what} lives on {t.device}: diffsci_amd computes only on an AMD GPU through "
+            "libdiffsci_hip.so (there is no CPU path; move the module and inputs to 'cuda').")
+    if t.dtype != torch.float32:
+        raise TypeError(f"{what} has dtype {t.dtype}; the HIP path is fp32 only")
+
+
+def _p(t, what="tensor"):
+    if t is None:
+        return None
+    require_device(t, what)
+    if not t.is_contiguous():
+        raise ValueError(f"{what} must be contiguous")
+    return t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _same_numel(*ts):
+    n = None
+    for t in ts:
+        if t is None:
+            continue
+        if n is None:
+            n = t.numel()
+        elif t.numel() != n:
+            raise ValueError(f"size mismatch: {t.numel()} vs {n} elements")
+    return n
+
+
+def scale(x, s, out=None):
+    out = torch.empty_like(x) if out is None else out
+    n = _same_numel(x, out)
+    N.check(N.lib().ds_karras_scale(_p(out, "out"), _p(x, "x"), float(s), n, _stream()), "ds_karras_scale")
+    return out
+
+
+def add(a, b, out=None):
+    out = torch.empty_like(a) if out is None else out
+    n = _same_numel(a, b, out)
+    N.check(N.lib().ds_add(_p(out), _p(a), _p(b), n, _stream()), "ds_add")
+    return out
+
+
+def drift(x, f, k, fu=None, out=None):
+    out = torch.empty_like(f) if out is None else out
+    n = _same_numel(x, f, fu, out)
+    N.check(N.lib().ds_karras_drift(_p(out), _p(x), _p(f), _p(fu), ctypes.byref(k), n, _stream()),
+            "ds_karras_drift")
+    return out
+
+
+def score(x, f, k, fu=None, out=None):
+    out = torch.empty_like(f) if out is None else out
+    n = _same_numel(x, f, fu, out)
+    N.check(N.lib().ds_karras_score(_p(out), _p(x), _p(f), _p(fu), ctypes.byref(k), n, _stream()),
+            "ds_karras_score")
+    return out
+
+
+def euler(x, f, k, dt, fu=None, x_out=None, xin_out=None, c_in_next=1.0, eps=None, noise_coef=0.0,
+          sqrt_abs_dt=0.0):
+    n = _same_numel(x, f, fu, x_out, xin_out, eps)
+    N.check(N.lib().ds_karras_euler(_p(x_out), _p(xin_out), _p(x), _p(f), _p(fu), ctypes.byref(k),
+                                    float(dt), float(c_in_next), _p(eps), float(noise_coef),
+                                    float(sqrt_abs_dt), n, _stream()), "ds_karras_euler")
+    return x_out
+
+
+def heun(x, f1, k1, f2, k2, dt, f1u=None, f2u=None, x_out=None, xin_out=None, c_in_next=1.0):
+    n = _same_numel(x, f1, f2, f1u, f2u, x_out, xin_out)
+    N.check(N.lib().ds_karras_heun(_p(x_out), _p(xin_out), _p(x), _p(f1), _p(f1u), ctypes.byref(k1),
+                                   _p(f2), _p(f2u), ctypes.byref(k2), float(dt), float(c_in_next), n,
+                                   _stream()), "ds_karras_heun")
+    return x_out
+
+
+def churn(x, eps, coef, xhat_out, xin_out=None, c_in=1.0):
+    n = _same_numel(x, eps, xhat_out, xin_out)
+    N.check(N.lib().ds_karras_churn(_p(xhat_out), _p(xin_out), _p(x), _p(eps), float(coef), float(c_in), n,
+                                    _stream()), "ds_karras_churn")
+    return xhat_out
+
+
+def denoiser(x, f, c_out, c_skip, fu=None, guidance=1.0, out=None):
+    out = torch.empty_like(x) if out is None else out
+    B = x.shape[0]
+    if c_out.numel() != B or c_skip.numel() != B:
+        raise ValueError("c_out / c_skip must have one entry per sample")
+    _same_numel(x, f, fu, out)
+    N.check(N.lib().ds_karras_denoiser(_p(out), _p(x), _p(f), _p(fu), float(guidance), float(1 - guidance),
+                                       _p(c_out), _p(c_skip), B, x.numel() // max(B, 1), _stream()),
+            "ds_karras_denoiser")
+    return out
+
+
+def inorm_silu(x, w, b, kind, eps=1e-5, out=None):
+    """kind 0: GroupNorm(C, C)+SiLU, kind 1: GroupRMSNorm(C, C)+SiLU; x [B, C, *spatial]."""
+    out = torch.empty_like(x) if out is None else out
+    B, C = x.shape[0], x.shape[1]
+    HW = x.numel() // max(B * C, 1)
+    if w is not None and (w.numel() != C or b.numel() != C):
+        raise ValueError("norm affine parameters must have C entries")
+    _same_numel(x, out)
+    N.check(N.lib().ds_inorm_silu(_p(out), _p(x), _p(w), _p(b), B, C, HW, float(eps), int(kind), _stream()),
+            "ds_inorm_silu")
+    return out
+
+
+def pack_conv_weight(w):
+    """torch [Cout, Cin, k, k] (device, fp32) -> packed MFMA operand stream."""
+    require_device(w, "conv weight")
+    Cout, Cin, k, k2 = w.shape
+    if k != k2 or k not in (1, 3):
+        raise NotImplementedError(f"conv kernel {k}x{k2}: only 1x1 and 3x3 are implemented")
+    n = N.lib().ds_conv2d_packed_floats(Cout, Cin, k)
+    packed = torch.empty(n, dtype=torch.float32, device=w.device)
+    N.check(N.lib().ds_conv2d_pack_weights(_p(packed), _p(w.contiguous()), Cout, Cin, k, _stream()),
+            "ds_conv2d_pack_weights")
+    return packed
+
+
+def conv2d(x, w_packed, Cout, ks, bias=None, shift=None, res1=None, res2=None,
+           load_mode=N.DS_LOAD_PLAIN, out=None):
+    """'same' zero-padded conv; x [B, Cin, Hin, Win]; shift [1 or B, Cout] or None."""
+    B, Cin, Hin, Win = x.shape
+    if load_mode == N.DS_LOAD_MAXPOOL2:
+        if Hin % 2 or Win % 2:
+            raise ValueError("max-pool load needs even input H, W")
+        H, W = Hin // 2, Win // 2
+    elif load_mode == N.DS_LOAD_UPSAMPLE2:
+        H, W = Hin * 2, Win * 2
+    else:
+        H, W = Hin, Win
+    if out is None:
+        out = torch.empty((B, Cout, H, W), dtype=torch.float32, device=x.device)
+    elif tuple(out.shape) != (B, Cout, H, W):
+        raise ValueError(f"out has shape {tuple(out.shape)}, expected {(B, Cout, H, W)}")
+    if w_packed.numel() != N.lib().ds_conv2d_packed_floats(Cout, Cin, ks):
+        raise ValueError("packed weight size does not match (Cout, Cin, ks)")
+    stride = 0
+    if shift is not None:
+        if shift.dim() != 2 or shift.shape[1] != Cout or shift.shape[0] not in (1, B):
+            raise ValueError(f"shift must be [1 or B, Cout]; got {tuple(shift.shape)}")
+        stride = 0 if shift.shape[0] == 1 else Cout
+    for r in (res1, res2):
+        if r is not None and tuple(r.shape) != (B, Cout, H, W):
+            raise ValueError("residual shape mismatch")
+    if bias is not None and bias.numel() != Cout:
+        raise ValueError("bias must have Cout entries")
+    N.check(N.lib().ds_conv2d(_p(out), _p(x), _p(w_packed), _p(bias), _p(shift), stride, _p(res1), _p(res2),
+                              B, Cin, Cout, H, W, ks, load_mode, _stream()), "ds_conv2d")
+    return out
+
+
+def attention(qkv, E, out=None):
+    """qkv [B, 3E, L] channel-major -> out [B, E, L]."""
+    B, E3, L = qkv.shape
+    if E3 != 3 * E:
+        raise ValueError("qkv must be [B, 3E, L]")
+    if out is None:
+        out = torch.empty((B, E, L), dtype=torch.float32, device=qkv.device)
+    N.check(N.lib().ds_attention(_p(out), _p(qkv), B, E, L, _stream()), "ds_attention")
+    return out
+
+
+def linear(x, w, b=None, act=0, out=None):
+    M, K = x.shape
+    Nn, K2 = w.shape
+    if K != K2:
+        raise ValueError("linear: inner dimensions differ")
+    if out is None:
+        out = torch.empty((M, Nn), dtype=torch.float32, device=x.device)
+    N.check(N.lib().ds_linear(_p(out), _p(x), _p(w), _p(b), M, K, Nn, act, _stream()), "ds_linear")
+    return out
+
+
+def fourier_features(t, W, add=None, out=None):
+    M, half = t.numel(), W.numel()
+    if out is None:
+        out = torch.empty((M, 2 * half), dtype=torch.float32, device=t.device)
+    add_rows = 0
+    if add is not None:
+        add = add.reshape(-1, 2 * half)
+        add_rows = add.shape[0]
+    N.check(N.lib().ds_fourier_features(_p(out), _p(t), _p(W), _p(add), add_rows, M, half, _stream()),
+            "ds_fourier_features")
+    return out
+
+
+class Graph:
+    """A captured launch sequence (hipGraph) on torch's current stream."""
+
+    def __init__(self):
+        self._h = ctypes.c_void_p()
+        self.nodes = 0
+
+    def __enter__(self):
+        self._stream = _stream()
+        N.check(N.lib().ds_graph_begin_capture(self._stream), "ds_graph_begin_capture")
+        return self
+
+    def __exit__(self, et, ev, tb):
+        n = ctypes.c_int(0)
+        rc = N.lib().ds_graph_end_capture(self._stream, ctypes.byref(self._h), ctypes.byref(n))
+        if et is None:
+            N.check(rc, "ds_graph_end_capture")
+        self.nodes = n.value
+        return False
+
+    def launch(self):
+        N.check(N.lib().ds_graph_launch(self._h, _stream()), "ds_graph_launch")
+
+    def __del__(self):
+        try:
+            if self._h:
+                N.lib().ds_graph_destroy(self._h)
+        except Exception:
+            pass

@@ -1,0 +1,181 @@
+/*
+ * diffsci_hip.h -- C ABI of libdiffsci_hip.so: the MI355X (gfx950) kernels behind the
+ * Karras-EDM sampling path of DiffSci.
+ *
+ * The reference (Lacadame/DiffSci) is pure Python on PyTorch; it has no FFI of its own.
+ * The boundary it exposes for this path is the Python object protocol
+ * (KarrasModule.sample / Scheduler.propagate / Integrator.step / model(x, c_noise, y)),
+ * which diffsci_amd mirrors in Python.  Below that protocol every per-step tensor
+ * operation the reference issues as ATen calls is one of the entry points declared
+ * here; each cites the reference code it replaces (paths relative to the reference
+ * root).
+ *
+ * Conventions
+ *   - plain C, no torch types: raw device pointers, sizes, a hipStream_t passed as void*;
+ *   - every function returns 0 on success, a negative ds_status otherwise; the text of
+ *     the last failure on the calling thread is available from ds_last_error();
+ *   - all pointers are caller-owned device memory (fp32, contiguous NCHW unless stated);
+ *     nothing is allocated or freed inside, nothing synchronises with the host, so every
+ *     launch may be captured into a hipGraph (ds_graph_*);
+ *   - launches are asynchronous on the given stream; distinct streams may be driven from
+ *     distinct host threads;
+ *   - argument shapes are validated on the host before any launch (DS_ERR_SHAPE).
+ */
+#ifndef DIFFSCI_HIP_H
+#define DIFFSCI_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum ds_status {
+  DS_OK = 0,
+  DS_ERR_SHAPE = -1,     /* an argument violates a documented shape/alignment rule */
+  DS_ERR_NULL = -2,      /* required pointer is NULL */
+  DS_ERR_HIP = -3,       /* a HIP runtime call failed (see ds_last_error) */
+  DS_ERR_UNSUPPORTED = -4
+} ds_status;
+
+/* Library / device introspection. */
+int ds_version(void);                       /* ABI version, currently 1 */
+const char* ds_last_error(void);            /* thread-local, never NULL */
+int ds_device_info(int* cu_count, int* lds_bytes_per_cu, char* arch_name, int arch_name_len);
+
+/* ------------------------------------------------------------------------------------
+ * Karras stepper.  Per-evaluation scalars come from a host-built table: in one sampling
+ * run every sample of the batch sits at the same noise level (schedulers.py:254), so
+ * sigma, dt and the preconditioner values are per-step constants computed once on the
+ * host with the reference's own fp32 torch-CPU operation sequence.
+ * ---------------------------------------------------------------------------------- */
+typedef struct ds_eval_coef {
+  float c_out;      /* preconditioners.py:41-44  output_scaling(sigma)                    */
+  float c_skip;     /* preconditioners.py:35-39  skip_scaling(sigma)                      */
+  float sigma_sq;   /* karrasmodule.py:733       sigma**2                                 */
+  float neg_mult;   /* schedulers.py:266-268     -(sigma * sigma')                        */
+  float neg_lang;   /* schedulers.py:269-274     -langevin_factor(t); 0 when deterministic */
+  float guidance;   /* karrasmodule.py:709-713   g of (1-g)*F_u + g*F_c; unused if fu NULL */
+  float one_minus_guidance; /* (1-g) rounded to fp32 from the host's double, as torch does     */
+  int   input_kind; /* what `f` holds: 0 network output F (apply the preconditioner),
+                       1 score (generic score_fn path of Scheduler.rhs), 2 drift (already rhs) */
+  int   stochastic; /* 1: add neg_lang*score to the drift                                 */
+} ds_eval_coef;
+
+enum { DS_IN_NETWORK = 0, DS_IN_SCORE = 1, DS_IN_DRIFT = 2 };
+
+/* out = s * x.  karrasmodule.py:881 (x * maximum_scale) and :702 (c_in * x). */
+int ds_karras_scale(float* out, const float* x, float s, size_t n, void* stream);
+
+/* d = drift(x, f) written out (see ds_karras_euler for the formula): Scheduler.rhs
+ * (schedulers.py:247-274) composed with KarrasModule.get_score (karrasmodule.py:721-733) when
+ * k->input_kind == 0, or Scheduler.rhs alone on a score tensor when input_kind == 1. */
+int ds_karras_drift(float* d_out, const float* x, const float* f, const float* fu,
+                    const ds_eval_coef* k, size_t n, void* stream);
+
+/* Score (D - x)/sigma^2 from a network output: karrasmodule.py:717-733 (uniform sigma). */
+int ds_karras_score(float* s_out, const float* x, const float* f, const float* fu,
+                    const ds_eval_coef* k, size_t n, void* stream);
+
+/* Euler move from one evaluation:  d = drift(x, f);  x_out = x + dt*d  [+ (noise_coef*eps)*sqrt_abs_dt]
+ * and, when xin_out != NULL, xin_out = c_in_next * x_out (the next evaluation's network input).
+ *   drift: D = c_out*F + c_skip*x; score = (D - x)/sigma_sq; d = neg_mult*score [+ neg_lang*score]
+ *   F = f, or (1-g)*fu + g*f when fu != NULL.
+ * Replaces EulerIntegrator.step (integrators.py:29-35), the predictor half of
+ * HeunIntegrator.step (integrators.py:44-47), EulerMaruyamaIntegrator.step (integrators.py:66-69,
+ * eps != NULL) together with Scheduler.rhs (schedulers.py:247-274) and
+ * KarrasModule.get_denoiser/get_score (karrasmodule.py:690-733).
+ * x_out may be NULL (only xin_out wanted) ; x_out may alias x. */
+int ds_karras_euler(float* x_out, float* xin_out, const float* x, const float* f, const float* fu,
+                    const ds_eval_coef* k, float dt, float c_in_next,
+                    const float* eps, float noise_coef, float sqrt_abs_dt,
+                    size_t n, void* stream);
+
+/* Heun corrector:  x_out = x + (0.5*(d1 + d2))*dt, with d1 recomputed from (x, f1) and d2 from
+ * (x_e = x + dt*d1, f2) -- x_e is recomputed, never read.  integrators.py:44-53.
+ * When k2->input_kind != 0, f2 is the score / drift at x_e and x_e is not needed.
+ * xin_out (optional) = c_in_next * x_out.  x_out may alias x. */
+int ds_karras_heun(float* x_out, float* xin_out, const float* x,
+                   const float* f1, const float* f1u, const ds_eval_coef* k1,
+                   const float* f2, const float* f2u, const ds_eval_coef* k2,
+                   float dt, float c_in_next, size_t n, void* stream);
+
+/* Noise injection x_hat = x + coef*eps; xin_out (optional) = c_in * x_hat.
+ * KarrasIntegrator.step sigma-churn (integrators.py:98-105, coef = std*s_noise, scale ratio = 1)
+ * and Scheduler.renoise (schedulers.py:166-176). */
+int ds_karras_churn(float* xhat_out, float* xin_out, const float* x, const float* eps,
+                    float coef, float c_in, size_t n, void* stream);
+
+/* Denoiser with per-sample coefficients (sigma differs across the batch):
+ * out = c_out[b]*F + c_skip[b]*x, F as above.  karrasmodule.py:717-718.  Coefficient arrays are
+ * device pointers of length B; n_per_sample = C*H*W. */
+int ds_karras_denoiser(float* out, const float* x, const float* f, const float* fu, float guidance,
+                       float one_minus_guidance,
+                       const float* c_out, const float* c_skip, int B, size_t n_per_sample, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Score network (PUNetG) layers.
+ * ---------------------------------------------------------------------------------- */
+
+/* Per-(sample, channel) normalisation over H*W fused with SiLU:
+ *   kind 0: GroupNorm(num_groups=C) -- (x-mean)/sqrt(var_biased+eps)*w[c]+b[c]  (commonlayers.py:766-770,824)
+ *   kind 1: GroupRMSNorm(C, C)      -- x/sqrt(mean(x^2)+eps)*w[c]+b[c]          (commonlayers.py:372-384,829)
+ * followed by x*sigmoid(x).  x, out: [B, C, HW]. out may alias x. */
+int ds_inorm_silu(float* out, const float* x, const float* w, const float* b,
+                  int B, int C, int HW, float eps, int kind, void* stream);
+
+/* Weight repacking for ds_conv2d: torch layout [Cout, Cin, ks, ks] -> the MFMA A-operand stream
+ * [ceil(Cout/64)][ceil(Cin/8)][ks*ks][8][64], zero padded.  ds_conv2d_packed_floats gives the
+ * destination size in floats. */
+size_t ds_conv2d_packed_floats(int Cout, int Cin, int ks);
+int ds_conv2d_pack_weights(float* packed, const float* w, int Cout, int Cin, int ks, void* stream);
+
+enum { DS_LOAD_PLAIN = 0, DS_LOAD_MAXPOOL2 = 1, DS_LOAD_UPSAMPLE2 = 2 };
+
+/* "same"-padded (zero) ks x ks convolution, ks in {1,3}, fp32 MFMA implicit GEMM.
+ *   out[b,co,y,x] = sum w[co,ci,ky,kx]*src(b,ci,y+ky-ks/2,x+kx-ks/2) + bias[co]
+ *                   + shift[b*shift_stride + co] + res1[b,co,y,x] + res2[b,co,y,x]
+ * (each optional term skipped when its pointer is NULL; added in that order).
+ *   load_mode PLAIN:     src = in,                      in is [B,Cin,H,W]
+ *             MAXPOOL2:  src = maxpool2x2(in),          in is [B,Cin,2H,2W]     (DownSampler, commonlayers.py:81)
+ *             UPSAMPLE2: src = nearest_upsample2x(in),  in is [B,Cin,H/2,W/2]   (UpSampler, commonlayers.py:145)
+ * out is [B,Cout,H,W].  Replaces conv1 + time shift (commonlayers.py:824-828), conv2 + residual
+ * (commonlayers.py:829-833), convin/convout (punetg.py:395,415), the skip add (punetg.py:374),
+ * x + xa (punetg.py:385), and the MultiheadAttention in/out projections (ks = 1). */
+int ds_conv2d(float* out, const float* in, const float* w_packed, const float* bias,
+              const float* shift, int shift_stride, const float* res1, const float* res2,
+              int B, int Cin, int Cout, int H, int W, int ks, int load_mode, void* stream);
+
+/* Single-head self-attention over L = H*W positions, channel-major operands:
+ *   qkv [B, 3E, L] (rows 0..E-1 = Q^T, E..2E-1 = K^T, 2E..3E-1 = V^T), out [B, E, L] = (softmax(Q K^T / sqrt(E)) V)^T.
+ * nn.MultiheadAttention(E, num_heads=1) core, attention.py:41-43,67.  E and L multiples of 32, E <= 256. */
+int ds_attention(float* out, const float* qkv, int B, int E, int L, void* stream);
+
+/* y[m, n] = act(sum_k x[m,k]*w[n,k] + b[n]); act 0 none, 1 SiLU, 2 ReLU.  torch Linear layout.
+ * ResnetTimeBlock (commonlayers.py:516-522) and MLPUncond (mlp.py:30-37). b may be NULL. */
+int ds_linear(float* y, const float* x, const float* w, const float* b, int M, int K, int N, int act, void* stream);
+
+/* out[m, j] = sin(2*pi*t[m]*W[j]), out[m, half+j] = cos(...).  GaussianFourierProjection.forward,
+ * commonlayers.py:185-190.  add (optional, [m_add, 2*half], m_add in {1, M}) is added afterwards
+ * (te + cond_dropout(ye), punetg.py:410). */
+int ds_fourier_features(float* out, const float* t, const float* W, const float* add, int add_rows,
+                        int M, int half, void* stream);
+
+/* out = a + b (n floats). */
+int ds_add(float* out, const float* a, const float* b, size_t n, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * hipGraph capture of a launch sequence (the whole N-step loop is captured once per
+ * (network, nsteps, batch) and replayed).
+ * ---------------------------------------------------------------------------------- */
+typedef struct ds_graph ds_graph;
+int ds_graph_begin_capture(void* stream);
+int ds_graph_end_capture(void* stream, ds_graph** out_graph, int* node_count);
+int ds_graph_launch(ds_graph* g, void* stream);
+int ds_graph_destroy(ds_graph* g);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DIFFSCI_HIP_H */
