@@ -1,0 +1,238 @@
+#!/usr/bin/env python3
+"""Headline benchmark: samples/s of the 50-step Karras-Heun sampler, PUNetG 64ch, 1x128x128,
+batch 64 per GPU (BASELINE.json configs[1]); synthetic random-init weights and Gaussian noise.
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one full sampling run (50 Heun steps = 99 network evaluations) of one batch per
+rank, replayed from the captured hipGraph, followed (N>1) by the RCCL all-gather of the samples.
+Rank 0 prints ONE JSON line (schema: task contract + `roofline` + `cpu_baseline`).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+MFMA_F32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: fp32-input MFMA, dense
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E spec
+
+
+def conv_flops(B, Cin, Cout, H, W, ks):
+    return 2.0 * B * Cout * Cin * ks * ks * H * W
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=64, help="samples per GPU")
+    ap.add_argument("--nsteps", type=int, default=50, help="Heun steps per sample")
+    ap.add_argument("--size", type=int, default=128)
+    ap.add_argument("--channels", type=int, default=64)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    return ap.parse_args()
+
+
+def build_module(args, dev):
+    import diffsci_amd.models as M
+    from oracle import punetg_ref                       # synthetic weight generator only
+    cfg = punetg_ref.default_config(model_channels=args.channels)
+    sd = punetg_ref.random_state_dict(cfg, seed=0)
+    net = M.PUNetG(M.PUNetGConfig(model_channels=args.channels))
+    net.load_state_dict(sd)
+    module = M.KarrasModule(net, M.KarrasModuleConfig.from_edm()).to(dev).eval()
+    module.use_graph = not args.no_graph
+    return module, sd, cfg
+
+
+def dominant_kernel_roofline(module, args, dev):
+    """Average launch duration of the dominant kernel (k_conv<3, PLAIN>: the 3x3 convolutions of
+    the residual blocks, convin and convout) over one network evaluation's worth of its launches,
+    timed with events on the launch stream, against its algorithmic FLOPs."""
+    from diffsci_amd import ops
+    net = module.model
+    pk = net.packed_weights()
+    B, S = args.batch, args.size
+    mods = [net.convin] + [c for blk in net._resblocks() for c in (blk.conv1, blk.conv2)] + [net.convout]
+    # spatial size of every launch, in forward order
+    mult = net.config.extended_channel_expansion
+    def side(c):
+        return S // (c // args.channels) if c >= args.channels else S
+    launches = []
+    for m in mods:
+        cin, cout = m.in_channels, m.out_channels
+        s = side(max(cin, cout)) if m not in (net.convin, net.convout) else S
+        launches.append((m, cin, cout, s))
+    del mult
+    bufs = {}
+    def buf(c, s):
+        k = (c, s)
+        if k not in bufs:
+            bufs[k] = torch.randn(B, c, s, s, device=dev)
+        return bufs[k]
+    outs = {(m.out_channels, s): torch.empty(B, m.out_channels, s, s, device=dev) for m, _, _, s in launches}
+    flops = sum(conv_flops(B, cin, cout, s, s, 3) for _, cin, cout, s in launches)
+
+    def run():
+        for m, cin, cout, s in launches:
+            ops.conv2d(buf(cin, s), pk[id(m)], cout, 3, bias=m.bias, out=outs[(cout, s)])
+    run()
+    torch.cuda.synchronize()
+    reps = 3
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    n = len(launches)
+    achieved = flops / (ms * 1e-3) / 1e12
+    return {"bound": "mfma", "kernel": "k_conv<3,PLAIN> (ds_conv2d 3x3)", "achieved": round(achieved, 2),
+            "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4),
+            "traffic": None, "launches_per_eval": n, "avg_launch_ms": round(ms / n, 4),
+            "flop_per_launch_avg": flops / n}
+
+
+def hbm_class(module, args, dev):
+    """Achieved HBM GB/s of the two HBM-bound kernel classes at this workload's shapes."""
+    from diffsci_amd import ops
+    from diffsci_amd._native import EvalCoef
+    out = {}
+    B, S, C = args.batch, args.size, args.channels
+    x = torch.randn(B, C, S, S, device=dev)
+    y = torch.empty_like(x)
+    w = torch.ones(C, device=dev)
+    def timed(fn, reps=20):
+        fn(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record(); torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+    ms = timed(lambda: ops.inorm_silu(x, w, w, 0, out=y))
+    gbs = x.numel() * 8 / (ms * 1e-3) / 1e9
+    out["inorm_silu_L0"] = {"bytes_per_elt": 8, "GB/s": round(gbs, 1), "frac_hbm_peak": round(gbs / HBM_PEAK_GBS, 4),
+                            "ms": round(ms, 4)}
+    k = EvalCoef(c_out=0.4, c_skip=0.1, sigma_sq=2.0, neg_mult=-1.4, neg_lang=0.0, guidance=1.0,
+                 one_minus_guidance=0.0, input_kind=0, stochastic=0)
+    for label, n in (("heun_step_cfg2_4MiB", B * S * S), ("heun_step_256MiB", B * C * S * S)):
+        xs, f1, f2 = (torch.randn(n, device=dev) for _ in range(3))
+        xo, xi = torch.empty(n, device=dev), torch.empty(n, device=dev)
+        ms = timed(lambda: ops.heun(xs, f1, k, f2, k, -0.5, x_out=xo, xin_out=xi, c_in_next=0.3))
+        gbs = n * 20 / (ms * 1e-3) / 1e9          # corrector: R x, F1, F2; W x', c_in*x'  = 20 B/elt
+        out[label] = {"bytes_per_elt": 20, "GB/s": round(gbs, 1), "frac_hbm_peak": round(gbs / HBM_PEAK_GBS, 4),
+                      "ms": round(ms, 5)}
+    return out
+
+
+def cpu_baseline(sd, cfg, args):
+    """The CPU oracle (a port: the reference itself cannot travel) on this host's cores, on a
+    bounded sample of the same workload."""
+    from oracle import karras_ref as K
+    from oracle import punetg_ref
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    torch.set_num_threads(cores)
+    B, N = 4, 3                                   # 3-step Heun = 5 network evaluations
+    g = torch.Generator().manual_seed(1)
+    wn = torch.randn(B, 1, args.size, args.size, generator=g)
+    net = punetg_ref.make_net(sd, cfg)
+    with torch.inference_mode():
+        K.propagate_white_noise(net, wn[:1], 1)    # warm-up (1 evaluation)
+        t0 = time.time()
+        K.propagate_white_noise(net, wn, N)
+        dt = time.time() - t0
+    evals = 2 * N - 1
+    full = 2 * args.nsteps - 1
+    sps = B / (dt * full / evals)
+    return {"value": round(sps, 5), "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": f"oracle (torch-CPU restatement), batch {B}, {N}-step Heun = {evals} evaluations in {dt:.1f} s, "
+                      f"scaled by {full}/{evals} evaluations to the {args.nsteps}-step workload"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    from diffsci_amd.parallel import gather_samples, global_white_noise, shard_rows
+    module, sd, cfg = build_module(args, dev)
+    shape = [1, args.size, args.size]
+    B = args.batch
+    lo, hi = shard_rows(B * world, world, rank)
+    # inputs resident in HBM before the timed region: this rank's rows of the global noise tensor
+    noise = [global_white_noise(B * world, shape, seed=s, rows=(lo, hi)).to(dev)
+             for s in range(args.steps + args.warmup)]
+
+    def one_step(i):
+        out = module.propagate_white_noise(noise[i], nsteps=args.nsteps)
+        return gather_samples(out) if world > 1 else out
+
+    for i in range(args.warmup):
+        one_step(args.steps + i)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = one_step(i)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert out.shape[0] == B * world and bool(torch.isfinite(out).all())
+    if rank == 0:
+        value = B * world * args.steps / dt
+        line = {
+            "metric": "samples/sec (50-step Karras Heun), PUNetG 64ch 128x128",
+            "value": round(value, 3), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic (random-init weights, Gaussian noise)",
+            "config": {"workload": f"PUNetG {args.channels}-base-ch, 1x{args.size}x{args.size} fields, batch {B} per GPU, "
+                                   f"{args.nsteps}-step Heun deterministic sampler ({2*args.nsteps-1} network evaluations)",
+                       "global_batch": B * world, "parallelism": f"dp{world} (batch shards, all-gather of samples)",
+                       "hipgraph": not args.no_graph},
+        }
+        line["roofline"] = dominant_kernel_roofline(module, args, dev)
+        line["roofline_hbm_class"] = hbm_class(module, args, dev)
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(sd, cfg, args)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -111,6 +111,7 @@ class KarrasModule(torch.nn.Module):
         self.norm = 1.0
         self.use_graph = True          # capture the loop as a hipGraph for HIP-native networks
         self._plans = {}
+        self._stream = None
 
     # ---------------------------------------------------------------- bookkeeping
     @property
@@ -262,27 +263,36 @@ class KarrasModule(torch.nn.Module):
         sch = self.config.noisescheduler
         ykey = None if y is None else repr(dict_map(lambda t: (tuple(t.shape), t.flatten()[:8].tolist()), y))
         key = (tuple(x.shape), str(x.device), nsteps, i0, i1, record_history, table.kind,
-               tuple(sorted(vars(integ).items(), key=str)) if table.kind == "karras" else None,
+               (integ.s_schurn, integ.s_tmin, integ.s_tmax, integ.s_noise) if table.kind == "karras" else None,
                float(guidance), ykey, float(sch.langevin_const), repr(sch.langevin_interval),
                tuple(float(v) for v in table.t.tolist()),
                tuple((p.data_ptr(), p._version) for p in self.model.parameters()))
-        plan = self._plans.get(key)
-        if plan is None:
-            loop = Loop(table, src, x, record_history)
-            loop.load(x, scale)
-            loop.set_noise(eps)
-            loop.launch()                      # eager pass: allocates the workspace, validates shapes
-            torch.cuda.current_stream().synchronize()
-            with ops.Graph() as g:
-                loop.launch()
-            plan = _Plan(loop, g)
-            if len(self._plans) >= 4:
-                self._plans.pop(next(iter(self._plans)))
-            self._plans[key] = plan
-        plan.loop.load(x, scale)
-        plan.loop.set_noise(eps)
-        plan.graph.launch()
-        return plan.loop.result().clone()
+        # hipGraph capture needs a non-default stream: planned runs live on a side stream that is
+        # ordered after the caller's stream on entry and before it on exit.
+        if self._stream is None or self._stream.device != x.device:
+            self._stream = torch.cuda.Stream(device=x.device)
+        caller = torch.cuda.current_stream(x.device)
+        self._stream.wait_stream(caller)
+        with torch.cuda.stream(self._stream):
+            plan = self._plans.get(key)
+            if plan is None:
+                loop = Loop(table, src, x, record_history)
+                loop.load(x, scale)
+                loop.set_noise(eps)
+                loop.launch()                  # eager pass: allocates the workspace, validates shapes
+                self._stream.synchronize()
+                with ops.Graph() as g:
+                    loop.launch()
+                plan = _Plan(loop, g)
+                if len(self._plans) >= 4:
+                    self._plans.pop(next(iter(self._plans)))
+                self._plans[key] = plan
+            plan.loop.load(x, scale)
+            plan.loop.set_noise(eps)
+            plan.graph.launch()
+            out = plan.loop.result().clone()
+        caller.wait_stream(self._stream)
+        return out
 
     # ---------------------------------------------------------------- encode / decode (non-latent)
     def encode(self, x, y=None, record_history=False):

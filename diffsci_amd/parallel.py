@@ -1,0 +1,61 @@
+"""Multi-GPU sampling: one process per GPU, the batch sharded by rows, no collective inside the
+loop, one RCCL all-gather of the finished samples.
+
+Samples are independent (every norm and the attention are per sample), so rank r simply owns
+rows [r*G/W, (r+1)*G/W) of the global batch.  The white noise is defined exactly as the
+single-process reference defines it -- ``torch.manual_seed(seed); torch.randn(G, *shape)`` on the
+CPU generator (karrasmodule.py:837) -- and each rank keeps its rows, so the gathered result does
+not depend on the number of ranks."""
+import torch
+import torch.distributed as dist
+
+
+def shard_rows(total, world, rank):
+    """Contiguous row range of `rank`; the first total % world ranks get one extra row."""
+    base, extra = divmod(total, world)
+    start = rank * base + min(rank, extra)
+    return start, start + base + (1 if rank < extra else 0)
+
+
+def global_white_noise(total, shape, seed, rows=None):
+    """Rows [rows[0], rows[1]) of torch.randn(total, *shape) under manual_seed(seed) (CPU
+    generator), without disturbing the global generator."""
+    g = torch.Generator()
+    g.manual_seed(seed)
+    full = torch.randn(total, *shape, generator=g)
+    return full if rows is None else full[rows[0]:rows[1]].contiguous()
+
+
+def sample_sharded(module, nsamples, shape, nsteps=100, seed=0, y=None, guidance=1.0, integrator=None,
+                   gather=True, white_noise=None):
+    """Global batch of `nsamples` across the ranks of the default process group.
+    Returns all samples on every rank (gather=True) or the local shard."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    lo, hi = shard_rows(nsamples, world, rank)
+    if white_noise is None:
+        local = global_white_noise(nsamples, list(shape), seed, rows=(lo, hi))
+    else:
+        local = white_noise[lo:hi]
+    local = local.to(module.device)
+    out = module.propagate_white_noise(local, y=y, guidance=guidance, nsteps=nsteps, integrator=integrator)
+    if world == 1 or not gather:
+        return out
+    return gather_samples(out, nsamples)
+
+
+def gather_samples(out, nsamples=None):
+    """All-gather the per-rank sample shards (RCCL over xGMI; backend "nccl" is RCCL on ROCm)."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    if world == 1:
+        return out
+    if nsamples is None:
+        nsamples = out.shape[0] * world
+    if nsamples % world == 0:
+        full = torch.empty((nsamples,) + tuple(out.shape[1:]), dtype=out.dtype, device=out.device)
+        dist.all_gather_into_tensor(full, out.contiguous())
+        return full
+    sizes = [shard_rows(nsamples, world, r) for r in range(world)]
+    parts = [torch.empty((b - a,) + tuple(out.shape[1:]), dtype=out.dtype, device=out.device) for a, b in sizes]
+    dist.all_gather(parts, out.contiguous())
+    return torch.cat(parts, dim=0)

@@ -195,6 +195,10 @@ def punetg():
     mod64 = M.KarrasModule(net64, M.KarrasModuleConfig.from_edm()).eval()
     arrs["hist_heun_N6_f64"] = mod64.propagate_white_noise(wn.double(), nsteps=6, record_history=True)
     arrs["out_heun_N18_f64"] = mod64.propagate_white_noise(wn.double(), nsteps=18)
+    torch.manual_seed(5)          # the same draws sample(3, maximum_batch_size=2) makes: 2 then 1
+    wn5 = torch.cat([torch.randn(2, 1, 32, 32), torch.randn(1, 1, 32, 32)])
+    arrs["sample_seed5_white_noise"] = wn5
+    arrs["sample_seed5_n3_N4_f64"] = mod64.propagate_white_noise(wn5.double(), nsteps=4)
     npz("punetg8_traj", **arrs)
 
     # classifier-free guidance with a conditional embedding (config 5 shape of the path)

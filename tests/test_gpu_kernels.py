@@ -1,0 +1,209 @@
+"""Kernel-level parity on a real MI355X: each C-ABI entry point against the CPU oracle /
+the reference's torch-CPU arithmetic on the same seeded inputs."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import karras_ref as K  # noqa: E402
+from oracle import punetg_ref  # noqa: E402
+from tests.golden_util import rel_l2  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+def _ops():
+    from diffsci_amd import ops
+    return ops
+
+
+def _coef(**kw):
+    from diffsci_amd._native import EvalCoef
+    base = dict(c_out=1.0, c_skip=0.0, sigma_sq=1.0, neg_mult=-1.0, neg_lang=0.0, guidance=1.0,
+                one_minus_guidance=0.0, input_kind=0, stochastic=0)
+    base.update(kw)
+    return EvalCoef(**base)
+
+
+def test_library_reports_gfx950(dev):
+    import ctypes
+    from diffsci_amd import _native as N
+    cu, lds = ctypes.c_int(), ctypes.c_int()
+    name = ctypes.create_string_buffer(64)
+    N.check(N.lib().ds_device_info(ctypes.byref(cu), ctypes.byref(lds), name, 64), "ds_device_info")
+    assert name.value.decode().startswith("gfx950"), name.value
+    assert cu.value == 256
+
+
+@pytest.mark.parametrize("n", [1, 3, 4, 1023, 4096, 2 * 128 * 128 + 4])
+def test_stepper_kernels_bit_exact(dev, n):
+    """The step kernels follow the reference's op order: bit-identical to torch-CPU fp32."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(n)
+    x, f1, f2, fu1, fu2, eps = (torch.randn(n, generator=g) * s for s in (80.0, 1.0, 1.0, 1.0, 1.0, 1.0))
+    sig1, sig2 = torch.tensor(57.586), torch.tensor(40.786)
+    dt = sig2 - sig1
+    rows = []
+    for sg in (sig1, sig2):
+        cs, co, ci, cn = K.edm_precond(sg)
+        rows.append(dict(c_out=float(co), c_skip=float(cs), sigma_sq=float(sg ** 2), neg_mult=float(-(sg * (1 + 0 * sg)))))
+    ci2 = float(K.edm_precond(sig2)[2])
+
+    def drift_cpu(xx, ff, fuu, r, g_):
+        Fv = ff if fuu is None else (1 - g_) * fuu + g_ * ff
+        D = r["c_out"] * Fv + r["c_skip"] * xx
+        sc = (D - xx) / r["sigma_sq"]
+        return r["neg_mult"] * sc
+
+    D = lambda t: t.to(dev)  # noqa: E731
+    for g_, u1, u2 in ((1.0, None, None), (2.0, fu1, fu2)):
+        k1 = _coef(guidance=g_, one_minus_guidance=1 - g_, **rows[0])
+        k2 = _coef(guidance=g_, one_minus_guidance=1 - g_, **rows[1])
+        d1 = drift_cpu(x, f1, u1, rows[0], g_)
+        xe = x + float(dt) * d1
+        xo, xi = torch.empty(n, device=dev), torch.empty(n, device=dev)
+        ops.euler(D(x), D(f1), k1, float(dt), fu=None if u1 is None else D(u1), x_out=xo, xin_out=xi, c_in_next=ci2)
+        assert torch.equal(xo.cpu(), xe)
+        assert torch.equal(xi.cpu(), ci2 * xe)
+        d2 = drift_cpu(xe, f2, u2, rows[1], g_)
+        want = x + (0.5 * (d1 + d2)) * float(dt)
+        ops.heun(D(x), D(f1), k1, D(f2), k2, float(dt), f1u=None if u1 is None else D(u1),
+                 f2u=None if u2 is None else D(u2), x_out=xo, xin_out=xi, c_in_next=0.25)
+        assert torch.equal(xo.cpu(), want)
+        assert torch.equal(xi.cpu(), 0.25 * want)
+        got = ops.drift(D(x), D(f1), k1, fu=None if u1 is None else D(u1))
+        assert torch.equal(got.cpu(), d1)
+    # Euler-Maruyama move and churn
+    k = _coef(stochastic=1, neg_lang=-0.7 * 57.586, **rows[0])
+    sc = ((rows[0]["c_out"] * f1 + rows[0]["c_skip"] * x) - x) / rows[0]["sigma_sq"]
+    d = rows[0]["neg_mult"] * sc
+    d = d + (-0.7 * 57.586) * sc
+    dtf = float(dt)
+    want = x + d * dtf + (1.3 * eps) * 0.9
+    xo = torch.empty(n, device=dev)
+    ops.euler(D(x), D(f1), k, dtf, x_out=xo, eps=D(eps), noise_coef=1.3, sqrt_abs_dt=0.9)
+    assert torch.equal(xo.cpu(), want)
+    xh, xi = torch.empty(n, device=dev), torch.empty(n, device=dev)
+    ops.churn(D(x), D(eps), 3.25, xhat_out=xh, xin_out=xi, c_in=0.125)
+    assert torch.equal(xh.cpu(), x + 3.25 * eps)
+    assert torch.equal(xi.cpu(), 0.125 * (x + 3.25 * eps))
+    assert torch.equal(ops.scale(D(x), 80.0).cpu(), x * 80.0)
+    assert torch.equal(ops.add(D(x), D(f1)).cpu(), x + f1)
+
+
+@pytest.mark.parametrize("shape", [(2, 8, 32, 32), (3, 5, 8, 8), (2, 4, 64, 64), (1, 3, 128, 128),
+                                   (2, 2, 256, 256), (2, 3, 5, 7), (1, 2, 2, 2)])
+@pytest.mark.parametrize("kind", [0, 1])
+def test_inorm_silu(dev, shape, kind):
+    ops = _ops()
+    g = torch.Generator().manual_seed(sum(shape) + kind)
+    x = torch.randn(shape, generator=g) * 3 + 0.5
+    C = shape[1]
+    w, b = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    if kind == 0:
+        want = F.silu(F.group_norm(x, C, w, b, 1e-5))
+    else:
+        want = F.silu(punetg_ref.group_rms_norm(x, w, b))
+    got = ops.inorm_silu(x.to(dev), w.to(dev), b.to(dev), kind).cpu()
+    # fp32 tolerance: statistics are reduced in a different order than torch's CPU kernels
+    torch.testing.assert_close(got, want, rtol=2e-5, atol=2e-6)
+    # in-place form
+    xd = x.to(dev)
+    ops.inorm_silu(xd, w.to(dev), b.to(dev), kind, out=xd)
+    torch.testing.assert_close(xd.cpu(), want, rtol=2e-5, atol=2e-6)
+
+
+CONV_CASES = [
+    # B, Cin, Cout, H, W, ks, mode
+    (2, 8, 8, 32, 32, 3, 0),
+    (1, 1, 64, 16, 40, 3, 0),      # convin-like, ragged width
+    (2, 64, 1, 24, 24, 3, 0),      # convout-like
+    (2, 16, 24, 9, 13, 3, 0),      # nothing divides anything
+    (1, 64, 128, 16, 16, 3, 1),    # DownSampler: maxpool fused in the load
+    (1, 24, 12, 16, 32, 3, 2),     # UpSampler: nearest fused in the load
+    (2, 32, 96, 8, 8, 1, 0),       # attention in_proj
+    (1, 70, 33, 8, 40, 1, 0),
+    (1, 128, 128, 64, 64, 3, 0),   # multiple chunks and channel tiles
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d(dev, case):
+    ops = _ops()
+    B, Cin, Cout, H, W, ks, mode = case
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    Hin, Win = (2 * H, 2 * W) if mode == 1 else ((H // 2, W // 2) if mode == 2 else (H, W))
+    x = torch.randn(B, Cin, Hin, Win, generator=g)
+    w = torch.randn(Cout, Cin, ks, ks, generator=g) / math.sqrt(Cin * ks * ks)
+    bias = torch.randn(Cout, generator=g)
+    shift = torch.randn(B, Cout, generator=g)
+    r1, r2 = torch.randn(B, Cout, H, W, generator=g), torch.randn(B, Cout, H, W, generator=g)
+    src = F.max_pool2d(x, 2) if mode == 1 else (F.interpolate(x, scale_factor=2.0, mode="nearest") if mode == 2 else x)
+    ref64 = F.conv2d(src.double(), w.double(), bias.double(), padding="same")
+    want = ref64 + shift.double()[:, :, None, None] + r1.double() + r2.double()
+    wp = ops.pack_conv_weight(w.to(dev))
+    got = ops.conv2d(x.to(dev), wp, Cout, ks, bias=bias.to(dev), shift=shift.to(dev), res1=r1.to(dev),
+                     res2=r2.to(dev), load_mode=mode).cpu()
+    # exact-fp32 MFMA = one k-ordered fmaf chain per output (K up to 1152 here); torch's CPU conv
+    # sums in blocks, so its worst-case rounding error is a few times smaller.  Bound ours by 8x.
+    err = (got.double() - want).abs().max().item()
+    ref32 = F.conv2d(src, w, bias, padding="same") + shift[:, :, None, None] + r1 + r2
+    err32 = (ref32.double() - want).abs().max().item()
+    assert err <= max(8 * err32, 1e-5), (err, err32)
+    # plain variant: no epilogue terms, broadcast shift
+    got = ops.conv2d(x.to(dev), wp, Cout, ks, shift=shift[:1].to(dev).contiguous(), load_mode=mode).cpu()
+    want2 = F.conv2d(src.double(), w.double(), None, padding="same") + shift.double()[:1, :, None, None]
+    assert (got.double() - want2).abs().max().item() <= max(8 * err32, 1e-5)
+
+
+@pytest.mark.parametrize("B,E,L", [(2, 32, 64), (1, 64, 96), (2, 128, 256), (2, 256, 1024)])
+def test_attention(dev, B, E, L):
+    ops = _ops()
+    g = torch.Generator().manual_seed(E + L)
+    qkv = torch.randn(B, 3 * E, L, generator=g)
+    q, k, v = (t.transpose(1, 2).double() for t in qkv.split(E, dim=1))    # [B, L, E]
+    att = torch.softmax((q * math.sqrt(1.0 / E)) @ k.transpose(1, 2), dim=-1) @ v
+    want = att.transpose(1, 2)
+    got = ops.attention(qkv.to(dev), E).cpu()
+    assert rel_l2(got, want) < 2e-6
+    assert (got.double() - want).abs().max().item() < 2e-5
+
+
+def test_linear_and_fourier(dev):
+    ops = _ops()
+    g = torch.Generator().manual_seed(0)
+    x, w, b = torch.randn(7, 65, generator=g), torch.randn(40, 65, generator=g), torch.randn(40, generator=g)
+    for act, fn in ((0, lambda t: t), (1, F.silu), (2, F.relu)):
+        got = ops.linear(x.to(dev), w.to(dev), b.to(dev), act=act).cpu()
+        torch.testing.assert_close(got, fn(F.linear(x, w, b)), rtol=1e-5, atol=1e-5)
+    t = torch.tensor([2.19, -3.1, 0.0, 0.37])
+    W = torch.randn(32, generator=g) * 30
+    want = punetg_ref.fourier_features(t, W)
+    got = ops.fourier_features(t.to(dev), W.to(dev)).cpu()
+    # arguments reach ~1e3 rad: compare against the fp64 sine of the same fp32 argument
+    arg = ((t[:, None] * torch.tensor(2 * math.pi, dtype=torch.float32)) * W).double()
+    exact = torch.cat([torch.sin(arg), torch.cos(arg)], -1)
+    assert (got.double() - exact).abs().max().item() < 1e-7
+    assert (got - want).abs().max().item() < 5e-7
+    add = torch.randn(1, 64, generator=g)
+    got = ops.fourier_features(t.to(dev), W.to(dev), add=add.to(dev)).cpu()
+    assert (got - (want + add)).abs().max().item() < 5e-7
+
+
+def test_bad_arguments_fail_loudly(dev):
+    ops = _ops()
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ops.scale(torch.zeros(4), 2.0)
+    with pytest.raises(TypeError):
+        ops.scale(torch.zeros(4, device=dev, dtype=torch.float64), 2.0)
+    with pytest.raises(RuntimeError, match="multiple of 32"):
+        ops.attention(torch.zeros(1, 96, 40, device=dev), 32)
+    with pytest.raises(ValueError):
+        ops.conv2d(torch.zeros(1, 4, 8, 8, device=dev), torch.zeros(10, device=dev), 4, 3)
