@@ -24,6 +24,23 @@ MFMA_F32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: fp32-input MFMA, dense
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E spec
 
 
+def host_cores():
+    """CPU share of this process: cgroup quota if set, else the affinity mask, capped at 16
+    (the GPU box gives 16 cores per GPU)."""
+    n = os.cpu_count() or 1
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(p))))
+    except Exception:
+        pass
+    return max(1, min(n, 16))
+
+
 def conv_flops(B, Cin, Cout, H, W, ks):
     return 2.0 * B * Cout * Cin * ks * ks * H * W
 
@@ -141,18 +158,15 @@ def cpu_baseline(sd, cfg, args):
     bounded sample of the same workload."""
     from oracle import karras_ref as K
     from oracle import punetg_ref
-    cores = os.cpu_count() or 1
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except Exception:
-        pass
+    cores = host_cores()
     torch.set_num_threads(cores)
-    B, N = 4, 3                                   # 3-step Heun = 5 network evaluations
+    print(f"[bench] cpu baseline on {cores} host threads ...", file=sys.stderr, flush=True)
+    B, N = 8, 8                                   # 8-step Heun = 15 network evaluations (~10-20 s)
     g = torch.Generator().manual_seed(1)
     wn = torch.randn(B, 1, args.size, args.size, generator=g)
     net = punetg_ref.make_net(sd, cfg)
     with torch.inference_mode():
-        K.propagate_white_noise(net, wn[:1], 1)    # warm-up (1 evaluation)
+        K.propagate_white_noise(net, wn[:1], 2)    # warm-up (3 evaluations of one sample)
         t0 = time.time()
         K.propagate_white_noise(net, wn, N)
         dt = time.time() - t0
@@ -224,8 +238,11 @@ def main():
                        "global_batch": B * world, "parallelism": f"dp{world} (batch shards, all-gather of samples)",
                        "hipgraph": not args.no_graph},
         }
+        print(f"[bench] {value:.3f} samples/s, {dt / args.steps * 1e3:.1f} ms per {B}-sample batch", file=sys.stderr, flush=True)
         line["roofline"] = dominant_kernel_roofline(module, args, dev)
+        print(f"[bench] roofline {line['roofline']}", file=sys.stderr, flush=True)
         line["roofline_hbm_class"] = hbm_class(module, args, dev)
+        print(f"[bench] hbm class {line['roofline_hbm_class']}", file=sys.stderr, flush=True)
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(sd, cfg, args)
         print(json.dumps(line), flush=True)
