@@ -55,7 +55,11 @@ def gather_samples(out, nsamples=None):
         full = torch.empty((nsamples,) + tuple(out.shape[1:]), dtype=out.dtype, device=out.device)
         dist.all_gather_into_tensor(full, out.contiguous())
         return full
+    # ragged split: pad every shard to the largest one, gather, drop the padding rows
     sizes = [shard_rows(nsamples, world, r) for r in range(world)]
-    parts = [torch.empty((b - a,) + tuple(out.shape[1:]), dtype=out.dtype, device=out.device) for a, b in sizes]
-    dist.all_gather(parts, out.contiguous())
-    return torch.cat(parts, dim=0)
+    most = max(b - a for a, b in sizes)
+    padded = torch.zeros((most,) + tuple(out.shape[1:]), dtype=out.dtype, device=out.device)
+    padded[:out.shape[0]] = out
+    full = torch.empty((world * most,) + tuple(out.shape[1:]), dtype=out.dtype, device=out.device)
+    dist.all_gather_into_tensor(full, padded)
+    return torch.cat([full[r * most:r * most + (b - a)] for r, (a, b) in enumerate(sizes)], dim=0)
