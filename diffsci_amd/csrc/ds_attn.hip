@@ -21,6 +21,7 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));   // native vector: HIP's float4 struct defeats SROA here
 constexpr int NT = 256;
 constexpr int KB = 32;       // keys per tile
 constexpr int VSTR = KB + 1; // padded V^T row
@@ -52,14 +53,14 @@ __global__ __launch_bounds__(NT) void k_attn(float* out, const float* __restrict
     for (int r = 0; r < 16; ++r) O[t][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
 
-  float4 kr[NLD], vr[NLD];
+  f32x4 kr[NLD], vr[NLD];
   auto tile_load = [&](int key0) {
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
       const int e = tid + NT * i;          // float4 index in [E][8]
       const int d = e >> 3, c4 = e & 7;
-      kr[i] = *reinterpret_cast<const float4*>(Kt + (size_t)d * L + key0 + 4 * c4);
-      vr[i] = *reinterpret_cast<const float4*>(Vt + (size_t)d * L + key0 + 4 * c4);
+      kr[i] = *reinterpret_cast<const f32x4*>(Kt + (size_t)d * L + key0 + 4 * c4);
+      vr[i] = *reinterpret_cast<const f32x4*>(Vt + (size_t)d * L + key0 + 4 * c4);
     }
   };
   auto tile_store = [&]() {
@@ -67,7 +68,7 @@ __global__ __launch_bounds__(NT) void k_attn(float* out, const float* __restrict
     for (int i = 0; i < NLD; ++i) {
       const int e = tid + NT * i;
       const int d = e >> 3, c4 = e & 7;
-      reinterpret_cast<float4*>(Ks)[e] = kr[i];
+      reinterpret_cast<f32x4*>(Ks)[e] = kr[i];
       float* vd = Vs + d * VSTR + 4 * c4;
       vd[0] = vr[i].x; vd[1] = vr[i].y; vd[2] = vr[i].z; vd[3] = vr[i].w;
     }

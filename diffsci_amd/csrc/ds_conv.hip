@@ -22,6 +22,7 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int TH = 8;     // tile rows
 constexpr int TW = 32;    // tile columns (= MFMA N)
@@ -53,13 +54,26 @@ struct ConvArgs {
   int tiles_x, tiles_y, n_cot, n_chunks;
 };
 
+// One prefetch group of MFMA operands: G channel pairs x (all taps).  Two such register sets are
+// alternated so that the ds_reads of group g+1 are in flight while the MFMAs of group g issue.
+template <int KS> struct Frag {
+  static constexpr int G = (KS == 3) ? 1 : 4;            // channel pairs per group
+  static constexpr int ROWS = KS + 1;                    // input rows feeding the wave's 2 output rows
+  float a[G][KS * KS][2];
+  float b[G][ROWS][KS];
+};
+
 template <int KS, int MODE>
 __global__ __launch_bounds__(NT, 2) void k_conv(const ConvArgs a) {
   using G = Geo<KS>;
-  constexpr int KC = G::KC, TAPS = G::TAPS, PH = G::PH, PW = G::PW;
+  using F = Frag<KS>;
+  constexpr int KC = G::KC, PH = G::PH, PW = G::PW;
+  constexpr int NG = (KC / 2) / F::G;                     // groups per chunk (4 for 3x3, 4 for 1x1)
+  static_assert(NG % 2 == 0, "group loop is unrolled by two");
   extern __shared__ __attribute__((aligned(16))) float smem[];   // [2][NW | NX]
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wv = tid >> 6;
+  const int lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lh = lane >> 5;
 
   int bid = blockIdx.x;
@@ -70,11 +84,10 @@ __global__ __launch_bounds__(NT, 2) void k_conv(const ConvArgs a) {
   const int x0 = tx * TW, y0 = ty * TH;
   const int HWin = a.Hin * a.Win;
 
-  // ---- per-thread staging plan (identical for every chunk) ----
+  // ---- per-thread staging plan (identical for every chunk): offsets are always in bounds,
+  //      out-of-image / out-of-range elements are zeroed by a select, never by a branch ----
   int xoff[G::NXI];
-  unsigned xvalid = 0;    // bit i: position inside the image
-  unsigned xchan = 0;     // packed channel-in-chunk of element i is recomputed (cheap) below
-  (void)xchan;
+  unsigned xvalid = 0;
 #pragma unroll
   for (int i = 0; i < G::NXI; ++i) {
     const int e = tid + NT * i;
@@ -88,40 +101,47 @@ __global__ __launch_bounds__(NT, 2) void k_conv(const ConvArgs a) {
     if (MODE == DS_LOAD_PLAIN) off = gy * a.Win + gx;
     else if (MODE == DS_LOAD_MAXPOOL2) off = (2 * gy) * a.Win + 2 * gx;
     else off = (gy >> 1) * a.Win + (gx >> 1);
-    xoff[i] = ok ? (c * HWin + off) : -1;
+    xoff[i] = ok ? (c * HWin + off) : 0;
     if (ok) xvalid |= (1u << i);
   }
   const float* in_b = a.in + (size_t)b * a.Cin * HWin;
-  const float4* wp4 = reinterpret_cast<const float4*>(a.wp) + (size_t)cot * a.n_chunks * (G::NW / 4);
+  const f32x4* wp4 = reinterpret_cast<const f32x4*>(a.wp) + (size_t)cot * a.n_chunks * (G::NW / 4);
 
   float xr[G::NXI];
-  float4 wr[G::NW4I];
+  f32x4 wr[G::NW4I];
 
+  // stage_load only ISSUES the global loads (plus the max of the pooled mode); zeroing of the
+  // halo / out-of-range elements happens in stage_store, after the MFMA block, so that no
+  // s_waitcnt vmcnt lands in front of the matrix instructions.
+  unsigned xok = 0;
   auto stage_load = [&](int chunk) {
     const int cbase = chunk * KC;
     const float* src = in_b + (size_t)cbase * HWin;
+    const bool full = cbase + KC <= a.Cin;                 // uniform: only the last chunk can be partial
+    xok = xvalid;
 #pragma unroll
     for (int i = 0; i < G::NXI; ++i) {
       const int e = tid + NT * i;
       const int c = e / (PH * PW);
-      float v = 0.f;
-      if (((xvalid >> i) & 1u) && (cbase + c < a.Cin)) {
-        const float* p = src + xoff[i];
-        if (MODE == DS_LOAD_MAXPOOL2) {
-          const float2 t0 = *reinterpret_cast<const float2*>(p);
-          const float2 t1 = *reinterpret_cast<const float2*>(p + a.Win);
-          v = fmaxf(fmaxf(t0.x, t0.y), fmaxf(t1.x, t1.y));
-        } else {
-          v = *p;
-        }
+      bool ok = (xvalid >> i) & 1u;
+      if (!full && !(cbase + c < a.Cin)) {
+        ok = false;
+        xok &= ~(1u << i);
       }
-      xr[i] = v;
+      const float* p = src + (ok ? xoff[i] : 0);
+      if (MODE == DS_LOAD_MAXPOOL2) {
+        const float2 t0 = *reinterpret_cast<const float2*>(p);
+        const float2 t1 = *reinterpret_cast<const float2*>(p + a.Win);
+        xr[i] = fmaxf(fmaxf(t0.x, t0.y), fmaxf(t1.x, t1.y));
+      } else {
+        xr[i] = *p;
+      }
     }
-    const float4* wsrc = wp4 + (size_t)chunk * (G::NW / 4);
+    const f32x4* wsrc = wp4 + (size_t)chunk * (G::NW / 4);
 #pragma unroll
     for (int i = 0; i < G::NW4I; ++i) {
       const int e = tid + NT * i;
-      if (e < G::NW / 4) wr[i] = wsrc[e];
+      wr[i] = wsrc[e < G::NW / 4 ? e : G::NW / 4 - 1];     // tail lanes re-read the last vector (never stored)
     }
   };
   auto stage_store = [&](int buf) {
@@ -130,12 +150,12 @@ __global__ __launch_bounds__(NT, 2) void k_conv(const ConvArgs a) {
 #pragma unroll
     for (int i = 0; i < G::NXI; ++i) {
       const int e = tid + NT * i;
-      if (e < G::NX) xs[e] = xr[i];
+      if (NT * (i + 1) <= G::NX || e < G::NX) xs[e] = ((xok >> i) & 1u) ? xr[i] : 0.f;
     }
 #pragma unroll
     for (int i = 0; i < G::NW4I; ++i) {
       const int e = tid + NT * i;
-      if (e < G::NW / 4) reinterpret_cast<float4*>(ws)[e] = wr[i];
+      if (NT * (i + 1) <= G::NW / 4 || e < G::NW / 4) reinterpret_cast<f32x4*>(ws)[e] = wr[i];
     }
   };
 
@@ -147,67 +167,112 @@ __global__ __launch_bounds__(NT, 2) void k_conv(const ConvArgs a) {
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[m][r][q] = 0.f;
 
+  auto frag_load = [&](F& f, const float* wl, const float* xl, int g) {
+#pragma unroll
+    for (int pp = 0; pp < F::G; ++pp) {
+      const int p = g * F::G + pp;
+#pragma unroll
+      for (int tap = 0; tap < KS * KS; ++tap) {
+        f.a[pp][tap][0] = wl[(tap * KC + 2 * p) * COT];
+        f.a[pp][tap][1] = wl[(tap * KC + 2 * p) * COT + 32];
+      }
+#pragma unroll
+      for (int row = 0; row < F::ROWS; ++row)
+#pragma unroll
+        for (int kx = 0; kx < KS; ++kx) f.b[pp][row][kx] = xl[2 * p * (PH * PW) + row * PW + kx];
+    }
+  };
+  auto frag_mma = [&](const F& f) {
+#pragma unroll
+    for (int pp = 0; pp < F::G; ++pp)
+#pragma unroll
+      for (int ky = 0; ky < KS; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < KS; ++kx) {
+          const int tap = ky * KS + kx;
+          acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[pp][tap][0], f.b[pp][0 + ky][kx], acc[0][0], 0, 0, 0);
+          acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[pp][tap][0], f.b[pp][1 + ky][kx], acc[0][1], 0, 0, 0);
+          acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[pp][tap][1], f.b[pp][0 + ky][kx], acc[1][0], 0, 0, 0);
+          acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[pp][tap][1], f.b[pp][1 + ky][kx], acc[1][1], 0, 0, 0);
+        }
+  };
+
   stage_load(0);
   stage_store(0);
   __syncthreads();
 
+  F f0, f1;
   for (int chunk = 0; chunk < a.n_chunks; ++chunk) {
     const int buf = chunk & 1;
     const bool more = chunk + 1 < a.n_chunks;
-    if (more) stage_load(chunk + 1);
-
     const float* ws = smem + buf * G::STAGE_FLOATS;
     const float* xs = ws + G::NW;
-    // lane-resolved bases
     const float* wl = ws + lh * COT + li;                       // + (tap*KC + 2p)*COT + 32m
-    const float* xl = xs + lh * (PH * PW) + (2 * wv) * PW + li; // + 2p*PH*PW + (rt+ky)*PW + kx
+    const float* xl = xs + lh * (PH * PW) + (2 * wv) * PW + li; // + 2p*PH*PW + row*PW + kx
+    frag_load(f0, wl, xl, 0);
+    if (more) stage_load(chunk + 1);                            // global loads fly under the MFMAs
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int p = 0; p < KC / 2; ++p) {
-#pragma unroll
-      for (int ky = 0; ky < KS; ++ky) {
-#pragma unroll
-        for (int kx = 0; kx < KS; ++kx) {
-          const int tap = ky * KS + kx;
-          const float a0 = wl[(tap * KC + 2 * p) * COT];
-          const float a1 = wl[(tap * KC + 2 * p) * COT + 32];
-          const float b0 = xl[2 * p * (PH * PW) + (0 + ky) * PW + kx];
-          const float b1 = xl[2 * p * (PH * PW) + (1 + ky) * PW + kx];
-          acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-          acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-          acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-          acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-        }
-      }
+    for (int g = 0; g < NG; g += 2) {
+      // the scheduling fences keep each operand prefetch ahead of the previous group's MFMAs
+      frag_load(f1, wl, xl, g + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      frag_mma(f0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (g + 2 < NG) frag_load(f0, wl, xl, g + 2);
+      __builtin_amdgcn_sched_barrier(0);
+      frag_mma(f1);
+      __builtin_amdgcn_sched_barrier(0);
     }
     if (more) stage_store(buf ^ 1);
     __syncthreads();
   }
 
-  // ---- epilogue: bias, time shift, residuals; 128-byte row segments per half wave ----
+  // ---- epilogue: bias, time shift, residuals.  All loads of a 16-register group are issued
+  //      before any is consumed; invalid lanes read a safe address and are masked at the store.
   const int gx = x0 + li;
   const size_t plane = (size_t)a.H * a.W;
+  const bool has_bias = a.bias != nullptr, has_shift = a.shift != nullptr;
+  const bool has_r1 = a.res1 != nullptr, has_r2 = a.res2 != nullptr;
 #pragma unroll
   for (int m = 0; m < 2; ++m) {
+    float bv[16], sv[16];
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
       const int co = cot * COT + 32 * m + (q & 3) + 8 * (q >> 2) + 4 * lh;
-      if (co >= a.Cout) continue;
-      float add = a.bias ? a.bias[co] : 0.f;
-      const bool has_bias = a.bias != nullptr;
-      float sh = 0.f;
-      if (a.shift) sh = a.shift[(size_t)b * a.shift_stride + co];
+      const int cs = co < a.Cout ? co : 0;
+      bv[q] = has_bias ? a.bias[cs] : 0.f;
+      sv[q] = has_shift ? a.shift[(size_t)b * a.shift_stride + cs] : 0.f;
+    }
 #pragma unroll
-      for (int r = 0; r < 2; ++r) {
-        const int gy = y0 + 2 * wv + r;
-        if (gy < a.H && gx < a.W) {
-          const size_t idx = ((size_t)b * a.Cout + co) * plane + (size_t)gy * a.W + gx;
-          float v = acc[m][r][q];
-          if (has_bias) v = v + add;
-          if (a.shift) v = v + sh;
-          if (a.res1) v = v + a.res1[idx];
-          if (a.res2) v = v + a.res2[idx];
-          a.out[idx] = v;
-        }
+    for (int r = 0; r < 2; ++r) {
+      const int gy = y0 + 2 * wv + r;
+      const bool rowok = gy < a.H && gx < a.W;
+      size_t idx[16];
+      float r1[16], r2[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int co = cot * COT + 32 * m + (q & 3) + 8 * (q >> 2) + 4 * lh;
+        const bool ok = rowok && co < a.Cout;
+        idx[q] = ok ? ((size_t)b * a.Cout + co) * plane + (size_t)gy * a.W + gx : (size_t)0;
+      }
+      if (has_r1) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) r1[q] = a.res1[idx[q]];
+      }
+      if (has_r2) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) r2[q] = a.res2[idx[q]];
+      }
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int co = cot * COT + 32 * m + (q & 3) + 8 * (q >> 2) + 4 * lh;
+        float v = acc[m][r][q];
+        if (has_bias) v = v + bv[q];
+        if (has_shift) v = v + sv[q];
+        if (has_r1) v = v + r1[q];
+        if (has_r2) v = v + r2[q];
+        if (rowok && co < a.Cout) a.out[idx[q]] = v;
       }
     }
   }
