@@ -132,6 +132,9 @@ class PUNetG(torch.nn.Module):
         self.attn_resnet_block = blocks(mult[-1], config.number_resnet_attn_block)
         self.attn_block = torch.nn.ModuleList(
             [_Attn(mult[-1] * mc) for _ in range(config.number_resnet_attn_block - 1)])
+        # "bf16x6": 3x3 convolutions on the bf16 matrix cores with exact 3-way operand splitting
+        # (fp32-level error, 2.67x the exact-fp32 MFMA peak); "fp32": exact-fp32 MFMA everywhere.
+        self.conv_precision = "bf16x6"
         self._packed = None
         self._packed_sig = None
         self._ws = _Workspace()
@@ -206,24 +209,24 @@ class PUNetG(torch.nn.Module):
     def packed_weights(self):
         """MFMA-operand repack of every conv / projection weight, cached per parameter version."""
         mods = list(self._conv_modules())
-        sig = tuple((m.weight.data_ptr(), m.weight._version) for m in mods) + tuple(
+        sig = (self.conv_precision,) + tuple((m.weight.data_ptr(), m.weight._version) for m in mods) + tuple(
             (a.mhattn.in_proj_weight.data_ptr(), a.mhattn.in_proj_weight._version) for a in self.attn_block)
         if self._packed is not None and sig == self._packed_sig:
             return self._packed
         pk = {}
         with torch.no_grad():
             for m in mods:
-                pk[id(m)] = ops.pack_conv_weight(m.weight.detach())
+                pk[id(m)] = ops.pack_conv(m.weight.detach(), self.conv_precision)
             for a in self.attn_block:
                 E = a.mhattn.embed_dim
-                pk[(id(a), "in")] = ops.pack_conv_weight(a.mhattn.in_proj_weight.detach().reshape(3 * E, E, 1, 1))
-                pk[(id(a), "out")] = ops.pack_conv_weight(a.mhattn.out_proj.weight.detach().reshape(E, E, 1, 1))
+                pk[(id(a), "in")] = ops.pack_conv(a.mhattn.in_proj_weight.detach().reshape(3 * E, E, 1, 1), "fp32")
+                pk[(id(a), "out")] = ops.pack_conv(a.mhattn.out_proj.weight.detach().reshape(E, E, 1, 1), "fp32")
         self._packed, self._packed_sig = pk, sig
         return pk
 
     # ------------------------------------------------------------------ the network
     def _conv(self, m, x, pk, **kw):
-        return ops.conv2d(x, pk[id(m)], m.out_channels, m.kernel_size[0], bias=m.bias, **kw)
+        return ops.conv(x, pk[id(m)], bias=m.bias, **kw)
 
     def _res(self, blk, x, shift, pk, ws, res2=None):
         """ResnetBlockC.forward (commonlayers.py:824-833); returns a fresh buffer, x untouched."""
@@ -309,12 +312,11 @@ class PUNetG(torch.nn.Module):
         B, E, Hh, Ww = x.shape
         L = Hh * Ww
         m = att.mhattn
-        qkv = ops.conv2d(x, pk[(id(att), "in")], 3 * E, 1, bias=m.in_proj_bias,
-                         out=ws.take((B, 3 * E, Hh, Ww), x.device))
+        qkv = ops.conv(x, pk[(id(att), "in")], bias=m.in_proj_bias, out=ws.take((B, 3 * E, Hh, Ww), x.device))
         o = ops.attention(qkv.view(B, 3 * E, L), E, out=ws.take((B, E, L), x.device))
         res1 = x if self.config.attn_residual else None
-        y = ops.conv2d(o.view(B, E, Hh, Ww), pk[(id(att), "out")], E, 1, bias=m.out_proj.bias,
-                       res1=res1, res2=res2, out=ws.take(x.shape, x.device))
+        y = ops.conv(o.view(B, E, Hh, Ww), pk[(id(att), "out")], bias=m.out_proj.bias,
+                     res1=res1, res2=res2, out=ws.take(x.shape, x.device))
         ws.give(qkv)
         ws.give(o)
         return y

@@ -136,8 +136,36 @@ def pack_conv_weight(w):
     return packed
 
 
+class PackedConv:
+    """A convolution weight repacked for one of the two MFMA kernels."""
+    __slots__ = ("data", "Cout", "Cin", "ks", "x6")
+
+    def __init__(self, data, Cout, Cin, ks, x6):
+        self.data, self.Cout, self.Cin, self.ks, self.x6 = data, Cout, Cin, ks, x6
+
+
+def pack_conv(w, precision="bf16x6"):
+    """precision "bf16x6": fp32-accurate split-bf16 MFMA (3x3 only); "fp32": exact-fp32 MFMA."""
+    require_device(w, "conv weight")
+    Cout, Cin, k, _ = w.shape
+    if precision == "bf16x6" and k == 3:
+        nbytes = N.lib().ds_conv2d_x6_packed_bytes(Cout, Cin)
+        data = torch.empty(nbytes // 4, dtype=torch.float32, device=w.device)
+        N.check(N.lib().ds_conv2d_x6_pack_weights(data.data_ptr(), _p(w.contiguous()), Cout, Cin, _stream()),
+                "ds_conv2d_x6_pack_weights")
+        return PackedConv(data, Cout, Cin, 3, True)
+    if precision not in ("bf16x6", "fp32"):
+        raise ValueError(f"unknown conv precision {precision!r}")
+    return PackedConv(pack_conv_weight(w), Cout, Cin, k, False)
+
+
+def conv(x, pw, **kw):
+    """Dispatch on the packing: ds_conv2d_x6 or ds_conv2d."""
+    return conv2d(x, pw.data, pw.Cout, pw.ks, x6=pw.x6, **kw)
+
+
 def conv2d(x, w_packed, Cout, ks, bias=None, shift=None, res1=None, res2=None,
-           load_mode=N.DS_LOAD_PLAIN, out=None):
+           load_mode=N.DS_LOAD_PLAIN, out=None, x6=False):
     """'same' zero-padded conv; x [B, Cin, Hin, Win]; shift [1 or B, Cout] or None."""
     B, Cin, Hin, Win = x.shape
     if load_mode == N.DS_LOAD_MAXPOOL2:
@@ -152,7 +180,9 @@ def conv2d(x, w_packed, Cout, ks, bias=None, shift=None, res1=None, res2=None,
         out = torch.empty((B, Cout, H, W), dtype=torch.float32, device=x.device)
     elif tuple(out.shape) != (B, Cout, H, W):
         raise ValueError(f"out has shape {tuple(out.shape)}, expected {(B, Cout, H, W)}")
-    if w_packed.numel() != N.lib().ds_conv2d_packed_floats(Cout, Cin, ks):
+    expect = (N.lib().ds_conv2d_x6_packed_bytes(Cout, Cin) // 4 if x6
+              else N.lib().ds_conv2d_packed_floats(Cout, Cin, ks))
+    if w_packed.numel() != expect or (x6 and ks != 3):
         raise ValueError("packed weight size does not match (Cout, Cin, ks)")
     stride = 0
     if shift is not None:
@@ -164,8 +194,12 @@ def conv2d(x, w_packed, Cout, ks, bias=None, shift=None, res1=None, res2=None,
             raise ValueError("residual shape mismatch")
     if bias is not None and bias.numel() != Cout:
         raise ValueError("bias must have Cout entries")
-    N.check(N.lib().ds_conv2d(_p(out), _p(x), _p(w_packed), _p(bias), _p(shift), stride, _p(res1), _p(res2),
-                              B, Cin, Cout, H, W, ks, load_mode, _stream()), "ds_conv2d")
+    if x6:
+        N.check(N.lib().ds_conv2d_x6(_p(out), _p(x), _p(w_packed), _p(bias), _p(shift), stride, _p(res1),
+                                     _p(res2), B, Cin, Cout, H, W, load_mode, _stream()), "ds_conv2d_x6")
+    else:
+        N.check(N.lib().ds_conv2d(_p(out), _p(x), _p(w_packed), _p(bias), _p(shift), stride, _p(res1), _p(res2),
+                                  B, Cin, Cout, H, W, ks, load_mode, _stream()), "ds_conv2d")
     return out
 
 

@@ -147,6 +147,18 @@ int ds_conv2d(float* out, const float* in, const float* w_packed, const float* b
               const float* shift, int shift_stride, const float* res1, const float* res2,
               int B, int Cin, int Cout, int H, int W, int ks, int load_mode, void* stream);
 
+/* The same 3x3 convolution computed on the bf16 matrix cores with fp32 accuracy ("bf16x6"):
+ * each fp32 operand is split exactly into three bf16 pieces and the six leading piece products
+ * are accumulated in fp32 (v_mfma_f32_32x32x16_bf16); dropped terms are <= 2^-24 relative, so the
+ * rounding error is that of an fp32 convolution, at 2.67x the exact-fp32 MFMA rate.  Same
+ * arguments and epilogue as ds_conv2d with ks = 3; weights are packed (and pre-split) by
+ * ds_conv2d_x6_pack_weights into ds_conv2d_x6_packed_bytes(Cout, Cin) bytes. */
+size_t ds_conv2d_x6_packed_bytes(int Cout, int Cin);
+int ds_conv2d_x6_pack_weights(void* packed, const float* w, int Cout, int Cin, void* stream);
+int ds_conv2d_x6(float* out, const float* in, const void* w_packed, const float* bias,
+                 const float* shift, int shift_stride, const float* res1, const float* res2,
+                 int B, int Cin, int Cout, int H, int W, int load_mode, void* stream);
+
 /* Single-head self-attention over L = H*W positions, channel-major operands:
  *   qkv [B, 3E, L] (rows 0..E-1 = Q^T, E..2E-1 = K^T, 2E..3E-1 = V^T), out [B, E, L] = (softmax(Q K^T / sqrt(E)) V)^T.
  * nn.MultiheadAttention(E, num_heads=1) core, attention.py:41-43,67.  E and L multiples of 32, E <= 256. */
