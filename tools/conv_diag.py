@@ -33,7 +33,10 @@ def _case(B, Cin, Cout, S, ks, mode, res, reps, prec):
     print(f"{prec:7s} B={B} Cin={Cin} Cout={Cout} S={S} ks={ks} mode={mode} res={res}: {ms:.3f} ms  {fl/ms/1e9:.1f} TF/s", flush=True)
 
 if __name__ == "__main__":
-    for args in [(64, 64, 64, 128), (64, 64, 64, 128, 3, 0, True), (64, 512, 64, 128), (64, 128, 128, 64), (64, 256, 256, 32),
-                 (64, 1024, 256, 32), (64, 64, 128, 64, 3, 1), (64, 128, 64, 128, 3, 2), (64, 256, 768, 32, 1), (64, 1, 64, 128), (64, 64, 1, 128),
-                 (16, 64, 64, 128), (64, 64, 64, 32)]:
+    cases = [(64, 64, 64, 128), (64, 64, 64, 128, 3, 0, True), (64, 512, 64, 128), (64, 128, 128, 64), (64, 256, 256, 32),
+             (64, 1024, 256, 32), (64, 64, 128, 64, 3, 1), (64, 128, 64, 128, 3, 2), (64, 256, 768, 32, 1), (64, 1, 64, 128), (64, 64, 1, 128),
+             (16, 64, 64, 128), (64, 64, 64, 32)]
+    if len(sys.argv) > 1 and sys.argv[1] == "short":
+        cases = cases[:5]
+    for args in cases:
         case(*args)
