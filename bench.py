@@ -21,7 +21,7 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 MFMA_F32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: fp32-input MFMA, dense
-BF16_PEAK_TFLOPS = 2500.0       # MI355X_MICROARCH.md: bf16 MFMA, dense; the x6 kernel issues 6 bf16 products per fp32 product
+BF16_PEAK_TFLOPS = 2500.0       # MI355X_MICROARCH.md: bf16 / fp16 MFMA, dense; split kernels issue 3 or 6 products per fp32 product
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E spec
 
 
@@ -57,8 +57,9 @@ def parse():
     ap.add_argument("--channels", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--precision", default="bf16x6", choices=["bf16x6", "fp32"],
-                    help="3x3 conv arithmetic: fp32 emulated on bf16 MFMA (6 products) or exact-fp32 MFMA")
+    ap.add_argument("--precision", default="fp16x3", choices=["fp16x3", "bf16x6", "fp32"],
+                    help="3x3 conv arithmetic: fp32 emulated on the 16-bit matrix cores (fp16 hi/lo split, 3 products; "
+                         "bf16 3-way split, 6 products) or exact-fp32 MFMA")
     return ap.parse_args()
 
 
@@ -124,9 +125,10 @@ def dominant_kernel_roofline(module, args, dev):
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
     n = len(launches)
-    x6 = net.conv_precision == "bf16x6"
-    kname = "k_conv6<PLAIN> (ds_conv2d_x6, 3x3, fp32 via 6 bf16 MFMA products)" if x6 else "k_conv<3,PLAIN> (ds_conv2d 3x3, exact-fp32 MFMA)"
-    peak = BF16_PEAK_TFLOPS / 6.0 if x6 else MFMA_F32_PEAK_TFLOPS
+    kname, peak = {
+        "fp16x3": ("k_conv3h<PLAIN> (ds_conv2d_h3, 3x3, fp32 via 3 fp16 MFMA products)", BF16_PEAK_TFLOPS / 3.0),
+        "bf16x6": ("k_conv6<PLAIN> (ds_conv2d_x6, 3x3, fp32 via 6 bf16 MFMA products)", BF16_PEAK_TFLOPS / 6.0),
+        "fp32": ("k_conv<3,PLAIN> (ds_conv2d 3x3, exact-fp32 MFMA)", MFMA_F32_PEAK_TFLOPS)}[net.conv_precision]
     achieved = flops / (ms * 1e-3) / 1e12
     return {"bound": "mfma", "kernel": kname, "achieved": round(achieved, 2),
             "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
@@ -246,7 +248,8 @@ def main():
             "value": round(value, 3), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.precision == "fp32" else "f32 (3x3 convs: exact 3-way bf16 split, 6 bf16 MFMA products, fp32 accumulate)",
+            "dtype": {"fp32": "f32", "bf16x6": "f32 (3x3 convs: exact 3-way bf16 split, 6 bf16 MFMA products, fp32 accumulate)",
+                      "fp16x3": "f32 (3x3 convs: fp16 hi+lo split, 3 fp16 MFMA products, fp32 accumulate)"}[args.precision],
             "data": "synthetic (random-init weights, Gaussian noise)",
             "config": {"workload": f"PUNetG {args.channels}-base-ch, 1x{args.size}x{args.size} fields, batch {B} per GPU, "
                                    f"{args.nsteps}-step Heun deterministic sampler ({2*args.nsteps-1} network evaluations)",

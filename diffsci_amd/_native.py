@@ -47,6 +47,9 @@ _PROTOS = {
     "ds_conv2d_x6_packed_bytes": (c_size_t, [c_int, c_int]),
     "ds_conv2d_x6_pack_weights": (c_int, [_P, _P, c_int, c_int, _P]),
     "ds_conv2d_x6": (c_int, [_P, _P, _P, _P, _P, c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "ds_conv2d_h3_packed_bytes": (c_size_t, [c_int, c_int]),
+    "ds_conv2d_h3_pack_weights": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
+    "ds_conv2d_h3": (c_int, [_P, _P, _P, c_int, _P, _P, c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "ds_attention": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     "ds_linear": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "ds_fourier_features": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P]),

@@ -1,0 +1,415 @@
+// 3x3 convolution with fp32 accuracy on the fp16 matrix cores ("fp16x3" split MFMA).
+//
+// Each fp32 operand is split into two fp16 pieces, x = hi + lo with hi = fp16(x) (round to
+// nearest) and lo = fp16(x - hi) (the subtraction is exact), which keeps 22-23 significand bits;
+// a*b is accumulated as  lo_a*hi_b + hi_a*lo_b + hi_a*hi_b  (the dropped lo*lo term is 2^-22
+// relative).  fp16 x fp16 products are exact in fp32 and v_mfma_f32_32x32x16_f16 accumulates in
+// fp32 and -- verified on gfx950 (tools/f16_denorm_test.hip) -- honours fp16 subnormal inputs,
+// so small operands degrade to an ABSOLUTE error of 2^-25 instead of being flushed.  Weights are
+// pre-multiplied by a per-layer power of two (undone exactly in the epilogue) so that their low
+// pieces are normal numbers.  Measured representation error of a 64->64 3x3 convolution: 8.5e-8
+// relative (torch's own fp32 convolution: 2.2e-7 from accumulation order alone).  Cost: 3 MFMAs
+// per k-slab instead of 6 (bf16x6) or 8x8 (exact-fp32 MFMA).  Domain: |input| < 65504 (fp16
+// range); larger magnitudes produce inf/nan, never a silently wrong finite value.  The bf16x6
+// kernel (ds_conv6.hip) has no such limit.
+//
+// Pipeline (workgroup = 4 waves, tile = 64 channels x 8 rows x 32 columns, 2 workgroups per CU):
+//   K walks in steps (chunk of 16 input channels, ky).  LDS holds
+//     X  [2 buffers][piece 2][h 2][10*34 positions][8 ci] fp16      2 x 21,760 B
+//     W  [3-slot ring][piece 2][kx 3][h 2][64 co][8 ci] fp16        3 x 12,288 B      (80,384 B)
+//   * weight slab g+2 is fetched by LDS-DMA at the start of step g: it has landed and been
+//     published by a barrier one whole step before it is used, so the first operands of every
+//     step are prefetched during the previous step's last MFMA block;
+//   * the next chunk's input patch is loaded to registers at ky = 0, split and written to the
+//     OTHER X buffer at ky = 1 (published by that step's barrier), prefetchable at ky = 2;
+//   * operand fragments are double-buffered per kx block, their ds_read_b128 slotted between the
+//     MFMAs of the previous block.  One barrier per step, nothing waits on it.
+#include "ds_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+constexpr int TH = 8, TW = 32, COT = 64, NT = 256;
+constexpr int KC = 16;
+constexpr int PH = TH + 2, PW = TW + 2, NPOS = PH * PW;     // 340
+constexpr int XITEMS = 2 * NPOS;                            // (h, position) staging items: 680
+constexpr int XI = (XITEMS + NT - 1) / NT;                  // 3 per thread
+constexpr int XBUF_VEC = 2 * 2 * NPOS;                      // 16-byte vectors per X buffer: 1360
+constexpr int WSLAB_VEC = 2 * 3 * 2 * COT;                  // 16-byte vectors per (chunk, ky) slab: 768
+constexpr int WDMA = WSLAB_VEC / 64 / 4;                    // LDS-DMA wave-instructions per wave: 3
+constexpr int LDS_BYTES = (2 * XBUF_VEC + 3 * WSLAB_VEC) * 16;   // 80,384
+
+struct Conv3hArgs {
+  float* out;
+  const float* in;
+  const u32x4* wp;
+  const float* bias;
+  const float* shift;
+  const float* res1;
+  const float* res2;
+  float unscale;        // 2^-wshift
+  int shift_stride;
+  int B, Cin, Cout, H, W, Hin, Win;
+  int tiles_x, tiles_y, n_cot, n_chunks;
+};
+
+__device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned& lo) {
+  const _Float16 ah = (_Float16)a, bh = (_Float16)b;
+  const _Float16 al = (_Float16)(a - (float)ah), bl = (_Float16)(b - (float)bh);
+  f16x2 h = {ah, bh}, l = {al, bl};
+  hi = __builtin_bit_cast(unsigned, h);
+  lo = __builtin_bit_cast(unsigned, l);
+}
+
+struct Frags { f16x8 a[2][2]; f16x8 b[2][2]; };   // [piece][m] weights, [piece][r] input
+
+template <int MODE>
+__global__ __launch_bounds__(NT, 2) void k_conv3h(const Conv3hArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  u32x4* Xs = reinterpret_cast<u32x4*>(smem);                        // [buf][piece][h][pos]
+  u32x4* Ws = Xs + 2 * XBUF_VEC;                                     // [slot][piece][kx][h][co]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+
+  int bid = blockIdx.x;
+  const int cot = bid % a.n_cot; bid /= a.n_cot;
+  const int tx = bid % a.tiles_x; bid /= a.tiles_x;
+  const int ty = bid % a.tiles_y; bid /= a.tiles_y;
+  const int b = bid;
+  const int x0 = tx * TW, y0 = ty * TH;
+  const int HWin = a.Hin * a.Win;
+  const int n_steps = a.n_chunks * 3;
+
+  // ---- input staging plan: item e -> (h, position); addresses always in bounds ----
+  int xoff[XI];
+  unsigned xvalid = 0;
+#pragma unroll
+  for (int i = 0; i < XI; ++i) {
+    const int e = tid + NT * i;
+    const int h = e / NPOS;
+    const int pos = e - h * NPOS;
+    const int r = pos / PW;
+    const int col = pos - r * PW;
+    const int gy = y0 + r - 1, gx = x0 + col - 1;
+    const bool ok = (e < XITEMS) && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+    int off;
+    if (MODE == DS_LOAD_PLAIN) off = gy * a.Win + gx;
+    else if (MODE == DS_LOAD_MAXPOOL2) off = (2 * gy) * a.Win + 2 * gx;
+    else off = (gy >> 1) * a.Win + (gx >> 1);
+    xoff[i] = ok ? off : 0;
+    if (ok) xvalid |= (1u << i);
+  }
+  const float* in_b = a.in + (size_t)b * a.Cin * HWin;
+  const u32x4* wp = a.wp + (size_t)cot * n_steps * WSLAB_VEC;
+
+  float xr[XI][8];
+  int xnch = KC;
+  auto x_fetch = [&](int chunk) {                     // issue the global loads of one patch
+    const int cbase = chunk * KC;
+    const float* src = in_b + (size_t)cbase * HWin;
+    xnch = a.Cin - cbase < KC ? a.Cin - cbase : KC;   // uniform; < KC only for a ragged last chunk
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+      const int e = tid + NT * i;
+      const int h = (e / NPOS) & 1;
+      const float* p0 = src + xoff[i];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int c = 8 * h + k;
+        const float* p = p0 + (c < xnch ? c : 0) * HWin;       // channels past Cin read channel 0 (zeroed later)
+        if (MODE == DS_LOAD_MAXPOOL2) {
+          const float2 t0 = *reinterpret_cast<const float2*>(p);
+          const float2 t1 = *reinterpret_cast<const float2*>(p + a.Win);
+          xr[i][k] = fmaxf(fmaxf(t0.x, t0.y), fmaxf(t1.x, t1.y));
+        } else {
+          xr[i][k] = *p;
+        }
+      }
+      if (MODE == DS_LOAD_MAXPOOL2) __builtin_amdgcn_sched_barrier(0);   // one item at a time (registers)
+    }
+  };
+  auto x_store = [&](int buf) {                       // split to fp16 pieces, write the LDS image
+    u32x4* xb = Xs + buf * XBUF_VEC;
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+      const int e = tid + NT * i;
+      if (NT * (i + 1) <= XITEMS || e < XITEMS) {
+        const int h = e / NPOS;
+        const bool item_ok = (xvalid >> i) & 1u;
+        u32x4 qh, ql;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float v0 = (item_ok && 8 * h + 2 * k < xnch) ? xr[i][2 * k] : 0.f;
+          const float v1 = (item_ok && 8 * h + 2 * k + 1 < xnch) ? xr[i][2 * k + 1] : 0.f;
+          unsigned ph, pl;
+          split2(v0, v1, ph, pl);
+          qh[k] = ph; ql[k] = pl;
+        }
+        xb[e] = qh;                      // piece 0: [h][pos] with e = h*NPOS + pos
+        xb[2 * NPOS + e] = ql;           // piece 1
+      }
+    }
+  };
+  auto w_fetch = [&](int step, int slot) {            // LDS-DMA of slab `step` into ring slot (= step % 3)
+    const u32x4* src = wp + (size_t)step * WSLAB_VEC;
+    u32x4* dst = Ws + slot * WSLAB_VEC;
+#pragma unroll
+    for (int i = 0; i < WDMA; ++i) {
+      const int k = wv + 4 * i;                       // wave-uniform
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)(src + 64 * k + lane),
+          (__attribute__((address_space(3))) void*)(dst + 64 * k), 16, 0, 0);
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[m][r][q] = 0.f;
+
+  // operand fetch for (weight slot, X buffer, ky, kx)
+  auto frag_load = [&](Frags& f, int slot, int xbuf, int ky, int kx) {
+    const u32x4* wb = Ws + slot * WSLAB_VEC;
+    const u32x4* xb = Xs + xbuf * XBUF_VEC;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+        f.a[p][m] = *reinterpret_cast<const f16x8*>(&wb[((p * 3 + kx) * 2 + lh) * COT + 32 * m + li]);
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+        f.b[p][r] = *reinterpret_cast<const f16x8*>(&xb[(p * 2 + lh) * NPOS + (2 * wv + r + ky) * PW + li + kx]);
+    }
+  };
+  auto frag_mma = [&](const Frags& f) {               // lo*hi, hi*lo, hi*hi
+    constexpr int PA[3] = {1, 0, 0};
+    constexpr int PB[3] = {0, 1, 0};
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+          acc[m][r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[PA[t]][m], f.b[PB[t]][r], acc[m][r], 0, 0, 0);
+  };
+  auto reads_between_mfmas = [&]() {                  // 8 ds_read_b128 slotted behind the first 8 MFMAs
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+  };
+
+  // ---- prologue: patch 0, weight slabs 0 and 1 ----
+  x_fetch(0);
+  w_fetch(0, 0);
+  if (n_steps > 1) w_fetch(1, 1);
+  x_store(0);
+  __syncthreads();
+
+  Frags fA, fB;
+  frag_load(fA, 0, 0, 0, 0);
+
+  // One step = (chunk, ky).  `cur` holds the operands of kx = 0 on entry; on exit `oth` holds
+  // the operands of the NEXT step's kx = 0 (three blocks per step flip the roles).
+  // The ring slot of step g = 3*chunk + ky is g % 3 = ky and the X buffer is chunk & 1: both are
+  // compile-time constants at every call site below, so all LDS addresses are base + immediate.
+  auto step = [&](Frags& cur, Frags& oth, int chunk, int ky, int xbuf) {
+    const int g = chunk * 3 + ky;
+    const int slot = ky;
+    const bool more_chunks = chunk + 1 < a.n_chunks;
+    if (g + 2 < n_steps) w_fetch(g + 2, (ky + 2) % 3);         // lands a whole step ahead of its use
+    if (ky == 0 && more_chunks) x_fetch(chunk + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    frag_load(oth, slot, xbuf, ky, 1);
+    frag_mma(cur);
+    reads_between_mfmas();
+    __builtin_amdgcn_sched_barrier(0);
+    frag_load(cur, slot, xbuf, ky, 2);
+    frag_mma(oth);
+    reads_between_mfmas();
+    __builtin_amdgcn_sched_barrier(0);
+    if (g + 1 < n_steps) {                                     // next step's kx = 0 operands
+      const int nky = ky == 2 ? 0 : ky + 1;
+      frag_load(oth, nky, ky == 2 ? xbuf ^ 1 : xbuf, nky, 0);
+    }
+    frag_mma(cur);
+    if (g + 1 < n_steps) reads_between_mfmas();
+    __builtin_amdgcn_sched_barrier(0);
+    if (ky == 1 && more_chunks) x_store(xbuf ^ 1);             // published by this step's barrier
+    __syncthreads();
+  };
+
+  // Three blocks per step flip the operand-set roles, so the loop body is two chunks (six steps)
+  // of straight-line code -- a parity branch instead costs ~100 VGPRs in the allocator.
+  int chunk = 0;
+  for (; chunk + 1 < a.n_chunks; chunk += 2) {
+    step(fA, fB, chunk, 0, 0);
+    step(fB, fA, chunk, 1, 0);
+    step(fA, fB, chunk, 2, 0);
+    step(fB, fA, chunk + 1, 0, 1);
+    step(fA, fB, chunk + 1, 1, 1);
+    step(fB, fA, chunk + 1, 2, 1);
+  }
+  if (chunk < a.n_chunks) {
+    step(fA, fB, chunk, 0, 0);
+    step(fB, fA, chunk, 1, 0);
+    step(fA, fB, chunk, 2, 0);
+  }
+
+  // ---- epilogue: undo the weight scale, bias, time shift, residuals ----
+  const int gx = x0 + li;
+  const size_t plane = (size_t)a.H * a.W;
+  const bool has_bias = a.bias != nullptr, has_shift = a.shift != nullptr;
+  const bool has_r1 = a.res1 != nullptr, has_r2 = a.res2 != nullptr;
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    const int co0 = cot * COT + 32 * m + 4 * lh;               // register q adds (q&3) + 8*(q>>2) channels
+    float bv[16], sv[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int co = co0 + (q & 3) + 8 * (q >> 2);
+      const int cs = co < a.Cout ? co : 0;
+      bv[q] = has_bias ? a.bias[cs] : 0.f;
+      sv[q] = has_shift ? a.shift[(size_t)b * a.shift_stride + cs] : 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int gy = y0 + 2 * wv + r;
+      const bool rowok = gy < a.H && gx < a.W;
+      const size_t base = ((size_t)b * a.Cout + co0) * plane + (size_t)gy * a.W + gx;
+      float r1[16], r2[16];
+      if (has_r1) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int dq = (q & 3) + 8 * (q >> 2);
+          const bool ok = rowok && co0 + dq < a.Cout;
+          r1[q] = a.res1[ok ? base + (size_t)dq * plane : (size_t)0];
+        }
+      }
+      if (has_r2) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int dq = (q & 3) + 8 * (q >> 2);
+          const bool ok = rowok && co0 + dq < a.Cout;
+          r2[q] = a.res2[ok ? base + (size_t)dq * plane : (size_t)0];
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int dq = (q & 3) + 8 * (q >> 2);
+        float v = acc[m][r][q] * a.unscale;
+        if (has_bias) v = v + bv[q];
+        if (has_shift) v = v + sv[q];
+        if (has_r1) v = v + r1[q];
+        if (has_r2) v = v + r2[q];
+        if (rowok && co0 + dq < a.Cout) a.out[base + (size_t)dq * plane] = v;
+      }
+    }
+  }
+}
+
+// torch [Cout][Cin][3][3] fp32 (times 2^wshift) -> [cot][chunk][ky][piece][kx][h][co 64][ci 8] fp16
+__global__ void k_pack3h(_Float16* packed, const float* __restrict__ w, int Cout, int Cin, int n_chunks, float scale,
+                         size_t total) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  size_t t = i;
+  const int c8 = t % 8; t /= 8;
+  const int co64 = t % COT; t /= COT;
+  const int h = t % 2; t /= 2;
+  const int kx = t % 3; t /= 3;
+  const int piece = t % 2; t /= 2;
+  const int ky = t % 3; t /= 3;
+  const int chunk = t % n_chunks; t /= n_chunks;
+  const int cot = (int)t;
+  const int co = cot * COT + co64, ci = chunk * KC + 8 * h + c8;
+  float v = 0.f;
+  if (co < Cout && ci < Cin) v = w[((size_t)co * Cin + ci) * 9 + ky * 3 + kx] * scale;   // exact: power of two
+  const _Float16 hi = (_Float16)v;
+  const _Float16 lo = (_Float16)(v - (float)hi);
+  packed[i] = piece == 0 ? hi : lo;
+}
+
+template <int MODE>
+int launch_conv3h(const Conv3hArgs& a, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3h<MODE>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    if (e != hipSuccess) return ds::hip_fail(e, "hipFuncSetAttribute(conv3h)");
+    attr_set = true;
+  }
+  const long long blocks = (long long)a.B * a.tiles_y * a.tiles_x * a.n_cot;
+  DS_REQUIRE(blocks > 0 && blocks < (1ll << 31), DS_ERR_SHAPE, "ds_conv2d_h3: grid of %lld workgroups is out of range", blocks);
+  hipLaunchKernelGGL((k_conv3h<MODE>), dim3((unsigned)blocks), dim3(NT), LDS_BYTES, s, a);
+  DS_CHECK_LAUNCH("ds_conv2d_h3");
+  return DS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t ds_conv2d_h3_packed_bytes(int Cout, int Cin) {
+  if (Cout <= 0 || Cin <= 0) return 0;
+  const size_t n_cot = (Cout + COT - 1) / COT, n_chunks = (Cin + KC - 1) / KC;
+  return n_cot * n_chunks * 3 * (size_t)WSLAB_VEC * 16;
+}
+
+int ds_conv2d_h3_pack_weights(void* packed, const float* w, int Cout, int Cin, int wshift, void* stream) {
+  DS_REQUIRE(packed && w, DS_ERR_NULL, "ds_conv2d_h3_pack_weights: NULL pointer");
+  DS_REQUIRE(Cout > 0 && Cin > 0, DS_ERR_SHAPE, "ds_conv2d_h3_pack_weights: Cout=%d Cin=%d", Cout, Cin);
+  DS_REQUIRE(wshift >= -40 && wshift <= 40, DS_ERR_SHAPE, "ds_conv2d_h3_pack_weights: wshift %d out of range", wshift);
+  const int n_chunks = (Cin + KC - 1) / KC;
+  const size_t total = ds_conv2d_h3_packed_bytes(Cout, Cin) / 2;
+  hipLaunchKernelGGL(k_pack3h, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ds::as_stream(stream),
+                     reinterpret_cast<_Float16*>(packed), w, Cout, Cin, n_chunks, ldexpf(1.0f, wshift), total);
+  DS_CHECK_LAUNCH("ds_conv2d_h3_pack_weights");
+  return DS_OK;
+}
+
+int ds_conv2d_h3(float* out, const float* in, const void* w_packed, int wshift, const float* bias, const float* shift,
+                 int shift_stride, const float* res1, const float* res2, int B, int Cin, int Cout, int H, int W,
+                 int load_mode, void* stream) {
+  DS_REQUIRE(out && in && w_packed, DS_ERR_NULL, "ds_conv2d_h3: NULL pointer");
+  DS_REQUIRE(B >= 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, DS_ERR_SHAPE,
+             "ds_conv2d_h3: bad shape B=%d Cin=%d Cout=%d H=%d W=%d", B, Cin, Cout, H, W);
+  DS_REQUIRE(load_mode >= 0 && load_mode <= 2, DS_ERR_UNSUPPORTED, "ds_conv2d_h3: load_mode %d", load_mode);
+  DS_REQUIRE(load_mode != DS_LOAD_UPSAMPLE2 || (H % 2 == 0 && W % 2 == 0), DS_ERR_SHAPE,
+             "ds_conv2d_h3: UPSAMPLE2 needs even output H, W (got %d x %d)", H, W);
+  DS_REQUIRE(shift == nullptr || shift_stride == 0 || shift_stride >= Cout, DS_ERR_SHAPE,
+             "ds_conv2d_h3: shift_stride %d < Cout %d", shift_stride, Cout);
+  DS_REQUIRE((reinterpret_cast<uintptr_t>(w_packed) & 15u) == 0, DS_ERR_SHAPE, "ds_conv2d_h3: w_packed must be 16-byte aligned");
+  DS_REQUIRE(load_mode != DS_LOAD_MAXPOOL2 || (reinterpret_cast<uintptr_t>(in) & 7u) == 0, DS_ERR_SHAPE,
+             "ds_conv2d_h3: MAXPOOL2 input must be 8-byte aligned");
+  DS_REQUIRE(wshift >= -40 && wshift <= 40, DS_ERR_SHAPE, "ds_conv2d_h3: wshift %d out of range", wshift);
+  if (B == 0) return DS_OK;
+  Conv3hArgs a;
+  a.out = out; a.in = in; a.wp = reinterpret_cast<const u32x4*>(w_packed); a.bias = bias; a.shift = shift;
+  a.res1 = res1; a.res2 = res2; a.shift_stride = shift_stride;
+  a.unscale = ldexpf(1.0f, -wshift);
+  a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W;
+  a.Hin = load_mode == DS_LOAD_MAXPOOL2 ? 2 * H : (load_mode == DS_LOAD_UPSAMPLE2 ? H / 2 : H);
+  a.Win = load_mode == DS_LOAD_MAXPOOL2 ? 2 * W : (load_mode == DS_LOAD_UPSAMPLE2 ? W / 2 : W);
+  DS_REQUIRE((long long)Cin * a.Hin * a.Win < (1ll << 31), DS_ERR_SHAPE, "ds_conv2d_h3: per-sample input exceeds 2^31 floats");
+  a.tiles_x = (W + TW - 1) / TW; a.tiles_y = (H + TH - 1) / TH;
+  a.n_cot = (Cout + COT - 1) / COT;
+  a.n_chunks = (Cin + KC - 1) / KC;
+  hipStream_t s = ds::as_stream(stream);
+  if (load_mode == DS_LOAD_PLAIN) return launch_conv3h<DS_LOAD_PLAIN>(a, s);
+  if (load_mode == DS_LOAD_MAXPOOL2) return launch_conv3h<DS_LOAD_MAXPOOL2>(a, s);
+  return launch_conv3h<DS_LOAD_UPSAMPLE2>(a, s);
+}
+
+}  // extern "C"

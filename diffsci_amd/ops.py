@@ -137,35 +137,58 @@ def pack_conv_weight(w):
 
 
 class PackedConv:
-    """A convolution weight repacked for one of the two MFMA kernels."""
-    __slots__ = ("data", "Cout", "Cin", "ks", "x6")
+    """A convolution weight repacked for one of the MFMA kernels.
+    kind: "fp32" (exact-fp32 MFMA), "bf16x6" or "fp16x3" (fp32 emulated on the 16-bit matrix cores)."""
+    __slots__ = ("data", "Cout", "Cin", "ks", "kind", "wshift")
 
-    def __init__(self, data, Cout, Cin, ks, x6):
-        self.data, self.Cout, self.Cin, self.ks, self.x6 = data, Cout, Cin, ks, x6
+    def __init__(self, data, Cout, Cin, ks, kind, wshift=0):
+        self.data, self.Cout, self.Cin, self.ks, self.kind, self.wshift = data, Cout, Cin, ks, kind, wshift
+
+    @property
+    def x6(self):
+        return self.kind == "bf16x6"
+
+
+CONV_PRECISIONS = ("fp16x3", "bf16x6", "fp32")
 
 
 def pack_conv(w, precision="bf16x6"):
-    """precision "bf16x6": fp32-accurate split-bf16 MFMA (3x3 only); "fp32": exact-fp32 MFMA."""
+    """Repack a torch conv weight [Cout, Cin, k, k] (device, fp32).  3x3 kernels honour
+    `precision`; 1x1 kernels always use the exact-fp32 MFMA kernel."""
     require_device(w, "conv weight")
+    if precision not in CONV_PRECISIONS:
+        raise ValueError(f"unknown conv precision {precision!r}; choose from {CONV_PRECISIONS}")
     Cout, Cin, k, _ = w.shape
+    w = w.contiguous()
     if precision == "bf16x6" and k == 3:
         nbytes = N.lib().ds_conv2d_x6_packed_bytes(Cout, Cin)
         data = torch.empty(nbytes // 4, dtype=torch.float32, device=w.device)
-        N.check(N.lib().ds_conv2d_x6_pack_weights(data.data_ptr(), _p(w.contiguous()), Cout, Cin, _stream()),
+        N.check(N.lib().ds_conv2d_x6_pack_weights(data.data_ptr(), _p(w), Cout, Cin, _stream()),
                 "ds_conv2d_x6_pack_weights")
-        return PackedConv(data, Cout, Cin, 3, True)
-    if precision not in ("bf16x6", "fp32"):
-        raise ValueError(f"unknown conv precision {precision!r}")
-    return PackedConv(pack_conv_weight(w), Cout, Cin, k, False)
+        return PackedConv(data, Cout, Cin, 3, "bf16x6")
+    if precision == "fp16x3" and k == 3:
+        # per-layer power-of-two scale: largest weight lands in [2^13, 2^14), far inside fp16's
+        # range, and typical weights get normal (not subnormal) low pieces
+        wmax = float(w.abs().max())
+        wshift = 0
+        if wmax > 0 and wmax == wmax and wmax != float("inf"):
+            import math
+            wshift = max(-40, min(40, 13 - math.floor(math.log2(wmax))))
+        nbytes = N.lib().ds_conv2d_h3_packed_bytes(Cout, Cin)
+        data = torch.empty(nbytes // 4, dtype=torch.float32, device=w.device)
+        N.check(N.lib().ds_conv2d_h3_pack_weights(data.data_ptr(), _p(w), Cout, Cin, wshift, _stream()),
+                "ds_conv2d_h3_pack_weights")
+        return PackedConv(data, Cout, Cin, 3, "fp16x3", wshift)
+    return PackedConv(pack_conv_weight(w), Cout, Cin, k, "fp32")
 
 
 def conv(x, pw, **kw):
-    """Dispatch on the packing: ds_conv2d_x6 or ds_conv2d."""
-    return conv2d(x, pw.data, pw.Cout, pw.ks, x6=pw.x6, **kw)
+    """Dispatch on the packing: ds_conv2d_h3, ds_conv2d_x6 or ds_conv2d."""
+    return conv2d(x, pw.data, pw.Cout, pw.ks, kind=pw.kind, wshift=pw.wshift, **kw)
 
 
 def conv2d(x, w_packed, Cout, ks, bias=None, shift=None, res1=None, res2=None,
-           load_mode=N.DS_LOAD_PLAIN, out=None, x6=False):
+           load_mode=N.DS_LOAD_PLAIN, out=None, kind="fp32", wshift=0):
     """'same' zero-padded conv; x [B, Cin, Hin, Win]; shift [1 or B, Cout] or None."""
     B, Cin, Hin, Win = x.shape
     if load_mode == N.DS_LOAD_MAXPOOL2:
@@ -180,9 +203,10 @@ def conv2d(x, w_packed, Cout, ks, bias=None, shift=None, res1=None, res2=None,
         out = torch.empty((B, Cout, H, W), dtype=torch.float32, device=x.device)
     elif tuple(out.shape) != (B, Cout, H, W):
         raise ValueError(f"out has shape {tuple(out.shape)}, expected {(B, Cout, H, W)}")
-    expect = (N.lib().ds_conv2d_x6_packed_bytes(Cout, Cin) // 4 if x6
-              else N.lib().ds_conv2d_packed_floats(Cout, Cin, ks))
-    if w_packed.numel() != expect or (x6 and ks != 3):
+    expect = {"bf16x6": lambda: N.lib().ds_conv2d_x6_packed_bytes(Cout, Cin) // 4,
+              "fp16x3": lambda: N.lib().ds_conv2d_h3_packed_bytes(Cout, Cin) // 4,
+              "fp32": lambda: N.lib().ds_conv2d_packed_floats(Cout, Cin, ks)}[kind]()
+    if w_packed.numel() != expect or (kind != "fp32" and ks != 3):
         raise ValueError("packed weight size does not match (Cout, Cin, ks)")
     stride = 0
     if shift is not None:
@@ -194,7 +218,10 @@ def conv2d(x, w_packed, Cout, ks, bias=None, shift=None, res1=None, res2=None,
             raise ValueError("residual shape mismatch")
     if bias is not None and bias.numel() != Cout:
         raise ValueError("bias must have Cout entries")
-    if x6:
+    if kind == "fp16x3":
+        N.check(N.lib().ds_conv2d_h3(_p(out), _p(x), _p(w_packed), int(wshift), _p(bias), _p(shift), stride,
+                                     _p(res1), _p(res2), B, Cin, Cout, H, W, load_mode, _stream()), "ds_conv2d_h3")
+    elif kind == "bf16x6":
         N.check(N.lib().ds_conv2d_x6(_p(out), _p(x), _p(w_packed), _p(bias), _p(shift), stride, _p(res1),
                                      _p(res2), B, Cin, Cout, H, W, load_mode, _stream()), "ds_conv2d_x6")
     else:

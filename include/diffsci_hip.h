@@ -159,6 +159,18 @@ int ds_conv2d_x6(float* out, const float* in, const void* w_packed, const float*
                  const float* shift, int shift_stride, const float* res1, const float* res2,
                  int B, int Cin, int Cout, int H, int W, int load_mode, void* stream);
 
+/* The same convolution on the fp16 matrix cores ("fp16x3"): operands split into fp16 hi + lo
+ * pieces (22-23 significand bits kept), three piece products accumulated in fp32; weights are
+ * pre-scaled by 2^wshift at pack time (undone exactly in the epilogue) so that their low pieces
+ * stay normal; gfx950's fp16 MFMA honours subnormal inputs.  Representation error ~1e-7 relative,
+ * i.e. below the accumulation-order noise of an fp32 convolution.  Domain: |in| < 65504 (larger
+ * magnitudes give inf/nan).  Twice the rate of ds_conv2d_x6. */
+size_t ds_conv2d_h3_packed_bytes(int Cout, int Cin);
+int ds_conv2d_h3_pack_weights(void* packed, const float* w, int Cout, int Cin, int wshift, void* stream);
+int ds_conv2d_h3(float* out, const float* in, const void* w_packed, int wshift, const float* bias,
+                 const float* shift, int shift_stride, const float* res1, const float* res2,
+                 int B, int Cin, int Cout, int H, int W, int load_mode, void* stream);
+
 /* Single-head self-attention over L = H*W positions, channel-major operands:
  *   qkv [B, 3E, L] (rows 0..E-1 = Q^T, E..2E-1 = K^T, 2E..3E-1 = V^T), out [B, E, L] = (softmax(Q K^T / sqrt(E)) V)^T.
  * nn.MultiheadAttention(E, num_heads=1) core, attention.py:41-43,67.  E and L multiples of 32, E <= 256. */

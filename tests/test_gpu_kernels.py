@@ -164,7 +164,8 @@ def test_conv2d(dev, case):
 
 
 @pytest.mark.parametrize("case", [c for c in CONV_CASES if c[5] == 3] + [(2, 256, 256, 32, 32, 3, 0), (1, 40, 72, 20, 36, 3, 0)])
-def test_conv2d_bf16x6_is_fp32_accurate(dev, case):
+@pytest.mark.parametrize("prec", ["bf16x6", "fp16x3"])
+def test_conv2d_split_mfma_is_fp32_accurate(dev, case, prec):
     """The split-bf16 MFMA path: error against fp64 at the level of torch's own fp32 convolution
     (and no worse than the exact-fp32 MFMA kernel's bound) -- it is fp32 arithmetic, not bf16."""
     ops = _ops()
@@ -172,7 +173,7 @@ def test_conv2d_bf16x6_is_fp32_accurate(dev, case):
     g = torch.Generator().manual_seed(hash(case) % 1000 + 1)
     Hin, Win = (2 * H, 2 * W) if mode == 1 else ((H // 2, W // 2) if mode == 2 else (H, W))
     x = torch.randn(B, Cin, Hin, Win, generator=g) * 3.0
-    x[0, 0, 0, :4] = torch.tensor([1e-30, -3e-39, 65504.0, -1e4])         # tiny / denormal / large operands
+    x[0, 0, 0, :4] = torch.tensor([1e-30, -3e-39, 6.0e4, -1e4])           # tiny / denormal / large operands
     w = torch.randn(Cout, Cin, ks, ks, generator=g) / math.sqrt(Cin * ks * ks)
     bias = torch.randn(Cout, generator=g)
     shift = torch.randn(B, Cout, generator=g)
@@ -180,8 +181,8 @@ def test_conv2d_bf16x6_is_fp32_accurate(dev, case):
     src = F.max_pool2d(x, 2) if mode == 1 else (F.interpolate(x, scale_factor=2.0, mode="nearest") if mode == 2 else x)
     want = F.conv2d(src.double(), w.double(), bias.double(), padding="same") + shift.double()[:, :, None, None] + r1.double()
     ref32 = F.conv2d(src, w, bias, padding="same") + shift[:, :, None, None] + r1
-    pw = ops.pack_conv(w.to(dev), "bf16x6")
-    assert pw.x6
+    pw = ops.pack_conv(w.to(dev), prec)
+    assert pw.kind == prec
     got = ops.conv(x.to(dev), pw, bias=bias.to(dev), shift=shift.to(dev), res1=r1.to(dev), load_mode=mode).cpu()
     err = (got.double() - want).abs().max().item()
     err32 = (ref32.double() - want).abs().max().item()

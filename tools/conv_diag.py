@@ -16,7 +16,7 @@ def timeit(fn, reps=20):
     return e0.elapsed_time(e1) / reps
 
 def case(B, Cin, Cout, S, ks=3, mode=0, res=False, reps=20):
-    for prec in (("fp32", "bf16x6") if ks == 3 else ("fp32",)):
+    for prec in (("fp32", "bf16x6", "fp16x3") if ks == 3 else ("fp32",)):
         _case(B, Cin, Cout, S, ks, mode, res, reps, prec)
 
 
