@@ -25,10 +25,18 @@
 //   * operand fragments are double-buffered per kx block, their ds_read_b128 slotted between the
 //     MFMAs of the previous block.  One barrier per step, nothing waits on it.
 #include "ds_common.h"
+#include "ds_conv_epilogue.h"
+
+#ifdef DS_STAMP
+unsigned long long* g_stamps = nullptr;
+#define STAMP(slot) do { if (threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define STAMP(slot) do {} while (0)
+#endif
 
 namespace {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+using ds_epi::f32x16;
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
@@ -41,7 +49,8 @@ constexpr int XI = (XITEMS + NT - 1) / NT;                  // 3 per thread
 constexpr int XBUF_VEC = 2 * 2 * NPOS;                      // 16-byte vectors per X buffer: 1360
 constexpr int WSLAB_VEC = 2 * 3 * 2 * COT;                  // 16-byte vectors per (chunk, ky) slab: 768
 constexpr int WDMA = WSLAB_VEC / 64 / 4;                    // LDS-DMA wave-instructions per wave: 3
-constexpr int LDS_BYTES = (2 * XBUF_VEC + 3 * WSLAB_VEC) * 16;   // 80,384
+constexpr int STAGE_BYTES = (2 * XBUF_VEC + 3 * WSLAB_VEC) * 16;   // 80,384
+constexpr int LDS_BYTES = STAGE_BYTES + 128 * 4;              // + bias / shift of the channel tile = 80,896
 
 struct Conv3hArgs {
   float* out;
@@ -55,6 +64,9 @@ struct Conv3hArgs {
   int shift_stride;
   int B, Cin, Cout, H, W, Hin, Win;
   int tiles_x, tiles_y, n_cot, n_chunks;
+#ifdef DS_STAMP
+  unsigned long long* stamps;   // diagnostic build only (tools/conv3h_stamp.hip)
+#endif
 };
 
 __device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned& lo) {
@@ -72,6 +84,7 @@ __global__ __launch_bounds__(NT, 2) void k_conv3h(const Conv3hArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   u32x4* Xs = reinterpret_cast<u32x4*>(smem);                        // [buf][piece][h][pos]
   u32x4* Ws = Xs + 2 * XBUF_VEC;                                     // [slot][piece][kx][h][co]
+  float* BS = reinterpret_cast<float*>(smem + STAGE_BYTES);           // [2][64] bias, shift
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -86,6 +99,7 @@ __global__ __launch_bounds__(NT, 2) void k_conv3h(const Conv3hArgs a) {
   const int HWin = a.Hin * a.Win;
   const int n_steps = a.n_chunks * 3;
 
+  STAMP(0);
   // ---- input staging plan: item e -> (h, position); addresses always in bounds ----
   int xoff[XI];
   unsigned xvalid = 0;
@@ -211,11 +225,14 @@ __global__ __launch_bounds__(NT, 2) void k_conv3h(const Conv3hArgs a) {
   };
 
   // ---- prologue: patch 0, weight slabs 0 and 1 ----
+  ds_epi::load_bias_shift(BS, a.bias, a.shift, a.shift_stride, b, cot * COT, a.Cout);
   x_fetch(0);
   w_fetch(0, 0);
   if (n_steps > 1) w_fetch(1, 1);
+  STAMP(1);
   x_store(0);
   __syncthreads();
+  STAMP(2);
 
   Frags fA, fB;
   frag_load(fA, 0, 0, 0, 0);
@@ -267,56 +284,23 @@ __global__ __launch_bounds__(NT, 2) void k_conv3h(const Conv3hArgs a) {
     step(fA, fB, chunk, 2, 0);
   }
 
-  // ---- epilogue: undo the weight scale, bias, time shift, residuals ----
-  const int gx = x0 + li;
-  const size_t plane = (size_t)a.H * a.W;
-  const bool has_bias = a.bias != nullptr, has_shift = a.shift != nullptr;
-  const bool has_r1 = a.res1 != nullptr, has_r2 = a.res2 != nullptr;
-#pragma unroll
-  for (int m = 0; m < 2; ++m) {
-    const int co0 = cot * COT + 32 * m + 4 * lh;               // register q adds (q&3) + 8*(q>>2) channels
-    float bv[16], sv[16];
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const int co = co0 + (q & 3) + 8 * (q >> 2);
-      const int cs = co < a.Cout ? co : 0;
-      bv[q] = has_bias ? a.bias[cs] : 0.f;
-      sv[q] = has_shift ? a.shift[(size_t)b * a.shift_stride + cs] : 0.f;
-    }
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      const int gy = y0 + 2 * wv + r;
-      const bool rowok = gy < a.H && gx < a.W;
-      const size_t base = ((size_t)b * a.Cout + co0) * plane + (size_t)gy * a.W + gx;
-      float r1[16], r2[16];
-      if (has_r1) {
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          const int dq = (q & 3) + 8 * (q >> 2);
-          const bool ok = rowok && co0 + dq < a.Cout;
-          r1[q] = a.res1[ok ? base + (size_t)dq * plane : (size_t)0];
-        }
-      }
-      if (has_r2) {
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          const int dq = (q & 3) + 8 * (q >> 2);
-          const bool ok = rowok && co0 + dq < a.Cout;
-          r2[q] = a.res2[ok ? base + (size_t)dq * plane : (size_t)0];
-        }
-      }
-#pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const int dq = (q & 3) + 8 * (q >> 2);
-        float v = acc[m][r][q] * a.unscale;
-        if (has_bias) v = v + bv[q];
-        if (has_shift) v = v + sv[q];
-        if (has_r1) v = v + r1[q];
-        if (has_r2) v = v + r2[q];
-        if (rowok && co0 + dq < a.Cout) a.out[base + (size_t)dq * plane] = v;
-      }
-    }
+  STAMP(3);
+  // ---- epilogue (ds_conv_epilogue.h): LDS transpose -> 16-byte stores.  The staging buffers are
+  //      dead after the last step's barrier; each wave takes a private 16 KiB of them. ----
+  {
+    ds_epi::Args e;
+    e.out = a.out; e.bias = a.bias; e.shift = a.shift; e.res1 = a.res1; e.res2 = a.res2;
+    e.unscale = a.unscale; e.shift_stride = a.shift_stride;
+    e.b = b; e.co_base = cot * COT; e.y0 = y0 + 2 * wv; e.x0 = x0;
+    e.Cout = a.Cout; e.H = a.H; e.W = a.W;
+    float* tile = reinterpret_cast<float*>(smem) + wv * (64 * 2 * 32);
+    ds_epi::store_tile(acc, tile, BS, e);
   }
+#ifdef DS_STAMP
+  STAMP(4);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  STAMP(5);
+#endif
 }
 
 // torch [Cout][Cin][3][3] fp32 (times 2^wshift) -> [cot][chunk][ky][piece][kx][h][co 64][ci 8] fp16
@@ -406,6 +390,9 @@ int ds_conv2d_h3(float* out, const float* in, const void* w_packed, int wshift, 
   a.tiles_x = (W + TW - 1) / TW; a.tiles_y = (H + TH - 1) / TH;
   a.n_cot = (Cout + COT - 1) / COT;
   a.n_chunks = (Cin + KC - 1) / KC;
+#ifdef DS_STAMP
+  a.stamps = g_stamps;
+#endif
   hipStream_t s = ds::as_stream(stream);
   if (load_mode == DS_LOAD_PLAIN) return launch_conv3h<DS_LOAD_PLAIN>(a, s);
   if (load_mode == DS_LOAD_MAXPOOL2) return launch_conv3h<DS_LOAD_MAXPOOL2>(a, s);

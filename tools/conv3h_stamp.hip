@@ -1,0 +1,33 @@
+// Diagnostic: where does a fp16x3 conv workgroup spend its life?  (s_memrealtime stamps, 100 MHz)
+#define DS_STAMP 1
+#include "../diffsci_amd/csrc/ds_api.hip"
+#include "../diffsci_amd/csrc/ds_conv3h.hip"
+#include <vector>
+#include <algorithm>
+int main(int argc, char** argv) {
+  int B = argc > 1 ? atoi(argv[1]) : 64, Cin = argc > 2 ? atoi(argv[2]) : 64, Cout = 64, S = 128;
+  size_t nin = (size_t)B * Cin * S * S, nout = (size_t)B * Cout * S * S;
+  float *in, *out, *w; void* wp;
+  hipMalloc(&in, nin * 4); hipMalloc(&out, nout * 4); hipMalloc(&w, (size_t)Cout * Cin * 9 * 4);
+  hipMemset(in, 0, nin * 4); hipMemset(w, 0, (size_t)Cout * Cin * 36);
+  hipMalloc(&wp, ds_conv2d_h3_packed_bytes(Cout, Cin));
+  ds_conv2d_h3_pack_weights(wp, w, Cout, Cin, 0, nullptr);
+  int blocks = B * (S / 8) * (S / 32);
+  hipMalloc(&g_stamps, (size_t)blocks * 8 * 8);
+  for (int it = 0; it < 3; ++it) ds_conv2d_h3(out, in, wp, 0, nullptr, nullptr, 0, nullptr, nullptr, B, Cin, Cout, S, S, 0, nullptr);
+  hipDeviceSynchronize();
+  std::vector<unsigned long long> h((size_t)blocks * 8);
+  hipMemcpy(h.data(), g_stamps, h.size() * 8, hipMemcpyDeviceToHost);
+  unsigned long long t0 = ~0ull, t1 = 0;
+  for (int b = 0; b < blocks; ++b) { t0 = std::min(t0, h[b * 8]); t1 = std::max(t1, h[b * 8 + 5]); }
+  double seg[5] = {0, 0, 0, 0, 0};
+  for (int b = 0; b < blocks; ++b) for (int k = 0; k < 5; ++k) seg[k] += (double)(h[b * 8 + k + 1] - h[b * 8 + k]);
+  printf("B=%d Cin=%d blocks=%d: kernel span %.1f us\n", B, Cin, blocks, (t1 - t0) / 100.0);
+  const char* names[5] = {"plan+issue loads", "x_store+barrier (load latency)", "main loop", "epilogue issue", "store drain"};
+  for (int k = 0; k < 5; ++k) printf("  %-32s avg %.2f us\n", names[k], seg[k] / blocks / 100.0);
+  // start-time distribution
+  std::vector<double> st; for (int b = 0; b < blocks; ++b) st.push_back((h[b * 8] - t0) / 100.0);
+  std::sort(st.begin(), st.end());
+  printf("  WG start times: p0 %.1f p25 %.1f p50 %.1f p75 %.1f p100 %.1f us\n", st[0], st[blocks / 4], st[blocks / 2], st[3 * blocks / 4], st[blocks - 1]);
+  return 0;
+}
