@@ -57,6 +57,8 @@ def parse():
     ap.add_argument("--channels", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--roofline-only", action="store_true",
+                    help="only run the dominant kernel's launch set (for rocprofv3 --pmc passes)")
     ap.add_argument("--precision", default="fp16x3", choices=["fp16x3", "bf16x6", "fp32"],
                     help="3x3 conv arithmetic: fp32 emulated on the 16-bit matrix cores (fp16 hi/lo split, 3 products; "
                          "bf16 3-way split, 6 products) or exact-fp32 MFMA")
@@ -76,7 +78,7 @@ def build_module(args, dev):
     return module, sd, cfg
 
 
-def dominant_kernel_roofline(module, args, dev):
+def dominant_kernel_roofline(module, args, dev, reps=40):
     """Average launch duration of the dominant kernel (k_conv<3, PLAIN>: the 3x3 convolutions of
     the residual blocks, convin and convout) over one network evaluation's worth of its launches,
     timed with events on the launch stream, against its algorithmic FLOPs."""
@@ -114,7 +116,7 @@ def dominant_kernel_roofline(module, args, dev):
                        res1=buf(cout, s, "res") if id(m) in conv2s else None, out=outs[(cout, s)])
     run()
     torch.cuda.synchronize()
-    reps = 40       # ~1 s of sustained launches: short bursts run at a higher clock than the real loop
+    # default reps: ~0.3-1 s of sustained launches (short bursts run at a higher clock than the real loop)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     for _ in range(5):
         run()
@@ -130,9 +132,18 @@ def dominant_kernel_roofline(module, args, dev):
         "bf16x6": ("k_conv6<PLAIN> (ds_conv2d_x6, 3x3, fp32 via 6 bf16 MFMA products)", BF16_PEAK_TFLOPS / 6.0),
         "fp32": ("k_conv<3,PLAIN> (ds_conv2d 3x3, exact-fp32 MFMA)", MFMA_F32_PEAK_TFLOPS)}[net.conv_precision]
     achieved = flops / (ms * 1e-3) / 1e12
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r01_dominant_kernel_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))
+            if tj.get("precision") == net.conv_precision:
+                traffic = tj.get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
     return {"bound": "mfma", "kernel": kname, "achieved": round(achieved, 2),
             "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-            "traffic": None, "launches_per_eval": n, "avg_launch_ms": round(ms / n, 4),
+            "traffic": traffic, "launches_per_eval": n, "avg_launch_ms": round(ms / n, 4),
             "flop_per_launch_avg": flops / n}
 
 
@@ -211,6 +222,9 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
     from diffsci_amd.parallel import gather_samples, global_white_noise, shard_rows
     module, sd, cfg = build_module(args, dev)
+    if args.roofline_only:
+        print(json.dumps(dominant_kernel_roofline(module, args, dev, reps=2)), flush=True)
+        return
     shape = [1, args.size, args.size]
     B = args.batch
     lo, hi = shard_rows(B * world, world, rank)

@@ -200,6 +200,26 @@ def test_graph_and_eager_identical(M, net8, dev):
     assert torch.equal(a, b) and torch.equal(b, c)
 
 
+@pytest.mark.parametrize("precision", ["fp16x3", "bf16x6", "fp32"])
+def test_conv_precision_modes_all_meet_the_tolerance(M, dev, grids, precision):
+    """The three convolution arithmetic modes (fp16x3 default, bf16x6, exact fp32 MFMA) are all
+    fp32-accurate: same trajectory tolerance against the reference."""
+    v, _ = load("punetg8_traj")
+    _, sd = load("punetg8_forward")
+    net = M.PUNetG(M.PUNetGConfig(model_channels=8))
+    net.load_state_dict(sd)
+    net.conv_precision = precision
+    module = M.KarrasModule(net, M.KarrasModuleConfig.from_edm()).to(dev)
+    _pin_grid(module, grids)
+    o = module.propagate_white_noise(v["white_noise"].to(dev), nsteps=18).cpu()
+    assert rel_l2(o, v["out_heun_N18_f32"]) < REL
+    ref_err = rel_l2(v["out_heun_N18_f32"], v["out_heun_N18_f64"])
+    assert rel_l2(o, v["out_heun_N18_f64"]) < max(4 * ref_err, 2e-6)
+    with pytest.raises(ValueError, match="unknown conv precision"):
+        net.conv_precision = "fp8"
+        net.packed_weights()
+
+
 def test_euler_maruyama_through_module(M, net8, dev, grids):
     v, _ = load("punetg8_traj")
     module = M.KarrasModule(net8, M.KarrasModuleConfig.from_edm())
