@@ -51,6 +51,7 @@ _PROTOS = {
     "ds_conv2d_h3_pack_weights": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     "ds_conv2d_h3": (c_int, [_P, _P, _P, c_int, _P, _P, c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "ds_attention": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
+    "ds_attention_h3": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     "ds_linear": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "ds_fourier_features": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P]),
     "ds_add": (c_int, [_P, _P, _P, c_size_t, _P]),

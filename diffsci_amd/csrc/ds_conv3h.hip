@@ -69,11 +69,18 @@ struct Conv3hArgs {
 #endif
 };
 
+// Exact-sum split of two fp32 values into packed fp16 hi / lo pairs.  The low piece MUST be the
+// remainder against the very same rounded high piece that is stored: hipcc otherwise rounds the
+// stored pair with v_cvt_pk_f16_f32 and the remainder's reference with v_cvt_f16_f32, and the two
+// disagree on exact ties (measured on gfx950: hi + lo off by one fp16 ulp, 2^-11 relative, for one
+// value in ~8000).  Deriving the reference from the packed bits removes the second rounding.
 __device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned& lo) {
-  const _Float16 ah = (_Float16)a, bh = (_Float16)b;
-  const _Float16 al = (_Float16)(a - (float)ah), bl = (_Float16)(b - (float)bh);
-  f16x2 h = {ah, bh}, l = {al, bl};
-  hi = __builtin_bit_cast(unsigned, h);
+  f16x2 h = {(_Float16)a, (_Float16)b};
+  unsigned hp = __builtin_bit_cast(unsigned, h);
+  asm volatile("" : "+v"(hp));                       // opaque: both uses below see these exact bits
+  const f16x2 hq = __builtin_bit_cast(f16x2, hp);
+  f16x2 l = {(_Float16)(a - (float)hq[0]), (_Float16)(b - (float)hq[1])};
+  hi = hp;
   lo = __builtin_bit_cast(unsigned, l);
 }
 

@@ -315,7 +315,8 @@ class PUNetG(torch.nn.Module):
         L = Hh * Ww
         m = att.mhattn
         qkv = ops.conv(x, pk[(id(att), "in")], bias=m.in_proj_bias, out=ws.take((B, 3 * E, Hh, Ww), x.device))
-        o = ops.attention(qkv.view(B, 3 * E, L), E, out=ws.take((B, E, L), x.device))
+        o = ops.attention(qkv.view(B, 3 * E, L), E, out=ws.take((B, E, L), x.device),
+                          precision=self.conv_precision)
         res1 = x if self.config.attn_residual else None
         y = ops.conv(o.view(B, E, Hh, Ww), pk[(id(att), "out")], bias=m.out_proj.bias,
                      res1=res1, res2=res2, out=ws.take(x.shape, x.device))

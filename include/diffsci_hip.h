@@ -176,6 +176,11 @@ int ds_conv2d_h3(float* out, const float* in, const void* w_packed, int wshift, 
  * nn.MultiheadAttention(E, num_heads=1) core, attention.py:41-43,67.  E and L multiples of 32, E <= 256. */
 int ds_attention(float* out, const float* qkv, int B, int E, int L, void* stream);
 
+/* The same attention with both matrix products on the fp16 matrix cores in the fp16x3 scheme of
+ * ds_conv2d_h3 (operands split into fp16 hi + lo, three products, fp32 accumulation and fp32
+ * softmax statistics): fp32-level accuracy for |q|, |k|, |v| < 65504. Same layouts and limits. */
+int ds_attention_h3(float* out, const float* qkv, int B, int E, int L, void* stream);
+
 /* y[m, n] = act(sum_k x[m,k]*w[n,k] + b[n]); act 0 none, 1 SiLU, 2 ReLU.  torch Linear layout.
  * ResnetTimeBlock (commonlayers.py:516-522) and MLPUncond (mlp.py:30-37). b may be NULL. */
 int ds_linear(float* y, const float* x, const float* w, const float* b, int M, int K, int N, int act, void* stream);
