@@ -54,6 +54,11 @@ _PROTOS = {
     "ds_attention_h3": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     "ds_linear": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "ds_fourier_features": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P]),
+    "ds_gnorm1_workspace_bytes": (c_size_t, [c_int]),
+    "ds_gnorm1_stats": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_float, c_int, _P]),
+    "ds_gnorm1_apply": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "ds_concat2": (c_int, [_P, _P, _P, c_int, c_size_t, c_size_t, _P]),
+    "ds_add_act": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "ds_add": (c_int, [_P, _P, _P, c_size_t, _P]),
     "ds_graph_begin_capture": (c_int, [_P]),
     "ds_graph_end_capture": (c_int, [_P, POINTER(_P), POINTER(c_int)]),

@@ -123,6 +123,63 @@ def inorm_silu(x, w, b, kind, eps=1e-5, out=None):
     return out
 
 
+def gnorm1_stats(x, kind, eps=1e-5, stats=None, workspace=None):
+    """Per-sample (mean, rstd) [kind 0] or (0, rms denominator) [kind 1] over (C, H, W)."""
+    B, C = x.shape[0], x.shape[1]
+    HW = x.numel() // max(B * C, 1)
+    if stats is None:
+        stats = torch.empty((B, 2), dtype=torch.float32, device=x.device)
+    need = N.lib().ds_gnorm1_workspace_bytes(B)
+    if workspace is None:
+        workspace = torch.empty(need // 4, dtype=torch.float32, device=x.device)
+    elif workspace.numel() * 4 < need:
+        raise ValueError("gnorm1 workspace too small")
+    N.check(N.lib().ds_gnorm1_stats(_p(stats), _p(workspace), _p(x), B, C, HW, float(eps), int(kind), _stream()),
+            "ds_gnorm1_stats")
+    return stats
+
+
+def gnorm1_apply(x, stats, w, b, kind, pool=False, film=None, out=None):
+    """kind 0: SiLU(GroupNorm1(x)); kind 1: SiLU(FiLM(GroupRMSNorm1(x))); kind 2: identity;
+    then optional 2x2 average pooling.  film: [1 or B, 2C] rows of embed_linear(te)."""
+    B, C, H, W = x.shape
+    Ho, Wo = (H // 2, W // 2) if pool else (H, W)
+    if out is None:
+        out = torch.empty((B, C, Ho, Wo), dtype=torch.float32, device=x.device)
+    f1 = f2 = None
+    stride = 0
+    if kind == 1:
+        if film is None or film.dim() != 2 or film.shape[1] != 2 * C or film.shape[0] not in (1, B):
+            raise ValueError("film must be [1 or B, 2C]")
+        require_device(film, "film")
+        stride = 0 if film.shape[0] == 1 else 2 * C
+        f1, f2 = film.data_ptr(), film.data_ptr() + 4 * C
+    N.check(N.lib().ds_gnorm1_apply(_p(out), _p(x), _p(stats), _p(w), _p(b), f1, f2, stride, B, C, H, W, int(kind),
+                                    1 if pool else 0, _stream()), "ds_gnorm1_apply")
+    return out
+
+
+def concat2(a, b, out=None):
+    """cat([a, b], dim=1) for [B, C, H, W] tensors."""
+    B = a.shape[0]
+    na, nb = a.numel() // max(B, 1), b.numel() // max(B, 1)
+    if out is None:
+        out = torch.empty((B, a.shape[1] + b.shape[1]) + tuple(a.shape[2:]), dtype=torch.float32, device=a.device)
+    N.check(N.lib().ds_concat2(_p(out), _p(a), _p(b), B, na, nb, _stream()), "ds_concat2")
+    return out
+
+
+def add_act(a, add=None, act=0, out=None):
+    M, Nn = a.shape
+    out = torch.empty_like(a) if out is None else out
+    rows = 0
+    if add is not None:
+        add = add.reshape(-1, Nn)
+        rows = add.shape[0]
+    N.check(N.lib().ds_add_act(_p(out), _p(a), _p(add), rows, M, Nn, int(act), _stream()), "ds_add_act")
+    return out
+
+
 def pack_conv_weight(w):
     """torch [Cout, Cin, k, k] (device, fp32) -> packed MFMA operand stream."""
     require_device(w, "conv weight")

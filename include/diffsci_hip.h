@@ -191,6 +191,36 @@ int ds_linear(float* y, const float* x, const float* w, const float* b, int M, i
 int ds_fourier_features(float* out, const float* t, const float* W, const float* add, int add_rows,
                         int M, int half, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * ADM score-network layers (adm.py) not shared with PUNetG.
+ * ---------------------------------------------------------------------------------- */
+
+/* Per-sample statistics over the whole (C, H, W) volume: GroupNorm(num_groups=1) / GroupRMSNorm(1, C),
+ * adm.py:385-406.  stats[2b] = mean, stats[2b+1] = 1/sqrt(var_biased+eps) (kind 0), or
+ * stats[2b] = 0, stats[2b+1] = sqrt(mean(x^2)+eps) (kind 1).  x: [B, C, HW].  workspace: device
+ * scratch of ds_gnorm1_workspace_bytes(B) bytes (fp64 partial sums of the two-phase reduction). */
+size_t ds_gnorm1_workspace_bytes(int B);
+int ds_gnorm1_stats(float* stats, void* workspace, const float* x, int B, int C, int HW, float eps, int kind,
+                    void* stream);
+
+/* One elementwise pass fusing the normalisation with what follows it in ADMBaseBlock (adm.py:306-343):
+ *   kind 0: SiLU((x-mean)*rstd*w[c]+b[c])                        norm1 -> act          (adm.py:327-328)
+ *   kind 1: SiLU((x/denom*w[c]+b[c])*scale[b,c] + shift[b,c])    norm2 -> FiLM -> act  (adm.py:331,307,335)
+ *   kind 2: x                                                    residual-branch input (adm.py:345-347)
+ * then, pool = 1, the block's AvgPool2d(2) (adm.py:316-319).  x [B,C,H,W] -> out [B,C,H(/2),W(/2)].
+ * scale/shift: rows of embed_linear(te), film_stride floats between samples (0 = shared row). */
+int ds_gnorm1_apply(float* out, const float* x, const float* stats, const float* w, const float* b,
+                    const float* film_scale, const float* film_shift, int film_stride,
+                    int B, int C, int H, int W, int kind, int pool, void* stream);
+
+/* out[b] = cat(a[b], b[b]) along channels (na, nb floats per sample): the decoder's skip concat,
+ * adm.py:764-766. */
+int ds_concat2(float* out, const float* a, const float* b, int B, size_t na, size_t nb, void* stream);
+
+/* out[m,n] = act(a[m,n] + add[m or 0, n]); act as in ds_linear.  ADMTimeEmbedding's "te + ye" and
+ * final SiLU (adm.py:1050-1052). */
+int ds_add_act(float* out, const float* a, const float* add, int add_rows, int M, int N, int act, void* stream);
+
 /* out = a + b (n floats). */
 int ds_add(float* out, const float* a, const float* b, size_t n, void* stream);
 

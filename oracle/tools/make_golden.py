@@ -215,7 +215,49 @@ def punetg():
     npz("punetg8_cfg", **arrs)
 
 
+# ---------------------------------------------------------------- 4. ADM (config 3 family, tiny)
+def adm():
+    for skip in ("concat", "add"):
+        torch.manual_seed(10)
+        cfg = M.nets.ADMConfig(model_channels=8, time_embed_dim=8, output_embed_dim=16,
+                               skip_integration_type=skip)
+        net = M.nets.ADM(cfg).eval()
+        with torch.no_grad():
+            for k, v in net.state_dict().items():
+                if "norm" in k or k.endswith("in_proj_bias") or k.endswith("out_proj.bias"):
+                    v.add_(0.25 * torch.randn_like(v))
+        sd = net.state_dict()
+        torch.manual_seed(11)
+        x = torch.randn(2, 1, 32, 32)
+        t = torch.tensor([0.4, -1.1])
+        arrs = dict(sd_arrays(sd), x=x, t=t)
+        with torch.inference_mode():
+            arrs["out_f32"] = net(x, t)
+            te = net.time_embedding(t, None)
+            arrs["te"] = te
+            h = net.input_layer(x)
+            arrs["stem"] = h
+            blk = net.encoder.layers[0].input_blocks[0]
+            arrs["enc00"] = blk(h, te)
+            blk = net.encoder.layers[0].input_blocks[1]
+            arrs["enc01_down"] = blk(arrs["enc00"], te)
+        net64 = M.nets.ADM(cfg).double()
+        net64.load_state_dict({k: v.double() for k, v in sd.items()})
+        with torch.inference_mode():
+            arrs["out_f64"] = net64.eval()(x.double(), t.double())
+        module = M.KarrasModule(net, M.KarrasModuleConfig.from_edm()).eval()
+        torch.manual_seed(12)
+        wn = torch.randn(2, 1, 32, 32)
+        arrs["white_noise"] = wn
+        arrs["out_heun_N6_f32"] = module.propagate_white_noise(wn, nsteps=6)
+        with RandnRecorder() as rec:
+            arrs["hist_karras_N4_f32"] = module.propagate_white_noise(wn, nsteps=4, record_history=True,
+                                                                      integrator="karras")
+        arrs["eps_karras_N4"] = torch.stack(rec.draws)
+        npz(f"adm8_{skip}", **arrs)
+
+
 if __name__ == "__main__":
-    schedule()
-    toy()
-    punetg()
+    which = sys.argv[1:] or ["schedule", "toy", "punetg", "adm"]
+    for name in which:
+        globals()[name]()

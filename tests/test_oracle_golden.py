@@ -184,3 +184,30 @@ def test_punetg_cfg_guidance():
     assert_exact_or_rel(o, v["out_cond_g1_N4_f32"], "out_cond_g1_N4_f32", 2e-6)
     o = K.propagate_white_noise(net, wn, 4, y=y, guidance=0.0, conditional=True)
     assert_exact_or_rel(o, v["out_cond_g0_N4_f32"], "out_cond_g0_N4_f32", 2e-6)
+
+
+@pytest.mark.parametrize("skip", ["concat", "add"])
+def test_adm_forward_and_trajectories(skip):
+    from oracle import adm_ref
+    v, sd = load(f"adm8_{skip}")
+    cfg = adm_ref.default_config(model_channels=8, time_embed_dim=8, output_embed_dim=16,
+                                 skip_integration_type=skip)
+    with torch.inference_mode():
+        x, t = v["x"], v["t"]
+        te = adm_ref.time_embedding(sd, t)
+        assert_exact_or_ulp(te, v["te"], "ADMTimeEmbedding")
+        b0 = adm_ref.block(sd, "encoder.layers.0.input_blocks.0.", v["stem"], te)
+        assert_exact_or_rel(b0, v["enc00"], "encoder block", 2e-6)
+        b1 = adm_ref.block(sd, "encoder.layers.0.input_blocks.1.", v["enc00"], te, sample="down")
+        assert_exact_or_rel(b1, v["enc01_down"], "encoder block + avg-pool", 2e-6)
+        out = adm_ref.adm_forward(sd, cfg, x, t)
+        assert_exact_or_rel(out, v["out_f32"], "out_f32", 2e-6)
+        sd64 = {k: w.double() for k, w in sd.items()}
+        out64 = adm_ref.adm_forward(sd64, cfg, x.double(), t.double())
+        assert_exact_or_rel(out64, v["out_f64"], "out_f64", 1e-13)
+        net = adm_ref.make_net(sd, cfg)
+        o = K.propagate_white_noise(net, v["white_noise"], 6)
+        assert_exact_or_rel(o, v["out_heun_N6_f32"], "heun N6", 2e-6)
+        h = K.propagate_white_noise(net, v["white_noise"], 4, integrator="karras", record_history=True,
+                                    eps=v["eps_karras_N4"])
+        assert_exact_or_rel(h, v["hist_karras_N4_f32"], "karras N4", 2e-6)
