@@ -26,13 +26,18 @@ constexpr int NT = 256;
 constexpr int KB = 32;       // keys per tile
 constexpr int VSTR = KB + 1; // padded V^T row
 
-template <int ET>
+// ET = E/32; ETO = output channels per workgroup / 32.  ETO < ET (E > 256, where Q^T alone takes
+// half the register file) splits the output channels over blockIdx.z; every such workgroup
+// recomputes the full-E scores, which is cheap at the small L these wide bottlenecks have.
+template <int ET, int ETO>
 __global__ __launch_bounds__(NT) void k_attn(float* out, const float* __restrict__ qkv, int L, float scale) {
   constexpr int E = 32 * ET;
-  constexpr int NLD = (E * KB / 4) / NT;   // float4 per thread per operand tile (E*8/256 = ET)
+  constexpr int EO = 32 * ETO;
+  constexpr int NLD = (E * KB / 4) / NT;   // float4 per thread per K^T tile (E*8/256 = ET)
+  constexpr int NLV = (EO * KB / 4) / NT;  // ... per V^T tile
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Ks = smem;              // [E][32]
-  float* Vs = smem + E * KB;     // [E][33]
+  float* Vs = smem + E * KB;     // [EO][33]
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
   const int b = blockIdx.y;
@@ -40,35 +45,41 @@ __global__ __launch_bounds__(NT) void k_attn(float* out, const float* __restrict
   const bool active = q0 < L;
   const float* Qt = qkv + (size_t)b * 3 * E * L;
   const float* Kt = Qt + (size_t)E * L;
-  const float* Vt = Kt + (size_t)E * L;
+  const float* Vt = Kt + (size_t)E * L + (size_t)blockIdx.z * EO * L;
 
   float qreg[E / 2];
 #pragma unroll
   for (int s = 0; s < E / 2; ++s) qreg[s] = active ? Qt[(size_t)(2 * s + lh) * L + q0 + li] * scale : 0.f;
 
-  f32x16 O[ET];
+  f32x16 O[ETO];
 #pragma unroll
-  for (int t = 0; t < ET; ++t)
+  for (int t = 0; t < ETO; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) O[t][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
 
-  f32x4 kr[NLD], vr[NLD];
+  f32x4 kr[NLD], vr[NLV];
   auto tile_load = [&](int key0) {
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
       const int e = tid + NT * i;          // float4 index in [E][8]
       const int d = e >> 3, c4 = e & 7;
       kr[i] = *reinterpret_cast<const f32x4*>(Kt + (size_t)d * L + key0 + 4 * c4);
+    }
+#pragma unroll
+    for (int i = 0; i < NLV; ++i) {
+      const int e = tid + NT * i;
+      const int d = e >> 3, c4 = e & 7;
       vr[i] = *reinterpret_cast<const f32x4*>(Vt + (size_t)d * L + key0 + 4 * c4);
     }
   };
   auto tile_store = [&]() {
 #pragma unroll
-    for (int i = 0; i < NLD; ++i) {
+    for (int i = 0; i < NLD; ++i) reinterpret_cast<f32x4*>(Ks)[tid + NT * i] = kr[i];
+#pragma unroll
+    for (int i = 0; i < NLV; ++i) {
       const int e = tid + NT * i;
       const int d = e >> 3, c4 = e & 7;
-      reinterpret_cast<f32x4*>(Ks)[e] = kr[i];
       float* vd = Vs + d * VSTR + 4 * c4;
       vd[0] = vr[i].x; vd[1] = vr[i].y; vd[2] = vr[i].z; vd[3] = vr[i].w;
     }
@@ -104,11 +115,11 @@ __global__ __launch_bounds__(NT) void k_attn(float* out, const float* __restrict
       l_run = l_run * alpha + rs;
       m_run = m_new;
 #pragma unroll
-      for (int t = 0; t < ET; ++t)
+      for (int t = 0; t < ETO; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) O[t][r] *= alpha;
 #pragma unroll
-      for (int t = 0; t < ET; ++t) {
+      for (int t = 0; t < ETO; ++t) {
         const float* vl = Vs + (32 * t + li) * VSTR + 4 * lh;
 #pragma unroll
         for (int r = 0; r < 16; ++r)
@@ -123,9 +134,9 @@ __global__ __launch_bounds__(NT) void k_attn(float* out, const float* __restrict
   }
   if (active) {
     const float inv = 1.0f / l_run;
-    float* ob = out + (size_t)b * E * L;
+    float* ob = out + (size_t)b * E * L + (size_t)blockIdx.z * EO * L;
 #pragma unroll
-    for (int t = 0; t < ET; ++t)
+    for (int t = 0; t < ETO; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int d = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -134,19 +145,19 @@ __global__ __launch_bounds__(NT) void k_attn(float* out, const float* __restrict
   }
 }
 
-template <int ET>
+template <int ET, int ETO = ET>
 int launch_attn(float* out, const float* qkv, int B, int L, float scale, hipStream_t s) {
   constexpr int E = 32 * ET;
-  const size_t lds = (size_t)(E * KB + E * VSTR) * sizeof(float);
+  const size_t lds = (size_t)(E * KB + 32 * ETO * VSTR) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set && lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn<ET>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn<ET, ETO>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return ds::hip_fail(e, "hipFuncSetAttribute(attn)");
     attr_set = true;
   }
-  dim3 g((L + 127) / 128, B);
-  hipLaunchKernelGGL((k_attn<ET>), g, dim3(NT), lds, s, out, qkv, L, scale);
+  dim3 g((L + 127) / 128, B, ET / ETO);
+  hipLaunchKernelGGL((k_attn<ET, ETO>), g, dim3(NT), lds, s, out, qkv, L, scale);
   DS_CHECK_LAUNCH("ds_attention");
   return DS_OK;
 }
@@ -167,8 +178,10 @@ extern "C" int ds_attention(float* out, const float* qkv, int B, int E, int L, v
     case 64: return launch_attn<2>(out, qkv, B, L, scale, s);
     case 128: return launch_attn<4>(out, qkv, B, L, scale, s);
     case 256: return launch_attn<8>(out, qkv, B, L, scale, s);
+    case 384: return launch_attn<12, 4>(out, qkv, B, L, scale, s);
+    case 512: return launch_attn<16, 2>(out, qkv, B, L, scale, s);
     default:
-      ds::set_error("ds_attention: E=%d unsupported (32, 64, 128, 256)", E);
+      ds::set_error("ds_attention: E=%d unsupported (32, 64, 128, 256, 384, 512)", E);
       return DS_ERR_UNSUPPORTED;
   }
 }

@@ -289,13 +289,13 @@ def conv2d(x, w_packed, Cout, ks, bias=None, shift=None, res1=None, res2=None,
 
 def attention(qkv, E, out=None, precision="fp32"):
     """qkv [B, 3E, L] channel-major -> out [B, E, L].  precision "fp16x3": split-fp16 MFMA
-    (fp32-level accuracy, |operands| < 65504); anything else: exact-fp32 MFMA."""
+    (fp32-level accuracy, |operands| < 65504, E <= 256); anything else, or wider heads: exact-fp32 MFMA."""
     B, E3, L = qkv.shape
     if E3 != 3 * E:
         raise ValueError("qkv must be [B, 3E, L]")
     if out is None:
         out = torch.empty((B, E, L), dtype=torch.float32, device=qkv.device)
-    if precision == "fp16x3":
+    if precision == "fp16x3" and E <= 256:
         N.check(N.lib().ds_attention_h3(_p(out), _p(qkv), B, E, L, _stream()), "ds_attention_h3")
     else:
         N.check(N.lib().ds_attention(_p(out), _p(qkv), B, E, L, _stream()), "ds_attention")

@@ -173,12 +173,12 @@ int ds_conv2d_h3(float* out, const float* in, const void* w_packed, int wshift, 
 
 /* Single-head self-attention over L = H*W positions, channel-major operands:
  *   qkv [B, 3E, L] (rows 0..E-1 = Q^T, E..2E-1 = K^T, 2E..3E-1 = V^T), out [B, E, L] = (softmax(Q K^T / sqrt(E)) V)^T.
- * nn.MultiheadAttention(E, num_heads=1) core, attention.py:41-43,67.  E and L multiples of 32, E <= 256. */
+ * nn.MultiheadAttention(E, num_heads=1) core, attention.py:41-43,67.  L a multiple of 32; E in {32, 64, 128, 256, 384, 512}. */
 int ds_attention(float* out, const float* qkv, int B, int E, int L, void* stream);
 
 /* The same attention with both matrix products on the fp16 matrix cores in the fp16x3 scheme of
  * ds_conv2d_h3 (operands split into fp16 hi + lo, three products, fp32 accumulation and fp32
- * softmax statistics): fp32-level accuracy for |q|, |k|, |v| < 65504. Same layouts and limits. */
+ * softmax statistics): fp32-level accuracy for |q|, |k|, |v| < 65504. Same layouts; E <= 256. */
 int ds_attention_h3(float* out, const float* qkv, int B, int E, int L, void* stream);
 
 /* y[m, n] = act(sum_k x[m,k]*w[n,k] + b[n]); act 0 none, 1 SiLU, 2 ReLU.  torch Linear layout.

@@ -224,7 +224,7 @@ def test_split_mfma_handles_exact_fp16_ties(dev):
 
 
 @pytest.mark.parametrize("precision", ["fp32", "fp16x3"])
-@pytest.mark.parametrize("B,E,L", [(2, 32, 64), (1, 64, 96), (2, 128, 256), (2, 256, 1024)])
+@pytest.mark.parametrize("B,E,L", [(2, 32, 64), (1, 64, 96), (2, 128, 256), (2, 256, 1024), (2, 384, 64), (3, 512, 256)])
 def test_attention(dev, B, E, L, precision):
     ops = _ops()
     g = torch.Generator().manual_seed(E + L)
