@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "_lib", "libdiffsci_hip.so")
 
 DS_IN_NETWORK, DS_IN_SCORE, DS_IN_DRIFT = 0, 1, 2
-DS_LOAD_PLAIN, DS_LOAD_MAXPOOL2, DS_LOAD_UPSAMPLE2 = 0, 1, 2
+DS_LOAD_PLAIN, DS_LOAD_MAXPOOL2, DS_LOAD_UPSAMPLE2, DS_LOAD_AVGPOOL2 = 0, 1, 2, 3
 
 
 class EvalCoef(Structure):
@@ -50,6 +50,9 @@ _PROTOS = {
     "ds_conv2d_h3_packed_bytes": (c_size_t, [c_int, c_int]),
     "ds_conv2d_h3_pack_weights": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     "ds_conv2d_h3": (c_int, [_P, _P, _P, c_int, _P, _P, c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "ds_conv1x1_h3_packed_bytes": (c_size_t, [c_int, c_int]),
+    "ds_conv1x1_h3_pack_weights": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
+    "ds_conv1x1_h3": (c_int, [_P, _P, _P, c_int, _P, _P, c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "ds_attention": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     "ds_attention_h3": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     "ds_linear": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),

@@ -1,0 +1,312 @@
+// 1x1 convolution (pointwise channel mixing) with fp32 accuracy on the fp16 matrix cores -- the
+// fp16x3 split of ds_conv3h.hip (x = hi + lo in fp16, lo*hi + hi*lo + hi*hi, fp32 accumulation).
+// Used for ADM's residual projections (adm.py:345-349, with the block's nearest-upsampling or
+// average pooling folded into the load) and the attention in/out projections.
+//
+// A 1x1 convolution has 1/9 of the 3x3's FLOPs per byte: with C <= 256 it is HBM-bound
+// (C/4 flop/byte), so this kernel is organised around the loads, not the MFMAs:
+//   workgroup = 4 waves, tile = 64 channels x 8 rows x 32 columns, 2 workgroups per CU;
+//   one step = 16 input channels = 12 MFMAs per wave; thread t owns pixel t of the tile and
+//   fetches its 16 channel values two steps ahead (two register sets), splits them to fp16
+//   pieces one step ahead into a 3-deep ring of LDS images; the chunk's 4 KiB weight slab rides
+//   the same path (one 16-byte vector per thread).  The step barrier is a bare s_barrier behind
+//   lgkmcnt(0) only, so the global loads of the next two steps stay in flight across it.
+//   blockIdx -> tile is XCD-aware: the Cout/64 workgroups sharing an input tile run on one XCD.
+#include "ds_common.h"
+#include "ds_conv_epilogue.h"
+
+namespace {
+
+using ds_epi::f32x16;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+constexpr int TH = 8, TW = 32, COT = 64, NT = 256, KC = 16;
+constexpr int NPOS = TH * TW;                      // 256 = NT: one pixel per thread
+constexpr int XBUF_VEC = 2 * 2 * NPOS;             // [piece][h][pos] 16-byte vectors: 1024 (16 KiB)
+constexpr int WSLAB_VEC = 2 * 2 * COT;             // [piece][h][co] per chunk: 256 (4 KiB)
+constexpr int NXB = 3, NWS = 3;
+constexpr int RING_BYTES = (NXB * XBUF_VEC + NWS * WSLAB_VEC) * 16;     // 61,440
+constexpr int EPI_BYTES = 4 * 64 * 2 * 32 * 4;                          // the epilogue's 4 x 16 KiB transposition tiles
+constexpr int STAGE_BYTES = RING_BYTES > EPI_BYTES ? RING_BYTES : EPI_BYTES;
+constexpr int LDS_BYTES = STAGE_BYTES + 128 * 4;
+constexpr int NXCD = 8;
+
+struct Conv1hArgs {
+  float* out;
+  const float* in;
+  const u32x4* wp;
+  const float* bias;
+  const float* shift;
+  const float* res1;
+  const float* res2;
+  float unscale;
+  int shift_stride;
+  int B, Cin, Cout, H, W, Hin, Win;
+  int tiles_x, tiles_y, n_cot, n_chunks;
+  unsigned n_blocks;
+};
+
+// see ds_conv3h.hip: the remainder must be taken against the stored (packed-converted) high piece
+__device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned& lo) {
+  f16x2 h = {(_Float16)a, (_Float16)b};
+  unsigned hp = __builtin_bit_cast(unsigned, h);
+  asm volatile("" : "+v"(hp));
+  const f16x2 hq = __builtin_bit_cast(f16x2, hp);
+  f16x2 l = {(_Float16)(a - (float)hq[0]), (_Float16)(b - (float)hq[1])};
+  hi = hp;
+  lo = __builtin_bit_cast(unsigned, l);
+}
+
+__device__ __forceinline__ void step_barrier() {
+  // LDS writes of this wave are done (lgkmcnt); outstanding global loads are NOT waited for
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+template <int MODE>
+__global__ __launch_bounds__(NT, 2) void k_conv1h(const Conv1hArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  u32x4* Xs = reinterpret_cast<u32x4*>(smem);                        // [buf 3][piece][h][pos]
+  u32x4* Ws = Xs + NXB * XBUF_VEC;                                   // [slot 3][piece][h][co]
+  float* BS = reinterpret_cast<float*>(smem + STAGE_BYTES);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+
+  // XCD-aware order: hardware sends workgroup i to XCD i % 8; give each XCD a contiguous run of
+  // logical tiles so the n_cot workgroups reading one input tile share an L2.
+  unsigned bid;
+  {
+    const unsigned x = blockIdx.x % NXCD, k = blockIdx.x / NXCD;
+    const unsigned per = a.n_blocks / NXCD, rem = a.n_blocks % NXCD;
+    bid = x * per + (x < rem ? x : rem) + k;
+  }
+  const int cot = bid % a.n_cot; bid /= a.n_cot;
+  const int tx = bid % a.tiles_x; bid /= a.tiles_x;
+  const int ty = bid % a.tiles_y; bid /= a.tiles_y;
+  const int b = bid;
+  const int x0 = tx * TW, y0 = ty * TH;
+  const int HWin = a.Hin * a.Win;
+  const int n = a.n_chunks;
+
+  const int gy = y0 + (tid >> 5), gx = x0 + (tid & 31);
+  const bool ok = gy < a.H && gx < a.W;
+  int off;
+  if (MODE == DS_LOAD_PLAIN) off = gy * a.Win + gx;
+  else if (MODE == DS_LOAD_UPSAMPLE2) off = (gy >> 1) * a.Win + (gx >> 1);
+  else off = (2 * gy) * a.Win + 2 * gx;                               // DS_LOAD_AVGPOOL2
+  if (!ok) off = 0;
+  const float* in_b = a.in + (size_t)b * a.Cin * HWin + off;
+  const u32x4* wp = a.wp + (size_t)cot * n * WSLAB_VEC;
+
+  auto x_fetch = [&](float (&R)[KC], int chunk) {
+    const int cbase = chunk * KC;
+    const int nch = a.Cin - cbase < KC ? a.Cin - cbase : KC;
+    const float* src = in_b + (size_t)cbase * HWin;
+#pragma unroll
+    for (int c = 0; c < KC; ++c) {
+      const float* p = src + (c < nch ? c : 0) * HWin;                 // past Cin: read channel 0 (zeroed at the split)
+      if (MODE == DS_LOAD_AVGPOOL2) {
+        const float2 t0 = *reinterpret_cast<const float2*>(p);
+        const float2 t1 = *reinterpret_cast<const float2*>(p + a.Win);
+        R[c] = (((t0.x + t0.y) + t1.x) + t1.y) / 4.0f;                 // torch avg_pool2d's summation order
+      } else {
+        R[c] = *p;
+      }
+    }
+  };
+  auto x_store = [&](const float (&R)[KC], int buf, int chunk) {
+    const int nch = a.Cin - chunk * KC;
+    u32x4* xb = Xs + buf * XBUF_VEC;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      u32x4 qh, ql;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float v0 = (ok && 8 * h + 2 * k < nch) ? R[8 * h + 2 * k] : 0.f;
+        const float v1 = (ok && 8 * h + 2 * k + 1 < nch) ? R[8 * h + 2 * k + 1] : 0.f;
+        unsigned ph, pl;
+        split2(v0, v1, ph, pl);
+        qh[k] = ph; ql[k] = pl;
+      }
+      xb[h * NPOS + tid] = qh;
+      xb[(2 + h) * NPOS + tid] = ql;
+    }
+  };
+  // the 4 KiB weight slab of a chunk is one 16-byte vector per thread; it rides along with the
+  // thread's pixel through the same register prefetch (no LDS-DMA: the compiler orders every later
+  // ds_read behind an LDS-DMA with a full vmcnt wait, which would serialise the prefetch)
+  auto w_fetch = [&](u32x4& Wr, int chunk) { Wr = wp[(size_t)chunk * WSLAB_VEC + tid]; };
+  auto w_store = [&](const u32x4& Wr, int slot) { Ws[slot * WSLAB_VEC + tid] = Wr; };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[m][r][q] = 0.f;
+
+  auto mma = [&](int slot, int buf) {
+    const u32x4* wb = Ws + slot * WSLAB_VEC;
+    const u32x4* xb = Xs + buf * XBUF_VEC;
+    f16x8 fa[2][2], fb[2][2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+#pragma unroll
+      for (int m = 0; m < 2; ++m) fa[p][m] = *reinterpret_cast<const f16x8*>(&wb[(p * 2 + lh) * COT + 32 * m + li]);
+#pragma unroll
+      for (int r = 0; r < 2; ++r) fb[p][r] = *reinterpret_cast<const f16x8*>(&xb[(p * 2 + lh) * NPOS + (2 * wv + r) * TW + li]);
+    }
+    constexpr int PA[3] = {1, 0, 0};
+    constexpr int PB[3] = {0, 1, 0};
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+          acc[m][r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[PA[t]][m], fb[PB[t]][r], acc[m][r], 0, 0, 0);
+  };
+
+  float R0[KC], R1[KC];
+  u32x4 W0, W1;
+  ds_epi::load_bias_shift(BS, a.bias, a.shift, a.shift_stride, b, cot * COT, a.Cout);
+  w_fetch(W0, 0);
+  x_fetch(R0, 0);
+  w_fetch(W1, n > 1 ? 1 : 0);
+  x_fetch(R1, n > 1 ? 1 : 0);
+  w_store(W0, 0);
+  x_store(R0, 0, 0);
+  __syncthreads();
+
+  // chunk k: fetched into R[k & 1] at step k-2, split into image k % 3 at step k-1, used at step k
+  int buf = 0;
+  auto step = [&](float (&Ra)[KC], u32x4& Wa, float (&Rb)[KC], u32x4& Wb, int g) {
+    // unconditional (clamped to the last chunk: a redundant, never-consumed fetch in the last two
+    // steps) so the number of loads in flight is static and the waits below stay partial
+    const int gf = g + 2 < n ? g + 2 : n - 1;
+    w_fetch(Wa, gf);
+    x_fetch(Ra, gf);
+    mma(g % NWS, buf);
+    const int nb = buf == NXB - 1 ? 0 : buf + 1;
+    w_store(Wb, (g + 1) % NWS);          // never-consumed slots in the last step
+    x_store(Rb, nb, g + 1 < n ? g + 1 : n - 1);
+    buf = nb;
+    step_barrier();
+  };
+  int g = 0;
+  for (; g + 1 < n; g += 2) {
+    step(R0, W0, R1, W1, g);
+    step(R1, W1, R0, W0, g + 1);
+  }
+  if (g < n) step(R0, W0, R1, W1, g);
+  __syncthreads();       // full fence before the staging buffers are reused by the epilogue
+
+  {
+    ds_epi::Args e;
+    e.out = a.out; e.bias = a.bias; e.shift = a.shift; e.res1 = a.res1; e.res2 = a.res2;
+    e.unscale = a.unscale; e.shift_stride = a.shift_stride;
+    e.b = b; e.co_base = cot * COT; e.y0 = y0 + 2 * wv; e.x0 = x0;
+    e.Cout = a.Cout; e.H = a.H; e.W = a.W;
+    float* tile = reinterpret_cast<float*>(smem) + wv * (64 * 2 * 32);
+    ds_epi::store_tile(acc, tile, BS, e);
+  }
+}
+
+// torch [Cout][Cin][1][1] fp32 (times 2^wshift) -> [cot][chunk][piece][h][co 64][ci 8] fp16
+__global__ void k_pack1h(_Float16* packed, const float* __restrict__ w, int Cout, int Cin, int n_chunks, float scale,
+                         size_t total) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  size_t t = i;
+  const int c8 = t % 8; t /= 8;
+  const int co64 = t % COT; t /= COT;
+  const int h = t % 2; t /= 2;
+  const int piece = t % 2; t /= 2;
+  const int chunk = t % n_chunks; t /= n_chunks;
+  const int cot = (int)t;
+  const int co = cot * COT + co64, ci = chunk * KC + 8 * h + c8;
+  float v = 0.f;
+  if (co < Cout && ci < Cin) v = w[(size_t)co * Cin + ci] * scale;
+  const _Float16 hi = (_Float16)v;
+  const _Float16 lo = (_Float16)(v - (float)hi);
+  packed[i] = piece == 0 ? hi : lo;
+}
+
+template <int MODE>
+int launch_conv1h(const Conv1hArgs& a, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv1h<MODE>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    if (e != hipSuccess) return ds::hip_fail(e, "hipFuncSetAttribute(conv1h)");
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((k_conv1h<MODE>), dim3(a.n_blocks), dim3(NT), LDS_BYTES, s, a);
+  DS_CHECK_LAUNCH("ds_conv1x1_h3");
+  return DS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t ds_conv1x1_h3_packed_bytes(int Cout, int Cin) {
+  if (Cout <= 0 || Cin <= 0) return 0;
+  const size_t n_cot = (Cout + COT - 1) / COT, n_chunks = (Cin + KC - 1) / KC;
+  return n_cot * n_chunks * (size_t)WSLAB_VEC * 16;
+}
+
+int ds_conv1x1_h3_pack_weights(void* packed, const float* w, int Cout, int Cin, int wshift, void* stream) {
+  DS_REQUIRE(packed && w, DS_ERR_NULL, "ds_conv1x1_h3_pack_weights: NULL pointer");
+  DS_REQUIRE(Cout > 0 && Cin > 0, DS_ERR_SHAPE, "ds_conv1x1_h3_pack_weights: Cout=%d Cin=%d", Cout, Cin);
+  DS_REQUIRE(wshift >= -40 && wshift <= 40, DS_ERR_SHAPE, "ds_conv1x1_h3_pack_weights: wshift %d out of range", wshift);
+  const int n_chunks = (Cin + KC - 1) / KC;
+  const size_t total = ds_conv1x1_h3_packed_bytes(Cout, Cin) / 2;
+  hipLaunchKernelGGL(k_pack1h, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ds::as_stream(stream),
+                     reinterpret_cast<_Float16*>(packed), w, Cout, Cin, n_chunks, ldexpf(1.0f, wshift), total);
+  DS_CHECK_LAUNCH("ds_conv1x1_h3_pack_weights");
+  return DS_OK;
+}
+
+int ds_conv1x1_h3(float* out, const float* in, const void* w_packed, int wshift, const float* bias, const float* shift,
+                  int shift_stride, const float* res1, const float* res2, int B, int Cin, int Cout, int H, int W,
+                  int load_mode, void* stream) {
+  DS_REQUIRE(out && in && w_packed, DS_ERR_NULL, "ds_conv1x1_h3: NULL pointer");
+  DS_REQUIRE(B >= 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, DS_ERR_SHAPE,
+             "ds_conv1x1_h3: bad shape B=%d Cin=%d Cout=%d H=%d W=%d", B, Cin, Cout, H, W);
+  DS_REQUIRE(load_mode == DS_LOAD_PLAIN || load_mode == DS_LOAD_UPSAMPLE2 || load_mode == DS_LOAD_AVGPOOL2,
+             DS_ERR_UNSUPPORTED, "ds_conv1x1_h3: load_mode %d", load_mode);
+  DS_REQUIRE(load_mode != DS_LOAD_UPSAMPLE2 || (H % 2 == 0 && W % 2 == 0), DS_ERR_SHAPE,
+             "ds_conv1x1_h3: UPSAMPLE2 needs even output H, W (got %d x %d)", H, W);
+  DS_REQUIRE(shift == nullptr || shift_stride == 0 || shift_stride >= Cout, DS_ERR_SHAPE,
+             "ds_conv1x1_h3: shift_stride %d < Cout %d", shift_stride, Cout);
+  DS_REQUIRE((reinterpret_cast<uintptr_t>(w_packed) & 15u) == 0, DS_ERR_SHAPE, "ds_conv1x1_h3: w_packed must be 16-byte aligned");
+  DS_REQUIRE(load_mode != DS_LOAD_AVGPOOL2 || (reinterpret_cast<uintptr_t>(in) & 7u) == 0, DS_ERR_SHAPE,
+             "ds_conv1x1_h3: AVGPOOL2 input must be 8-byte aligned");
+  DS_REQUIRE(wshift >= -40 && wshift <= 40, DS_ERR_SHAPE, "ds_conv1x1_h3: wshift %d out of range", wshift);
+  if (B == 0) return DS_OK;
+  Conv1hArgs a;
+  a.out = out; a.in = in; a.wp = reinterpret_cast<const u32x4*>(w_packed); a.bias = bias; a.shift = shift;
+  a.res1 = res1; a.res2 = res2; a.shift_stride = shift_stride;
+  a.unscale = ldexpf(1.0f, -wshift);
+  a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W;
+  a.Hin = load_mode == DS_LOAD_AVGPOOL2 ? 2 * H : (load_mode == DS_LOAD_UPSAMPLE2 ? H / 2 : H);
+  a.Win = load_mode == DS_LOAD_AVGPOOL2 ? 2 * W : (load_mode == DS_LOAD_UPSAMPLE2 ? W / 2 : W);
+  DS_REQUIRE((long long)Cin * a.Hin * a.Win < (1ll << 31), DS_ERR_SHAPE, "ds_conv1x1_h3: per-sample input exceeds 2^31 floats");
+  a.tiles_x = (W + TW - 1) / TW; a.tiles_y = (H + TH - 1) / TH;
+  a.n_cot = (Cout + COT - 1) / COT;
+  a.n_chunks = (Cin + KC - 1) / KC;
+  const long long blocks = (long long)B * a.tiles_y * a.tiles_x * a.n_cot;
+  DS_REQUIRE(blocks > 0 && blocks < (1ll << 31), DS_ERR_SHAPE, "ds_conv1x1_h3: grid of %lld workgroups is out of range", blocks);
+  a.n_blocks = (unsigned)blocks;
+  hipStream_t s = ds::as_stream(stream);
+  if (load_mode == DS_LOAD_PLAIN) return launch_conv1h<DS_LOAD_PLAIN>(a, s);
+  if (load_mode == DS_LOAD_UPSAMPLE2) return launch_conv1h<DS_LOAD_UPSAMPLE2>(a, s);
+  return launch_conv1h<DS_LOAD_AVGPOOL2>(a, s);
+}
+
+}  // extern "C"

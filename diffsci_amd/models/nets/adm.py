@@ -21,7 +21,7 @@ import torch
 import yaml
 
 from ... import ops
-from ..._native import DS_LOAD_PLAIN, DS_LOAD_UPSAMPLE2
+from ..._native import DS_LOAD_AVGPOOL2, DS_LOAD_PLAIN, DS_LOAD_UPSAMPLE2
 from .punetg import _AffineHolder, _Attn, _Fourier, _Workspace
 
 _FIELDS = dict(
@@ -244,8 +244,9 @@ class ADM(torch.nn.Module):
                 pk[id(m)] = ops.pack_conv(m.weight.detach(), self.conv_precision)
             for a in attns:
                 E = a.mhattn.embed_dim
-                pk[(id(a), "in")] = ops.pack_conv(a.mhattn.in_proj_weight.detach().reshape(3 * E, E, 1, 1), "fp32")
-                pk[(id(a), "out")] = ops.pack_conv(a.mhattn.out_proj.weight.detach().reshape(E, E, 1, 1), "fp32")
+                prec = "fp16x3" if self.conv_precision == "fp16x3" else "fp32"
+                pk[(id(a), "in")] = ops.pack_conv(a.mhattn.in_proj_weight.detach().reshape(3 * E, E, 1, 1), prec)
+                pk[(id(a), "out")] = ops.pack_conv(a.mhattn.out_proj.weight.detach().reshape(E, E, 1, 1), prec)
         self._packed, self._packed_sig = pk, sig
         return pk
 
@@ -269,7 +270,9 @@ class ADM(torch.nn.Module):
                              out=ws.take((B, Ci, Hm, Wm), dev))
         y = self._conv(blk.conv1, a, pk, load_mode=mode, out=ws.take((B, blk.cout, Ho, Wo), dev))
         # residual_block: convresidual(resample(x))                               (adm.py:345-349)
-        if down:
+        if down and pk[id(blk.convresidual)].kind == "fp16x3":
+            r = self._conv(blk.convresidual, x, pk, load_mode=DS_LOAD_AVGPOOL2, out=ws.take((B, blk.cout, Ho, Wo), dev))
+        elif down:
             ops.gnorm1_apply(x, None, None, None, 2, pool=True, out=a)
             r = self._conv(blk.convresidual, a, pk, out=ws.take((B, blk.cout, Ho, Wo), dev))
         else:

@@ -221,8 +221,9 @@ class PUNetG(torch.nn.Module):
                 pk[id(m)] = ops.pack_conv(m.weight.detach(), self.conv_precision)
             for a in self.attn_block:
                 E = a.mhattn.embed_dim
-                pk[(id(a), "in")] = ops.pack_conv(a.mhattn.in_proj_weight.detach().reshape(3 * E, E, 1, 1), "fp32")
-                pk[(id(a), "out")] = ops.pack_conv(a.mhattn.out_proj.weight.detach().reshape(E, E, 1, 1), "fp32")
+                prec = "fp16x3" if self.conv_precision == "fp16x3" else "fp32"
+                pk[(id(a), "in")] = ops.pack_conv(a.mhattn.in_proj_weight.detach().reshape(3 * E, E, 1, 1), prec)
+                pk[(id(a), "out")] = ops.pack_conv(a.mhattn.out_proj.weight.detach().reshape(E, E, 1, 1), prec)
         self._packed, self._packed_sig = pk, sig
         return pk
 

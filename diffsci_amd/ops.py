@@ -211,7 +211,7 @@ CONV_PRECISIONS = ("fp16x3", "bf16x6", "fp32")
 
 def pack_conv(w, precision="bf16x6"):
     """Repack a torch conv weight [Cout, Cin, k, k] (device, fp32).  3x3 kernels honour
-    `precision`; 1x1 kernels always use the exact-fp32 MFMA kernel."""
+    `precision`; 1x1 kernels use the fp16x3 kernel for "fp16x3" and the exact-fp32 MFMA kernel otherwise."""
     require_device(w, "conv weight")
     if precision not in CONV_PRECISIONS:
         raise ValueError(f"unknown conv precision {precision!r}; choose from {CONV_PRECISIONS}")
@@ -223,7 +223,7 @@ def pack_conv(w, precision="bf16x6"):
         N.check(N.lib().ds_conv2d_x6_pack_weights(data.data_ptr(), _p(w), Cout, Cin, _stream()),
                 "ds_conv2d_x6_pack_weights")
         return PackedConv(data, Cout, Cin, 3, "bf16x6")
-    if precision == "fp16x3" and k == 3:
+    if precision == "fp16x3" and k in (1, 3):
         # per-layer power-of-two scale: largest weight lands in [2^13, 2^14), far inside fp16's
         # range, and typical weights get normal (not subnormal) low pieces
         wmax = float(w.abs().max())
@@ -231,11 +231,11 @@ def pack_conv(w, precision="bf16x6"):
         if wmax > 0 and wmax == wmax and wmax != float("inf"):
             import math
             wshift = max(-40, min(40, 13 - math.floor(math.log2(wmax))))
-        nbytes = N.lib().ds_conv2d_h3_packed_bytes(Cout, Cin)
-        data = torch.empty(nbytes // 4, dtype=torch.float32, device=w.device)
-        N.check(N.lib().ds_conv2d_h3_pack_weights(data.data_ptr(), _p(w), Cout, Cin, wshift, _stream()),
-                "ds_conv2d_h3_pack_weights")
-        return PackedConv(data, Cout, Cin, 3, "fp16x3", wshift)
+        size_fn, pack_fn = ((N.lib().ds_conv2d_h3_packed_bytes, N.lib().ds_conv2d_h3_pack_weights) if k == 3 else
+                            (N.lib().ds_conv1x1_h3_packed_bytes, N.lib().ds_conv1x1_h3_pack_weights))
+        data = torch.empty(size_fn(Cout, Cin) // 4, dtype=torch.float32, device=w.device)
+        N.check(pack_fn(data.data_ptr(), _p(w), Cout, Cin, wshift, _stream()), "ds_conv*_h3_pack_weights")
+        return PackedConv(data, Cout, Cin, k, "fp16x3", wshift)
     return PackedConv(pack_conv_weight(w), Cout, Cin, k, "fp32")
 
 
@@ -248,9 +248,11 @@ def conv2d(x, w_packed, Cout, ks, bias=None, shift=None, res1=None, res2=None,
            load_mode=N.DS_LOAD_PLAIN, out=None, kind="fp32", wshift=0):
     """'same' zero-padded conv; x [B, Cin, Hin, Win]; shift [1 or B, Cout] or None."""
     B, Cin, Hin, Win = x.shape
-    if load_mode == N.DS_LOAD_MAXPOOL2:
+    if load_mode in (N.DS_LOAD_MAXPOOL2, N.DS_LOAD_AVGPOOL2):
         if Hin % 2 or Win % 2:
-            raise ValueError("max-pool load needs even input H, W")
+            raise ValueError("pooling load needs even input H, W")
+        if (load_mode == N.DS_LOAD_AVGPOOL2) != (kind == "fp16x3" and ks == 1):
+            raise ValueError("load modes: AVGPOOL2 is for the fp16x3 1x1 kernel, MAXPOOL2 for the others")
         H, W = Hin // 2, Win // 2
     elif load_mode == N.DS_LOAD_UPSAMPLE2:
         H, W = Hin * 2, Win * 2
@@ -261,9 +263,10 @@ def conv2d(x, w_packed, Cout, ks, bias=None, shift=None, res1=None, res2=None,
     elif tuple(out.shape) != (B, Cout, H, W):
         raise ValueError(f"out has shape {tuple(out.shape)}, expected {(B, Cout, H, W)}")
     expect = {"bf16x6": lambda: N.lib().ds_conv2d_x6_packed_bytes(Cout, Cin) // 4,
-              "fp16x3": lambda: N.lib().ds_conv2d_h3_packed_bytes(Cout, Cin) // 4,
+              "fp16x3": lambda: (N.lib().ds_conv2d_h3_packed_bytes if ks == 3 else
+                                 N.lib().ds_conv1x1_h3_packed_bytes)(Cout, Cin) // 4,
               "fp32": lambda: N.lib().ds_conv2d_packed_floats(Cout, Cin, ks)}[kind]()
-    if w_packed.numel() != expect or (kind != "fp32" and ks != 3):
+    if w_packed.numel() != expect or (kind == "bf16x6" and ks != 3) or ks not in (1, 3):
         raise ValueError("packed weight size does not match (Cout, Cin, ks)")
     stride = 0
     if shift is not None:
@@ -275,7 +278,10 @@ def conv2d(x, w_packed, Cout, ks, bias=None, shift=None, res1=None, res2=None,
             raise ValueError("residual shape mismatch")
     if bias is not None and bias.numel() != Cout:
         raise ValueError("bias must have Cout entries")
-    if kind == "fp16x3":
+    if kind == "fp16x3" and ks == 1:
+        N.check(N.lib().ds_conv1x1_h3(_p(out), _p(x), _p(w_packed), int(wshift), _p(bias), _p(shift), stride,
+                                      _p(res1), _p(res2), B, Cin, Cout, H, W, load_mode, _stream()), "ds_conv1x1_h3")
+    elif kind == "fp16x3":
         N.check(N.lib().ds_conv2d_h3(_p(out), _p(x), _p(w_packed), int(wshift), _p(bias), _p(shift), stride,
                                      _p(res1), _p(res2), B, Cin, Cout, H, W, load_mode, _stream()), "ds_conv2d_h3")
     elif kind == "bf16x6":

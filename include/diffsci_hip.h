@@ -131,7 +131,7 @@ int ds_inorm_silu(float* out, const float* x, const float* w, const float* b,
 size_t ds_conv2d_packed_floats(int Cout, int Cin, int ks);
 int ds_conv2d_pack_weights(float* packed, const float* w, int Cout, int Cin, int ks, void* stream);
 
-enum { DS_LOAD_PLAIN = 0, DS_LOAD_MAXPOOL2 = 1, DS_LOAD_UPSAMPLE2 = 2 };
+enum { DS_LOAD_PLAIN = 0, DS_LOAD_MAXPOOL2 = 1, DS_LOAD_UPSAMPLE2 = 2, DS_LOAD_AVGPOOL2 = 3 /* ds_conv1x1_h3 only */ };
 
 /* "same"-padded (zero) ks x ks convolution, ks in {1,3}, fp32 MFMA implicit GEMM.
  *   out[b,co,y,x] = sum w[co,ci,ky,kx]*src(b,ci,y+ky-ks/2,x+kx-ks/2) + bias[co]
@@ -170,6 +170,17 @@ int ds_conv2d_h3_pack_weights(void* packed, const float* w, int Cout, int Cin, i
 int ds_conv2d_h3(float* out, const float* in, const void* w_packed, int wshift, const float* bias,
                  const float* shift, int shift_stride, const float* res1, const float* res2,
                  int B, int Cin, int Cout, int H, int W, int load_mode, void* stream);
+
+/* 1x1 convolution in the fp16x3 scheme of ds_conv2d_h3 (same epilogue terms, same domain
+ * |in| < 65504).  ADM's residual projection convresidual(resample(x)) (adm.py:345-349) with the
+ * resampling folded into the load: load_mode PLAIN, UPSAMPLE2 (nearest x2, in is [B,Cin,H/2,W/2])
+ * or AVGPOOL2 (AvgPool2d(2) in torch's summation order, in is [B,Cin,2H,2W]); also the attention
+ * in/out projections.  Packed weights: [ceil(Cout/64)][ceil(Cin/16)][piece 2][h 2][64 co][8 ci] fp16. */
+size_t ds_conv1x1_h3_packed_bytes(int Cout, int Cin);
+int ds_conv1x1_h3_pack_weights(void* packed, const float* w, int Cout, int Cin, int wshift, void* stream);
+int ds_conv1x1_h3(float* out, const float* in, const void* w_packed, int wshift, const float* bias,
+                  const float* shift, int shift_stride, const float* res1, const float* res2,
+                  int B, int Cin, int Cout, int H, int W, int load_mode, void* stream);
 
 /* Single-head self-attention over L = H*W positions, channel-major operands:
  *   qkv [B, 3E, L] (rows 0..E-1 = Q^T, E..2E-1 = K^T, 2E..3E-1 = V^T), out [B, E, L] = (softmax(Q K^T / sqrt(E)) V)^T.

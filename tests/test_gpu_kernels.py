@@ -195,6 +195,52 @@ def test_conv2d_split_mfma_is_fp32_accurate(dev, case, prec):
     assert rel <= 2 * rel_l2(exact, want) + 1e-7
 
 
+CONV1X1_CASES = [
+    # B, Cin, Cout, H, W, mode (0 plain, 2 nearest-up, 3 avg-pool)
+    (2, 32, 96, 8, 8, 0),          # attention in_proj
+    (1, 70, 33, 8, 40, 0),         # ragged channels
+    (2, 16, 24, 9, 13, 0),         # nothing divides anything
+    (3, 128, 128, 64, 64, 0),      # ADM residual projection, several tiles per XCD
+    (1, 1, 8, 16, 32, 0),          # a single input channel (one clamped chunk)
+    (2, 48, 64, 16, 32, 2),        # decoder block: nearest-up folded into the load
+    (2, 40, 72, 12, 20, 3),        # encoder block: AvgPool2d(2) folded into the load
+    (1, 256, 512, 32, 32, 3),
+    (1, 1024, 256, 16, 16, 2),     # 64 steps
+]
+
+
+@pytest.mark.parametrize("case", CONV1X1_CASES)
+def test_conv1x1_fp16x3(dev, case):
+    """ds_conv1x1_h3: fp32-level error against fp64, never worse than twice the exact-fp32 MFMA kernel."""
+    ops = _ops()
+    B, Cin, Cout, H, W, mode = case
+    g = torch.Generator().manual_seed(hash(case) % 1000 + 2)
+    Hin, Win = (2 * H, 2 * W) if mode == 3 else ((H // 2, W // 2) if mode == 2 else (H, W))
+    x = torch.randn(B, Cin, Hin, Win, generator=g) * 3.0
+    x[0, 0, 0, :4] = torch.tensor([1e-30, -3e-39, 6.0e4, -1e4])
+    w = torch.randn(Cout, Cin, 1, 1, generator=g) / math.sqrt(Cin)
+    bias, shift = torch.randn(Cout, generator=g), torch.randn(B, Cout, generator=g)
+    r1, r2 = torch.randn(B, Cout, H, W, generator=g), torch.randn(B, Cout, H, W, generator=g)
+    src = F.avg_pool2d(x, 2) if mode == 3 else (F.interpolate(x, scale_factor=2.0, mode="nearest") if mode == 2 else x)
+    want = (F.conv2d(src.double(), w.double(), bias.double()) + shift.double()[:, :, None, None] + r1.double() + r2.double())
+    ref32 = F.conv2d(src, w, bias) + shift[:, :, None, None] + r1 + r2
+    pw = ops.pack_conv(w.to(dev), "fp16x3")
+    assert pw.kind == "fp16x3" and pw.ks == 1
+    got = ops.conv(x.to(dev), pw, bias=bias.to(dev), shift=shift.to(dev), res1=r1.to(dev), res2=r2.to(dev),
+                   load_mode=mode).cpu()
+    err, err32 = (got.double() - want).abs().max().item(), (ref32.double() - want).abs().max().item()
+    rel, rel32 = rel_l2(got, want), rel_l2(ref32, want)
+    assert err <= max(4 * err32, 1e-5), (err, err32)
+    assert rel <= max(3 * rel32, 3e-7), (rel, rel32)
+    if mode != 3:
+        exact = ops.conv(x.to(dev), ops.pack_conv(w.to(dev), "fp32"), bias=bias.to(dev), shift=shift.to(dev),
+                         res1=r1.to(dev), res2=r2.to(dev), load_mode=mode).cpu()
+        assert rel <= 2 * rel_l2(exact, want) + 1e-7
+    # no epilogue terms
+    got = ops.conv(x.to(dev), pw, load_mode=mode).cpu()
+    assert rel_l2(got, F.conv2d(src.double(), w.double())) <= max(3 * rel_l2(F.conv2d(src, w), F.conv2d(src.double(), w.double())), 3e-7)
+
+
 def test_split_mfma_handles_exact_fp16_ties(dev):
     """Regression: inputs lying EXACTLY halfway between two fp16 values.  hipcc rounds the stored
     hi piece (v_cvt_pk_f16_f32) and the remainder's reference (v_cvt_f16_f32) with different tie
