@@ -21,6 +21,10 @@ using ds_epi::f32x16;
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(1))) float* gfloat_ptr;
+typedef const __attribute__((address_space(1))) char* gchar_ptr;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(1))) f32x2* gfloat2_ptr;
 
 constexpr int TH = 8, TW = 32, COT = 64, NT = 256, KC = 16;
 constexpr int NPOS = TH * TW;                      // 256 = NT: one pixel per thread
@@ -91,44 +95,50 @@ __global__ __launch_bounds__(NT, 2) void k_conv1h(const Conv1hArgs a) {
   const int HWin = a.Hin * a.Win;
   const int n = a.n_chunks;
 
+  // Pixel offset of this thread inside a channel plane.  Out-of-range pixels of a ragged tile and
+  // channels past Cin of a ragged last chunk are fetched from clamped (valid) addresses and NOT
+  // zeroed: a 1x1 convolution has no halo, so an out-of-range pixel only feeds outputs that are
+  // never stored, and the padded weight rows of the channels past Cin are zero.
   const int gy = y0 + (tid >> 5), gx = x0 + (tid & 31);
   const bool ok = gy < a.H && gx < a.W;
-  int off;
+  unsigned off;
   if (MODE == DS_LOAD_PLAIN) off = gy * a.Win + gx;
   else if (MODE == DS_LOAD_UPSAMPLE2) off = (gy >> 1) * a.Win + (gx >> 1);
   else off = (2 * gy) * a.Win + 2 * gx;                               // DS_LOAD_AVGPOOL2
   if (!ok) off = 0;
-  const float* in_b = a.in + (size_t)b * a.Cin * HWin + off;
+  const unsigned offb = off * 4u, rowb = (unsigned)a.Win * 4u;        // BYTE offsets: a plane is < 2^29 floats (host check)
+  const float* in_b = a.in + (size_t)b * a.Cin * HWin;                // uniform: loads are s[base] + v offset
   const u32x4* wp = a.wp + (size_t)cot * n * WSLAB_VEC;
 
   auto x_fetch = [&](float (&R)[KC], int chunk) {
     const int cbase = chunk * KC;
-    const int nch = a.Cin - cbase < KC ? a.Cin - cbase : KC;
-    const float* src = in_b + (size_t)cbase * HWin;
+    unsigned ob = offb;
+    asm volatile("" : "+v"(ob));       // keep the zero-extension next to the loads (scalar-base + 32-bit offset form)
 #pragma unroll
     for (int c = 0; c < KC; ++c) {
-      const float* p = src + (c < nch ? c : 0) * HWin;                 // past Cin: read channel 0 (zeroed at the split)
+      const int ch = cbase + c < a.Cin ? cbase + c : a.Cin - 1;        // scalar clamp
+      // uniform base, pinned to an SGPR pair (opaque to the optimiser, which would otherwise fold the
+      // lane offset into a hoisted 64-bit vector base and pay a 64-bit VALU add per load)
+      gchar_ptr p = (gchar_ptr)(in_b + (size_t)ch * HWin);
+      asm volatile("" : "+s"(p));
       if (MODE == DS_LOAD_AVGPOOL2) {
-        const float2 t0 = *reinterpret_cast<const float2*>(p);
-        const float2 t1 = *reinterpret_cast<const float2*>(p + a.Win);
+        const f32x2 t0 = *(gfloat2_ptr)(p + ob);
+        const f32x2 t1 = *(gfloat2_ptr)(p + (ob + rowb));
         R[c] = (((t0.x + t0.y) + t1.x) + t1.y) / 4.0f;                 // torch avg_pool2d's summation order
       } else {
-        R[c] = *p;
+        R[c] = *(gfloat_ptr)(p + ob);
       }
     }
   };
-  auto x_store = [&](const float (&R)[KC], int buf, int chunk) {
-    const int nch = a.Cin - chunk * KC;
+  auto x_store = [&](const float (&R)[KC], int buf) {
     u32x4* xb = Xs + buf * XBUF_VEC;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       u32x4 qh, ql;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const float v0 = (ok && 8 * h + 2 * k < nch) ? R[8 * h + 2 * k] : 0.f;
-        const float v1 = (ok && 8 * h + 2 * k + 1 < nch) ? R[8 * h + 2 * k + 1] : 0.f;
         unsigned ph, pl;
-        split2(v0, v1, ph, pl);
+        split2(R[8 * h + 2 * k], R[8 * h + 2 * k + 1], ph, pl);
         qh[k] = ph; ql[k] = pl;
       }
       xb[h * NPOS + tid] = qh;
@@ -179,7 +189,7 @@ __global__ __launch_bounds__(NT, 2) void k_conv1h(const Conv1hArgs a) {
   w_fetch(W1, n > 1 ? 1 : 0);
   x_fetch(R1, n > 1 ? 1 : 0);
   w_store(W0, 0);
-  x_store(R0, 0, 0);
+  x_store(R0, 0);
   __syncthreads();
 
   // chunk k: fetched into R[k & 1] at step k-2, split into image k % 3 at step k-1, used at step k
@@ -193,7 +203,7 @@ __global__ __launch_bounds__(NT, 2) void k_conv1h(const Conv1hArgs a) {
     mma(g % NWS, buf);
     const int nb = buf == NXB - 1 ? 0 : buf + 1;
     w_store(Wb, (g + 1) % NWS);          // never-consumed slots in the last step
-    x_store(Rb, nb, g + 1 < n ? g + 1 : n - 1);
+    x_store(Rb, nb);
     buf = nb;
     step_barrier();
   };
@@ -296,7 +306,7 @@ int ds_conv1x1_h3(float* out, const float* in, const void* w_packed, int wshift,
   a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W;
   a.Hin = load_mode == DS_LOAD_AVGPOOL2 ? 2 * H : (load_mode == DS_LOAD_UPSAMPLE2 ? H / 2 : H);
   a.Win = load_mode == DS_LOAD_AVGPOOL2 ? 2 * W : (load_mode == DS_LOAD_UPSAMPLE2 ? W / 2 : W);
-  DS_REQUIRE((long long)Cin * a.Hin * a.Win < (1ll << 31), DS_ERR_SHAPE, "ds_conv1x1_h3: per-sample input exceeds 2^31 floats");
+  DS_REQUIRE((long long)a.Hin * a.Win < (1ll << 29), DS_ERR_SHAPE, "ds_conv1x1_h3: a channel plane exceeds 2^29 floats");
   a.tiles_x = (W + TW - 1) / TW; a.tiles_y = (H + TH - 1) / TH;
   a.n_cot = (Cout + COT - 1) / COT;
   a.n_chunks = (Cin + KC - 1) / KC;

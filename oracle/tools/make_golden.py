@@ -216,6 +216,34 @@ def punetg():
 
 
 # ---------------------------------------------------------------- 4. ADM (config 3 family, tiny)
+def porosity():
+    """BASELINE config 5's shape of the path: 4-channel conditional PUNetG with the in-repo dict-style
+    PorosityEmbedder (nets/embedder.py:198-229), classifier-free guidance, un-batched dict y."""
+    torch.manual_seed(20)
+    cfg = M.nets.PUNetGConfig(model_channels=8, input_channels=4, output_channels=4)
+    from diffsci.models.nets.embedder import PorosityEmbedder
+    emb = PorosityEmbedder(dembed=8)
+    net = M.nets.PUNetG(cfg, conditional_embedding=emb).eval()
+    with torch.no_grad():
+        for k, v in net.state_dict().items():
+            if "gnorm" in k or k.endswith("in_proj_bias") or k.endswith("out_proj.bias"):
+                v.add_(0.25 * torch.randn_like(v))
+    sd = net.state_dict()
+    module = M.KarrasModule(net, M.KarrasModuleConfig.from_edm(), conditional=True).eval()
+    torch.manual_seed(21)
+    wn = torch.randn(2, 4, 32, 32)
+    y = {"porosity": torch.tensor([0.37])}
+    arrs = dict(sd_arrays(sd), white_noise=wn, porosity=y["porosity"])
+    with torch.inference_mode():
+        arrs["ye"] = emb({"porosity": y["porosity"].unsqueeze(0)})
+        yb = {"porosity": torch.tensor([[0.1], [0.9]])}
+        arrs["ye_batch"] = emb(yb)
+        arrs["porosity_batch"] = yb["porosity"]
+    arrs["hist_cfg_g2_N4_f32"] = module.propagate_white_noise(wn, y=y, guidance=2.0, nsteps=4, record_history=True)
+    arrs["out_cond_g1_N4_f32"] = module.propagate_white_noise(wn, y=y, guidance=1.0, nsteps=4)
+    npz("punetg8_porosity", **arrs)
+
+
 def adm():
     for skip in ("concat", "add"):
         torch.manual_seed(10)
@@ -258,6 +286,6 @@ def adm():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["schedule", "toy", "punetg", "adm"]
+    which = sys.argv[1:] or ["schedule", "toy", "punetg", "porosity", "adm"]
     for name in which:
         globals()[name]()

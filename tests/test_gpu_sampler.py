@@ -295,3 +295,26 @@ def test_cpu_tensors_are_refused(M, net8):
     module = M.KarrasModule(net8, M.KarrasModuleConfig.from_edm())
     with pytest.raises(RuntimeError, match="no CPU path"):
         module.propagate_white_noise(torch.randn(1, 1, 32, 32), nsteps=2)
+
+
+def test_porosity_conditional_cfg_dict_y(M, dev, grids):
+    """BASELINE config 5's shape of the path: 4-channel conditional PUNetG, dict-style y through the
+    HIP PorosityEmbedder, classifier-free guidance (two network evaluations per score)."""
+    v, sd = load("punetg8_porosity")
+    net = M.PUNetG(M.PUNetGConfig(model_channels=8, input_channels=4, output_channels=4),
+                   conditional_embedding=M.nets.PorosityEmbedder(dembed=8))
+    r = net.load_state_dict(sd, strict=True)
+    assert not r.missing_keys and not r.unexpected_keys
+    module = M.KarrasModule(net, M.KarrasModuleConfig.from_edm(), conditional=True).to(dev)
+    _pin_grid(module, grids)
+    emb = net.conditional_embedding
+    ye = emb({"porosity": v["porosity_batch"].to(dev)}).cpu()
+    assert (ye - v["ye_batch"]).abs().max() < 2e-6 * v["ye_batch"].abs().max()
+    y = {"porosity": v["porosity"].to(dev)}                          # un-batched: unsqueezed by the module (karrasmodule.py:916-917)
+    wn = v["white_noise"].to(dev)
+    for use_graph in (False, True):
+        module.use_graph = use_graph
+        h = module.propagate_white_noise(wn, y=y, guidance=2.0, nsteps=4, record_history=True).cpu()
+        assert rel_l2(h, v["hist_cfg_g2_N4_f32"]) < REL
+        o = module.propagate_white_noise(wn, y=y, guidance=1.0, nsteps=4).cpu()
+        assert rel_l2(o, v["out_cond_g1_N4_f32"]) < REL

@@ -211,3 +211,20 @@ def test_adm_forward_and_trajectories(skip):
         h = K.propagate_white_noise(net, v["white_noise"], 4, integrator="karras", record_history=True,
                                     eps=v["eps_karras_N4"])
         assert_exact_or_rel(h, v["hist_karras_N4_f32"], "karras N4", 2e-6)
+
+
+def test_porosity_conditional_cfg():
+    """Config-5 shape of the path: 4-channel PUNetG + dict-style PorosityEmbedder + CFG."""
+    from oracle import embedder_ref
+    v, sd = load("punetg8_porosity")
+    cfg = punetg_ref.default_config(model_channels=8, input_channels=4, output_channels=4)
+    embed = lambda y: embedder_ref.porosity_embed(sd, "conditional_embedding.", y)   # noqa: E731
+    with torch.inference_mode():
+        assert_exact_or_ulp(embed({"porosity": v["porosity"].unsqueeze(0)}), v["ye"], "porosity embedding")
+        assert_exact_or_ulp(embed({"porosity": v["porosity_batch"]}), v["ye_batch"], "batched porosity embedding")
+    net = punetg_ref.make_net(sd, cfg, embed=embed)
+    y = {"porosity": v["porosity"]}                      # un-batched, as the caller passes it
+    h = K.propagate_white_noise(net, v["white_noise"], 4, y=y, guidance=2.0, conditional=True, record_history=True)
+    assert_exact_or_rel(h, v["hist_cfg_g2_N4_f32"], "hist_cfg_g2_N4_f32", 2e-6)
+    o = K.propagate_white_noise(net, v["white_noise"], 4, y=y, guidance=1.0, conditional=True)
+    assert_exact_or_rel(o, v["out_cond_g1_N4_f32"], "out_cond_g1_N4_f32", 2e-6)
