@@ -26,8 +26,8 @@ typedef const __attribute__((address_space(1))) char* gchar_ptr;
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef const __attribute__((address_space(1))) f32x2* gfloat2_ptr;
 
-constexpr int TH = 8, TW = 32, COT = 64, NT = 256, KC = 16;
-constexpr int NPOS = TH * TW;                      // 256 = NT: one pixel per thread
+constexpr int COT = 64, NT = 256, KC = 16;
+constexpr int NPOS = 256;                          // pixels per tile = NT: one pixel per thread
 constexpr int XBUF_VEC = 2 * 2 * NPOS;             // [piece][h][pos] 16-byte vectors: 1024 (16 KiB)
 constexpr int WSLAB_VEC = 2 * 2 * COT;             // [piece][h][co] per chunk: 256 (4 KiB)
 constexpr int NXB = 3, NWS = 3;
@@ -68,8 +68,10 @@ __device__ __forceinline__ void step_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-template <int MODE>
+// W16: the 256 pixels of the tile are 16 rows x 16 columns (narrow feature maps) instead of 8 x 32.
+template <int MODE, bool W16>
 __global__ __launch_bounds__(NT, 2) void k_conv1h(const Conv1hArgs a) {
+  constexpr int TW = W16 ? 16 : 32, TH = W16 ? 16 : 8;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   u32x4* Xs = reinterpret_cast<u32x4*>(smem);                        // [buf 3][piece][h][pos]
   u32x4* Ws = Xs + NXB * XBUF_VEC;                                   // [slot 3][piece][h][co]
@@ -99,7 +101,7 @@ __global__ __launch_bounds__(NT, 2) void k_conv1h(const Conv1hArgs a) {
   // channels past Cin of a ragged last chunk are fetched from clamped (valid) addresses and NOT
   // zeroed: a 1x1 convolution has no halo, so an out-of-range pixel only feeds outputs that are
   // never stored, and the padded weight rows of the channels past Cin are zero.
-  const int gy = y0 + (tid >> 5), gx = x0 + (tid & 31);
+  const int gy = y0 + (W16 ? tid >> 4 : tid >> 5), gx = x0 + (W16 ? tid & 15 : tid & 31);
   const bool ok = gy < a.H && gx < a.W;
   unsigned off;
   if (MODE == DS_LOAD_PLAIN) off = gy * a.Win + gx;
@@ -168,7 +170,7 @@ __global__ __launch_bounds__(NT, 2) void k_conv1h(const Conv1hArgs a) {
 #pragma unroll
       for (int m = 0; m < 2; ++m) fa[p][m] = *reinterpret_cast<const f16x8*>(&wb[(p * 2 + lh) * COT + 32 * m + li]);
 #pragma unroll
-      for (int r = 0; r < 2; ++r) fb[p][r] = *reinterpret_cast<const f16x8*>(&xb[(p * 2 + lh) * NPOS + (2 * wv + r) * TW + li]);
+      for (int r = 0; r < 2; ++r) fb[p][r] = *reinterpret_cast<const f16x8*>(&xb[(p * 2 + lh) * NPOS + (2 * wv + r) * 32 + li]);
     }
     constexpr int PA[3] = {1, 0, 0};
     constexpr int PB[3] = {0, 1, 0};
@@ -219,10 +221,10 @@ __global__ __launch_bounds__(NT, 2) void k_conv1h(const Conv1hArgs a) {
     ds_epi::Args e;
     e.out = a.out; e.bias = a.bias; e.shift = a.shift; e.res1 = a.res1; e.res2 = a.res2;
     e.unscale = a.unscale; e.shift_stride = a.shift_stride;
-    e.b = b; e.co_base = cot * COT; e.y0 = y0 + 2 * wv; e.x0 = x0;
+    e.b = b; e.co_base = cot * COT; e.y0 = y0 + (W16 ? 4 : 2) * wv; e.x0 = x0;
     e.Cout = a.Cout; e.H = a.H; e.W = a.W;
     float* tile = reinterpret_cast<float*>(smem) + wv * (64 * 2 * 32);
-    ds_epi::store_tile(acc, tile, BS, e);
+    ds_epi::store_tile<W16>(acc, tile, BS, e);
   }
 }
 
@@ -246,16 +248,16 @@ __global__ void k_pack1h(_Float16* packed, const float* __restrict__ w, int Cout
   packed[i] = piece == 0 ? hi : lo;
 }
 
-template <int MODE>
+template <int MODE, bool W16>
 int launch_conv1h(const Conv1hArgs& a, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv1h<MODE>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv1h<MODE, W16>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (e != hipSuccess) return ds::hip_fail(e, "hipFuncSetAttribute(conv1h)");
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_conv1h<MODE>), dim3(a.n_blocks), dim3(NT), LDS_BYTES, s, a);
+  hipLaunchKernelGGL((k_conv1h<MODE, W16>), dim3(a.n_blocks), dim3(NT), LDS_BYTES, s, a);
   DS_CHECK_LAUNCH("ds_conv1x1_h3");
   return DS_OK;
 }
@@ -307,6 +309,10 @@ int ds_conv1x1_h3(float* out, const float* in, const void* w_packed, int wshift,
   a.Hin = load_mode == DS_LOAD_AVGPOOL2 ? 2 * H : (load_mode == DS_LOAD_UPSAMPLE2 ? H / 2 : H);
   a.Win = load_mode == DS_LOAD_AVGPOOL2 ? 2 * W : (load_mode == DS_LOAD_UPSAMPLE2 ? W / 2 : W);
   DS_REQUIRE((long long)a.Hin * a.Win < (1ll << 29), DS_ERR_SHAPE, "ds_conv1x1_h3: a channel plane exceeds 2^29 floats");
+  const long long pad32 = (long long)((W + 31) / 32 * 32) * ((H + 7) / 8 * 8);
+  const long long pad16 = (long long)((W + 15) / 16 * 16) * ((H + 15) / 16 * 16);
+  const bool w16 = pad16 < pad32;                    // the tile shape that pads the image with fewer pixels
+  const int TW = w16 ? 16 : 32, TH = w16 ? 16 : 8;
   a.tiles_x = (W + TW - 1) / TW; a.tiles_y = (H + TH - 1) / TH;
   a.n_cot = (Cout + COT - 1) / COT;
   a.n_chunks = (Cin + KC - 1) / KC;
@@ -314,9 +320,14 @@ int ds_conv1x1_h3(float* out, const float* in, const void* w_packed, int wshift,
   DS_REQUIRE(blocks > 0 && blocks < (1ll << 31), DS_ERR_SHAPE, "ds_conv1x1_h3: grid of %lld workgroups is out of range", blocks);
   a.n_blocks = (unsigned)blocks;
   hipStream_t s = ds::as_stream(stream);
-  if (load_mode == DS_LOAD_PLAIN) return launch_conv1h<DS_LOAD_PLAIN>(a, s);
-  if (load_mode == DS_LOAD_UPSAMPLE2) return launch_conv1h<DS_LOAD_UPSAMPLE2>(a, s);
-  return launch_conv1h<DS_LOAD_AVGPOOL2>(a, s);
+  if (w16) {
+    if (load_mode == DS_LOAD_PLAIN) return launch_conv1h<DS_LOAD_PLAIN, true>(a, s);
+    if (load_mode == DS_LOAD_UPSAMPLE2) return launch_conv1h<DS_LOAD_UPSAMPLE2, true>(a, s);
+    return launch_conv1h<DS_LOAD_AVGPOOL2, true>(a, s);
+  }
+  if (load_mode == DS_LOAD_PLAIN) return launch_conv1h<DS_LOAD_PLAIN, false>(a, s);
+  if (load_mode == DS_LOAD_UPSAMPLE2) return launch_conv1h<DS_LOAD_UPSAMPLE2, false>(a, s);
+  return launch_conv1h<DS_LOAD_AVGPOOL2, false>(a, s);
 }
 
 }  // extern "C"

@@ -41,12 +41,19 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
-constexpr int TH = 8, TW = 32, COT = 64, NT = 256;
+constexpr int COT = 64, NT = 256;
 constexpr int KC = 16;
-constexpr int PH = TH + 2, PW = TW + 2, NPOS = PH * PW;     // 340
-constexpr int XITEMS = 2 * NPOS;                            // (h, position) staging items: 680
-constexpr int XI = (XITEMS + NT - 1) / NT;                  // 3 per thread
-constexpr int XBUF_VEC = 2 * 2 * NPOS;                      // 16-byte vectors per X buffer: 1360
+// Pixel tile of a workgroup: 8 rows x 32 columns, or 16 x 16 for narrow feature maps (W16) where a
+// 32-wide tile would be mostly padding.  The 32 positions of one MFMA B operand are one 32-pixel row
+// segment, or two 16-pixel row segments.
+template <bool W16> struct Geo {
+  static constexpr int TH = W16 ? 16 : 8, TW = W16 ? 16 : 32;
+  static constexpr int PH = TH + 2, PW = TW + 2, NPOS = PH * PW;     // 340 / 324
+  static constexpr int XITEMS = 2 * NPOS;                            // (h, position) staging items
+  static constexpr int XI = (XITEMS + NT - 1) / NT;                  // 3 per thread
+  static constexpr int XBUF_VEC = 2 * 2 * NPOS;                      // 16-byte vectors per X buffer
+};
+constexpr int XBUF_VEC = Geo<false>::XBUF_VEC;              // LDS is sized for the larger geometry: 1360
 constexpr int WSLAB_VEC = 2 * 3 * 2 * COT;                  // 16-byte vectors per (chunk, ky) slab: 768
 constexpr int WDMA = WSLAB_VEC / 64 / 4;                    // LDS-DMA wave-instructions per wave: 3
 constexpr int STAGE_BYTES = (2 * XBUF_VEC + 3 * WSLAB_VEC) * 16;   // 80,384
@@ -86,8 +93,10 @@ __device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned&
 
 struct Frags { f16x8 a[2][2]; f16x8 b[2][2]; };   // [piece][m] weights, [piece][r] input
 
-template <int MODE>
+template <int MODE, bool W16>
 __global__ __launch_bounds__(NT, 2) void k_conv3h(const Conv3hArgs a) {
+  constexpr int TH = Geo<W16>::TH, TW = Geo<W16>::TW, PW = Geo<W16>::PW, NPOS = Geo<W16>::NPOS;
+  constexpr int XITEMS = Geo<W16>::XITEMS, XI = Geo<W16>::XI;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   u32x4* Xs = reinterpret_cast<u32x4*>(smem);                        // [buf][piece][h][pos]
   u32x4* Ws = Xs + 2 * XBUF_VEC;                                     // [slot][piece][kx][h][co]
@@ -96,6 +105,10 @@ __global__ __launch_bounds__(NT, 2) void k_conv3h(const Conv3hArgs a) {
   const int lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lh = lane >> 5;
+  // position of (wave, r, lane) inside the halo patch, before the (ky, kx) tap offset
+  const int lane_pos = W16 ? (li >> 4) * PW + (li & 15) : li;
+  const int wave_row = W16 ? 4 * wv : 2 * wv;
+  constexpr int ROWS_PER_R = W16 ? 2 : 1;
 
   int bid = blockIdx.x;
   const int cot = bid % a.n_cot; bid /= a.n_cot;
@@ -208,7 +221,7 @@ __global__ __launch_bounds__(NT, 2) void k_conv3h(const Conv3hArgs a) {
         f.a[p][m] = *reinterpret_cast<const f16x8*>(&wb[((p * 3 + kx) * 2 + lh) * COT + 32 * m + li]);
 #pragma unroll
       for (int r = 0; r < 2; ++r)
-        f.b[p][r] = *reinterpret_cast<const f16x8*>(&xb[(p * 2 + lh) * NPOS + (2 * wv + r + ky) * PW + li + kx]);
+        f.b[p][r] = *reinterpret_cast<const f16x8*>(&xb[(p * 2 + lh) * NPOS + (wave_row + ROWS_PER_R * r + ky) * PW + lane_pos + kx]);
     }
   };
   auto frag_mma = [&](const Frags& f) {               // lo*hi, hi*lo, hi*hi
@@ -298,10 +311,10 @@ __global__ __launch_bounds__(NT, 2) void k_conv3h(const Conv3hArgs a) {
     ds_epi::Args e;
     e.out = a.out; e.bias = a.bias; e.shift = a.shift; e.res1 = a.res1; e.res2 = a.res2;
     e.unscale = a.unscale; e.shift_stride = a.shift_stride;
-    e.b = b; e.co_base = cot * COT; e.y0 = y0 + 2 * wv; e.x0 = x0;
+    e.b = b; e.co_base = cot * COT; e.y0 = y0 + wave_row; e.x0 = x0;
     e.Cout = a.Cout; e.H = a.H; e.W = a.W;
     float* tile = reinterpret_cast<float*>(smem) + wv * (64 * 2 * 32);
-    ds_epi::store_tile(acc, tile, BS, e);
+    ds_epi::store_tile<W16>(acc, tile, BS, e);
   }
 #ifdef DS_STAMP
   STAMP(4);
@@ -332,18 +345,18 @@ __global__ void k_pack3h(_Float16* packed, const float* __restrict__ w, int Cout
   packed[i] = piece == 0 ? hi : lo;
 }
 
-template <int MODE>
+template <int MODE, bool W16>
 int launch_conv3h(const Conv3hArgs& a, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3h<MODE>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3h<MODE, W16>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (e != hipSuccess) return ds::hip_fail(e, "hipFuncSetAttribute(conv3h)");
     attr_set = true;
   }
   const long long blocks = (long long)a.B * a.tiles_y * a.tiles_x * a.n_cot;
   DS_REQUIRE(blocks > 0 && blocks < (1ll << 31), DS_ERR_SHAPE, "ds_conv2d_h3: grid of %lld workgroups is out of range", blocks);
-  hipLaunchKernelGGL((k_conv3h<MODE>), dim3((unsigned)blocks), dim3(NT), LDS_BYTES, s, a);
+  hipLaunchKernelGGL((k_conv3h<MODE, W16>), dim3((unsigned)blocks), dim3(NT), LDS_BYTES, s, a);
   DS_CHECK_LAUNCH("ds_conv2d_h3");
   return DS_OK;
 }
@@ -394,6 +407,11 @@ int ds_conv2d_h3(float* out, const float* in, const void* w_packed, int wshift, 
   a.Hin = load_mode == DS_LOAD_MAXPOOL2 ? 2 * H : (load_mode == DS_LOAD_UPSAMPLE2 ? H / 2 : H);
   a.Win = load_mode == DS_LOAD_MAXPOOL2 ? 2 * W : (load_mode == DS_LOAD_UPSAMPLE2 ? W / 2 : W);
   DS_REQUIRE((long long)Cin * a.Hin * a.Win < (1ll << 31), DS_ERR_SHAPE, "ds_conv2d_h3: per-sample input exceeds 2^31 floats");
+  // tile geometry: whichever pads the image with fewer pixels (16 x 16 wins for W <= 16, W = 48, ...)
+  const long long pad32 = (long long)((W + 31) / 32 * 32) * ((H + 7) / 8 * 8);
+  const long long pad16 = (long long)((W + 15) / 16 * 16) * ((H + 15) / 16 * 16);
+  const bool w16 = pad16 < pad32;
+  const int TW = w16 ? 16 : 32, TH = w16 ? 16 : 8;
   a.tiles_x = (W + TW - 1) / TW; a.tiles_y = (H + TH - 1) / TH;
   a.n_cot = (Cout + COT - 1) / COT;
   a.n_chunks = (Cin + KC - 1) / KC;
@@ -401,9 +419,14 @@ int ds_conv2d_h3(float* out, const float* in, const void* w_packed, int wshift, 
   a.stamps = g_stamps;
 #endif
   hipStream_t s = ds::as_stream(stream);
-  if (load_mode == DS_LOAD_PLAIN) return launch_conv3h<DS_LOAD_PLAIN>(a, s);
-  if (load_mode == DS_LOAD_MAXPOOL2) return launch_conv3h<DS_LOAD_MAXPOOL2>(a, s);
-  return launch_conv3h<DS_LOAD_UPSAMPLE2>(a, s);
+  if (w16) {
+    if (load_mode == DS_LOAD_PLAIN) return launch_conv3h<DS_LOAD_PLAIN, true>(a, s);
+    if (load_mode == DS_LOAD_MAXPOOL2) return launch_conv3h<DS_LOAD_MAXPOOL2, true>(a, s);
+    return launch_conv3h<DS_LOAD_UPSAMPLE2, true>(a, s);
+  }
+  if (load_mode == DS_LOAD_PLAIN) return launch_conv3h<DS_LOAD_PLAIN, false>(a, s);
+  if (load_mode == DS_LOAD_MAXPOOL2) return launch_conv3h<DS_LOAD_MAXPOOL2, false>(a, s);
+  return launch_conv3h<DS_LOAD_UPSAMPLE2, false>(a, s);
 }
 
 }  // extern "C"

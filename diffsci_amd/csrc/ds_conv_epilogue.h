@@ -24,9 +24,12 @@ struct Args {
   int Cout, H, W;
 };
 
+// W16 = false: the wave's 2 x 32 positions are 2 rows x 32 columns (row = y0 + r, column = x0 + x);
+// W16 = true (narrow feature maps): they are 4 rows x 16 columns (row = y0 + 2r + x/16, column = x0 + x%16).
 // tile:  wave-private LDS scratch of 64*2*32 floats (16 KiB), 16-byte aligned.
 // bs:    LDS array [2][64]: bias and shift of the workgroup's 64 channels (zeros where absent),
 //        written by the caller before the last barrier of the main loop.
+template <bool W16 = false>
 __device__ __forceinline__ void store_tile(const f32x16 (&acc)[2][2], float* tile, const float* bs, const Args& e) {
   const int lane = threadIdx.x & 63;
   const int li = lane & 31, lh = lane >> 5;
@@ -47,7 +50,8 @@ __device__ __forceinline__ void store_tile(const f32x16 (&acc)[2][2], float* til
     }
   // phase 2: 16 bytes per lane; lane -> (segment = 8*it + lane/8, quarter = lane%8)
   const int p4 = 4 * (lane & 7);
-  const int gx = e.x0 + p4;
+  const int gx = e.x0 + (W16 ? (p4 & 15) : p4);
+  const int yq = W16 ? (p4 >> 4) : 0;
   const size_t plane = (size_t)e.H * e.W;
   if ((e.W & 3) == 0) {
 #pragma unroll
@@ -59,7 +63,7 @@ __device__ __forceinline__ void store_tile(const f32x16 (&acc)[2][2], float* til
       for (int k = 0; k < 4; ++k) {
         const int seg = (half * 4 + k) * 8 + (lane >> 3);
         const int co = seg >> 1, r = seg & 1;
-        const int gy = e.y0 + r;
+        const int gy = e.y0 + (W16 ? 2 * r + yq : r);
         ok[k] = (e.co_base + co < e.Cout) && gy < e.H && gx < e.W;
         idx[k] = ok[k] ? ((size_t)e.b * e.Cout + e.co_base + co) * plane + (size_t)gy * e.W + gx : (size_t)0;
         v[k] = *reinterpret_cast<const f32x4*>(&tile[seg * 32 + p4]);
@@ -88,7 +92,7 @@ __device__ __forceinline__ void store_tile(const f32x16 (&acc)[2][2], float* til
     // ragged width: element-wise, compact loop (correctness path for odd shapes)
     for (int i = lane; i < 64 * 2 * 32; i += 64) {
       const int co = i >> 6, r = (i >> 5) & 1, x = i & 31;
-      const int gy = e.y0 + r, gxx = e.x0 + x;
+      const int gy = e.y0 + (W16 ? 2 * r + (x >> 4) : r), gxx = e.x0 + (W16 ? (x & 15) : x);
       if (e.co_base + co < e.Cout && gy < e.H && gxx < e.W) {
         const size_t idx = ((size_t)e.b * e.Cout + e.co_base + co) * plane + (size_t)gy * e.W + gxx;
         float v = tile[i];

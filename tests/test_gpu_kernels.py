@@ -131,6 +131,10 @@ CONV_CASES = [
     (2, 32, 96, 8, 8, 1, 0),       # attention in_proj
     (1, 70, 33, 8, 40, 1, 0),
     (1, 128, 128, 64, 64, 3, 0),   # multiple chunks and channel tiles
+    (2, 32, 64, 16, 16, 3, 0),     # narrow maps: the 16 x 16 pixel-tile geometry
+    (1, 24, 40, 20, 48, 3, 0),     # W = 48: three 16-wide tiles instead of two 32-wide
+    (1, 24, 12, 16, 16, 3, 2),     # UpSampler onto a 16 x 16 map
+    (2, 16, 32, 8, 8, 3, 1),       # DownSampler onto an 8 x 8 map
 ]
 
 
@@ -205,7 +209,10 @@ CONV1X1_CASES = [
     (2, 48, 64, 16, 32, 2),        # decoder block: nearest-up folded into the load
     (2, 40, 72, 12, 20, 3),        # encoder block: AvgPool2d(2) folded into the load
     (1, 256, 512, 32, 32, 3),
-    (1, 1024, 256, 16, 16, 2),     # 64 steps
+    (1, 1024, 256, 16, 16, 2),     # 64 steps, 16 x 16 tile geometry
+    (2, 64, 64, 16, 16, 0),
+    (1, 32, 48, 24, 48, 2),        # W = 48
+    (2, 16, 16, 8, 8, 3),
 ]
 
 
