@@ -5,7 +5,7 @@ point of diffsci_amd raises.  Build it with ``python build.py`` (hipcc, gfx950).
 """
 import ctypes
 import os
-from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_size_t, c_void_p
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_longlong, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "_lib", "libdiffsci_hip.so")
@@ -49,10 +49,14 @@ _PROTOS = {
     "ds_conv2d_x6": (c_int, [_P, _P, _P, _P, _P, c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "ds_conv2d_h3_packed_bytes": (c_size_t, [c_int, c_int]),
     "ds_conv2d_h3_pack_weights": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
-    "ds_conv2d_h3": (c_int, [_P, _P, _P, c_int, _P, _P, c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "ds_conv2d_h3": (c_int, [_P, _P, _P, c_int, _P, _P, c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P]),
+    "ds_conv_tile_count": (c_int, [c_int, c_int]),
+    "ds_inorm_table": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_int, _P]),
+    "ds_gnorm1_table": (c_int, [_P, _P, c_int, c_int, _P, c_int, c_int, _P, _P, _P, _P, c_int, c_int, c_longlong,
+                                c_float, c_int, _P]),
     "ds_conv1x1_h3_packed_bytes": (c_size_t, [c_int, c_int]),
     "ds_conv1x1_h3_pack_weights": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
-    "ds_conv1x1_h3": (c_int, [_P, _P, _P, c_int, _P, _P, c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "ds_conv1x1_h3": (c_int, [_P, _P, _P, c_int, _P, _P, c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "ds_attention": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     "ds_attention_h3": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     "ds_linear": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),

@@ -45,6 +45,7 @@ struct Conv1hArgs {
   const float* shift;
   const float* res1;
   const float* res2;
+  float* tile_stats;      // see ds_conv_epilogue.h, or NULL
   float unscale;
   int shift_stride;
   int B, Cin, Cout, H, W, Hin, Win;
@@ -223,8 +224,13 @@ __global__ __launch_bounds__(NT, 2) void k_conv1h(const Conv1hArgs a) {
     e.unscale = a.unscale; e.shift_stride = a.shift_stride;
     e.b = b; e.co_base = cot * COT; e.y0 = y0 + (W16 ? 4 : 2) * wv; e.x0 = x0;
     e.Cout = a.Cout; e.H = a.H; e.W = a.W;
+    e.tile_stats = a.tile_stats; e.tile = ty * a.tiles_x + tx; e.ntiles = a.tiles_x * a.tiles_y;
     float* tile = reinterpret_cast<float*>(smem) + wv * (64 * 2 * 32);
     ds_epi::store_tile<W16>(acc, tile, BS, e);
+    if (a.tile_stats) {
+      __syncthreads();
+      ds_epi::store_tile_stats(reinterpret_cast<const float*>(smem), 64 * 2 * 32, e);
+    }
   }
 }
 
@@ -286,7 +292,7 @@ int ds_conv1x1_h3_pack_weights(void* packed, const float* w, int Cout, int Cin, 
 
 int ds_conv1x1_h3(float* out, const float* in, const void* w_packed, int wshift, const float* bias, const float* shift,
                   int shift_stride, const float* res1, const float* res2, int B, int Cin, int Cout, int H, int W,
-                  int load_mode, void* stream) {
+                  int load_mode, float* tile_stats, void* stream) {
   DS_REQUIRE(out && in && w_packed, DS_ERR_NULL, "ds_conv1x1_h3: NULL pointer");
   DS_REQUIRE(B >= 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, DS_ERR_SHAPE,
              "ds_conv1x1_h3: bad shape B=%d Cin=%d Cout=%d H=%d W=%d", B, Cin, Cout, H, W);
@@ -303,7 +309,7 @@ int ds_conv1x1_h3(float* out, const float* in, const void* w_packed, int wshift,
   if (B == 0) return DS_OK;
   Conv1hArgs a;
   a.out = out; a.in = in; a.wp = reinterpret_cast<const u32x4*>(w_packed); a.bias = bias; a.shift = shift;
-  a.res1 = res1; a.res2 = res2; a.shift_stride = shift_stride;
+  a.res1 = res1; a.res2 = res2; a.shift_stride = shift_stride; a.tile_stats = tile_stats;
   a.unscale = ldexpf(1.0f, -wshift);
   a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W;
   a.Hin = load_mode == DS_LOAD_AVGPOOL2 ? 2 * H : (load_mode == DS_LOAD_UPSAMPLE2 ? H / 2 : H);

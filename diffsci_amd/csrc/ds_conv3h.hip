@@ -37,6 +37,7 @@ unsigned long long* g_stamps = nullptr;
 namespace {
 
 using ds_epi::f32x16;
+using ds_epi::f32x4;
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
@@ -67,6 +68,8 @@ struct Conv3hArgs {
   const float* shift;
   const float* res1;
   const float* res2;
+  const float* prenorm;   // [B][Cin][4] = (M, A, C, -) or NULL: the loader applies SiLU((x - M)*A + C)
+  float* tile_stats;      // see ds_conv_epilogue.h, or NULL
   float unscale;        // 2^-wshift
   int shift_stride;
   int B, Cin, Cout, H, W, Hin, Win;
@@ -93,7 +96,14 @@ __device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned&
 
 struct Frags { f16x8 a[2][2]; f16x8 b[2][2]; };   // [piece][m] weights, [piece][r] input
 
-template <int MODE, bool W16>
+// x * sigmoid(x) with the hardware exp2 / rcp (1 ulp each): the fused-normalisation loader's
+// activation (the standalone norm kernels use expf and an IEEE division; the difference is ~2e-7
+// relative, far inside the path's stated 1e-5 tolerance).
+__device__ __forceinline__ float fast_silu(float v) {
+  return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.44269504088896341f));
+}
+
+template <int MODE, bool W16, bool PRE>
 __global__ __launch_bounds__(NT, 2) void k_conv3h(const Conv3hArgs a) {
   constexpr int TH = Geo<W16>::TH, TW = Geo<W16>::TW, PW = Geo<W16>::PW, NPOS = Geo<W16>::NPOS;
   constexpr int XITEMS = Geo<W16>::XITEMS, XI = Geo<W16>::XI;
@@ -120,38 +130,45 @@ __global__ __launch_bounds__(NT, 2) void k_conv3h(const Conv3hArgs a) {
   const int n_steps = a.n_chunks * 3;
 
   STAMP(0);
-  // ---- input staging plan: item e -> (h, position); addresses always in bounds ----
-  int xoff[XI];
-  unsigned xvalid = 0;
+  // ---- input staging plan: item i of a thread -> (h = channel half, position of the halo patch);
+  //      items 0 / 1: position tid of h = 0 / 1; item 2: the patch's tail (positions 256..NPOS-1),
+  //      h = wave / 2, so h is wave-uniform for every item.  Addresses are always in bounds. ----
+  static_assert(XI == 3 && NPOS > NT && NPOS - NT <= NT / 2, "staging plan assumes 256 < NPOS <= 384");
+  const int tail_h = wv >> 1;                          // wave-uniform
+  int xoff[XI], xlds[XI];
+  unsigned xvalid = 0, xlive = 0;
 #pragma unroll
   for (int i = 0; i < XI; ++i) {
-    const int e = tid + NT * i;
-    const int h = e / NPOS;
-    const int pos = e - h * NPOS;
+    const int h = i == 0 ? 0 : (i == 1 ? 1 : tail_h);
+    const int pos = i < 2 ? tid : NT + (tid & (NT / 2 - 1));
+    const bool live = pos < NPOS;                      // the item exists
     const int r = pos / PW;
     const int col = pos - r * PW;
     const int gy = y0 + r - 1, gx = x0 + col - 1;
-    const bool ok = (e < XITEMS) && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+    const bool ok = live && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
     int off;
     if (MODE == DS_LOAD_PLAIN) off = gy * a.Win + gx;
     else if (MODE == DS_LOAD_MAXPOOL2) off = (2 * gy) * a.Win + 2 * gx;
     else off = (gy >> 1) * a.Win + (gx >> 1);
     xoff[i] = ok ? off : 0;
+    xlds[i] = h * NPOS + pos;
     if (ok) xvalid |= (1u << i);
+    if (live) xlive |= (1u << i);
   }
   const float* in_b = a.in + (size_t)b * a.Cin * HWin;
   const u32x4* wp = a.wp + (size_t)cot * n_steps * WSLAB_VEC;
 
   float xr[XI][8];
   int xnch = KC;
-  auto x_fetch = [&](int chunk) {                     // issue the global loads of one patch
+  int xchunk = 0;                                     // chunk held in xr (set by x_fetch)
+  auto x_fetch = [&](int chunk) __attribute__((always_inline)) {                     // issue the global loads of one patch
     const int cbase = chunk * KC;
     const float* src = in_b + (size_t)cbase * HWin;
+    xchunk = chunk;
     xnch = a.Cin - cbase < KC ? a.Cin - cbase : KC;   // uniform; < KC only for a ragged last chunk
 #pragma unroll
     for (int i = 0; i < XI; ++i) {
-      const int e = tid + NT * i;
-      const int h = (e / NPOS) & 1;
+      const int h = i == 0 ? 0 : (i == 1 ? 1 : tail_h);
       const float* p0 = src + xoff[i];
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
@@ -168,13 +185,27 @@ __global__ __launch_bounds__(NT, 2) void k_conv3h(const Conv3hArgs a) {
       if (MODE == DS_LOAD_MAXPOOL2) __builtin_amdgcn_sched_barrier(0);   // one item at a time (registers)
     }
   };
-  auto x_store = [&](int buf) {                       // split to fp16 pieces, write the LDS image
+  const float* pre_b = PRE ? a.prenorm + (size_t)b * a.Cin * 4 : nullptr;
+  auto x_store = [&](int buf) __attribute__((always_inline)) {                       // [normalise + SiLU,] split to fp16 pieces, write the LDS image
     u32x4* xb = Xs + buf * XBUF_VEC;
+    if (PRE) {
+      // (M, A, C) of the item's 8 channels: wave-uniform addresses -> scalar loads, SGPR operands
+      const f32x4* pp = reinterpret_cast<const f32x4*>(pre_b) + xchunk * KC;
+#pragma unroll
+      for (int i = 0; i < XI; ++i) {
+        const int h = i == 0 ? 0 : (i == 1 ? 1 : tail_h);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int c = 8 * h + k < xnch ? 8 * h + k : 0;                     // ragged last chunk: stay inside the table
+          const f32x4 p = pp[c];
+          xr[i][k] = fast_silu((xr[i][k] - p[0]) * p[1] + p[2]);
+        }
+      }
+    }
 #pragma unroll
     for (int i = 0; i < XI; ++i) {
-      const int e = tid + NT * i;
-      if (NT * (i + 1) <= XITEMS || e < XITEMS) {
-        const int h = e / NPOS;
+      if (i < 2 || ((xlive >> i) & 1u)) {
+        const int h = i == 0 ? 0 : (i == 1 ? 1 : tail_h);
         const bool item_ok = (xvalid >> i) & 1u;
         u32x4 qh, ql;
 #pragma unroll
@@ -185,12 +216,12 @@ __global__ __launch_bounds__(NT, 2) void k_conv3h(const Conv3hArgs a) {
           split2(v0, v1, ph, pl);
           qh[k] = ph; ql[k] = pl;
         }
-        xb[e] = qh;                      // piece 0: [h][pos] with e = h*NPOS + pos
-        xb[2 * NPOS + e] = ql;           // piece 1
+        xb[xlds[i]] = qh;                // piece 0: [h][pos]
+        xb[2 * NPOS + xlds[i]] = ql;     // piece 1
       }
     }
   };
-  auto w_fetch = [&](int step, int slot) {            // LDS-DMA of slab `step` into ring slot (= step % 3)
+  auto w_fetch = [&](int step, int slot) __attribute__((always_inline)) {            // LDS-DMA of slab `step` into ring slot (= step % 3)
     const u32x4* src = wp + (size_t)step * WSLAB_VEC;
     u32x4* dst = Ws + slot * WSLAB_VEC;
 #pragma unroll
@@ -211,7 +242,7 @@ __global__ __launch_bounds__(NT, 2) void k_conv3h(const Conv3hArgs a) {
       for (int q = 0; q < 16; ++q) acc[m][r][q] = 0.f;
 
   // operand fetch for (weight slot, X buffer, ky, kx)
-  auto frag_load = [&](Frags& f, int slot, int xbuf, int ky, int kx) {
+  auto frag_load = [&](Frags& f, int slot, int xbuf, int ky, int kx) __attribute__((always_inline)) {
     const u32x4* wb = Ws + slot * WSLAB_VEC;
     const u32x4* xb = Xs + xbuf * XBUF_VEC;
 #pragma unroll
@@ -224,7 +255,7 @@ __global__ __launch_bounds__(NT, 2) void k_conv3h(const Conv3hArgs a) {
         f.b[p][r] = *reinterpret_cast<const f16x8*>(&xb[(p * 2 + lh) * NPOS + (wave_row + ROWS_PER_R * r + ky) * PW + lane_pos + kx]);
     }
   };
-  auto frag_mma = [&](const Frags& f) {               // lo*hi, hi*lo, hi*hi
+  auto frag_mma = [&](const Frags& f) __attribute__((always_inline)) {               // lo*hi, hi*lo, hi*hi
     constexpr int PA[3] = {1, 0, 0};
     constexpr int PB[3] = {0, 1, 0};
 #pragma unroll
@@ -235,7 +266,7 @@ __global__ __launch_bounds__(NT, 2) void k_conv3h(const Conv3hArgs a) {
         for (int r = 0; r < 2; ++r)
           acc[m][r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[PA[t]][m], f.b[PB[t]][r], acc[m][r], 0, 0, 0);
   };
-  auto reads_between_mfmas = [&]() {                  // 8 ds_read_b128 slotted behind the first 8 MFMAs
+  auto reads_between_mfmas = [&]() __attribute__((always_inline)) {                  // 8 ds_read_b128 slotted behind the first 8 MFMAs
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -261,7 +292,7 @@ __global__ __launch_bounds__(NT, 2) void k_conv3h(const Conv3hArgs a) {
   // the operands of the NEXT step's kx = 0 (three blocks per step flip the roles).
   // The ring slot of step g = 3*chunk + ky is g % 3 = ky and the X buffer is chunk & 1: both are
   // compile-time constants at every call site below, so all LDS addresses are base + immediate.
-  auto step = [&](Frags& cur, Frags& oth, int chunk, int ky, int xbuf) {
+  auto step = [&](Frags& cur, Frags& oth, int chunk, int ky, int xbuf) __attribute__((always_inline)) {
     const int g = chunk * 3 + ky;
     const int slot = ky;
     const bool more_chunks = chunk + 1 < a.n_chunks;
@@ -313,8 +344,13 @@ __global__ __launch_bounds__(NT, 2) void k_conv3h(const Conv3hArgs a) {
     e.unscale = a.unscale; e.shift_stride = a.shift_stride;
     e.b = b; e.co_base = cot * COT; e.y0 = y0 + wave_row; e.x0 = x0;
     e.Cout = a.Cout; e.H = a.H; e.W = a.W;
+    e.tile_stats = a.tile_stats; e.tile = ty * a.tiles_x + tx; e.ntiles = a.tiles_x * a.tiles_y;
     float* tile = reinterpret_cast<float*>(smem) + wv * (64 * 2 * 32);
     ds_epi::store_tile<W16>(acc, tile, BS, e);
+    if (a.tile_stats) {
+      __syncthreads();
+      ds_epi::store_tile_stats(reinterpret_cast<const float*>(smem), 64 * 2 * 32, e);
+    }
   }
 #ifdef DS_STAMP
   STAMP(4);
@@ -345,18 +381,18 @@ __global__ void k_pack3h(_Float16* packed, const float* __restrict__ w, int Cout
   packed[i] = piece == 0 ? hi : lo;
 }
 
-template <int MODE, bool W16>
+template <int MODE, bool W16, bool PRE>
 int launch_conv3h(const Conv3hArgs& a, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3h<MODE, W16>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3h<MODE, W16, PRE>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (e != hipSuccess) return ds::hip_fail(e, "hipFuncSetAttribute(conv3h)");
     attr_set = true;
   }
   const long long blocks = (long long)a.B * a.tiles_y * a.tiles_x * a.n_cot;
   DS_REQUIRE(blocks > 0 && blocks < (1ll << 31), DS_ERR_SHAPE, "ds_conv2d_h3: grid of %lld workgroups is out of range", blocks);
-  hipLaunchKernelGGL((k_conv3h<MODE, W16>), dim3((unsigned)blocks), dim3(NT), LDS_BYTES, s, a);
+  hipLaunchKernelGGL((k_conv3h<MODE, W16, PRE>), dim3((unsigned)blocks), dim3(NT), LDS_BYTES, s, a);
   DS_CHECK_LAUNCH("ds_conv2d_h3");
   return DS_OK;
 }
@@ -385,7 +421,7 @@ int ds_conv2d_h3_pack_weights(void* packed, const float* w, int Cout, int Cin, i
 
 int ds_conv2d_h3(float* out, const float* in, const void* w_packed, int wshift, const float* bias, const float* shift,
                  int shift_stride, const float* res1, const float* res2, int B, int Cin, int Cout, int H, int W,
-                 int load_mode, void* stream) {
+                 int load_mode, const float* prenorm, float* tile_stats, void* stream) {
   DS_REQUIRE(out && in && w_packed, DS_ERR_NULL, "ds_conv2d_h3: NULL pointer");
   DS_REQUIRE(B >= 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, DS_ERR_SHAPE,
              "ds_conv2d_h3: bad shape B=%d Cin=%d Cout=%d H=%d W=%d", B, Cin, Cout, H, W);
@@ -398,8 +434,12 @@ int ds_conv2d_h3(float* out, const float* in, const void* w_packed, int wshift, 
   DS_REQUIRE(load_mode != DS_LOAD_MAXPOOL2 || (reinterpret_cast<uintptr_t>(in) & 7u) == 0, DS_ERR_SHAPE,
              "ds_conv2d_h3: MAXPOOL2 input must be 8-byte aligned");
   DS_REQUIRE(wshift >= -40 && wshift <= 40, DS_ERR_SHAPE, "ds_conv2d_h3: wshift %d out of range", wshift);
+  DS_REQUIRE(prenorm == nullptr || load_mode != DS_LOAD_MAXPOOL2, DS_ERR_UNSUPPORTED,
+             "ds_conv2d_h3: prenorm cannot be combined with the max-pool load (pooling follows the activation)");
+  DS_REQUIRE((reinterpret_cast<uintptr_t>(prenorm) & 15u) == 0, DS_ERR_SHAPE, "ds_conv2d_h3: prenorm must be 16-byte aligned");
   if (B == 0) return DS_OK;
   Conv3hArgs a;
+  a.prenorm = prenorm; a.tile_stats = tile_stats;
   a.out = out; a.in = in; a.wp = reinterpret_cast<const u32x4*>(w_packed); a.bias = bias; a.shift = shift;
   a.res1 = res1; a.res2 = res2; a.shift_stride = shift_stride;
   a.unscale = ldexpf(1.0f, -wshift);
@@ -419,14 +459,16 @@ int ds_conv2d_h3(float* out, const float* in, const void* w_packed, int wshift, 
   a.stamps = g_stamps;
 #endif
   hipStream_t s = ds::as_stream(stream);
+#define DS_L3(M, W) (prenorm ? launch_conv3h<M, W, true>(a, s) : launch_conv3h<M, W, false>(a, s))
   if (w16) {
-    if (load_mode == DS_LOAD_PLAIN) return launch_conv3h<DS_LOAD_PLAIN, true>(a, s);
-    if (load_mode == DS_LOAD_MAXPOOL2) return launch_conv3h<DS_LOAD_MAXPOOL2, true>(a, s);
-    return launch_conv3h<DS_LOAD_UPSAMPLE2, true>(a, s);
+    if (load_mode == DS_LOAD_PLAIN) return DS_L3(DS_LOAD_PLAIN, true);
+    if (load_mode == DS_LOAD_MAXPOOL2) return launch_conv3h<DS_LOAD_MAXPOOL2, true, false>(a, s);
+    return DS_L3(DS_LOAD_UPSAMPLE2, true);
   }
-  if (load_mode == DS_LOAD_PLAIN) return launch_conv3h<DS_LOAD_PLAIN, false>(a, s);
-  if (load_mode == DS_LOAD_MAXPOOL2) return launch_conv3h<DS_LOAD_MAXPOOL2, false>(a, s);
-  return launch_conv3h<DS_LOAD_UPSAMPLE2, false>(a, s);
+  if (load_mode == DS_LOAD_PLAIN) return DS_L3(DS_LOAD_PLAIN, false);
+  if (load_mode == DS_LOAD_MAXPOOL2) return launch_conv3h<DS_LOAD_MAXPOOL2, false, false>(a, s);
+  return DS_L3(DS_LOAD_UPSAMPLE2, false);
+#undef DS_L3
 }
 
 }  // extern "C"

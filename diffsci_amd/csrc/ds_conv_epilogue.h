@@ -22,7 +22,26 @@ struct Args {
   int b, co_base;         // sample, first channel of the workgroup's 64-channel tile
   int y0, x0;             // first row of the WAVE's two rows, first column of the tile
   int Cout, H, W;
+  // Optional per-(channel, tile) statistics of the stored values, for the normalisation that consumes
+  // this tensor: tile_stats[(b*Cout + co)*ntiles + tile] = float4 (K, S, Q, n) with n valid pixels,
+  // K one of the values, S = sum(x - K), Q = sum((x - K)^2).  Shifting by K keeps fp32 sums free of the
+  // mean^2 cancellation; the table kernels (ds_normtab.hip) combine the tiles in fp64.
+  float* tile_stats;
+  int tile, ntiles;
 };
+
+// sum over the 8 lanes of an aligned lane octet, then over the pair of octets of a 16-lane row
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, true));  // row_ror:8
+  return v;
+}
+// lane 0 of each 16-lane row, broadcast to the row
+__device__ __forceinline__ float row16_first(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x150, 0xF, 0xF, true));  // row_share:0
+}
 
 // W16 = false: the wave's 2 x 32 positions are 2 rows x 32 columns (row = y0 + r, column = x0 + x);
 // W16 = true (narrow feature maps): they are 4 rows x 16 columns (row = y0 + 2r + x/16, column = x0 + x%16).
@@ -53,7 +72,9 @@ __device__ __forceinline__ void store_tile(const f32x16 (&acc)[2][2], float* til
   const int gx = e.x0 + (W16 ? (p4 & 15) : p4);
   const int yq = W16 ? (p4 >> 4) : 0;
   const size_t plane = (size_t)e.H * e.W;
+  const bool stats = e.tile_stats != nullptr;
   if ((e.W & 3) == 0) {
+    float sK[16], ssum[16], ssq[16], scnt[16];        // per (half, k): channel 4*(4*half+k) + lane/16, valid in every lane of the row
 #pragma unroll
     for (int half = 0; half < 4; ++half) {            // 4 batches of 4 wave-instructions
       f32x4 v[4], r1[4], r2[4];
@@ -87,20 +108,79 @@ __device__ __forceinline__ void store_tile(const f32x16 (&acc)[2][2], float* til
 #pragma unroll
       for (int k = 0; k < 4; ++k)
         if (ok[k]) *reinterpret_cast<f32x4*>(e.out + idx[k]) = v[k];
+      if (stats) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          // the row's 16 lanes hold both rows of channel seg>>1 (lanes 0-7: r = 0, 8-15: r = 1); lane 0
+          // is the wave's first pixel of the channel: valid whenever any pixel of the wave is
+          const float K = row16_first(ok[k] ? v[k].x : 0.f);
+          const f32x4 d = v[k] - K;
+          const float sv = ok[k] ? (d.x + d.y) + (d.z + d.w) : 0.f;
+          const float qv = ok[k] ? (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w) : 0.f;
+          sK[half * 4 + k] = K;
+          ssum[half * 4 + k] = row16_sum(sv);
+          ssq[half * 4 + k] = row16_sum(qv);
+          scnt[half * 4 + k] = row16_sum(ok[k] ? 4.f : 0.f);
+        }
+      }
+    }
+    if (stats) {                                      // all reads of the wave's tile are done: reuse its head as [64 co][4]
+      if ((lane & 15) == 0) {
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+          f32x4 o = {sK[it], ssum[it], ssq[it], scnt[it]};
+          *reinterpret_cast<f32x4*>(&tile[4 * (4 * it + (lane >> 4))]) = o;
+        }
+      }
     }
   } else {
-    // ragged width: element-wise, compact loop (correctness path for odd shapes)
+    // ragged width: element-wise, compact loop (correctness path for odd shapes); one channel per iteration
     for (int i = lane; i < 64 * 2 * 32; i += 64) {
       const int co = i >> 6, r = (i >> 5) & 1, x = i & 31;
       const int gy = e.y0 + (W16 ? 2 * r + (x >> 4) : r), gxx = e.x0 + (W16 ? (x & 15) : x);
-      if (e.co_base + co < e.Cout && gy < e.H && gxx < e.W) {
+      float v = 0.f;
+      const bool okv = e.co_base + co < e.Cout && gy < e.H && gxx < e.W;
+      if (okv) {
         const size_t idx = ((size_t)e.b * e.Cout + e.co_base + co) * plane + (size_t)gy * e.W + gxx;
-        float v = tile[i];
+        v = tile[i];
         if (e.res1) v = v + e.res1[idx];
         if (e.res2) v = v + e.res2[idx];
         e.out[idx] = v;
       }
+      if (stats) {
+        const float K = __shfl(v, 0, 64);                              // the wave's first pixel of the channel
+        const float d = okv ? v - K : 0.f;
+        float sv = d, qv = d * d, nv = okv ? 1.f : 0.f;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { sv += __shfl_xor(sv, o, 64); qv += __shfl_xor(qv, o, 64); nv += __shfl_xor(nv, o, 64); }
+        // elements 4co .. 4co+3 of the tile belong to channel co' = co/16 <= co and were consumed
+        // (co = 0: by this very iteration's reads, which precede the write in program order)
+        if (lane == 0) { tile[4 * co] = K; tile[4 * co + 1] = sv; tile[4 * co + 2] = qv; tile[4 * co + 3] = nv; }
+      }
     }
+  }
+}
+
+// Second half of the statistics: combine the four waves' [64][4] partials (at the head of each
+// wave's tile region, `wave_stride` floats apart) about one shift and store them.  Call after a
+// __syncthreads().
+__device__ __forceinline__ void store_tile_stats(const float* tiles, int wave_stride, const Args& e) {
+  const int t = threadIdx.x;
+  if (t < 64 && e.co_base + t < e.Cout) {
+    f32x4 p[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) p[w] = *reinterpret_cast<const f32x4*>(&tiles[w * wave_stride + 4 * t]);
+    const float K = p[0][0];                              // wave 0 owns the tile's first rows: valid if the tile is
+    float S = 0.f, Q = 0.f, n = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float dk = p[w][3] > 0.f ? p[w][0] - K : 0.f;
+      S += p[w][1] + p[w][3] * dk;
+      Q += p[w][2] + 2.f * dk * p[w][1] + p[w][3] * dk * dk;
+      n += p[w][3];
+    }
+    f32x4 o = {K, S, Q, n};
+    *reinterpret_cast<f32x4*>(e.tile_stats + (((size_t)e.b * e.Cout + e.co_base + t) * e.ntiles + e.tile) * 4) = o;
   }
 }
 

@@ -1,0 +1,159 @@
+// Normalisation folded into the consuming convolution (ds_conv2d_h3 `prenorm`): the producing
+// convolution's epilogue leaves per-(sample, channel, pixel tile) shifted partial sums (`tile_stats`:
+// float4 (K, S = sum(x-K), Q = sum((x-K)^2), n), ds_conv_epilogue.h); the tiny kernels here
+// recombine them in fp64 (sum x = nK + S, sum x^2 = Q + 2KS + nK^2), in a fixed order, to the table
+//   table[b][c] = (M, A, C, 0)   with   activation(x) = SiLU((x - M) * A + C)
+// that the next convolution's loader applies while it stages its input -- the normalised tensor is
+// never written to or read from HBM.
+//   ds_inorm_table   PUNetG: GroupNorm(C,C) / GroupRMSNorm(C,C) per (sample, channel) plane
+//                    (commonlayers.py:766-770, 372-384):   M = mean | 0,  A = rstd*w[c],  C = b[c]
+//   ds_gnorm1_table  ADM: GroupNorm(1,C) / GroupRMSNorm(1,C)+FiLM per sample over (C,H,W), optionally
+//                    over the channel concatenation of two tensors (adm.py:306-343, 385-406, 764-766):
+//                    kind 0: M = mean_b, A = rstd_b*w[c], C = b[c]
+//                    kind 1: M = 0, A = w[c]/d_b*te1[b,c], C = b[c]*te1[b,c] + te2[b,c]
+#include "ds_common.h"
+
+namespace {
+
+__device__ __forceinline__ double group_sum_d(double v, int width) {
+  for (int o = width >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+__device__ __forceinline__ void acc_tile(const float4 v, double& s, double& q) {
+  const double K = v.x, S = v.y, Q = v.z, n = v.w;
+  s += n * K + S;
+  q += Q + 2.0 * K * S + n * K * K;
+}
+
+// 16 lanes per (b, c) plane
+__global__ __launch_bounds__(256) void k_inorm_table(float* table, const float* __restrict__ ts, const float* __restrict__ w,
+                                                     const float* __restrict__ bias, int planes, int C, int ntiles,
+                                                     double inv_n, float eps, int kind) {
+  const int plane = blockIdx.x * 16 + (threadIdx.x >> 4);
+  const int l = threadIdx.x & 15;
+  double s = 0.0, q = 0.0;
+  if (plane < planes) {
+    const float4* p = reinterpret_cast<const float4*>(ts) + (size_t)plane * ntiles;
+    for (int t = l; t < ntiles; t += 16) acc_tile(p[t], s, q);
+  }
+  s = group_sum_d(s, 16);
+  q = group_sum_d(q, 16);
+  if (plane < planes && l == 0) {
+    const int c = plane % C;
+    float M, rs;
+    if (kind == 0) {
+      const double mean = s * inv_n;
+      double var = q * inv_n - mean * mean;
+      if (var < 0.0) var = 0.0;
+      M = (float)mean;
+      rs = 1.0f / sqrtf((float)var + eps);
+    } else {
+      M = 0.f;
+      rs = 1.0f / sqrtf((float)(q * inv_n) + eps);
+    }
+    float4 o;
+    o.x = M; o.y = rs * (w ? w[c] : 1.f); o.z = bias ? bias[c] : 0.f; o.w = 0.f;
+    reinterpret_cast<float4*>(table)[plane] = o;
+  }
+}
+
+// one workgroup per sample
+__global__ __launch_bounds__(256) void k_gnorm1_table(float* table, const float* __restrict__ sa, int Ca, int nta,
+                                                      const float* __restrict__ sb, int Cb, int ntb,
+                                                      const float* __restrict__ w, const float* __restrict__ bias,
+                                                      const float* __restrict__ f1, const float* __restrict__ f2,
+                                                      int film_stride, double inv_n, float eps, int kind) {
+  __shared__ double red[2][4];
+  __shared__ float st[2];
+  const int b = blockIdx.x, C = Ca + Cb;
+  double s = 0.0, q = 0.0;
+  {
+    const float4* p = reinterpret_cast<const float4*>(sa) + (size_t)b * Ca * nta;
+    for (int i = threadIdx.x; i < Ca * nta; i += 256) acc_tile(p[i], s, q);
+  }
+  if (Cb > 0) {
+    const float4* p = reinterpret_cast<const float4*>(sb) + (size_t)b * Cb * ntb;
+    for (int i = threadIdx.x; i < Cb * ntb; i += 256) acc_tile(p[i], s, q);
+  }
+  s = group_sum_d(s, 64);
+  q = group_sum_d(q, 64);
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s; red[1][threadIdx.x >> 6] = q; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double ts = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    const double tq = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    if (kind == 0) {
+      const double mean = ts * inv_n;
+      double var = tq * inv_n - mean * mean;
+      if (var < 0.0) var = 0.0;
+      st[0] = (float)mean;
+      st[1] = 1.0f / sqrtf((float)var + eps);
+    } else {
+      st[0] = 0.f;
+      st[1] = 1.0f / sqrtf((float)(tq * inv_n) + eps);
+    }
+  }
+  __syncthreads();
+  const float M = st[0], rs = st[1];
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const float wc = w ? w[c] : 1.f, bc = bias ? bias[c] : 0.f;
+    float4 o;
+    if (kind == 0) {
+      o.x = M; o.y = rs * wc; o.z = bc;
+    } else {
+      const float t1 = f1[(size_t)b * film_stride + c], t2 = f2[(size_t)b * film_stride + c];
+      o.x = 0.f; o.y = rs * wc * t1; o.z = bc * t1 + t2;
+    }
+    o.w = 0.f;
+    reinterpret_cast<float4*>(table)[(size_t)b * C + c] = o;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int ds_inorm_table(float* table, const float* tile_stats, const float* w, const float* b, int B, int C, int ntiles,
+                   int count, float eps, int kind, void* stream) {
+  DS_REQUIRE(table && tile_stats, DS_ERR_NULL, "ds_inorm_table: NULL pointer");
+  DS_REQUIRE(B >= 0 && C > 0 && ntiles > 0 && count > 0, DS_ERR_SHAPE, "ds_inorm_table: bad shape");
+  DS_REQUIRE(kind == 0 || kind == 1, DS_ERR_UNSUPPORTED, "ds_inorm_table: kind %d", kind);
+  DS_REQUIRE((long long)B * C < (1ll << 31), DS_ERR_SHAPE, "ds_inorm_table: too many planes");
+  DS_REQUIRE((reinterpret_cast<uintptr_t>(table) & 15u) == 0 && (reinterpret_cast<uintptr_t>(tile_stats) & 15u) == 0,
+             DS_ERR_SHAPE, "ds_inorm_table: misaligned pointer");
+  if (B == 0) return DS_OK;
+  const int planes = B * C;
+  hipLaunchKernelGGL(k_inorm_table, dim3((planes + 15) / 16), dim3(256), 0, ds::as_stream(stream), table, tile_stats, w,
+                     b, planes, C, ntiles, 1.0 / (double)count, eps, kind);
+  DS_CHECK_LAUNCH("ds_inorm_table");
+  return DS_OK;
+}
+
+int ds_gnorm1_table(float* table, const float* stats_a, int Ca, int ntiles_a, const float* stats_b, int Cb,
+                    int ntiles_b, const float* w, const float* b, const float* film_scale, const float* film_shift,
+                    int film_stride, int B, long long count, float eps, int kind, void* stream) {
+  DS_REQUIRE(table && stats_a, DS_ERR_NULL, "ds_gnorm1_table: NULL pointer");
+  DS_REQUIRE(B >= 0 && Ca > 0 && ntiles_a > 0 && Cb >= 0 && count > 0, DS_ERR_SHAPE, "ds_gnorm1_table: bad shape");
+  DS_REQUIRE(Cb == 0 || (stats_b && ntiles_b > 0), DS_ERR_NULL, "ds_gnorm1_table: second source missing");
+  DS_REQUIRE(kind == 0 || kind == 1, DS_ERR_UNSUPPORTED, "ds_gnorm1_table: kind %d", kind);
+  DS_REQUIRE(kind != 1 || (film_scale && film_shift), DS_ERR_NULL, "ds_gnorm1_table: FiLM rows are NULL");
+  DS_REQUIRE(((reinterpret_cast<uintptr_t>(table) | reinterpret_cast<uintptr_t>(stats_a) | reinterpret_cast<uintptr_t>(stats_b)) & 15u) == 0,
+             DS_ERR_SHAPE, "ds_gnorm1_table: pointers must be 16-byte aligned");
+  if (B == 0) return DS_OK;
+  hipLaunchKernelGGL(k_gnorm1_table, dim3(B), dim3(256), 0, ds::as_stream(stream), table, stats_a, Ca, ntiles_a, stats_b,
+                     Cb, ntiles_b, w, b, film_scale, film_shift, film_stride, 1.0 / (double)count, eps, kind);
+  DS_CHECK_LAUNCH("ds_gnorm1_table");
+  return DS_OK;
+}
+
+/* Number of pixel tiles per channel plane that ds_conv2d_h3 / ds_conv1x1_h3 use for an H x W output
+ * (the `ntiles` of their tile_stats layout). */
+int ds_conv_tile_count(int H, int W) {
+  if (H <= 0 || W <= 0) return 0;
+  const long long pad32 = (long long)((W + 31) / 32 * 32) * ((H + 7) / 8 * 8);
+  const long long pad16 = (long long)((W + 15) / 16 * 16) * ((H + 15) / 16 * 16);
+  return pad16 < pad32 ? ((W + 15) / 16) * ((H + 15) / 16) : ((W + 31) / 32) * ((H + 7) / 8);
+}
+
+}  // extern "C"

@@ -173,6 +173,7 @@ class ADM(torch.nn.Module):
         self.input_layer = torch.nn.Conv2d(config.input_channels, mc, 3, padding="same")
         self.output_layer = torch.nn.Conv2d(mc, config.output_channels, 3, padding="same")
         self.conv_precision = "fp16x3"       # see PUNetG.conv_precision
+        self.fuse_norm = True                # see PUNetG.fuse_norm
         self._packed = None
         self._packed_sig = None
         self._ws = _Workspace()
@@ -254,46 +255,82 @@ class ADM(torch.nn.Module):
     def _conv(self, m, x, pk, **kw):
         return ops.conv(x, pk[id(m)], bias=m.bias, **kw)
 
-    def _block(self, blk, x, film, pk, ws):
-        """ADMBaseBlock.forward (adm.py:292-349); returns a fresh buffer, x untouched."""
+    def _fused(self):
+        return self.fuse_norm and self.conv_precision == "fp16x3"
+
+    def _stats_buf(self, ws, B, C, H, W, dev):
+        if not self._fused():
+            return None
+        return ws.take((B, C, ops.conv_tile_count(H, W), 4), dev)
+
+    def _block(self, blk, x, film, pk, ws, xs=None, want_stats=True):
+        """ADMBaseBlock.forward (adm.py:292-349); returns (fresh buffer, its tile statistics); x untouched.
+        xs: tile statistics of x -- one buffer, or a pair when x is the channel concatenation of two
+        convolution outputs -- or None (then norm1 runs as standalone kernels)."""
         B, Ci, H, W = x.shape
         dev = x.device
         down, up = blk.sample == "down", blk.sample == "up"
         Ho, Wo = (H // 2, W // 2) if down else ((2 * H, 2 * W) if up else (H, W))
-        Hm, Wm = (Ho, Wo) if down else (H, W)            # resolution conv1 / convresidual read at
-        stats = ws.take((B, 2), dev)
-        scratch = ws.take((ops.N.lib().ds_gnorm1_workspace_bytes(B) // 4,), dev)
         mode = DS_LOAD_UPSAMPLE2 if up else DS_LOAD_PLAIN
+        fused = self._fused()
+        ys = self._stats_buf(ws, B, blk.cout, Ho, Wo, dev)
         # first_block: norm1 -> act -> resample -> conv1                          (adm.py:312-323)
-        ops.gnorm1_stats(x, 0, eps=blk.norm1.eps, stats=stats, workspace=scratch)
-        a = ops.gnorm1_apply(x, stats, blk.norm1.weight, blk.norm1.bias, 0, pool=down,
-                             out=ws.take((B, Ci, Hm, Wm), dev))
-        y = self._conv(blk.conv1, a, pk, load_mode=mode, out=ws.take((B, blk.cout, Ho, Wo), dev))
+        if fused and xs is not None and not down:
+            sa, sb = xs if isinstance(xs, tuple) else (xs, None)
+            tab = ws.take((B, Ci, 4), dev)
+            ops.gnorm1_table(sa, blk.norm1.weight, blk.norm1.bias, 0, Ci * H * W, stats_b=sb, eps=blk.norm1.eps, out=tab)
+            y = self._conv(blk.conv1, x, pk, load_mode=mode, prenorm=tab, tile_stats=ys,
+                           out=ws.take((B, blk.cout, Ho, Wo), dev))
+            ws.give(tab)
+        else:                                                                     # pooling follows the activation
+            Hm, Wm = (Ho, Wo) if down else (H, W)
+            stats = ws.take((B, 2), dev)
+            scratch = ws.take((ops.N.lib().ds_gnorm1_workspace_bytes(B) // 4,), dev)
+            ops.gnorm1_stats(x, 0, eps=blk.norm1.eps, stats=stats, workspace=scratch)
+            a = ops.gnorm1_apply(x, stats, blk.norm1.weight, blk.norm1.bias, 0, pool=down,
+                                 out=ws.take((B, Ci, Hm, Wm), dev))
+            y = self._conv(blk.conv1, a, pk, load_mode=mode, tile_stats=ys, out=ws.take((B, blk.cout, Ho, Wo), dev))
+            ws.give(a)
+            ws.give(stats)
+            ws.give(scratch)
         # residual_block: convresidual(resample(x))                               (adm.py:345-349)
         if down and pk[id(blk.convresidual)].kind == "fp16x3":
             r = self._conv(blk.convresidual, x, pk, load_mode=DS_LOAD_AVGPOOL2, out=ws.take((B, blk.cout, Ho, Wo), dev))
         elif down:
-            ops.gnorm1_apply(x, None, None, None, 2, pool=True, out=a)
+            a = ops.gnorm1_apply(x, None, None, None, 2, pool=True, out=ws.take((B, Ci, Ho, Wo), dev))
             r = self._conv(blk.convresidual, a, pk, out=ws.take((B, blk.cout, Ho, Wo), dev))
+            ws.give(a)
         else:
             r = self._conv(blk.convresidual, x, pk, load_mode=mode, out=ws.take((B, blk.cout, Ho, Wo), dev))
-        ws.give(a)
         # norm2 -> FiLM -> act -> conv2, + residual                               (adm.py:325-337)
-        ops.gnorm1_stats(y, 1, eps=1e-5, stats=stats, workspace=scratch)
-        a2 = ops.gnorm1_apply(y, stats, blk.norm2.weight, blk.norm2.bias, 1, film=film,
-                              out=ws.take((B, blk.cout, Ho, Wo), dev))
-        self._conv(blk.conv2, a2, pk, res1=r, out=y)
-        ws.give(a2)
-        ws.give(r)
-        ws.give(stats)
-        ws.give(scratch)
-        if hasattr(blk, "attn"):
-            y2 = self._attention(blk.attn, y, pk, ws)
+        has_attn = hasattr(blk, "attn")
+        os_ = self._stats_buf(ws, B, blk.cout, Ho, Wo, dev) if (want_stats and not has_attn) else None
+        if fused:
+            tab = ws.take((B, blk.cout, 4), dev)
+            ops.gnorm1_table(ys, blk.norm2.weight, blk.norm2.bias, 1, blk.cout * Ho * Wo, film=film, eps=1e-5, out=tab)
+            out = self._conv(blk.conv2, y, pk, res1=r, prenorm=tab, tile_stats=os_, out=ws.take((B, blk.cout, Ho, Wo), dev))
+            ws.give(tab)
+            ws.give(ys)
             ws.give(y)
-            y = y2
-        return y
+        else:
+            stats = ws.take((B, 2), dev)
+            scratch = ws.take((ops.N.lib().ds_gnorm1_workspace_bytes(B) // 4,), dev)
+            ops.gnorm1_stats(y, 1, eps=1e-5, stats=stats, workspace=scratch)
+            a2 = ops.gnorm1_apply(y, stats, blk.norm2.weight, blk.norm2.bias, 1, film=film,
+                                  out=ws.take((B, blk.cout, Ho, Wo), dev))
+            out = self._conv(blk.conv2, a2, pk, res1=r, out=y)
+            ws.give(a2)
+            ws.give(stats)
+            ws.give(scratch)
+        ws.give(r)
+        if has_attn:
+            os_ = self._stats_buf(ws, B, blk.cout, Ho, Wo, dev) if want_stats else None
+            out2 = self._attention(blk.attn, out, pk, ws, tile_stats=os_)
+            ws.give(out)
+            out = out2
+        return out, os_
 
-    def _attention(self, att, x, pk, ws):
+    def _attention(self, att, x, pk, ws, tile_stats=None):
         """TwoDimensionalAttention.forward (attention.py:67-72,82-90), channel-major."""
         B, E, Hh, Ww = x.shape
         L = Hh * Ww
@@ -302,7 +339,8 @@ class ADM(torch.nn.Module):
         o = ops.attention(qkv.view(B, 3 * E, L), E, out=ws.take((B, E, L), x.device),
                           precision=self.conv_precision)
         y = ops.conv(o.view(B, E, Hh, Ww), pk[(id(att), "out")], bias=m.out_proj.bias,
-                     res1=x if self.config.attn_residual else None, out=ws.take(x.shape, x.device))
+                     res1=x if self.config.attn_residual else None, tile_stats=tile_stats,
+                     out=ws.take(x.shape, x.device))
         ws.give(qkv)
         ws.give(o)
         return y
@@ -323,37 +361,54 @@ class ADM(torch.nn.Module):
                 raise ValueError("time embedding batch does not match x")
             return s
 
-        h = self._conv(self.input_layer, x, pk, out=ws.take((B, cfg.model_channels) + tuple(x.shape[2:]), x.device))
-        skips = [h]                                                             # adm.py:667-675
+        dev = x.device
+        H, W = x.shape[2:]
+
+        def give(t, ts):
+            ws.give(t)
+            for q in (ts if isinstance(ts, tuple) else (ts,)):
+                if q is not None:
+                    ws.give(q)
+
+        hs = self._stats_buf(ws, B, cfg.model_channels, H, W, dev)
+        h = self._conv(self.input_layer, x, pk, tile_stats=hs, out=ws.take((B, cfg.model_channels, H, W), dev))
+        skips = [(h, hs)]                                                       # adm.py:667-675
         for lay in self.encoder.layers:
             for blk in lay.input_blocks:
-                h2 = self._block(blk, h, film(), pk, ws)
-                if not any(h is s for s in skips):
-                    ws.give(h)
-                h = h2
-            skips.append(h)
+                h2, hs2 = self._block(blk, h, film(), pk, ws, xs=hs)
+                if not any(h is s for s, _ in skips):
+                    give(h, hs)
+                h, hs = h2, hs2
+            skips.append((h, hs))
         for blk in self.middle_block.middle_blocks:
-            h2 = self._block(blk, h, film(), pk, ws)
-            if not any(h is s for s in skips):
-                ws.give(h)
-            h = h2
-        for lay in self.decoder.layers:                                         # adm.py:764-774, 927-934
-            skip = skips.pop()
+            h2, hs2 = self._block(blk, h, film(), pk, ws, xs=hs)
+            if not any(h is s for s, _ in skips):
+                give(h, hs)
+            h, hs = h2, hs2
+        nl = len(self.decoder.layers)
+        for li, lay in enumerate(self.decoder.layers):                          # adm.py:764-774, 927-934
+            skip, sks = skips.pop()
             if cfg.skip_integration_type == "concat":
-                h2 = ops.concat2(h, skip, out=ws.take((B, h.shape[1] + skip.shape[1]) + tuple(h.shape[2:]), x.device))
+                hc = ops.concat2(h, skip, out=ws.take((B, h.shape[1] + skip.shape[1]) + tuple(h.shape[2:]), dev))
+                hcs = (hs, sks) if (hs is not None and sks is not None) else None   # statistics of a concat are additive
             else:
-                h2 = ops.add(h, skip, out=ws.take(h.shape, x.device))
-            if h is not skip:
-                ws.give(h)
-            ws.give(skip)
-            h = h2
-            for blk in lay.input_blocks:
-                h2 = self._block(blk, h, film(), pk, ws)
-                ws.give(h)
-                h = h2
-        for s in skips:                                                          # the stem copy is never consumed
-            if s is not h:
-                ws.give(s)
+                hc = ops.add(h, skip, out=ws.take(h.shape, dev))
+                hcs = None
+            pending = [(h, hs)] + ([(skip, sks)] if skip is not h else [])         # statistics are read by block 0's table
+            for j, blk in enumerate(lay.input_blocks):
+                final = li == nl - 1 and j == len(lay.input_blocks) - 1           # feeds the output layer: no norm follows
+                h2, hs2 = self._block(blk, hc, film(), pk, ws, xs=hcs, want_stats=not final)
+                if j == 0:
+                    ws.give(hc)
+                    for t, ts in pending:
+                        give(t, ts)
+                else:
+                    give(hc, hcs)
+                hc, hcs = h2, hs2
+            h, hs = hc, hcs
+        for s_, ss in skips:                                                     # the stem copy is never consumed
+            if s_ is not h:
+                give(s_, ss)
         y = self._conv(self.output_layer, h, pk, out=out)
-        ws.give(h)
+        give(h, hs)
         return y

@@ -137,6 +137,10 @@ class PUNetG(torch.nn.Module):
         #   "bf16x6": exact 3-way bf16 split, 6 MFMA products (no range limit, half the speed)
         #   "fp32"  : exact-fp32 MFMA (1/16 of the 16-bit rate)
         self.conv_precision = "fp16x3"
+        # With the fp16x3 kernels the two norms of a residual block are folded into the convolutions
+        # around them (statistics from the producer's epilogue, normalise + SiLU in the consumer's
+        # loader): the normalised tensors never touch HBM.  False: standalone ds_inorm_silu kernels.
+        self.fuse_norm = True
         self._packed = None
         self._packed_sig = None
         self._ws = _Workspace()
@@ -231,24 +235,50 @@ class PUNetG(torch.nn.Module):
     def _conv(self, m, x, pk, **kw):
         return ops.conv(x, pk[id(m)], bias=m.bias, **kw)
 
-    def _res(self, blk, x, shift, pk, ws, res2=None):
-        """ResnetBlockC.forward (commonlayers.py:824-833); returns a fresh buffer, x untouched."""
+    def _fused(self):
+        return self.fuse_norm and self.conv_precision == "fp16x3"
+
+    def _stats_buf(self, ws, B, C, H, W, dev):
+        """Tile-statistics buffer for a [B, C, H, W] convolution output (None when norms are not fused)."""
+        if not self._fused():
+            return None
+        return ws.take((B, C, ops.conv_tile_count(H, W), 4), dev)
+
+    def _res(self, blk, x, shift, pk, ws, res2=None, xs=None, want_stats=True):
+        """ResnetBlockC.forward (commonlayers.py:824-833); returns (fresh buffer, its tile statistics);
+        x untouched.  xs = tile statistics of x (from the convolution that produced it) or None."""
+        B, C, H, W = x.shape
+        dev = x.device
+        if self._fused() and xs is not None:
+            tab = ws.take((B, C, 4), dev)
+            ops.inorm_table(xs, blk.gnorm1.weight, blk.gnorm1.bias, 0, H * W, eps=blk.gnorm1.eps, out=tab)
+            ys = self._stats_buf(ws, B, C, H, W, dev)
+            y = self._conv(blk.conv1, x, pk, shift=shift, prenorm=tab, tile_stats=ys, out=ws.take(x.shape, dev))
+            ops.inorm_table(ys, blk.gnorm2.weight, blk.gnorm2.bias, 1, H * W, eps=1e-5, out=tab)
+            os_ = self._stats_buf(ws, B, C, H, W, dev) if want_stats else None
+            out = self._conv(blk.conv2, y, pk, res1=x, res2=res2, prenorm=tab, tile_stats=os_, out=ws.take(x.shape, dev))
+            ws.give(y)
+            ws.give(ys)
+            ws.give(tab)
+            return out, os_
         a = ops.inorm_silu(x, blk.gnorm1.weight, blk.gnorm1.bias, kind=0, eps=blk.gnorm1.eps,
-                           out=ws.take(x.shape, x.device))
-        y = self._conv(blk.conv1, a, pk, shift=shift, out=ws.take(x.shape, x.device))
+                           out=ws.take(x.shape, dev))
+        y = self._conv(blk.conv1, a, pk, shift=shift, out=ws.take(x.shape, dev))
         ops.inorm_silu(y, blk.gnorm2.weight, blk.gnorm2.bias, kind=1, eps=1e-5, out=a)
-        self._conv(blk.conv2, a, pk, res1=x, res2=res2, out=y)
+        os_ = self._stats_buf(ws, B, C, H, W, dev) if want_stats else None
+        self._conv(blk.conv2, a, pk, res1=x, res2=res2, tile_stats=os_, out=y)
         ws.give(a)
-        return y
+        return y, os_
 
     def forward_with_shifts(self, x, shifts, row=None, out=None):
         """UNet body given the per-block time shifts.  shifts[k] is [M, C_k]; row selects one row
         shared by the whole batch (sampling: sigma is a per-step constant), row=None means one row
-        per sample (M == B)."""
+        per sample (M == B).  Every activation travels with the tile statistics its producer left."""
         pk = self.packed_weights()
         ws = self._ws
         cfg = self.config
         B = x.shape[0]
+        dev = x.device
         it = iter(range(len(shifts)))
 
         def sh():
@@ -259,58 +289,75 @@ class PUNetG(torch.nn.Module):
                 raise ValueError("time embedding batch does not match x")
             return s
 
-        h = self._conv(self.convin, x, pk, out=ws.take((B, cfg.model_channels) + tuple(x.shape[2:]), x.device))
+        def give(t, ts):
+            ws.give(t)
+            if ts is not None:
+                ws.give(ts)
+
+        H, W = x.shape[2:]
+        hs = self._stats_buf(ws, B, cfg.model_channels, H, W, dev)
+        h = self._conv(self.convin, x, pk, tile_stats=hs, out=ws.take((B, cfg.model_channels, H, W), dev))
         skips = []
         for lv, blocks in enumerate(self.downward_blocks):                      # punetg.py:356-365
             for blk in blocks:
-                h2 = self._res(blk, h, sh(), pk, ws)
-                ws.give(h)
-                h = h2
+                h2, hs2 = self._res(blk, h, sh(), pk, ws, xs=hs)
+                give(h, hs)
+                h, hs = h2, hs2
             skips.append(h)
+            if hs is not None:
+                ws.give(hs)                                                      # the skip is only added, never normalised
             ds = self.downsamplers[lv].conv
-            h = self._conv(ds, h, pk, load_mode=DS_LOAD_MAXPOOL2,
-                           out=ws.take((B, ds.out_channels, h.shape[2] // 2, h.shape[3] // 2), x.device))
+            Ho, Wo = h.shape[2] // 2, h.shape[3] // 2
+            hs = self._stats_buf(ws, B, ds.out_channels, Ho, Wo, dev)
+            h = self._conv(ds, h, pk, load_mode=DS_LOAD_MAXPOOL2, tile_stats=hs,
+                           out=ws.take((B, ds.out_channels, Ho, Wo), dev))
         for blk in self.before_block:                                             # punetg.py:378-387
-            h2 = self._res(blk, h, sh(), pk, ws)
-            ws.give(h)
-            h = h2
-        xa = h
+            h2, hs2 = self._res(blk, h, sh(), pk, ws, xs=hs)
+            give(h, hs)
+            h, hs = h2, hs2
+        xa, xas = h, hs
         nattn = len(self.attn_resnet_block)
         for i, blk in enumerate(self.attn_resnet_block):
             last = i == nattn - 1
             # x + xa is folded into the last residual block's epilogue when no attention follows it
-            xa2 = self._res(blk, xa, sh(), pk, ws, res2=h if (last and i >= len(self.attn_block)) else None)
+            xa2, xas2 = self._res(blk, xa, sh(), pk, ws, xs=xas,
+                                  res2=h if (last and i >= len(self.attn_block)) else None)
             if xa is not h:
-                ws.give(xa)
-            xa = xa2
+                give(xa, xas)
+            xa, xas = xa2, xas2
             if i < len(self.attn_block):
-                xa2 = self._attention(self.attn_block[i], xa, pk, ws, res2=h if last else None)
-                ws.give(xa)
-                xa = xa2
+                xas2 = self._stats_buf(ws, B, xa.shape[1], xa.shape[2], xa.shape[3], dev)
+                xa2 = self._attention(self.attn_block[i], xa, pk, ws, res2=h if last else None, tile_stats=xas2)
+                give(xa, xas)
+                xa, xas = xa2, xas2
         if nattn == 0:
-            xa = ops.add(h, h, out=ws.take(h.shape, x.device))
-        ws.give(h)
-        h = xa
+            xa, xas = ops.add(h, h, out=ws.take(h.shape, dev)), None
+        give(h, hs if xas is not hs else None)
+        h, hs = xa, xas
         for blk in self.after_block:
-            h2 = self._res(blk, h, sh(), pk, ws)
-            ws.give(h)
-            h = h2
+            h2, hs2 = self._res(blk, h, sh(), pk, ws, xs=hs)
+            give(h, hs)
+            h, hs = h2, hs2
+        nup = len(self.upward_blocks)
         for lv, blocks in enumerate(self.upward_blocks):                         # punetg.py:367-376
             us = self.upsamplers[lv].conv
             skip = skips.pop()
-            h2 = self._conv(us, h, pk, load_mode=DS_LOAD_UPSAMPLE2, res1=skip, out=ws.take(skip.shape, x.device))
-            ws.give(h)
+            hs2 = self._stats_buf(ws, B, skip.shape[1], skip.shape[2], skip.shape[3], dev)
+            h2 = self._conv(us, h, pk, load_mode=DS_LOAD_UPSAMPLE2, res1=skip, tile_stats=hs2,
+                            out=ws.take(skip.shape, dev))
+            give(h, hs)
             ws.give(skip)
-            h = h2
-            for blk in blocks:
-                h2 = self._res(blk, h, sh(), pk, ws)
-                ws.give(h)
-                h = h2
+            h, hs = h2, hs2
+            for j, blk in enumerate(blocks):
+                final = lv == nup - 1 and j == len(blocks) - 1                   # feeds convout: no norm follows
+                h2, hs2 = self._res(blk, h, sh(), pk, ws, xs=hs, want_stats=not final)
+                give(h, hs)
+                h, hs = h2, hs2
         y = self._conv(self.convout, h, pk, out=out)
-        ws.give(h)
+        give(h, hs)
         return y
 
-    def _attention(self, att, x, pk, ws, res2=None):
+    def _attention(self, att, x, pk, ws, res2=None, tile_stats=None):
         """TwoDimensionalAttention.forward (attention.py:67-72,82-90), channel-major throughout."""
         B, E, Hh, Ww = x.shape
         L = Hh * Ww
@@ -320,7 +367,7 @@ class PUNetG(torch.nn.Module):
                           precision=self.conv_precision)
         res1 = x if self.config.attn_residual else None
         y = ops.conv(o.view(B, E, Hh, Ww), pk[(id(att), "out")], bias=m.out_proj.bias,
-                     res1=res1, res2=res2, out=ws.take(x.shape, x.device))
+                     res1=res1, res2=res2, tile_stats=tile_stats, out=ws.take(x.shape, x.device))
         ws.give(qkv)
         ws.give(o)
         return y

@@ -244,9 +244,46 @@ def conv(x, pw, **kw):
     return conv2d(x, pw.data, pw.Cout, pw.ks, kind=pw.kind, wshift=pw.wshift, **kw)
 
 
+def conv_tile_count(H, W):
+    """Pixel tiles per channel plane in the fp16x3 kernels' tile_stats layout."""
+    return N.lib().ds_conv_tile_count(int(H), int(W))
+
+
+def inorm_table(tile_stats, w, b, kind, count, eps=1e-5, out=None):
+    """PUNetG norm table [B, C, 4] from a convolution's tile statistics [B, C, ntiles, 4]."""
+    B, C, nt, _ = tile_stats.shape
+    if out is None:
+        out = torch.empty((B, C, 4), dtype=torch.float32, device=tile_stats.device)
+    N.check(N.lib().ds_inorm_table(_p(out), _p(tile_stats), _p(w), _p(b), B, C, nt, int(count), float(eps), int(kind),
+                                   _stream()), "ds_inorm_table")
+    return out
+
+
+def gnorm1_table(stats_a, w, b, kind, count, stats_b=None, film=None, eps=1e-5, out=None):
+    """ADM norm table [B, Ca+Cb, 4] from tile statistics of one tensor or of the two halves of a concat."""
+    B, Ca, nta, _ = stats_a.shape
+    Cb, ntb = (0, 0) if stats_b is None else (stats_b.shape[1], stats_b.shape[2])
+    C = Ca + Cb
+    if out is None:
+        out = torch.empty((B, C, 4), dtype=torch.float32, device=stats_a.device)
+    f1 = f2 = None
+    stride = 0
+    if kind == 1:
+        if film is None or film.dim() != 2 or film.shape[1] != 2 * C or film.shape[0] not in (1, B):
+            raise ValueError("film must be [1 or B, 2C]")
+        require_device(film, "film")
+        stride = 0 if film.shape[0] == 1 else 2 * C
+        f1, f2 = film.data_ptr(), film.data_ptr() + 4 * C
+    N.check(N.lib().ds_gnorm1_table(_p(out), _p(stats_a), Ca, nta, _p(stats_b), Cb, ntb, _p(w), _p(b), f1, f2, stride,
+                                    B, int(count), float(eps), int(kind), _stream()), "ds_gnorm1_table")
+    return out
+
+
 def conv2d(x, w_packed, Cout, ks, bias=None, shift=None, res1=None, res2=None,
-           load_mode=N.DS_LOAD_PLAIN, out=None, kind="fp32", wshift=0):
-    """'same' zero-padded conv; x [B, Cin, Hin, Win]; shift [1 or B, Cout] or None."""
+           load_mode=N.DS_LOAD_PLAIN, out=None, kind="fp32", wshift=0, prenorm=None, tile_stats=None):
+    """'same' zero-padded conv; x [B, Cin, Hin, Win]; shift [1 or B, Cout] or None.
+    fp16x3 kernels only: prenorm [B, Cin, 4] (3x3) applies SiLU((x-M)*A+C) in the loader; tile_stats
+    [B, Cout, conv_tile_count(H, W), 4] receives per-tile (K, sum(x-K), sum((x-K)^2), n) of the output."""
     B, Cin, Hin, Win = x.shape
     if load_mode in (N.DS_LOAD_MAXPOOL2, N.DS_LOAD_AVGPOOL2):
         if Hin % 2 or Win % 2:
@@ -278,12 +315,20 @@ def conv2d(x, w_packed, Cout, ks, bias=None, shift=None, res1=None, res2=None,
             raise ValueError("residual shape mismatch")
     if bias is not None and bias.numel() != Cout:
         raise ValueError("bias must have Cout entries")
+    if (prenorm is not None or tile_stats is not None) and kind != "fp16x3":
+        raise ValueError("prenorm / tile_stats are features of the fp16x3 kernels")
+    if prenorm is not None and (ks != 3 or tuple(prenorm.shape) != (B, Cin, 4)):
+        raise ValueError(f"prenorm must be [B, Cin, 4] on a 3x3 convolution; got {tuple(prenorm.shape)}")
+    if tile_stats is not None and tuple(tile_stats.shape) != (B, Cout, conv_tile_count(H, W), 4):
+        raise ValueError(f"tile_stats must be {(B, Cout, conv_tile_count(H, W), 4)}; got {tuple(tile_stats.shape)}")
     if kind == "fp16x3" and ks == 1:
         N.check(N.lib().ds_conv1x1_h3(_p(out), _p(x), _p(w_packed), int(wshift), _p(bias), _p(shift), stride,
-                                      _p(res1), _p(res2), B, Cin, Cout, H, W, load_mode, _stream()), "ds_conv1x1_h3")
+                                      _p(res1), _p(res2), B, Cin, Cout, H, W, load_mode, _p(tile_stats), _stream()),
+                "ds_conv1x1_h3")
     elif kind == "fp16x3":
         N.check(N.lib().ds_conv2d_h3(_p(out), _p(x), _p(w_packed), int(wshift), _p(bias), _p(shift), stride,
-                                     _p(res1), _p(res2), B, Cin, Cout, H, W, load_mode, _stream()), "ds_conv2d_h3")
+                                     _p(res1), _p(res2), B, Cin, Cout, H, W, load_mode, _p(prenorm), _p(tile_stats),
+                                     _stream()), "ds_conv2d_h3")
     elif kind == "bf16x6":
         N.check(N.lib().ds_conv2d_x6(_p(out), _p(x), _p(w_packed), _p(bias), _p(shift), stride, _p(res1),
                                      _p(res2), B, Cin, Cout, H, W, load_mode, _stream()), "ds_conv2d_x6")

@@ -169,7 +169,31 @@ size_t ds_conv2d_h3_packed_bytes(int Cout, int Cin);
 int ds_conv2d_h3_pack_weights(void* packed, const float* w, int Cout, int Cin, int wshift, void* stream);
 int ds_conv2d_h3(float* out, const float* in, const void* w_packed, int wshift, const float* bias,
                  const float* shift, int shift_stride, const float* res1, const float* res2,
-                 int B, int Cin, int Cout, int H, int W, int load_mode, void* stream);
+                 int B, int Cin, int Cout, int H, int W, int load_mode,
+                 const float* prenorm, float* tile_stats, void* stream);
+/* Two optional fusions of the normalisation around the convolution (NULL = off):
+ *   prenorm    [B, Cin, 4] = (M, A, C, -): the loader applies SiLU((x - M)*A + C) to every input element
+ *              before the convolution (zero padding stays zero) -- the norm -> act of ResnetBlockC /
+ *              ADMBaseBlock (commonlayers.py:824-829, adm.py:312-337) without materialising its output.
+ *              Not with MAXPOOL2.  Tables come from ds_inorm_table / ds_gnorm1_table.
+ *   tile_stats [B, Cout, ntiles, 4]: per output channel and pixel tile of the stored values, (K, S, Q, n):
+ *              n valid pixels, K one of them, S = sum(x-K), Q = sum((x-K)^2) (shifted sums: no mean^2
+ *              cancellation in fp32); ntiles = ds_conv_tile_count(H, W); consumed by the *_table calls,
+ *              which recombine the tiles in fp64.  16-byte aligned. */
+int ds_conv_tile_count(int H, int W);
+
+/* PUNetG norms from tile statistics: table[b,c] = (mean | 0, rstd*w[c], b[c], 0) for GroupNorm(C,C)
+ * (kind 0) / GroupRMSNorm(C,C) (kind 1); count = H*W.  commonlayers.py:766-770, 372-384. */
+int ds_inorm_table(float* table, const float* tile_stats, const float* w, const float* b, int B, int C, int ntiles,
+                   int count, float eps, int kind, void* stream);
+
+/* ADM norms from tile statistics, per sample over (C, H, W), optionally over the channel concatenation
+ * of two tensors (Cb = 0: one source): kind 0 GroupNorm(1,C): (mean_b, rstd_b*w[c], b[c]); kind 1
+ * GroupRMSNorm(1,C) + FiLM: (0, w[c]/d_b*scale[b,c], b[c]*scale[b,c] + shift[b,c]).  count = C*H*W.
+ * adm.py:306-343, 385-406, 764-766. */
+int ds_gnorm1_table(float* table, const float* stats_a, int Ca, int ntiles_a, const float* stats_b, int Cb,
+                    int ntiles_b, const float* w, const float* b, const float* film_scale, const float* film_shift,
+                    int film_stride, int B, long long count, float eps, int kind, void* stream);
 
 /* 1x1 convolution in the fp16x3 scheme of ds_conv2d_h3 (same epilogue terms, same domain
  * |in| < 65504).  ADM's residual projection convresidual(resample(x)) (adm.py:345-349) with the
@@ -180,7 +204,7 @@ size_t ds_conv1x1_h3_packed_bytes(int Cout, int Cin);
 int ds_conv1x1_h3_pack_weights(void* packed, const float* w, int Cout, int Cin, int wshift, void* stream);
 int ds_conv1x1_h3(float* out, const float* in, const void* w_packed, int wshift, const float* bias,
                   const float* shift, int shift_stride, const float* res1, const float* res2,
-                  int B, int Cin, int Cout, int H, int W, int load_mode, void* stream);
+                  int B, int Cin, int Cout, int H, int W, int load_mode, float* tile_stats, void* stream);
 
 /* Single-head self-attention over L = H*W positions, channel-major operands:
  *   qkv [B, 3E, L] (rows 0..E-1 = Q^T, E..2E-1 = K^T, 2E..3E-1 = V^T), out [B, E, L] = (softmax(Q K^T / sqrt(E)) V)^T.

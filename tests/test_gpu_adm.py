@@ -86,9 +86,9 @@ def test_adm_layers_and_forward_vs_reference(M, dev, skip):
     stem = net._conv(net.input_layer, v["x"].to(dev), pk)
     assert rel_l2(stem.cpu(), v["stem"]) < 2e-6
     films = net.time_shifts(v["te"].to(dev))
-    b0 = net._block(net.encoder.layers[0].input_blocks[0], v["stem"].to(dev), films[0], pk, net._ws)
+    b0, _ = net._block(net.encoder.layers[0].input_blocks[0], v["stem"].to(dev), films[0], pk, net._ws)
     assert rel_l2(b0.cpu(), v["enc00"]) < 5e-6
-    b1 = net._block(net.encoder.layers[0].input_blocks[1], v["enc00"].to(dev), films[1], pk, net._ws)
+    b1, _ = net._block(net.encoder.layers[0].input_blocks[1], v["enc00"].to(dev), films[1], pk, net._ws)
     assert rel_l2(b1.cpu(), v["enc01_down"]) < 5e-6
     out = net(v["x"].to(dev), v["t"].to(dev)).cpu()
     assert rel_l2(out, v["out_f32"]) < REL
@@ -150,3 +150,14 @@ def test_adm_rejects_unsupported_configurations(M):
         M.ADM(M.ADMConfig(decoder_type=2))
     with pytest.raises(NotImplementedError, match="convolution_type"):
         M.ADM(M.ADMConfig(convolution_type="circular"))
+
+
+@pytest.mark.parametrize("skip", ["concat", "add"])
+def test_adm_fused_and_standalone_norms_agree(M, dev, skip):
+    net, v, _ = _net(M, dev, skip)
+    x, t = v["x"].to(dev), v["t"].to(dev)
+    fused = net(x, t).cpu()
+    net.fuse_norm = False
+    plain = net(x, t).cpu()
+    assert rel_l2(fused, plain) < 2e-6
+    assert rel_l2(plain, v["out_f32"]) < REL and rel_l2(fused, v["out_f32"]) < REL

@@ -321,3 +321,79 @@ def test_bad_arguments_fail_loudly(dev):
         ops.attention(torch.zeros(1, 96, 40, device=dev), 32)
     with pytest.raises(ValueError):
         ops.conv2d(torch.zeros(1, 4, 8, 8, device=dev), torch.zeros(10, device=dev), 4, 3)
+
+
+FUSED_NORM_CASES = [
+    # B, Cin, Cout, H, W, mode
+    (2, 16, 24, 32, 32, 0),
+    (1, 40, 72, 20, 36, 0),        # ragged channels (last chunk 8 of 16), ragged tiles
+    (2, 64, 64, 16, 16, 0),        # 16 x 16 tile geometry
+    (1, 24, 12, 16, 32, 2),        # nearest-upsampling load
+    (1, 8, 8, 9, 13, 0),           # ragged width: element-wise epilogue path
+]
+
+
+@pytest.mark.parametrize("case", FUSED_NORM_CASES)
+def test_conv_tile_stats_and_fused_prenorm(dev, case):
+    """Norm fusion around the fp16x3 convolution: (1) the epilogue's per-(channel, tile) sums add up
+    to the plane statistics of the stored output; (2) the table built from them reproduces the norm
+    parameters; (3) a convolution with that table applied in its loader equals norm+SiLU followed by
+    the plain convolution."""
+    ops = _ops()
+    B, Cin, Cout, H, W, mode = case
+    g = torch.Generator().manual_seed(hash(case) % 1000 + 7)
+    Hin, Win = (H // 2, W // 2) if mode == 2 else (H, W)
+    x0 = torch.randn(B, Cin, Hin, Win, generator=g) * 2.0 + 0.3
+    w0 = torch.randn(Cin, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)
+    res = torch.randn(B, Cin, Hin, Win, generator=g)
+    nt = ops.conv_tile_count(Hin, Win)
+    ts = torch.full((B, Cin, nt, 4), float("nan"), device=dev)
+    # producer: y = conv(x0) + res, leaving tile statistics
+    y = ops.conv(x0.to(dev), ops.pack_conv(w0.to(dev), "fp16x3"), res1=res.to(dev), tile_stats=ts)
+    yc = y.cpu().double()
+    def sums(t):                                      # (K, S, Q, n) per tile -> plane sums of x and x^2
+        K, S, Q, n = t.cpu().double().unbind(-1)
+        return (n * K + S).sum(-1), (Q + 2 * K * S + n * K * K).sum(-1), n.sum(-1)
+    assert torch.isfinite(ts).all()
+    sx, sxx, n = sums(ts)
+    assert torch.equal(n, torch.full_like(n, Hin * Win))
+    torch.testing.assert_close(sx, yc.sum(dim=(2, 3)), rtol=1e-6, atol=1e-4)
+    torch.testing.assert_close(sxx, (yc * yc).sum(dim=(2, 3)), rtol=1e-6, atol=1e-4)
+    # the 1x1 kernel leaves the same statistics
+    w1 = torch.randn(Cin, Cin, 1, 1, generator=g) / math.sqrt(Cin)
+    ts1 = torch.zeros((B, Cin, nt, 4), device=dev)
+    y1 = ops.conv(x0.to(dev), ops.pack_conv(w1.to(dev), "fp16x3"), tile_stats=ts1).cpu().double()
+    torch.testing.assert_close(sums(ts1)[1], (y1 * y1).sum(dim=(2, 3)), rtol=1e-6, atol=1e-4)
+    wn, bn = torch.randn(Cin, generator=g), torch.randn(Cin, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)
+    pw = ops.pack_conv(w.to(dev), "fp16x3")
+    up = (lambda t: F.interpolate(t, scale_factor=2.0, mode="nearest")) if mode == 2 else (lambda t: t)
+    for kind in (0, 1):
+        # PUNetG: per-(b, c) norms
+        tab = ops.inorm_table(ts, wn.to(dev), bn.to(dev), kind, Hin * Win).cpu().double()
+        mean = yc.mean(dim=(2, 3)) if kind == 0 else torch.zeros(B, Cin, dtype=torch.float64)
+        den = (yc.var(dim=(2, 3), unbiased=False) + 1e-5).sqrt() if kind == 0 else ((yc * yc).mean(dim=(2, 3)) + 1e-5).sqrt()
+        torch.testing.assert_close(tab[..., 0], mean, rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(tab[..., 1], wn.double() / den, rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(tab[..., 2], bn.double().expand(B, Cin), rtol=0, atol=0)
+        a = ops.inorm_silu(y, wn.to(dev), bn.to(dev), kind)
+        want = ops.conv(a, pw, load_mode=mode).cpu()
+        fused = ops.conv(y, pw, load_mode=mode, prenorm=ops.inorm_table(ts, wn.to(dev), bn.to(dev), kind, Hin * Win)).cpu()
+        assert rel_l2(fused, want) < 2e-6, (kind, rel_l2(fused, want))
+        ref64 = F.conv2d(up(F.silu(((yc - mean[..., None, None]) / den[..., None, None]) * wn.double()[None, :, None, None]
+                                   + bn.double()[None, :, None, None])), w.double(), padding="same")
+        assert rel_l2(fused, ref64) < 3e-6
+        # ADM: per-sample norms (+ FiLM for the RMS kind)
+        film = torch.randn(B, 2 * Cin, generator=g)
+        tab = ops.gnorm1_table(ts, wn.to(dev), bn.to(dev), kind, Cin * Hin * Win, film=film.to(dev) if kind else None)
+        st = ops.gnorm1_stats(y, kind)
+        a = ops.gnorm1_apply(y, st, wn.to(dev), bn.to(dev), kind, film=film.to(dev) if kind else None)
+        want = ops.conv(a, pw, load_mode=mode).cpu()
+        fused = ops.conv(y, pw, load_mode=mode, prenorm=tab).cpu()
+        assert rel_l2(fused, want) < 2e-6, ("g1", kind, rel_l2(fused, want))
+    # concat of two tensors: statistics are additive
+    tab2 = ops.gnorm1_table(ts, torch.cat([wn, wn]).to(dev), torch.cat([bn, bn]).to(dev), 0, 2 * Cin * Hin * Win,
+                            stats_b=ts).cpu()
+    tab1 = ops.gnorm1_table(ts, wn.to(dev), bn.to(dev), 0, Cin * Hin * Win).cpu()
+    torch.testing.assert_close(tab2[:, :Cin], tab1, rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(tab2[:, Cin:], tab1, rtol=1e-6, atol=1e-7)

@@ -152,7 +152,7 @@ def test_punetg_layers_vs_reference(net8, dev):
     assert rel_l2(a.cpu(), v["rms_silu"]) < 2e-6
     shifts = net8.time_shifts(v["te"].to(dev))
     assert rel_l2(shifts[0].cpu(), v["timeshift"].flatten(1)) < 2e-6
-    r = net8._res(blk, v["convin"].to(dev), shifts[0], pk, net8._ws)
+    r, _ = net8._res(blk, v["convin"].to(dev), shifts[0], pk, net8._ws)
     assert rel_l2(r.cpu(), v["resblock"]) < 5e-6
     d = net8._conv(net8.downsamplers[0].conv, v["resblock"].to(dev), pk, load_mode=1)
     assert rel_l2(d.cpu(), v["down"]) < 2e-6
@@ -318,3 +318,20 @@ def test_porosity_conditional_cfg_dict_y(M, dev, grids):
         assert rel_l2(h, v["hist_cfg_g2_N4_f32"]) < REL
         o = module.propagate_white_noise(wn, y=y, guidance=1.0, nsteps=4).cpu()
         assert rel_l2(o, v["out_cond_g1_N4_f32"]) < REL
+
+
+def test_fused_and_standalone_norms_agree(M, net8, dev):
+    """fuse_norm folds GroupNorm/GroupRMSNorm + SiLU into the convolutions around them (statistics
+    from the producer's epilogue, activation in the consumer's loader); the standalone-kernel route
+    must give the same network output to fp32 rounding."""
+    v, _ = load("punetg8_forward")
+    x, t = v["x"].to(dev), v["t"].to(dev)
+    assert net8.fuse_norm
+    fused = net8(x, t).cpu()
+    net8.fuse_norm = False
+    try:
+        plain = net8(x, t).cpu()
+    finally:
+        net8.fuse_norm = True
+    assert rel_l2(fused, plain) < 2e-6
+    assert rel_l2(plain, v["out_f32"]) < REL and rel_l2(fused, v["out_f32"]) < REL

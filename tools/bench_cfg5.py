@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--guidance", type=float, default=2.0)
     ap.add_argument("--precision", default="fp16x3")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-fuse-norm", action="store_true")
     a = ap.parse_args()
     import diffsci_amd.models as M
     dev = torch.device("cuda:0")
@@ -31,6 +32,7 @@ def main():
     net = M.PUNetG(M.PUNetGConfig(input_channels=4, output_channels=4),
                    conditional_embedding=M.nets.PorosityEmbedder(dembed=64))
     net.conv_precision = a.precision
+    net.fuse_norm = not a.no_fuse_norm
     module = M.KarrasModule(net, M.KarrasModuleConfig.from_edm(), conditional=True).to(dev).eval()
     module.use_graph = not a.no_graph
     wn = torch.randn(a.batch, 4, a.size, a.size, device=dev)
