@@ -186,22 +186,25 @@ __global__ __launch_bounds__(NT, 2) void k_conv3h(const Conv3hArgs a) {
     }
   };
   const float* pre_b = PRE ? a.prenorm + (size_t)b * a.Cin * 4 : nullptr;
+  // PRE: normalise + SiLU one staging item in registers, right before its fp16 split.  (Slotting this
+  // VALU / transcendental work between the MFMAs of the same wave was measured 2-3 % SLOWER than
+  // leaving it in one block: the co-resident workgroup's waves already fill the matrix pipe then.)
+  auto x_activate = [&](int i) __attribute__((always_inline)) {
+    // constant address space: the table was written by an earlier kernel and is read-only here, which
+    // is what lets the compiler use s_load (vector loads + vmcnt(0) per channel pair otherwise)
+    typedef const __attribute__((address_space(4))) f32x4* cptr;
+    cptr pp = (cptr)(reinterpret_cast<const f32x4*>(pre_b) + xchunk * KC);
+    const int h = i == 0 ? 0 : (i == 1 ? 1 : tail_h);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int c = 8 * h + k < xnch ? 8 * h + k : 0;                         // ragged last chunk: stay inside the table
+      const f32x4 p = pp[c];
+      xr[i][k] = fast_silu((xr[i][k] - p[0]) * p[1] + p[2]);
+    }
+  };
   auto x_store = [&](int buf) __attribute__((always_inline)) {                       // [normalise + SiLU,] split to fp16 pieces, write the LDS image
     u32x4* xb = Xs + buf * XBUF_VEC;
-    if (PRE) {
-      // (M, A, C) of the item's 8 channels: wave-uniform addresses -> scalar loads, SGPR operands
-      const f32x4* pp = reinterpret_cast<const f32x4*>(pre_b) + xchunk * KC;
-#pragma unroll
-      for (int i = 0; i < XI; ++i) {
-        const int h = i == 0 ? 0 : (i == 1 ? 1 : tail_h);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const int c = 8 * h + k < xnch ? 8 * h + k : 0;                     // ragged last chunk: stay inside the table
-          const f32x4 p = pp[c];
-          xr[i][k] = fast_silu((xr[i][k] - p[0]) * p[1] + p[2]);
-        }
-      }
-    }
+    if (PRE) { x_activate(0); x_activate(1); x_activate(2); }
 #pragma unroll
     for (int i = 0; i < XI; ++i) {
       if (i < 2 || ((xlive >> i) & 1u)) {

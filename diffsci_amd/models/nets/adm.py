@@ -173,7 +173,9 @@ class ADM(torch.nn.Module):
         self.input_layer = torch.nn.Conv2d(config.input_channels, mc, 3, padding="same")
         self.output_layer = torch.nn.Conv2d(mc, config.output_channels, 3, padding="same")
         self.conv_precision = "fp16x3"       # see PUNetG.conv_precision
-        self.fuse_norm = True                # see PUNetG.fuse_norm
+        # see PUNetG.fuse_norm; measured on MI355X at config 3 the folded norms are 1-2 % slower than the
+        # standalone two-phase kernels (per-sample table reductions, large-Cin loaders), so off by default
+        self.fuse_norm = False
         self._packed = None
         self._packed_sig = None
         self._ws = _Workspace()

@@ -156,6 +156,7 @@ def test_adm_rejects_unsupported_configurations(M):
 def test_adm_fused_and_standalone_norms_agree(M, dev, skip):
     net, v, _ = _net(M, dev, skip)
     x, t = v["x"].to(dev), v["t"].to(dev)
+    net.fuse_norm = True
     fused = net(x, t).cpu()
     net.fuse_norm = False
     plain = net(x, t).cpu()
