@@ -81,9 +81,12 @@ def build_module(args, dev):
 
 
 def dominant_kernel_roofline(module, args, dev, reps=40):
-    """Average launch duration of the dominant kernel (k_conv<3, PLAIN>: the 3x3 convolutions of
+    """Average launch duration of the dominant kernel (k_conv3h<PLAIN, *>: the 3x3 convolutions of
     the residual blocks, convin and convout) over one network evaluation's worth of its launches,
-    timed with events on the launch stream, against its algorithmic FLOPs."""
+    timed with events on the launch stream, against its algorithmic FLOPs.  The launches carry what
+    they carry in the network: conv1 = fused norm+SiLU loader + time shift + tile statistics,
+    conv2 = fused norm+SiLU loader + residual + tile statistics (the fused parts only with
+    fuse_norm, i.e. the default fp16x3 path)."""
     from diffsci_amd import ops
     net = module.model
     pk = net.packed_weights()
@@ -110,12 +113,25 @@ def dominant_kernel_roofline(module, args, dev, reps=40):
     conv1s = {id(blk.conv1) for blk in net._resblocks()}
     conv2s = {id(blk.conv2) for blk in net._resblocks()}
     shift = {c: torch.randn(1, c, device=dev) for c in {m.out_channels for m in mods}}
-
-    def run():      # the same epilogues as in the network: conv1 + time shift, conv2 + residual
+    fused = net._fused()
+    tabs, stats = {}, {}
+    if fused:
         for m, cin, cout, s in launches:
+            if (cin, s) not in tabs:
+                t = torch.zeros(B, cin, 4, device=dev)
+                t[..., 1] = 1.0                       # (M, A, C) = (0, 1, 0): the loader computes SiLU(x)
+                tabs[(cin, s)] = t
+            stats[(cout, s)] = torch.empty(B, cout, ops.conv_tile_count(s, s), 4, device=dev)
+
+    def run():      # the same loaders / epilogues as in the network
+        for m, cin, cout, s in launches:
+            block = id(m) in conv1s or id(m) in conv2s
             ops.conv(buf(cin, s), pk[id(m)], bias=m.bias,
-                       shift=shift[cout] if id(m) in conv1s else None,
-                       res1=buf(cout, s, "res") if id(m) in conv2s else None, out=outs[(cout, s)])
+                     shift=shift[cout] if id(m) in conv1s else None,
+                     res1=buf(cout, s, "res") if id(m) in conv2s else None,
+                     prenorm=tabs[(cin, s)] if (fused and block) else None,
+                     tile_stats=stats[(cout, s)] if (fused and m is not net.convout) else None,
+                     out=outs[(cout, s)])
     run()
     torch.cuda.synchronize()
     # default reps: ~0.3-1 s of sustained launches (short bursts run at a higher clock than the real loop)
@@ -130,7 +146,8 @@ def dominant_kernel_roofline(module, args, dev, reps=40):
     ms = e0.elapsed_time(e1) / reps
     n = len(launches)
     kname, peak = {
-        "fp16x3": ("k_conv3h<PLAIN> (ds_conv2d_h3, 3x3, fp32 via 3 fp16 MFMA products)", BF16_PEAK_TFLOPS / 3.0),
+        "fp16x3": ("k_conv3h<PLAIN> (ds_conv2d_h3, 3x3, fp32 via 3 fp16 MFMA products"
+                   + (", norm+SiLU in the loader, tile statistics in the epilogue)" if fused else ")"), BF16_PEAK_TFLOPS / 3.0),
         "bf16x6": ("k_conv6<PLAIN> (ds_conv2d_x6, 3x3, fp32 via 6 bf16 MFMA products)", BF16_PEAK_TFLOPS / 6.0),
         "fp32": ("k_conv<3,PLAIN> (ds_conv2d 3x3, exact-fp32 MFMA)", MFMA_F32_PEAK_TFLOPS)}[net.conv_precision]
     achieved = flops / (ms * 1e-3) / 1e12
