@@ -66,6 +66,8 @@ _PROTOS = {
     "ds_gnorm1_apply": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "ds_concat2": (c_int, [_P, _P, _P, c_int, c_size_t, c_size_t, _P]),
     "ds_add_act": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "ds_mask_blend": (c_int, [_P, _P, _P, _P, c_size_t, c_int, _P]),
+    "ds_lerp_stack": (c_int, [_P, _P, _P, c_int, c_size_t, _P]),
     "ds_add": (c_int, [_P, _P, _P, c_size_t, _P]),
     "ds_graph_begin_capture": (c_int, [_P]),
     "ds_graph_end_capture": (c_int, [_P, POINTER(_P), POINTER(c_int)]),

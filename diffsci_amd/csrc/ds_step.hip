@@ -186,6 +186,32 @@ __global__ __launch_bounds__(kThreads) void k_denoiser(float* out, const float* 
   }
 }
 
+// out = x*(1 - mask) + y*mask, mask broadcast over the batch (schedulers.py:112,116,146: inpaint / repaint)
+__global__ __launch_bounds__(kThreads) void k_mask_blend(float* out, const float* __restrict__ x,
+                                                         const float* __restrict__ y, const float* __restrict__ mask,
+                                                         size_t nps, size_t total) {
+  size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x;
+  size_t stride = (size_t)gridDim.x * kThreads;
+  for (; i < total; i += stride) {
+    const float m = mask[i % nps];
+    const float a = x[i] * (1.0f - m);
+    const float b = y[i] * m;
+    out[i] = a + b;
+  }
+}
+
+// out[i] = x1 + ((x2 - x1) * i) / (n - 1), i = 0..n-1  (torchutils.py:64-65, same operation order)
+__global__ __launch_bounds__(kThreads) void k_lerp_stack(float* out, const float* __restrict__ x1,
+                                                         const float* __restrict__ x2, int n, size_t numel) {
+  size_t e = (size_t)blockIdx.x * kThreads + threadIdx.x;
+  size_t stride = (size_t)gridDim.x * kThreads;
+  const float den = (float)(n - 1);
+  for (; e < numel; e += stride) {
+    const float a = x1[e], d = x2[e] - a;
+    for (int i = 0; i < n; ++i) out[(size_t)i * numel + e] = a + (d * (float)i) / den;
+  }
+}
+
 __global__ __launch_bounds__(kThreads) void k_add(float* out, const float* __restrict__ a,
                                                   const float* __restrict__ b, size_t n4, size_t n) {
   size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x;
@@ -318,6 +344,27 @@ int ds_karras_denoiser(float* out, const float* x, const float* f, const float* 
   hipLaunchKernelGGL(k_denoiser, dim3(grid_for((total + 3) / 4)), dim3(kThreads), 0, ds::as_stream(stream), out, x, f,
                      fu, guidance, one_minus_guidance, c_out, c_skip, n_per_sample, total);
   DS_CHECK_LAUNCH("ds_karras_denoiser");
+  return DS_OK;
+}
+
+int ds_mask_blend(float* out, const float* x, const float* y, const float* mask, size_t n_per_sample, int B,
+                  void* stream) {
+  DS_REQUIRE(out && x && y && mask, DS_ERR_NULL, "ds_mask_blend: NULL pointer");
+  DS_REQUIRE(B >= 0 && n_per_sample > 0, DS_ERR_SHAPE, "ds_mask_blend: bad shape");
+  if (B == 0) return DS_OK;
+  const size_t total = n_per_sample * (size_t)B;
+  hipLaunchKernelGGL(k_mask_blend, dim3(grid_for((total + 3) / 4)), dim3(kThreads), 0, ds::as_stream(stream), out, x, y,
+                     mask, n_per_sample, total);
+  DS_CHECK_LAUNCH("ds_mask_blend");
+  return DS_OK;
+}
+
+int ds_lerp_stack(float* out, const float* x1, const float* x2, int n, size_t numel, void* stream) {
+  DS_REQUIRE(out && x1 && x2, DS_ERR_NULL, "ds_lerp_stack: NULL pointer");
+  DS_REQUIRE(n >= 2 && numel > 0, DS_ERR_SHAPE, "ds_lerp_stack: need n >= 2 interpolation points (got %d)", n);
+  hipLaunchKernelGGL(k_lerp_stack, dim3(grid_for((numel + 3) / 4)), dim3(kThreads), 0, ds::as_stream(stream), out, x1,
+                     x2, n, numel);
+  DS_CHECK_LAUNCH("ds_lerp_stack");
   return DS_OK;
 }
 

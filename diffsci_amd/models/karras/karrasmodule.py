@@ -295,6 +295,73 @@ class KarrasModule(torch.nn.Module):
         return out
 
     # ---------------------------------------------------------------- encode / decode (non-latent)
+    # ---------------------------------------------------------------- inpainting / interpolation
+    def _score_rhs(self, y):
+        def rhs(x, sigma):
+            with torch.inference_mode():
+                return self.get_score(x, sigma, y)
+        return rhs
+
+    def propagate_toward_noise(self, x, y=None, nsteps: int = 100, record_history: bool = False,
+                               stochastic_integration: bool = False, eps=None):
+        """karrasmodule.py:1093-1115: forward propagation (data -> noise) of the probability-flow ODE or,
+        with stochastic_integration, of the forward SDE (Euler-Maruyama).  eps: see Scheduler.propagate."""
+        if y is not None:
+            y = dict_unsqueeze(y, 0)
+        with torch.inference_mode():
+            return self.config.noisescheduler.propagate_forward(x, self._score_rhs(y), nsteps,
+                                                                record_history=record_history,
+                                                                stochastic=stochastic_integration, eps=eps)
+
+    def propagate_inpaint_toward_sample(self, x, x_inpaint, mask, y=None, record_history: bool = False):
+        """karrasmodule.py:1043-1066."""
+        if y is not None:
+            y = dict_unsqueeze(y, 0)
+        with torch.inference_mode():
+            return self.config.noisescheduler.inpaint(x, x_inpaint, mask, self._score_rhs(y),
+                                                      x_inpaint.shape[0] - 1, record_history=record_history)
+
+    def propagate_repaint_toward_sample(self, x, x_inpaint, mask, y=None, record_history: bool = False, noise=None):
+        """karrasmodule.py:1068-1091."""
+        if y is not None:
+            y = dict_unsqueeze(y, 0)
+        with torch.inference_mode():
+            return self.config.noisescheduler.repaint(x, x_inpaint, mask, self._score_rhs(y),
+                                                      x_inpaint.shape[0] - 1, record_history=record_history,
+                                                      noise=noise)
+
+    def inpaint(self, x_orig, mask, y=None, nsteps: int = 100, record_history: bool = False,
+                maximum_batch_size: None | int = None, mode: str = "inpaint"):
+        """karrasmodule.py:978-1026: noise the original forward (SDE), start from fresh noise, denoise
+        while re-imposing the known region at every noise level."""
+        if maximum_batch_size is not None:
+            batch_sizes = get_minibatch_sizes(x_orig.shape[0], maximum_batch_size)
+            x_chunks, m_chunks = x_orig.chunk(len(batch_sizes)), mask.chunk(len(batch_sizes))
+            result = [self.inpaint(x_chunks[i], m_chunks[i], y, nsteps, record_history, maximum_batch_size=None)
+                      for i, _ in enumerate(batch_sizes)]
+            return torch.cat(result, dim=1 if record_history else 0)
+        x_orig_history = self.propagate_toward_noise(x_orig, nsteps=nsteps, y=y, record_history=True,
+                                                     stochastic_integration=True)
+        noise = ops.scale(torch.randn_like(x_orig), self.config.noisescheduler.maximum_scale)
+        fn = self.propagate_inpaint_toward_sample if mode == "inpaint" else self.propagate_repaint_toward_sample
+        return fn(noise, x_orig_history, mask, y=y, record_history=record_history)
+
+    def repaint(self, x_orig, mask, y=None, nsteps: int = 100, record_history: bool = False,
+                maximum_batch_size: None | int = None):
+        """karrasmodule.py:1028-1041."""
+        return self.inpaint(x_orig, mask, y, nsteps, record_history, maximum_batch_size, mode="repaint")
+
+    def interpolate_images(self, x1, x2, ninterp: int, jitter: None | float = 1e-2, y=None, nsteps: int = 100,
+                           record_history: bool = False):
+        """karrasmodule.py:1117-1144: noise both images with the deterministic forward ODE, interpolate
+        linearly in noise space, denoise."""
+        x = torch.stack([x1, x2], dim=0).contiguous()
+        if jitter is not None:
+            x = ops.churn(x, torch.randn_like(x), float(jitter), xhat_out=torch.empty_like(x))   # x + jitter*eps
+        x_noised = self.propagate_toward_noise(x, y, nsteps)            # unsqueezes y itself
+        x_interp = ops.lerp_stack(x_noised[0].contiguous(), x_noised[1].contiguous(), ninterp)
+        return self.propagate_toward_sample(x_interp, y=y, nsteps=nsteps, record_history=record_history)
+
     def encode(self, x, y=None, record_history=False):
         """karrasmodule.py:1192-1214 for a non-latent module."""
         return x / self.norm

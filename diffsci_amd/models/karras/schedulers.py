@@ -1,8 +1,8 @@
 """Scheduler / EDMScheduler with the reference's public surface
 (diffsci/models/karras/schedulers.py:27-390): create_steps, propagate / propagate_backward /
 propagate_forward / propagate_partial, rhs, langevin_factor, noise_injection, apply_noise, renoise,
-set/unset_temporary_integrator, the runtime knobs maximum_scale / langevin_const /
-langevin_interval.  inpaint / repaint are the next scope row.
+inpaint, repaint, set/unset_temporary_integrator, the runtime knobs maximum_scale / langevin_const /
+langevin_interval.
 
 The sigma grid and every per-step scalar are computed on the CPU in fp32 with the reference's
 operation sequence; all tensor-sized work goes through the HIP stepper (engine.py)."""
@@ -72,6 +72,59 @@ class Scheduler(torch.nn.Module):
             return run_table(table, src, x, record_history=record_history, eps=eps)
         return self._propagate_custom(x, score_fn, integrator, nsteps, record_history, True,
                                       initial_step, final_step)
+
+    # -------------------------------------------------------------- inpainting loops
+    def inpaint(self, x, y, mask, score_fn, nsteps: int = 100, record_history: bool = False):
+        """schedulers.py:91-121: one integrator step, then re-impose the known region from the
+        noised original ``y`` ([nsteps+1, B, *shape], most noised last); mask [*shape], 1 = known."""
+        ops.require_device(x, "x")
+        mask = mask.to(x).contiguous()
+        if record_history:
+            history = torch.zeros((nsteps + 1,) + tuple(x.shape), dtype=x.dtype, device=x.device)
+            history[0] = x
+        x = ops.mask_blend(x.contiguous(), y[-1].contiguous(), mask)
+        for i in range(nsteps):
+            x = self.propagate_partial(x, score_fn, nsteps, i, i + 1)
+            x = ops.mask_blend(x, y[-i - 2].contiguous(), mask, out=x)
+            if record_history:
+                history[i + 1] = x
+        return history if record_history else x
+
+    def repaint(self, x, y, mask, score_fn, nsteps: int = 100, rsteps: int = 10, nresamples: int = 10,
+                record_history: bool = False, noise=None):
+        """schedulers.py:123-164 (RePaint resampling).  ``noise`` (extension): an iterable of tensors
+        shaped like x used by the renoise draws in order, instead of the device generator."""
+        if not (nsteps % rsteps) == 0:
+            raise ValueError("rsteps should divide nsteps")
+        ops.require_device(x, "x")
+        mask = mask.to(x).contiguous()
+        draws = iter(noise) if noise is not None else None
+        t = self.create_steps(nsteps + 1)
+        if record_history:
+            history = torch.zeros((int(nresamples * (nsteps / rsteps - 1)) + 2,) + tuple(x.shape),
+                                  dtype=x.dtype, device=x.device)
+            history[0] = x
+        x = ops.mask_blend(x.contiguous(), y[-1].contiguous(), mask)
+        step, fstep = 0, rsteps
+        x = self.propagate_partial(x, score_fn, nsteps, step, fstep)
+        step, fstep = fstep, fstep + rsteps
+        level = 0
+        while fstep <= nsteps:
+            x = self.propagate_partial(x, score_fn, nsteps, step, fstep)
+            for i in range(nresamples):
+                x = ops.mask_blend(x, y[-fstep - 1].contiguous(), mask, out=x)
+                if record_history:
+                    history[level + i + 1] = x
+                x = self.renoise(x, t[fstep], t[step], noise=None if draws is None else next(draws))
+                x = self.propagate_partial(x, score_fn, nsteps, step, fstep)
+            step, fstep = fstep, fstep + rsteps
+            level = level + nresamples
+        if not step == nsteps:
+            raise ValueError('Wrong counting')
+        if record_history:
+            history[level + 1] = x
+            return history
+        return x
 
     def _propagate_custom(self, x, score_fn, integrator, nsteps, record_history, backward, i0, i1):
         """User-defined Integrator subclasses: the reference's own loop, step by step."""
@@ -152,8 +205,8 @@ class Scheduler(torch.nn.Module):
         noise = torch.randn(x.shape).to(x)
         return ops.churn(x.contiguous(), noise, float(scale * sigma), xhat_out=torch.empty_like(x))
 
-    def renoise(self, x, t: float, t_noise: float):
-        """schedulers.py:166-176."""
+    def renoise(self, x, t: float, t_noise: float, noise=None):
+        """schedulers.py:166-176.  noise (extension): the draw to use instead of randn_like(x)."""
         t = torch.as_tensor(t, dtype=torch.float32)
         t_noise = torch.as_tensor(t_noise, dtype=torch.float32)
         sigma = self.scheduler_fns.noise_fn(t)
@@ -163,7 +216,8 @@ class Scheduler(torch.nn.Module):
         if float(scale_noise / scale) != 1.0:
             raise NotImplementedError("renoise with a non-constant scaling function")
         std = scale_noise * torch.sqrt(sigma_noise ** 2 - sigma ** 2)
-        return ops.churn(x.contiguous(), torch.randn_like(x), float(std), xhat_out=torch.empty_like(x))
+        noise = torch.randn_like(x) if noise is None else noise.to(x).contiguous()
+        return ops.churn(x.contiguous(), noise, float(std), xhat_out=torch.empty_like(x))
 
     # -------------------------------------------------------------- integrator selection
     def unset_temporary_integrator(self):

@@ -58,6 +58,24 @@ def add(a, b, out=None):
     return out
 
 
+def mask_blend(x, y, mask, out=None):
+    """x*(1-mask) + y*mask with mask [*shape] broadcast over the batch."""
+    B = x.shape[0]
+    nps = x.numel() // max(B, 1)
+    if y.shape != x.shape or mask.numel() != nps:
+        raise ValueError(f"mask_blend: x {tuple(x.shape)}, y {tuple(y.shape)}, mask {tuple(mask.shape)}")
+    out = torch.empty_like(x) if out is None else out
+    N.check(N.lib().ds_mask_blend(_p(out), _p(x), _p(y), _p(mask), nps, B, _stream()), "ds_mask_blend")
+    return out
+
+
+def lerp_stack(x1, x2, n):
+    """stack([x1 + (x2 - x1)*i/(n-1) for i in range(n)])."""
+    out = torch.empty((n,) + tuple(x1.shape), dtype=torch.float32, device=x1.device)
+    N.check(N.lib().ds_lerp_stack(_p(out), _p(x1), _p(x2), int(n), x1.numel(), _stream()), "ds_lerp_stack")
+    return out
+
+
 def drift(x, f, k, fu=None, out=None):
     out = torch.empty_like(f) if out is None else out
     n = _same_numel(x, f, fu, out)

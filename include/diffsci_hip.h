@@ -256,6 +256,15 @@ int ds_concat2(float* out, const float* a, const float* b, int B, size_t na, siz
  * final SiLU (adm.py:1050-1052). */
 int ds_add_act(float* out, const float* a, const float* add, int add_rows, int M, int N, int act, void* stream);
 
+/* out[b, i] = x[b, i]*(1 - mask[i]) + y[b, i]*mask[i]: the known-region re-imposition of
+ * Scheduler.inpaint / repaint (schedulers.py:112,116,146); mask has n_per_sample entries. out may alias x. */
+int ds_mask_blend(float* out, const float* x, const float* y, const float* mask, size_t n_per_sample, int B,
+                  void* stream);
+
+/* out[i] = x1 + ((x2 - x1)*i)/(n - 1), i = 0..n-1, each of numel floats: linear_interpolation
+ * (torchutils.py:64-65) used by KarrasModule.interpolate_images (karrasmodule.py:1136-1138). */
+int ds_lerp_stack(float* out, const float* x1, const float* x2, int n, size_t numel, void* stream);
+
 /* out = a + b (n floats). */
 int ds_add(float* out, const float* a, const float* b, size_t n, void* stream);
 

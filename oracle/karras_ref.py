@@ -111,8 +111,8 @@ def noise_injection(t, **kw):
     return torch.sqrt(2 * langevin_factor(t, **kw))
 
 
-def rhs_edm(x, ti, score_fn, stochastic=False, langevin_const=1.0, langevin_interval=None):
-    """Backward-time drift.  schedulers.py:247-274 (constant_scaling_fn branch)."""
+def rhs_edm(x, ti, score_fn, stochastic=False, langevin_const=1.0, langevin_interval=None, backward=True):
+    """Drift.  schedulers.py:247-274 (constant_scaling_fn branch); forward mode flips the Langevin term."""
     t = ti * torch.ones(x.shape[0]).to(x)
     t_ = _bcast(t, x)
     sigma = 1 * t
@@ -121,7 +121,10 @@ def rhs_edm(x, ti, score_fn, stochastic=False, langevin_const=1.0, langevin_inte
     sc = score_fn(x, sigma)
     res = -multiplier * sc
     if stochastic:
-        res += -(langevin_factor(t_, langevin_const, langevin_interval) * sc)
+        stochastic_factor = -(langevin_factor(t_, langevin_const, langevin_interval) * sc)
+        if not backward:
+            stochastic_factor = -stochastic_factor
+        res += stochastic_factor
     return res
 
 
@@ -208,6 +211,102 @@ def propagate_backward(x, score_fn, nsteps, integrator="heun", record_history=Fa
         if record_history:
             history[i + 1] = x
     return history if record_history else x
+
+
+def _one_step(x, t, dt, rhs, integrator, eps, lv):
+    if integrator == "euler":
+        return step_euler(x, t, dt, rhs)
+    if integrator == "heun":
+        return step_heun(x, t, dt, rhs)
+    if integrator == "euler-maruyama":
+        return step_euler_maruyama(x, t, dt, rhs, eps, **lv)
+    raise ValueError(f"Unknown integrator: {integrator}")
+
+
+def propagate_forward(x, score_fn, nsteps, integrator="heun", record_history=False, eps=None,
+                      langevin_const=1.0, langevin_interval=None):
+    """schedulers.py:48-89 with backward=False: the grid is flipped (0, sigma_min, ..., sigma_max),
+    the step from t=0 is skipped, history[0] stays zero.  eps: one draw per executed step."""
+    t = edm_sigma_grid(nsteps + 1).to(x).flip(0)
+    dt = torch.diff(t)
+    lv = dict(langevin_const=langevin_const, langevin_interval=langevin_interval)
+
+    def rhs(xx, tt):
+        return rhs_edm(xx, tt, score_fn, stochastic=integrator == "euler-maruyama", backward=False, **lv)
+    if record_history:
+        history = torch.zeros([nsteps + 1] + list(x.shape)).to(x)
+        history[1] = x
+    for i in range(nsteps - 1):
+        x = _one_step(x, t[i + 1], dt[i + 1], rhs, integrator, None if eps is None else eps[i].to(x), lv)
+        if record_history:
+            history[i + 2] = x
+    return history if record_history else x
+
+
+def propagate_partial(x, score_fn, nsteps, initial_step, final_step, integrator="heun"):
+    """schedulers.py:178-217 (backward, deterministic integrators)."""
+    t = edm_sigma_grid(nsteps + 1).to(x)
+    dt = torch.diff(t)
+
+    def rhs(xx, tt):
+        return rhs_edm(xx, tt, score_fn)
+    for i in range(initial_step, final_step):
+        x = _one_step(x, t[i], dt[i], rhs, integrator, None, {})
+    return x
+
+
+def inpaint(x, y, mask, score_fn, nsteps, integrator="heun", record_history=False):
+    """Scheduler.inpaint, schedulers.py:91-121."""
+    if record_history:
+        history = torch.zeros([nsteps + 1] + list(x.shape)).to(x)
+        history[0] = x
+    x = x * (1 - mask) + y[-1] * mask
+    for i in range(nsteps):
+        x = propagate_partial(x, score_fn, nsteps, i, i + 1, integrator)
+        x = x * (1 - mask) + y[-i - 2] * mask
+        if record_history:
+            history[i + 1] = x
+    return history if record_history else x
+
+
+def renoise(x, t, t_noise, eps):
+    """Scheduler.renoise, schedulers.py:166-176 (EDM: scale = 1)."""
+    std = (1 + 0 * t_noise) * torch.sqrt((1 * t_noise) ** 2 - (1 * t) ** 2)
+    return ((1 + 0 * t_noise) / (1 + 0 * t)) * x + std * eps
+
+
+def repaint(x, y, mask, score_fn, nsteps, rsteps, nresamples, eps, integrator="heun", record_history=False):
+    """Scheduler.repaint, schedulers.py:123-164.  eps: the renoise draws in order."""
+    assert nsteps % rsteps == 0
+    t = edm_sigma_grid(nsteps + 1).to(x)
+    draws = iter(eps)
+    if record_history:
+        history = torch.zeros([int(nresamples * (nsteps / rsteps - 1)) + 2] + list(x.shape)).to(x)
+        history[0] = x
+    x = x * (1 - mask) + y[-1] * mask
+    step, fstep = 0, rsteps
+    x = propagate_partial(x, score_fn, nsteps, step, fstep, integrator)
+    step, fstep = fstep, fstep + rsteps
+    level = 0
+    while fstep <= nsteps:
+        x = propagate_partial(x, score_fn, nsteps, step, fstep, integrator)
+        for i in range(nresamples):
+            x = x * (1 - mask) + y[-fstep - 1] * mask
+            if record_history:
+                history[level + i + 1] = x
+            x = renoise(x, t[fstep], t[step], next(draws).to(x))
+            x = propagate_partial(x, score_fn, nsteps, step, fstep, integrator)
+        step, fstep = fstep, fstep + rsteps
+        level = level + nresamples
+    if record_history:
+        history[level + 1] = x
+        return history
+    return x
+
+
+def linear_interpolation(x1, x2, n):
+    """torchutils.py:64-65."""
+    return torch.stack([x1 + (x2 - x1) * i / (n - 1) for i in range(n)])
 
 
 def propagate_white_noise(net, white_noise, nsteps, integrator="heun", precond=edm_precond,

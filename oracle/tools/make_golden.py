@@ -216,6 +216,45 @@ def punetg():
 
 
 # ---------------------------------------------------------------- 4. ADM (config 3 family, tiny)
+def inpaint():
+    """inpaint / repaint / forward propagation / image interpolation."""
+    import diffsci.data
+    torch.manual_seed(30)
+    gs = diffsci.data.ZeroMeanGaussianDataset(num_samples=8, shape=[1, 8, 8], scale=0.7)
+    sch = M.EDMScheduler()
+    N = 6
+    x = torch.randn(3, 1, 8, 8) * 80.0
+    yh = torch.randn(N + 1, 3, 1, 8, 8) * torch.linspace(0.5, 80.0, N + 1).view(-1, 1, 1, 1, 1)
+    mask = (torch.rand(1, 8, 8) < 0.4).float()
+    arrs = dict(x=x, y_hist=yh, mask=mask)
+    arrs["sched_inpaint_hist"] = sch.inpaint(x, yh, mask, gs.gradlogprob, N, record_history=True)
+    arrs["sched_inpaint_out"] = sch.inpaint(x, yh, mask, gs.gradlogprob, N)
+    with RandnRecorder() as rec:
+        arrs["sched_repaint_hist"] = sch.repaint(x, yh, mask, gs.gradlogprob, N, rsteps=2, nresamples=2, record_history=True)
+    arrs["sched_repaint_eps"] = torch.stack(rec.draws)
+    arrs["sched_forward_heun_hist"] = sch.propagate_forward(x / 80.0, gs.gradlogprob, N, record_history=True)
+    # module level, PUNetG-8 (weights of the punetg8_forward fixture)
+    z = np.load(os.path.join(OUT, "punetg8_forward.npz"))
+    sd = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd/")}
+    net = M.nets.PUNetG(M.nets.PUNetGConfig(model_channels=8)).eval()
+    net.load_state_dict(sd)
+    module = M.KarrasModule(net, M.KarrasModuleConfig.from_edm()).eval()
+    torch.manual_seed(31)
+    x0 = torch.randn(2, 1, 32, 32) * 0.5
+    m2 = (torch.rand(1, 32, 32) < 0.5).float()
+    arrs.update(x0=x0, mask2=m2)
+    arrs["toward_noise_heun_N4"] = module.propagate_toward_noise(x0, nsteps=4, record_history=True)
+    with RandnRecorder() as rec:
+        fh = module.propagate_toward_noise(x0, nsteps=4, record_history=True, stochastic_integration=True)
+    arrs["toward_noise_em_N4"] = fh
+    arrs["toward_noise_em_eps"] = torch.stack(rec.draws)
+    noise = torch.randn(2, 1, 32, 32) * 80.0
+    arrs["inpaint_noise"] = noise
+    arrs["module_inpaint_hist"] = module.propagate_inpaint_toward_sample(noise, fh, m2, record_history=True)
+    arrs["interp_N4_n3"] = module.interpolate_images(x0[0], x0[1], 3, jitter=None, nsteps=4)
+    npz("inpaint8", **arrs)
+
+
 def porosity():
     """BASELINE config 5's shape of the path: 4-channel conditional PUNetG with the in-repo dict-style
     PorosityEmbedder (nets/embedder.py:198-229), classifier-free guidance, un-batched dict y."""
@@ -286,6 +325,6 @@ def adm():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["schedule", "toy", "punetg", "porosity", "adm"]
+    which = sys.argv[1:] or ["schedule", "toy", "punetg", "porosity", "inpaint", "adm"]
     for name in which:
         globals()[name]()

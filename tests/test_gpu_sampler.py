@@ -335,3 +335,48 @@ def test_fused_and_standalone_norms_agree(M, net8, dev):
         net8.fuse_norm = True
     assert rel_l2(fused, plain) < 2e-6
     assert rel_l2(plain, v["out_f32"]) < REL and rel_l2(fused, v["out_f32"]) < REL
+
+
+def test_inpaint_repaint_forward_and_interpolation(M, net8, dev):
+    """Scheduler.inpaint / repaint / propagate_forward and the module-level forward
+    propagation, inpainting and image interpolation, against goldens generated by the reference."""
+    from diffsci_amd import ops
+    v, _ = load("inpaint8")
+    sch = M.EDMScheduler()
+    fn = K.gaussian_target_score(0.7)                       # a user score function (torch ops on the GPU)
+    x, yh, mask = v["x"].to(dev), v["y_hist"].to(dev), v["mask"].to(dev)
+    want = v["x"] * (1 - v["mask"]) + v["y_hist"][-1] * v["mask"]
+    assert torch.equal(ops.mask_blend(x, yh[-1].contiguous(), mask).cpu(), want)          # bit-exact blend
+    h = sch.inpaint(x, yh, mask, fn, 6, record_history=True).cpu()
+    assert h.shape == v["sched_inpaint_hist"].shape
+    torch.testing.assert_close(h, v["sched_inpaint_hist"], rtol=2e-6, atol=2e-5)
+    torch.testing.assert_close(sch.inpaint(x, yh, mask, fn, 6).cpu(), v["sched_inpaint_out"], rtol=2e-6, atol=2e-5)
+    h = sch.repaint(x, yh, mask, fn, 6, rsteps=2, nresamples=2, record_history=True,
+                    noise=v["sched_repaint_eps"].to(dev)).cpu()
+    assert h.shape == v["sched_repaint_hist"].shape
+    torch.testing.assert_close(h, v["sched_repaint_hist"], rtol=2e-6, atol=2e-5)
+    with pytest.raises(ValueError, match="rsteps should divide nsteps"):
+        sch.repaint(x, yh, mask, fn, 6, rsteps=4)
+    h = sch.propagate_forward((v["x"] / 80.0).to(dev), fn, 6, record_history=True).cpu()
+    assert torch.equal(h[0], torch.zeros_like(h[0]))                                    # forward mode skips slot 0
+    torch.testing.assert_close(h, v["sched_forward_heun_hist"], rtol=2e-6, atol=2e-5)
+    # module level
+    module = M.KarrasModule(net8, M.KarrasModuleConfig.from_edm())
+    x0 = v["x0"].to(dev)
+    fh = module.propagate_toward_noise(x0, nsteps=4, record_history=True).cpu()
+    assert rel_l2(fh, v["toward_noise_heun_N4"]) < REL
+    fe = module.propagate_toward_noise(x0, nsteps=4, record_history=True, stochastic_integration=True,
+                                       eps=v["toward_noise_em_eps"].to(dev)).cpu()
+    assert rel_l2(fe, v["toward_noise_em_N4"]) < REL
+    ih = module.propagate_inpaint_toward_sample(v["inpaint_noise"].to(dev), v["toward_noise_em_N4"].to(dev),
+                                                v["mask2"].to(dev), record_history=True).cpu()
+    assert rel_l2(ih, v["module_inpaint_hist"]) < REL
+    known = v["mask2"].bool().expand_as(ih[-1])
+    assert torch.equal(ih[-1][known], v["toward_noise_em_N4"][0].expand_as(ih[-1])[known])   # known region = y[0] exactly
+    out = module.interpolate_images(x0[0], x0[1], 3, jitter=None, nsteps=4).cpu()
+    assert rel_l2(out, v["interp_N4_n3"]) < REL
+    # the random-draw entry points run end to end and keep the known region
+    res = module.inpaint(x0, v["mask2"].to(dev), nsteps=4).cpu()
+    assert res.shape == x0.shape and torch.isfinite(res).all()
+    res = module.repaint(x0, v["mask2"].to(dev), nsteps=20).cpu()
+    assert res.shape == x0.shape and torch.isfinite(res).all()

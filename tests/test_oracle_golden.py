@@ -228,3 +228,33 @@ def test_porosity_conditional_cfg():
     assert_exact_or_rel(h, v["hist_cfg_g2_N4_f32"], "hist_cfg_g2_N4_f32", 2e-6)
     o = K.propagate_white_noise(net, v["white_noise"], 4, y=y, guidance=1.0, conditional=True)
     assert_exact_or_rel(o, v["out_cond_g1_N4_f32"], "out_cond_g1_N4_f32", 2e-6)
+
+
+def test_inpaint_repaint_forward_and_interpolation():
+    """SURVEY 8f-1 rows against the reference: Scheduler.inpaint / repaint / propagate_forward with an
+    analytic score, and the module-level forward propagation, inpainting and image interpolation."""
+    v, _ = load("inpaint8")
+    _, sd = load("punetg8_forward")
+    fn = K.gaussian_target_score(0.7)
+    x, yh, mask = v["x"], v["y_hist"], v["mask"]
+    assert_exact_or_ulp(K.inpaint(x, yh, mask, fn, 6, record_history=True), v["sched_inpaint_hist"], "inpaint history")
+    assert_exact_or_ulp(K.inpaint(x, yh, mask, fn, 6), v["sched_inpaint_out"], "inpaint")
+    h = K.repaint(x, yh, mask, fn, 6, 2, 2, v["sched_repaint_eps"], record_history=True)
+    assert_exact_or_ulp(h, v["sched_repaint_hist"], "repaint history")
+    assert_exact_or_ulp(K.propagate_forward(x / 80.0, fn, 6, record_history=True), v["sched_forward_heun_hist"], "forward Heun")
+    net = punetg_ref.make_net(sd, punetg_ref.default_config(model_channels=8))
+
+    def score_fn(xx, sigma):
+        return K.score(net, xx, sigma)
+    with torch.inference_mode():
+        fh = K.propagate_forward(v["x0"], score_fn, 4, record_history=True)
+        assert_exact_or_rel(fh, v["toward_noise_heun_N4"], "toward noise (Heun)", 2e-6)
+        fe = K.propagate_forward(v["x0"], score_fn, 4, integrator="euler-maruyama", record_history=True,
+                                 eps=v["toward_noise_em_eps"])
+        assert_exact_or_rel(fe, v["toward_noise_em_N4"], "toward noise (EM)", 2e-6)
+        ih = K.inpaint(v["inpaint_noise"], v["toward_noise_em_N4"], v["mask2"], score_fn, 4, record_history=True)
+        assert_exact_or_rel(ih, v["module_inpaint_hist"], "module inpaint", 2e-6)
+        xn = K.propagate_forward(v["x0"], score_fn, 4)
+        xi = K.linear_interpolation(xn[0], xn[1], 3)
+        out = K.propagate_backward(xi, score_fn, 4)
+        assert_exact_or_rel(out, v["interp_N4_n3"], "interpolate_images", 2e-6)
