@@ -200,6 +200,24 @@ __global__ __launch_bounds__(kThreads) void k_mask_blend(float* out, const float
   }
 }
 
+// out = a*x + b*y (y optional) and out = x / s: the non-constant-scaling branch of Scheduler.rhs
+// (schedulers.py:275-293): score_fn(x/s, sigma);  (s'/s)*x - multiplier*score
+__global__ __launch_bounds__(kThreads) void k_axpby(float* out, const float* __restrict__ x, float a,
+                                                    const float* __restrict__ y, float b, size_t n) {
+  size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x;
+  size_t stride = (size_t)gridDim.x * kThreads;
+  for (; i < n; i += stride) {
+    float v = a * x[i];
+    if (y) { const float w = b * y[i]; v = v + w; }
+    out[i] = v;
+  }
+}
+__global__ __launch_bounds__(kThreads) void k_div_scalar(float* out, const float* __restrict__ x, float s, size_t n) {
+  size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x;
+  size_t stride = (size_t)gridDim.x * kThreads;
+  for (; i < n; i += stride) out[i] = x[i] / s;
+}
+
 // out[i] = x1 + ((x2 - x1) * i) / (n - 1), i = 0..n-1  (torchutils.py:64-65, same operation order)
 __global__ __launch_bounds__(kThreads) void k_lerp_stack(float* out, const float* __restrict__ x1,
                                                          const float* __restrict__ x2, int n, size_t numel) {
@@ -356,6 +374,22 @@ int ds_mask_blend(float* out, const float* x, const float* y, const float* mask,
   hipLaunchKernelGGL(k_mask_blend, dim3(grid_for((total + 3) / 4)), dim3(kThreads), 0, ds::as_stream(stream), out, x, y,
                      mask, n_per_sample, total);
   DS_CHECK_LAUNCH("ds_mask_blend");
+  return DS_OK;
+}
+
+int ds_axpby(float* out, const float* x, float a, const float* y, float b, size_t n, void* stream) {
+  DS_REQUIRE(out && x, DS_ERR_NULL, "ds_axpby: NULL pointer");
+  if (n == 0) return DS_OK;
+  hipLaunchKernelGGL(k_axpby, dim3(grid_for((n + 3) / 4)), dim3(kThreads), 0, ds::as_stream(stream), out, x, a, y, b, n);
+  DS_CHECK_LAUNCH("ds_axpby");
+  return DS_OK;
+}
+
+int ds_div_scalar(float* out, const float* x, float s, size_t n, void* stream) {
+  DS_REQUIRE(out && x, DS_ERR_NULL, "ds_div_scalar: NULL pointer");
+  if (n == 0) return DS_OK;
+  hipLaunchKernelGGL(k_div_scalar, dim3(grid_for((n + 3) / 4)), dim3(kThreads), 0, ds::as_stream(stream), out, x, s, n);
+  DS_CHECK_LAUNCH("ds_div_scalar");
   return DS_OK;
 }
 

@@ -74,12 +74,24 @@ class KarrasModuleConfig(object):
                    dynamic_loss_weight=dynamic_loss_weight, extra_args=extra_args, **kwargs)
 
     @classmethod
-    def from_vp(cls, *a, **k):
-        raise NotImplementedError("VP parameterisation is the next scope row (SURVEY 8f-2)")
+    def from_vp(cls, beta_data: float = 19.9, beta_min: float = 0.1, epsilon_min: float = 1e-3,
+                epsilon_sampler: float = 1e-5, M: int = 1000, loss_metric="huber", **kwargs):
+        """karrasmodule.py:177-237."""
+        noisescheduler = schedulers.VPScheduler(epsilon_min=epsilon_min, beta_data=beta_data, beta_min=beta_min)
+        extra_args = dict(beta_data=beta_data, beta_min=beta_min, epsilon_min=epsilon_min,
+                          epsilon_sampler=epsilon_sampler, M=M, loss_metric=loss_metric, **kwargs)
+        return cls(preconditioner=preconditioners.VPPreconditioner(scheduler=noisescheduler, M=M),
+                   noisesampler=noisesamplers.VPNoiseSampler(noise_scheduler=noisescheduler, epsilon=epsilon_sampler),
+                   noisescheduler=noisescheduler, loss_metric=loss_metric, tag="vp", extra_args=extra_args, **kwargs)
 
     @classmethod
-    def from_ve(cls, *a, **k):
-        raise NotImplementedError("VE parameterisation is the next scope row (SURVEY 8f-2)")
+    def from_ve(cls, sigma_min: float = 0.02, sigma_max: float = 100, loss_metric="huber", **kwargs):
+        """karrasmodule.py:239-290."""
+        extra_args = dict(sigma_min=sigma_min, sigma_max=sigma_max, loss_metric=loss_metric, **kwargs)
+        return cls(preconditioner=preconditioners.VEPreconditioner(),
+                   noisesampler=noisesamplers.VENoiseSampler(sigma_min=sigma_min, sigma_max=sigma_max),
+                   noisescheduler=schedulers.VEScheduler(sigma_min=sigma_min, sigma_max=sigma_max),
+                   loss_metric=loss_metric, tag="ve", extra_args=extra_args, **kwargs)
 
     def export_description(self) -> dict[str, Any]:
         return dict(tag=self.tag, extra_args=self.extra_args)
@@ -239,7 +251,7 @@ class KarrasModule(torch.nn.Module):
             sch.set_temporary_integrator(integrator)
         try:
             integ = sch.integrator
-            if not schedulers._is_builtin(integ):
+            if not schedulers._is_builtin(integ) or not sch.scheduler_fns.constant_scaling_fn:
                 def rhs(xx, sigma):
                     return self.get_score(xx, sigma, y, guidance)
                 xs = x if scale is None else ops.scale(x.contiguous(), scale)

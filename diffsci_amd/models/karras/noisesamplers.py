@@ -24,3 +24,37 @@ class EDMNoiseSampler(NoiseSampler):
 
     def loss_weighting(self, sigma):
         return (sigma ** 2 + self.sigma_data ** 2) / ((sigma * self.sigma_data) ** 2)
+
+
+class VPNoiseSampler(NoiseSampler):
+    """noisesamplers.py:44-63."""
+
+    def __init__(self, noise_scheduler, epsilon: float = 1e-3):
+        super().__init__()
+        self.noise_scheduler = noise_scheduler
+        self.register_buffer("epsilon", torch.tensor(epsilon))
+
+    def loss_weighting(self, sigma):
+        return 1 / (sigma ** 2)
+
+    def sample(self, shape):
+        t = torch.rand(shape).to(self.epsilon)
+        t = t * (1 - self.epsilon) + self.epsilon
+        return self.noise_scheduler.scheduler_fns.noise_fn(t)
+
+
+class VENoiseSampler(NoiseSampler):
+    """noisesamplers.py:66-87."""
+
+    def __init__(self, sigma_min: float = 0.02, sigma_max: float = 100):
+        super().__init__()
+        self.register_buffer("sigma_min", torch.tensor(sigma_min))
+        self.register_buffer("sigma_max", torch.tensor(sigma_max))
+
+    def loss_weighting(self, sigma):
+        return 1 / (sigma ** 2)
+
+    def sample(self, shape):
+        unif = torch.rand(shape).to(self.sigma_min.device)
+        logsigma_min, logsigma_max = torch.log(self.sigma_min), torch.log(self.sigma_max)
+        return torch.exp(logsigma_min + unif * (logsigma_max - logsigma_min))

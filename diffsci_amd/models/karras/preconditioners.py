@@ -40,6 +40,44 @@ class EDMPreconditioner(KarrasPreconditioner):
         return 0.5 * torch.log(sigma)
 
 
+class VPPreconditioner(KarrasPreconditioner):
+    """preconditioners.py:56-83."""
+
+    def __init__(self, scheduler, M: int = 1000):
+        super().__init__()
+        self.scheduler = scheduler
+        self.M = M
+
+    def skip_scaling(self, sigma):
+        return 1 + 0.0 * sigma
+
+    def output_scaling(self, sigma):
+        return -sigma
+
+    def input_scaling(self, sigma):
+        return 1 / torch.sqrt(sigma ** 2 + 1.0)
+
+    def noise_conditioner(self, sigma):
+        finv = self.scheduler.scheduler_fns.inverse_noise_fn
+        return (self.M - 1) * finv(sigma)
+
+
+class VEPreconditioner(KarrasPreconditioner):
+    """preconditioners.py:86-105."""
+
+    def skip_scaling(self, sigma):
+        return 1 + 0.0 * sigma
+
+    def output_scaling(self, sigma):
+        return sigma
+
+    def input_scaling(self, sigma):
+        return 1 + 0.0 * sigma
+
+    def noise_conditioner(self, sigma):
+        return torch.log(0.5 * sigma)
+
+
 class NullPreconditioner(KarrasPreconditioner):
     """preconditioners.py:139-161: D = F(x, sigma)."""
 

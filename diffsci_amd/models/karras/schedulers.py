@@ -45,7 +45,7 @@ class Scheduler(torch.nn.Module):
         """schedulers.py:48-89.  ``eps`` (extension): [nsteps, *x.shape] injected noise for the
         stochastic integrators instead of device-generator draws."""
         integrator = self.integrator if not stochastic else self.stochastic_integrator
-        if _is_builtin(integrator):
+        if _is_builtin(integrator) and self.scheduler_fns.constant_scaling_fn:
             table = build_step_table(self, integrator, nsteps, backward=backward)
             src = ScoreFnSource(score_fn, x.shape[0], x)
             out = run_table(table, src, x, record_history=record_history, eps=eps)
@@ -65,7 +65,7 @@ class Scheduler(torch.nn.Module):
         integrator = self.integrator if not stochastic else self.stochastic_integrator
         if not backward:
             raise NotImplementedError
-        if _is_builtin(integrator):
+        if _is_builtin(integrator) and self.scheduler_fns.constant_scaling_fn:
             table = build_step_table(self, integrator, nsteps, backward=True,
                                      initial_step=initial_step, final_step=final_step)
             src = ScoreFnSource(score_fn, x.shape[0], x)
@@ -183,10 +183,27 @@ class Scheduler(torch.nn.Module):
         one HIP pass.  ti: python float or 0-dim tensor (host)."""
         ops.require_device(x, "x")
         tt = torch.as_tensor(ti, dtype=torch.float32).cpu().reshape(())
-        row = make_eval_row(tt, self, stochastic=stochastic, backward=backward)
-        sigma = torch.full((x.shape[0],), row.sigma, dtype=torch.float32, device=x.device)
-        s = score_fn(x, sigma)
-        return ops.drift(None, s.contiguous(), row.coef(DS_IN_SCORE))
+        fns = self.scheduler_fns
+        if fns.constant_scaling_fn:
+            row = make_eval_row(tt, self, stochastic=stochastic, backward=backward)
+            sigma = torch.full((x.shape[0],), row.sigma, dtype=torch.float32, device=x.device)
+            s = score_fn(x, sigma)
+            return ops.drift(None, s.contiguous(), row.coef(DS_IN_SCORE))
+        # non-constant scaling (VP), schedulers.py:275-293: scalars on the host in the reference's order
+        sig = fns.noise_fn(tt)
+        s = fns.scaling_fn(tt)
+        scale_multiplier = fns.scaling_fn_deriv(tt) / s
+        if fns.has_pf_score_multiplier:
+            multiplier = fns.pf_score_multiplier(tt)
+        else:
+            multiplier = s * (fns.noise_fn_deriv(tt) * fns.noise_fn(tt))
+        sigma = torch.full((x.shape[0],), float(sig), dtype=torch.float32, device=x.device)
+        score = score_fn(ops.div_scalar(x.contiguous(), float(s)), sigma).contiguous()
+        res = ops.axpby(x.contiguous(), float(scale_multiplier), score, -float(multiplier))
+        if stochastic:
+            k = self.langevin_factor(tt) * 1 / s                      # -(lambda * 1/s * score), sign flipped forward
+            res = ops.axpby(res, 1.0, score, -float(k) if backward else float(k), out=res)
+        return res
 
     # -------------------------------------------------------------- noise application
     def create_steps(self, n: int):
@@ -200,9 +217,9 @@ class Scheduler(torch.nn.Module):
         t_step = t[step]
         sigma = self.scheduler_fns.noise_fn(t_step)
         scale = self.scheduler_fns.scaling_fn(t_step)
-        if float(scale) != 1.0:
-            raise NotImplementedError("apply_noise with a non-constant scaling function")
         noise = torch.randn(x.shape).to(x)
+        if float(scale) != 1.0:
+            return ops.axpby(x.contiguous(), float(scale), noise, float(scale * sigma))
         return ops.churn(x.contiguous(), noise, float(scale * sigma), xhat_out=torch.empty_like(x))
 
     def renoise(self, x, t: float, t_noise: float, noise=None):
@@ -213,10 +230,10 @@ class Scheduler(torch.nn.Module):
         sigma_noise = self.scheduler_fns.noise_fn(t_noise)
         scale = self.scheduler_fns.scaling_fn(t)
         scale_noise = self.scheduler_fns.scaling_fn(t_noise)
-        if float(scale_noise / scale) != 1.0:
-            raise NotImplementedError("renoise with a non-constant scaling function")
         std = scale_noise * torch.sqrt(sigma_noise ** 2 - sigma ** 2)
         noise = torch.randn_like(x) if noise is None else noise.to(x).contiguous()
+        if float(scale_noise / scale) != 1.0:
+            return ops.axpby(x.contiguous(), float(scale_noise / scale), noise, float(std))
         return ops.churn(x.contiguous(), noise, float(std), xhat_out=torch.empty_like(x))
 
     # -------------------------------------------------------------- integrator selection
@@ -271,4 +288,49 @@ class EDMScheduler(Scheduler):
         exp = 1 / rho
         t = torch.as_tensor(t).detach().to("cpu")
         step = (n - 1) * (t ** exp - smax ** exp) / (smin ** exp - smax ** exp)
+        return torch.round(step).int()
+
+
+class VPScheduler(Scheduler):
+    """schedulers.py:393-418: t runs linearly from 1 to epsilon_min (no trailing zero)."""
+
+    def __init__(self, epsilon_min: float = 0.001, scheduler_fns="VP", *args, **kwargs):
+        if type(scheduler_fns) is str:
+            scheduler_fns = schedulingfunctions.name_to_scheduling_functions(scheduler_fns, *args, **kwargs)
+        sigma_max = (scheduler_fns.noise_fn(torch.ones([1])) * scheduler_fns.scaling_fn(torch.ones([1]))).item()
+        super().__init__(scheduler_fns, integrators.HeunIntegrator(), sigma_max)
+        self.register_buffer("epsilon_min", torch.tensor(epsilon_min))
+
+    def create_steps(self, n: int):
+        eps = self.epsilon_min.detach().to("cpu", torch.float32)
+        s = torch.arange(n).to(eps) / (n - 1)
+        return 1 + s * (eps - 1)
+
+    def step_from_time(self, t, n: int):
+        eps = self.epsilon_min.detach().to("cpu", torch.float32)
+        step = (n - 1) * (torch.as_tensor(t).detach().cpu() - 1) / (eps - 1)
+        return torch.round(step).int()
+
+
+class VEScheduler(Scheduler):
+    """schedulers.py:421-448: t = sigma^2, geometric from sigma_max^2 to sigma_min^2."""
+
+    def __init__(self, sigma_min: float = 0.02, sigma_max: float = 100, scheduler_fns="VE", *args, **kwargs):
+        if type(scheduler_fns) is str:
+            scheduler_fns = schedulingfunctions.name_to_scheduling_functions(scheduler_fns, *args, **kwargs)
+        super().__init__(scheduler_fns, integrators.HeunIntegrator(), sigma_max)
+        self.register_buffer("sigma_min", torch.tensor(sigma_min))
+        self.register_buffer("sigma_max", torch.tensor(sigma_max))
+
+    def create_steps(self, n: int):
+        smin = self.sigma_min.detach().to("cpu", torch.float32)
+        smax = self.sigma_max.detach().to("cpu", torch.float32)
+        s = torch.arange(n).to(smin) / (n - 1)
+        return smax ** 2 * (smin ** 2 / smax ** 2) ** s
+
+    def step_from_time(self, t, n: int):
+        smin = self.sigma_min.detach().to("cpu", torch.float32)
+        smax = self.sigma_max.detach().to("cpu", torch.float32)
+        t = torch.as_tensor(t).detach().cpu()
+        step = (n - 1) * (torch.log(t) - torch.log(smax ** 2)) / (torch.log(smin ** 2) - torch.log(smax ** 2))
         return torch.round(step).int()

@@ -69,6 +69,21 @@ def mask_blend(x, y, mask, out=None):
     return out
 
 
+def axpby(x, a, y=None, b=0.0, out=None):
+    """a*x + b*y (y optional)."""
+    out = torch.empty_like(x) if out is None else out
+    _same_numel(x, y, out)
+    N.check(N.lib().ds_axpby(_p(out), _p(x), float(a), _p(y), float(b), x.numel(), _stream()), "ds_axpby")
+    return out
+
+
+def div_scalar(x, s, out=None):
+    """x / s."""
+    out = torch.empty_like(x) if out is None else out
+    N.check(N.lib().ds_div_scalar(_p(out), _p(x), float(s), x.numel(), _stream()), "ds_div_scalar")
+    return out
+
+
 def lerp_stack(x1, x2, n):
     """stack([x1 + (x2 - x1)*i/(n-1) for i in range(n)])."""
     out = torch.empty((n,) + tuple(x1.shape), dtype=torch.float32, device=x1.device)

@@ -261,6 +261,13 @@ int ds_add_act(float* out, const float* a, const float* add, int add_rows, int M
 int ds_mask_blend(float* out, const float* x, const float* y, const float* mask, size_t n_per_sample, int B,
                   void* stream);
 
+/* Non-constant-scaling (VP) branch of Scheduler.rhs, schedulers.py:275-293:
+ *   ds_div_scalar: out = x / s                 (the score is evaluated at x/s)
+ *   ds_axpby:      out = a*x + b*y (y may be NULL: out = a*x);  (s'/s)*x - multiplier*score is
+ *                  a = s'/s, b = -multiplier (the negation is exact). out may alias x or y. */
+int ds_axpby(float* out, const float* x, float a, const float* y, float b, size_t n, void* stream);
+int ds_div_scalar(float* out, const float* x, float s, size_t n, void* stream);
+
 /* out[i] = x1 + ((x2 - x1)*i)/(n - 1), i = 0..n-1, each of numel floats: linear_interpolation
  * (torchutils.py:64-65) used by KarrasModule.interpolate_images (karrasmodule.py:1136-1138). */
 int ds_lerp_stack(float* out, const float* x1, const float* x2, int n, size_t numel, void* stream);

@@ -255,6 +255,61 @@ def inpaint():
     npz("inpaint8", **arrs)
 
 
+def vpve():
+    """VP / VE parameterisations (schedulers, preconditioners, the non-constant-scaling rhs)."""
+    import diffsci.data
+    torch.manual_seed(40)
+    gs = diffsci.data.ZeroMeanGaussianDataset(num_samples=8, shape=[2], scale=0.7)
+    z = np.load(os.path.join(OUT, "punetg8_forward.npz"))
+    sd = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd/")}
+    x = torch.randn(8, 2)
+    wn = torch.randn(2, 1, 32, 32)
+    arrs = dict(x=x, white_noise=wn)
+    # VP with M = 2: c_noise = (M-1)*t stays O(1); the default M = 1000 feeds the random-init Fourier
+    # features arguments of ~1e5 rad, where one ulp of c_noise changes the trajectory (ill-conditioned
+    # for the reference's own fp32 as well)
+    for tag, mk in (("vp", lambda: M.KarrasModuleConfig.from_vp(M=2)), ("ve", M.KarrasModuleConfig.from_ve)):
+        cfg = mk()
+        sch = cfg.noisescheduler
+        for n in (4, 6, 18):
+            arrs[f"{tag}_steps_{n}"] = sch.create_steps(n + 1)
+        arrs[f"{tag}_maximum_scale"] = np.array(sch.maximum_scale, dtype=np.float64)
+        sig = torch.tensor([0.05, 0.7, 3.0, 40.0])
+        pc = cfg.preconditioner
+        arrs[f"{tag}_precond"] = torch.stack([pc.skip_scaling(sig), pc.output_scaling(sig), pc.input_scaling(sig),
+                                              pc.noise_conditioner(sig)])
+        for integ in ("heun", "euler"):
+            sch.set_temporary_integrator(integ)
+            arrs[f"{tag}_toy_{integ}_N18"] = sch.propagate_backward(x * sch.maximum_scale, gs.gradlogprob, 18,
+                                                                    record_history=True)
+            sch.unset_temporary_integrator()
+        with RandnRecorder() as rec:
+            arrs[f"{tag}_toy_em_N6"] = sch.propagate_backward(x * sch.maximum_scale, gs.gradlogprob, 6,
+                                                              record_history=True, stochastic=True)
+        arrs[f"{tag}_toy_em_eps"] = torch.stack(rec.draws)
+        arrs[f"{tag}_toy_forward_N6"] = sch.propagate_forward(x * 0.3, gs.gradlogprob, 6, record_history=True)
+        net = M.nets.PUNetG(M.nets.PUNetGConfig(model_channels=8)).eval()
+        net.load_state_dict(sd)
+        module = M.KarrasModule(net, cfg).eval()
+        arrs[f"{tag}_punetg_heun_N6"] = module.propagate_white_noise(wn, nsteps=6, record_history=True)
+        net64 = M.nets.PUNetG(M.nets.PUNetGConfig(model_channels=8)).double().eval()
+        net64.load_state_dict({k: w.double() for k, w in sd.items()})
+        arrs[f"{tag}_punetg_heun_N6_f64"] = M.KarrasModule(net64, mk()).eval().double().propagate_white_noise(
+            wn.double(), nsteps=6, record_history=True)
+        arrs[f"{tag}_punetg_euler_N6"] = module.propagate_white_noise(wn, nsteps=6, integrator="euler")
+        if tag == "ve":
+            with RandnRecorder() as rec:
+                arrs["ve_punetg_karras_N4"] = module.propagate_white_noise(wn, nsteps=4, record_history=True,
+                                                                           integrator="karras")
+            arrs["ve_punetg_karras_eps"] = torch.stack(rec.draws)
+        xs = torch.randn(2, 1, 32, 32) * 2.0
+        sg = torch.tensor([0.3, 5.0])
+        with torch.inference_mode():
+            arrs[f"{tag}_xs"] = xs
+            arrs[f"{tag}_score"] = module.get_score(xs, sg)
+    npz("vpve8", **arrs)
+
+
 def porosity():
     """BASELINE config 5's shape of the path: 4-channel conditional PUNetG with the in-repo dict-style
     PorosityEmbedder (nets/embedder.py:198-229), classifier-free guidance, un-batched dict y."""
@@ -325,6 +380,6 @@ def adm():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["schedule", "toy", "punetg", "porosity", "inpaint", "adm"]
+    which = sys.argv[1:] or ["schedule", "toy", "punetg", "porosity", "inpaint", "vpve", "adm"]
     for name in which:
         globals()[name]()

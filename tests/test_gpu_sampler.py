@@ -380,3 +380,72 @@ def test_inpaint_repaint_forward_and_interpolation(M, net8, dev):
     assert res.shape == x0.shape and torch.isfinite(res).all()
     res = module.repaint(x0, v["mask2"].to(dev), nsteps=20).cpu()
     assert res.shape == x0.shape and torch.isfinite(res).all()
+
+
+@pytest.mark.parametrize("tag", ["vp", "ve"])
+def test_vp_ve_parameterisations(M, net8, dev, tag):
+    """VP (non-constant scaling: the general rhs branch, one HIP launch per operation
+    group) and VE (constant scaling: fused stepper / hipGraph) against goldens from the reference."""
+    v, _ = load("vpve8")
+    cfg = M.KarrasModuleConfig.from_vp(M=2) if tag == "vp" else M.KarrasModuleConfig.from_ve()   # see make_golden.vpve on M
+    sch = cfg.noisescheduler
+    same_isa = load("schedule")[0]["cpu_capability"] == torch.backends.cpu.get_cpu_capability()
+    for n in (4, 6, 18):
+        got = sch.create_steps(n + 1)
+        if same_isa:
+            assert torch.equal(got, v[f"{tag}_steps_{n}"])
+        else:
+            torch.testing.assert_close(got, v[f"{tag}_steps_{n}"], rtol=3e-7, atol=0)
+    assert abs(sch.maximum_scale - float(v[f"{tag}_maximum_scale"])) <= 1e-7 * abs(sch.maximum_scale)
+    sig = torch.tensor([0.05, 0.7, 3.0, 40.0])
+    pc = cfg.preconditioner
+    torch.testing.assert_close(torch.stack([pc.skip_scaling(sig), pc.output_scaling(sig), pc.input_scaling(sig),
+                                            pc.noise_conditioner(sig)]), v[f"{tag}_precond"], rtol=3e-7, atol=0)
+    # pin the fixture's grid so host-ISA differences in exp/pow cannot leak in
+    orig = sch.create_steps
+    sch.create_steps = lambda n: v[f"{tag}_steps_{n - 1}"].clone() if f"{tag}_steps_{n - 1}" in v else orig(n)
+    fn = K.gaussian_target_score(0.7)
+    x = v["x"].to(dev)
+    scale = sch.maximum_scale
+    for integ in ("heun", "euler"):
+        sch.set_temporary_integrator(integ)
+        h = sch.propagate_backward(x * scale, fn, 18, record_history=True).cpu()
+        sch.unset_temporary_integrator()
+        torch.testing.assert_close(h, v[f"{tag}_toy_{integ}_N18"], rtol=1e-5, atol=1e-5 * scale)
+    h = sch.propagate_backward(x * scale, fn, 6, record_history=True, stochastic=True,
+                               eps=v[f"{tag}_toy_em_eps"].to(dev) if tag == "ve" else None)
+    if tag == "ve":                                        # VP's generic path draws its own noise
+        torch.testing.assert_close(h.cpu(), v["ve_toy_em_N6"], rtol=1e-5, atol=1e-5 * scale)
+    h = sch.propagate_forward(x * 0.3, fn, 6, record_history=True).cpu()
+    torch.testing.assert_close(h, v[f"{tag}_toy_forward_N6"], rtol=1e-5, atol=1e-5 * scale)
+    net = net8
+    if tag == "ve":
+        # VE feeds the network un-normalised inputs (c_in = 1) and this random-init network drives the
+        # trajectory to 1e6..1e8: outside the fp16x3 kernels' documented domain (|activation| < 65504,
+        # beyond which they return inf/nan, never a wrong finite value) -- use the range-free bf16x6 mode
+        _, sd = load("punetg8_forward")
+        net = M.PUNetG(M.PUNetGConfig(model_channels=8))
+        net.load_state_dict(sd)
+        net.conv_precision = "bf16x6"
+        net = net.to(dev)
+    module = M.KarrasModule(net, cfg)
+    s = module.get_score(v[f"{tag}_xs"].to(dev), torch.tensor([0.3, 5.0], device=dev)).cpu()
+    assert rel_l2(s, v[f"{tag}_score"]) < REL
+    wn = v["white_noise"].to(dev)
+    # A random-init network makes the VP trajectory grow to ~2.6e3 and the reference's own fp32 run
+    # differs from its fp64 run by 5e-5 there; the bound is the usual one: 4x the reference's own error.
+    ref_err = rel_l2(v[f"{tag}_punetg_heun_N6"], v[f"{tag}_punetg_heun_N6_f64"])
+    tol = max(REL, 4 * ref_err)
+    h = module.propagate_white_noise(wn, nsteps=6, record_history=True).cpu()
+    assert rel_l2(h[:2], v[f"{tag}_punetg_heun_N6"][:2]) < REL                     # the first step is well conditioned
+    assert rel_l2(h, v[f"{tag}_punetg_heun_N6"]) < tol
+    assert rel_l2(h, v[f"{tag}_punetg_heun_N6_f64"]) < tol
+    o = module.propagate_white_noise(wn, nsteps=6, integrator="euler").cpu()
+    assert rel_l2(o, v[f"{tag}_punetg_euler_N6"]) < tol
+    if tag == "ve":
+        h = module.propagate_white_noise(wn, nsteps=4, record_history=True, integrator="karras",
+                                         eps=v["ve_punetg_karras_eps"].to(dev)).cpu()
+        assert rel_l2(h, v["ve_punetg_karras_N4"]) < tol
+        # and the default fp16x3 mode reports the overflow instead of returning finite garbage
+        bad = M.KarrasModule(net8, cfg).propagate_white_noise(wn, nsteps=6).cpu()
+        assert not torch.isfinite(bad).all()

@@ -258,3 +258,42 @@ def test_inpaint_repaint_forward_and_interpolation():
         xi = K.linear_interpolation(xn[0], xn[1], 3)
         out = K.propagate_backward(xi, score_fn, 4)
         assert_exact_or_rel(out, v["interp_N4_n3"], "interpolate_images", 2e-6)
+
+
+@pytest.mark.parametrize("tag", ["vp", "ve"])
+def test_vp_ve_parameterisations(tag):
+    """VP / VE time grids, preconditioners, both branches of Scheduler.rhs, all integrators."""
+    from oracle import vpve_ref as V
+    v, _ = load("vpve8")
+    _, sd = load("punetg8_forward")
+    fns = V.VP() if tag == "vp" else V.VE()
+    steps = V.vp_steps if tag == "vp" else V.ve_steps
+    precond = V.vp_precond(fns, M=2) if tag == "vp" else V.ve_precond
+    for n in (4, 6, 18):
+        assert_exact_or_ulp(steps(n + 1), v[f"{tag}_steps_{n}"], f"{tag} grid {n}")
+    scale = float(v[f"{tag}_maximum_scale"])
+    sig = torch.tensor([0.05, 0.7, 3.0, 40.0])
+    assert_exact_or_ulp(torch.stack(precond(sig)), v[f"{tag}_precond"], "preconditioner")
+    fn = K.gaussian_target_score(0.7)
+    x = v["x"]
+    for integ in ("heun", "euler"):
+        h = V.propagate(fns, steps(19), x * scale, fn, integ, record_history=True)
+        assert_exact_or_ulp(h, v[f"{tag}_toy_{integ}_N18"], f"{tag} toy {integ}")
+    h = V.propagate(fns, steps(7), x * scale, fn, "euler-maruyama", record_history=True, eps=v[f"{tag}_toy_em_eps"])
+    assert_exact_or_ulp(h, v[f"{tag}_toy_em_N6"], f"{tag} toy EM")
+    h = V.propagate(fns, steps(7), x * 0.3, fn, "heun", backward=False, record_history=True)
+    assert_exact_or_ulp(h, v[f"{tag}_toy_forward_N6"], f"{tag} toy forward")
+    net = punetg_ref.make_net(sd, punetg_ref.default_config(model_channels=8))
+
+    def score_fn(xx, sigma):
+        return K.score(net, xx, sigma, precond=precond)
+    with torch.inference_mode():
+        assert_exact_or_rel(score_fn(v[f"{tag}_xs"], torch.tensor([0.3, 5.0])), v[f"{tag}_score"], "get_score", 2e-6)
+        h = V.propagate(fns, steps(7), v["white_noise"] * scale, score_fn, "heun", record_history=True)
+        assert_exact_or_rel(h, v[f"{tag}_punetg_heun_N6"], f"{tag} PUNetG Heun", 2e-6)
+        o = V.propagate(fns, steps(7), v["white_noise"] * scale, score_fn, "euler")
+        assert_exact_or_rel(o, v[f"{tag}_punetg_euler_N6"], f"{tag} PUNetG Euler", 2e-6)
+        if tag == "ve":
+            h = V.propagate(fns, steps(5), v["white_noise"] * scale, score_fn, "karras", record_history=True,
+                            eps=v["ve_punetg_karras_eps"])
+            assert_exact_or_rel(h, v["ve_punetg_karras_N4"], "VE PUNetG sigma-churn", 2e-6)
