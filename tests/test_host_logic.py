@@ -139,8 +139,11 @@ def test_config_factory_and_module_surface():
         assert callable(getattr(module, name))
     with pytest.raises(RuntimeError, match="no CPU path"):
         module.propagate_white_noise(torch.randn(1, 1, 32, 32), nsteps=2)
-    with pytest.raises(NotImplementedError):
-        M.KarrasModuleConfig.from_vp()
+    vp, ve = M.KarrasModuleConfig.from_vp(), M.KarrasModuleConfig.from_ve()
+    assert isinstance(vp.noisescheduler, M.VPScheduler) and isinstance(vp.preconditioner, M.VPPreconditioner) and vp.tag == "vp"
+    assert isinstance(ve.noisescheduler, M.VEScheduler) and isinstance(ve.preconditioner, M.VEPreconditioner) and ve.tag == "ve"
+    assert not vp.noisescheduler.scheduler_fns.constant_scaling_fn and ve.noisescheduler.scheduler_fns.constant_scaling_fn
+    assert ve.noisescheduler.create_steps(5)[0] == 100.0 ** 2 and vp.noisescheduler.create_steps(5)[0] == 1.0
 
 
 def test_punetg_state_dict_keys_match_reference():
