@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(_HERE, "_lib", "libdiffsci_hip.so")
 
 DS_IN_NETWORK, DS_IN_SCORE, DS_IN_DRIFT = 0, 1, 2
 DS_LOAD_PLAIN, DS_LOAD_MAXPOOL2, DS_LOAD_UPSAMPLE2, DS_LOAD_AVGPOOL2 = 0, 1, 2, 3
+DS_PAD_CIRCULAR = 16
 
 
 class EvalCoef(Structure):

@@ -72,6 +72,7 @@ struct Conv3hArgs {
   float* tile_stats;      // see ds_conv_epilogue.h, or NULL
   float unscale;        // 2^-wshift
   int shift_stride;
+  int circular;           // periodic padding in both dimensions (CircularConv2d, commonlayers.py:918-971)
   int B, Cin, Cout, H, W, Hin, Win;
   int tiles_x, tiles_y, n_cot, n_chunks;
 #ifdef DS_STAMP
@@ -144,7 +145,13 @@ __global__ __launch_bounds__(NT, 2) void k_conv3h(const Conv3hArgs a) {
     const bool live = pos < NPOS;                      // the item exists
     const int r = pos / PW;
     const int col = pos - r * PW;
-    const int gy = y0 + r - 1, gx = x0 + col - 1;
+    int gy = y0 + r - 1, gx = x0 + col - 1;
+    if (a.circular) {                                  // wrap instead of zero padding (also keeps ragged tiles in bounds)
+      gy = gy < 0 ? gy + a.H : gy;
+      gx = gx < 0 ? gx + a.W : gx;
+      gy = gy % a.H;
+      gx = gx % a.W;
+    }
     const bool ok = live && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
     int off;
     if (MODE == DS_LOAD_PLAIN) off = gy * a.Win + gx;
@@ -428,6 +435,8 @@ int ds_conv2d_h3(float* out, const float* in, const void* w_packed, int wshift, 
   DS_REQUIRE(out && in && w_packed, DS_ERR_NULL, "ds_conv2d_h3: NULL pointer");
   DS_REQUIRE(B >= 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, DS_ERR_SHAPE,
              "ds_conv2d_h3: bad shape B=%d Cin=%d Cout=%d H=%d W=%d", B, Cin, Cout, H, W);
+  const int circular = (load_mode & DS_PAD_CIRCULAR) ? 1 : 0;
+  load_mode &= ~DS_PAD_CIRCULAR;
   DS_REQUIRE(load_mode >= 0 && load_mode <= 2, DS_ERR_UNSUPPORTED, "ds_conv2d_h3: load_mode %d", load_mode);
   DS_REQUIRE(load_mode != DS_LOAD_UPSAMPLE2 || (H % 2 == 0 && W % 2 == 0), DS_ERR_SHAPE,
              "ds_conv2d_h3: UPSAMPLE2 needs even output H, W (got %d x %d)", H, W);
@@ -442,7 +451,7 @@ int ds_conv2d_h3(float* out, const float* in, const void* w_packed, int wshift, 
   DS_REQUIRE((reinterpret_cast<uintptr_t>(prenorm) & 15u) == 0, DS_ERR_SHAPE, "ds_conv2d_h3: prenorm must be 16-byte aligned");
   if (B == 0) return DS_OK;
   Conv3hArgs a;
-  a.prenorm = prenorm; a.tile_stats = tile_stats;
+  a.prenorm = prenorm; a.tile_stats = tile_stats; a.circular = circular;
   a.out = out; a.in = in; a.wp = reinterpret_cast<const u32x4*>(w_packed); a.bias = bias; a.shift = shift;
   a.res1 = res1; a.res2 = res2; a.shift_stride = shift_stride;
   a.unscale = ldexpf(1.0f, -wshift);

@@ -22,7 +22,7 @@ import yaml
 
 from ... import ops
 from ..._native import DS_LOAD_AVGPOOL2, DS_LOAD_PLAIN, DS_LOAD_UPSAMPLE2
-from .punetg import _AffineHolder, _Attn, _Fourier, _Workspace
+from .punetg import _AffineHolder, _Attn, _CircConv, _Fourier, _Workspace, make_conv
 
 _FIELDS = dict(
     input_channels=1, output_channels=1, dimension=2, model_channels=64, time_embed_dim=64,
@@ -82,7 +82,7 @@ class ADMConfig(object):
     def unsupported_reason(self):
         checks = [
             (self.dimension == 2, "only 2-D fields (dimension=2)"),
-            (self.convolution_type == "default", "only convolution_type='default'"),
+            (self.convolution_type in ("default", "circular"), "convolution_type 'default' or 'circular'"),
             (self.first_resblock_norm == "GroupLN" and self.second_resblock_norm == "GroupRMS",
              "only first_resblock_norm='GroupLN' with second_resblock_norm='GroupRMS'"),
             (self.num_groups == 1, "num_groups=1"),
@@ -102,15 +102,15 @@ class ADMConfig(object):
 class _Block(torch.nn.Module):
     """ADMBaseBlock parameters (adm.py:262-287); sample in {None, 'down', 'up'}."""
 
-    def __init__(self, cin, cout, cembed, sample=None, has_attn=False):
+    def __init__(self, cin, cout, cembed, sample=None, has_attn=False, circular=False):
         super().__init__()
         self.cin, self.cout, self.sample = cin, cout, sample
         self.norm1 = torch.nn.GroupNorm(1, cin)
         self.norm2 = _AffineHolder(cout)
-        self.conv1 = torch.nn.Conv2d(cin, cout, 3, padding="same")
-        self.conv2 = torch.nn.Conv2d(cout, cout, 3, padding="same")
+        self.conv1 = make_conv(cin, cout, 3, circular)          # conv_fn, adm.py:427-443
+        self.conv2 = make_conv(cout, cout, 3, circular)
         self.embed_linear = torch.nn.Linear(cembed, 2 * cout)
-        self.convresidual = torch.nn.Conv2d(cin, cout, 1)
+        self.convresidual = make_conv(cin, cout, 1, circular)
         if has_attn:
             self.attn = _Attn(cout)
 
@@ -154,21 +154,24 @@ class ADM(torch.nn.Module):
         mc, ce = config.model_channels, config.output_embed_dim
         mult = config.extended_channel_expansion
         self.time_embedding = _TimeEmbedding(config.time_embed_dim, ce, config.time_projection_scale)
+        circ = config.convolution_type == "circular"           # the blocks' convolutions; input/output layers stay zero-padded
         nb = config.number_resnet_downward_block
         enc = []
         for i in range(len(mult) - 1):                                   # adm.py:566-592
             cin, cout = mc * mult[i], mc * mult[i + 1]
-            enc.append(_Layer([_Block(cin, cin, ce) for _ in range(nb - 1)] + [_Block(cin, cout, ce, "down")]))
+            enc.append(_Layer([_Block(cin, cin, ce, circular=circ) for _ in range(nb - 1)] +
+                              [_Block(cin, cout, ce, "down", circular=circ)]))
         self.encoder = _Layers(enc)
         cm = config.middle_channel
-        self.middle_block = _Middle([_Block(cm, cm, ce, None, a) for a in config.middle_block_attn_config])
+        self.middle_block = _Middle([_Block(cm, cm, ce, None, a, circular=circ) for a in config.middle_block_attn_config])
         rmult = mult[::-1]
         nb = config.number_resnet_upward_block
         dec = []
         for i in range(len(mult) - 1):                                   # adm.py:731-762
             cin, cout = mc * rmult[i], mc * rmult[i + 1]
             cb = 2 * cin if config.skip_integration_type == "concat" else cin
-            dec.append(_Layer([_Block(cb, cb, ce) for _ in range(nb - 1)] + [_Block(cb, cout, ce, "up")]))
+            dec.append(_Layer([_Block(cb, cb, ce, circular=circ) for _ in range(nb - 1)] +
+                              [_Block(cb, cout, ce, "up", circular=circ)]))
         self.decoder = _Layers(dec)
         self.input_layer = torch.nn.Conv2d(config.input_channels, mc, 3, padding="same")
         self.output_layer = torch.nn.Conv2d(mc, config.output_channels, 3, padding="same")
@@ -255,7 +258,7 @@ class ADM(torch.nn.Module):
 
     # ------------------------------------------------------------------ the network
     def _conv(self, m, x, pk, **kw):
-        return ops.conv(x, pk[id(m)], bias=m.bias, **kw)
+        return ops.conv(x, pk[id(m)], bias=m.bias, circular=isinstance(m, _CircConv), **kw)
 
     def _fused(self):
         return self.fuse_norm and self.conv_precision == "fp16x3"

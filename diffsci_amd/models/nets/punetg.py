@@ -42,22 +42,43 @@ class _TimeBlock(torch.nn.Module):
             torch.nn.Linear(4 * embed, out))
 
 
+class _CircConv(torch.nn.Module):
+    """CircularConv2d parameters (commonlayers.py:918-971): the weights live one level down, in .conv."""
+
+    def __init__(self, cin, cout, k):
+        super().__init__()
+        self.conv = torch.nn.Conv2d(cin, cout, k)
+        self.in_channels, self.out_channels = cin, cout
+
+    @property
+    def weight(self):
+        return self.conv.weight
+
+    @property
+    def bias(self):
+        return self.conv.bias
+
+
+def make_conv(cin, cout, k, circular):
+    return _CircConv(cin, cout, k) if circular else torch.nn.Conv2d(cin, cout, k, padding="same")
+
+
 class _ResBlock(torch.nn.Module):
     """ResnetBlockC parameters (commonlayers.py:766-807)."""
 
-    def __init__(self, C, embed):
+    def __init__(self, C, embed, circular=False):
         super().__init__()
         self.gnorm1 = torch.nn.GroupNorm(C, C)
         self.gnorm2 = _AffineHolder(C)
-        self.conv1 = torch.nn.Conv2d(C, C, 3, padding="same")
-        self.conv2 = torch.nn.Conv2d(C, C, 3, padding="same")
+        self.conv1 = make_conv(C, C, 3, circular)
+        self.conv2 = make_conv(C, C, 3, circular)
         self.timeblock = _TimeBlock(embed, C)
 
 
 class _Sampler(torch.nn.Module):
-    def __init__(self, cin, cout):
+    def __init__(self, cin, cout, circular=False):
         super().__init__()
-        self.conv = torch.nn.Conv2d(cin, cout, 3, padding="same")
+        self.conv = make_conv(cin, cout, 3, circular)
 
 
 class _Attn(torch.nn.Module):
@@ -112,21 +133,22 @@ class PUNetG(torch.nn.Module):
         mult = config.extended_channel_expansion
         self.time_projection = _Fourier(mc, config.time_projection_scale)
         self.conditional_embedding = conditional_embedding
-        self.convin = torch.nn.Conv2d(config.input_channels, mc, 3, padding="same")
-        self.convout = torch.nn.Conv2d(mc, config.output_channels, 3, padding="same")
+        circ = self.circular = config.convolution_type == "circular"
+        self.convin = make_conv(config.input_channels, mc, 3, circ)
+        self.convout = make_conv(mc, config.output_channels, 3, circ)
 
         def blocks(m, n):
-            return torch.nn.ModuleList([_ResBlock(m * mc, mc) for _ in range(n)])
+            return torch.nn.ModuleList([_ResBlock(m * mc, mc, circ) for _ in range(n)])
 
         self.downward_blocks = torch.nn.ModuleList(
             [blocks(mult[i], config.number_resnet_downward_block) for i in range(len(mult) - 1)])
         self.downsamplers = torch.nn.ModuleList(
-            [_Sampler(mult[i] * mc, mult[i + 1] * mc) for i in range(len(mult) - 1)])
+            [_Sampler(mult[i] * mc, mult[i + 1] * mc, circ) for i in range(len(mult) - 1)])
         rmult = list(reversed(mult))
         self.upward_blocks = torch.nn.ModuleList(
             [blocks(rmult[i + 1], config.number_resnet_upward_block) for i in range(len(mult) - 1)])
         self.upsamplers = torch.nn.ModuleList(
-            [_Sampler(rmult[i] * mc, rmult[i + 1] * mc) for i in range(len(mult) - 1)])
+            [_Sampler(rmult[i] * mc, rmult[i + 1] * mc, circ) for i in range(len(mult) - 1)])
         self.before_block = blocks(mult[-1], config.number_resnet_before_attn_block)
         self.after_block = blocks(mult[-1], config.number_resnet_after_attn_block)
         self.attn_resnet_block = blocks(mult[-1], config.number_resnet_attn_block)
@@ -233,7 +255,7 @@ class PUNetG(torch.nn.Module):
 
     # ------------------------------------------------------------------ the network
     def _conv(self, m, x, pk, **kw):
-        return ops.conv(x, pk[id(m)], bias=m.bias, **kw)
+        return ops.conv(x, pk[id(m)], bias=m.bias, circular=self.circular, **kw)
 
     def _fused(self):
         return self.fuse_norm and self.conv_precision == "fp16x3"

@@ -313,7 +313,7 @@ def gnorm1_table(stats_a, w, b, kind, count, stats_b=None, film=None, eps=1e-5, 
 
 
 def conv2d(x, w_packed, Cout, ks, bias=None, shift=None, res1=None, res2=None,
-           load_mode=N.DS_LOAD_PLAIN, out=None, kind="fp32", wshift=0, prenorm=None, tile_stats=None):
+           load_mode=N.DS_LOAD_PLAIN, out=None, kind="fp32", wshift=0, prenorm=None, tile_stats=None, circular=False):
     """'same' zero-padded conv; x [B, Cin, Hin, Win]; shift [1 or B, Cout] or None.
     fp16x3 kernels only: prenorm [B, Cin, 4] (3x3) applies SiLU((x-M)*A+C) in the loader; tile_stats
     [B, Cout, conv_tile_count(H, W), 4] receives per-tile (K, sum(x-K), sum((x-K)^2), n) of the output."""
@@ -350,6 +350,8 @@ def conv2d(x, w_packed, Cout, ks, bias=None, shift=None, res1=None, res2=None,
         raise ValueError("bias must have Cout entries")
     if (prenorm is not None or tile_stats is not None) and kind != "fp16x3":
         raise ValueError("prenorm / tile_stats are features of the fp16x3 kernels")
+    if circular and ks == 3 and kind != "fp16x3":
+        raise NotImplementedError("periodic padding is implemented in the fp16x3 convolution only")
     if prenorm is not None and (ks != 3 or tuple(prenorm.shape) != (B, Cin, 4)):
         raise ValueError(f"prenorm must be [B, Cin, 4] on a 3x3 convolution; got {tuple(prenorm.shape)}")
     if tile_stats is not None and tuple(tile_stats.shape) != (B, Cout, conv_tile_count(H, W), 4):
@@ -360,7 +362,8 @@ def conv2d(x, w_packed, Cout, ks, bias=None, shift=None, res1=None, res2=None,
                 "ds_conv1x1_h3")
     elif kind == "fp16x3":
         N.check(N.lib().ds_conv2d_h3(_p(out), _p(x), _p(w_packed), int(wshift), _p(bias), _p(shift), stride,
-                                     _p(res1), _p(res2), B, Cin, Cout, H, W, load_mode, _p(prenorm), _p(tile_stats),
+                                     _p(res1), _p(res2), B, Cin, Cout, H, W,
+                                     load_mode | (N.DS_PAD_CIRCULAR if circular else 0), _p(prenorm), _p(tile_stats),
                                      _stream()), "ds_conv2d_h3")
     elif kind == "bf16x6":
         N.check(N.lib().ds_conv2d_x6(_p(out), _p(x), _p(w_packed), _p(bias), _p(shift), stride, _p(res1),

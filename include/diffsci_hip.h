@@ -131,7 +131,9 @@ int ds_inorm_silu(float* out, const float* x, const float* w, const float* b,
 size_t ds_conv2d_packed_floats(int Cout, int Cin, int ks);
 int ds_conv2d_pack_weights(float* packed, const float* w, int Cout, int Cin, int ks, void* stream);
 
-enum { DS_LOAD_PLAIN = 0, DS_LOAD_MAXPOOL2 = 1, DS_LOAD_UPSAMPLE2 = 2, DS_LOAD_AVGPOOL2 = 3 /* ds_conv1x1_h3 only */ };
+enum { DS_LOAD_PLAIN = 0, DS_LOAD_MAXPOOL2 = 1, DS_LOAD_UPSAMPLE2 = 2, DS_LOAD_AVGPOOL2 = 3 /* ds_conv1x1_h3 only */,
+       DS_PAD_CIRCULAR = 16 /* OR-ed into load_mode of ds_conv2d_h3: periodic instead of zero padding in H and W
+                               (CircularConv2d, commonlayers.py:918-971; applied to the pooled / upsampled image) */ };
 
 /* "same"-padded (zero) ks x ks convolution, ks in {1,3}, fp32 MFMA implicit GEMM.
  *   out[b,co,y,x] = sum w[co,ci,ky,kx]*src(b,ci,y+ky-ks/2,x+kx-ks/2) + bias[co]

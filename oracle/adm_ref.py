@@ -14,7 +14,7 @@ inside the last block of each layer, decoder_type 1, attention only in the middl
 import torch
 import torch.nn.functional as F
 
-from .punetg_ref import attention_2d, fourier_features
+from .punetg_ref import attention_2d, conv3x3, fourier_features
 
 
 def default_config(**over):
@@ -46,8 +46,9 @@ def time_embedding(sd, t, ye=None):
     return F.silu(te)
 
 
-def block(sd, p, x, te, sample=None, has_attn=False, attn_residual=True):
-    """ADMBaseBlock.forward for a block without its own skip input (adm.py:292-349)."""
+def block(sd, p, x, te, sample=None, has_attn=False, attn_residual=True, circular=False):
+    """ADMBaseBlock.forward for a block without its own skip input (adm.py:292-349).  circular: the block's
+    convolutions are CircularConv2d (conv_fn, adm.py:427-443; parameters under `.conv`)."""
     def resample(v):
         if sample == "down":
             return F.avg_pool2d(v, 2)
@@ -55,13 +56,14 @@ def block(sd, p, x, te, sample=None, has_attn=False, attn_residual=True):
             return F.interpolate(v, scale_factor=2.0, mode="nearest")
         return v
     y = F.silu(F.group_norm(x, 1, sd[p + "norm1.weight"], sd[p + "norm1.bias"], 1e-5))
-    y = F.conv2d(resample(y), sd[p + "conv1.weight"], sd[p + "conv1.bias"], padding="same")
+    y = conv3x3(sd, p + "conv1", resample(y), circular)
     y = group1_rms_norm(y, sd[p + "norm2.weight"], sd[p + "norm2.bias"])
     e = F.linear(te, sd[p + "embed_linear.weight"], sd[p + "embed_linear.bias"])
     te1, te2 = torch.chunk(e, 2, dim=-1)
     y = y * te1[:, :, None, None] + te2[:, :, None, None]
-    y = F.conv2d(F.silu(y), sd[p + "conv2.weight"], sd[p + "conv2.bias"], padding="same")
-    y = y + F.conv2d(resample(x), sd[p + "convresidual.weight"], sd[p + "convresidual.bias"])
+    y = conv3x3(sd, p + "conv2", F.silu(y), circular)
+    rk = p + ("convresidual.conv." if circular else "convresidual.")
+    y = y + F.conv2d(resample(x), sd[rk + "weight"], sd[rk + "bias"])
     if has_attn:
         y = attention_2d(sd, p + "attn.", y, attn_residual)
     return y
@@ -70,13 +72,14 @@ def block(sd, p, x, te, sample=None, has_attn=False, attn_residual=True):
 def adm_forward(sd, cfg, x, t, ye=None):
     """ADM.forward, adm.py:199-216 (ye = conditional_embedding(y) or None)."""
     nl = len(cfg["channel_expansion"])
+    circ = cfg.get("convolution_type", "default") == "circular"
     te = time_embedding(sd, t, ye)
     x = F.conv2d(x, sd["input_layer.weight"], sd["input_layer.bias"], padding="same")
     skips = [x]
     for i in range(nl):
         nb = cfg["number_resnet_downward_block"]
         for j in range(nb):
-            x = block(sd, f"encoder.layers.{i}.input_blocks.{j}.", x, te, sample="down" if j == nb - 1 else None)
+            x = block(sd, f"encoder.layers.{i}.input_blocks.{j}.", x, te, sample="down" if j == nb - 1 else None, circular=circ)
         skips.append(x)
     nmid = (cfg["number_resnet_before_attn_block"] + cfg["number_resnet_attn_block"] +
             cfg["number_resnet_after_attn_block"])
@@ -85,13 +88,13 @@ def adm_forward(sd, cfg, x, t, ye=None):
              [False] * cfg["number_resnet_after_attn_block"])
     for j in range(nmid):
         x = block(sd, f"middle_block.middle_blocks.{j}.", x, te, has_attn=flags[j],
-                  attn_residual=cfg["attn_residual"])
+                  attn_residual=cfg["attn_residual"], circular=circ)
     for i in range(nl):
         h = skips.pop()
         x = torch.cat([x, h], dim=1) if cfg["skip_integration_type"] == "concat" else x + h
         nb = cfg["number_resnet_upward_block"]
         for j in range(nb):
-            x = block(sd, f"decoder.layers.{i}.input_blocks.{j}.", x, te, sample="up" if j == nb - 1 else None)
+            x = block(sd, f"decoder.layers.{i}.input_blocks.{j}.", x, te, sample="up" if j == nb - 1 else None, circular=circ)
     return F.conv2d(x, sd["output_layer.weight"], sd["output_layer.bias"], padding="same")
 
 

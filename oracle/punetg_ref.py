@@ -48,6 +48,16 @@ def group_rms_norm(x, weight, bias, eps=1e-5):
     return x * w + b
 
 
+def conv3x3(sd, name, x, circular=False):
+    """torch.nn.Conv2d(padding='same'), or CircularConv2d (commonlayers.py:918-971: F.pad circular in W,
+    then in H, then an unpadded convolution; parameters one level down, in `<name>.conv`)."""
+    if circular:
+        x = F.pad(x, (1, 1, 0, 0), mode="circular")
+        x = F.pad(x, (0, 0, 1, 1), mode="circular")
+        return F.conv2d(x, sd[name + ".conv.weight"], sd[name + ".conv.bias"])
+    return F.conv2d(x, sd[name + ".weight"], sd[name + ".bias"], padding="same")
+
+
 def time_shift(sd, prefix, te):
     """ResnetTimeBlock: Linear-SiLU-Linear-SiLU-Linear, commonlayers.py:516-522,546-549."""
     h = F.linear(te, sd[prefix + "net.0.weight"], sd[prefix + "net.0.bias"])
@@ -58,14 +68,14 @@ def time_shift(sd, prefix, te):
     return h.view(*h.shape, 1, 1)
 
 
-def resnet_block(sd, prefix, x, te):
+def resnet_block(sd, prefix, x, te, circular=False):
     """ResnetBlockC.forward, commonlayers.py:824-833."""
     C = x.shape[1]
     h = F.group_norm(x, C, sd[prefix + "gnorm1.weight"], sd[prefix + "gnorm1.bias"], 1e-5)
-    y = F.conv2d(F.silu(h), sd[prefix + "conv1.weight"], sd[prefix + "conv1.bias"], padding="same")
+    y = conv3x3(sd, prefix + "conv1", F.silu(h), circular)
     y = y + time_shift(sd, prefix + "timeblock.", te)
     h = group_rms_norm(y, sd[prefix + "gnorm2.weight"], sd[prefix + "gnorm2.bias"])
-    y = F.conv2d(F.silu(h), sd[prefix + "conv2.weight"], sd[prefix + "conv2.bias"], padding="same")
+    y = conv3x3(sd, prefix + "conv2", F.silu(h), circular)
     return y + x
 
 
@@ -88,36 +98,35 @@ def punetg_forward(sd, cfg, x, t, ye=None):
     """PUNetG.forward, punetg.py:389-416.  ``ye`` is the already-embedded condition
     (conditional_embedding(y), shape [B or 1, model_channels]) or None."""
     nlev = len(cfg["channel_expansion"])
-    x = F.conv2d(x, sd["convin.weight"], sd["convin.bias"], padding="same")
+    circ = cfg.get("convolution_type", "default") == "circular"
+    x = conv3x3(sd, "convin", x, circ)
     te = fourier_features(t, sd["time_projection.W"])
     if ye is not None:
         te = te + ye
     skips = []
     for lv in range(nlev):                                           # encode, punetg.py:356-365
         for r in range(cfg["number_resnet_downward_block"]):
-            x = resnet_block(sd, f"downward_blocks.{lv}.{r}.", x, te)
+            x = resnet_block(sd, f"downward_blocks.{lv}.{r}.", x, te, circ)
         skips.append(x)
-        x = F.conv2d(F.max_pool2d(x, 2), sd[f"downsamplers.{lv}.conv.weight"],
-                     sd[f"downsamplers.{lv}.conv.bias"], padding="same")
+        x = conv3x3(sd, f"downsamplers.{lv}.conv", F.max_pool2d(x, 2), circ)
     for r in range(cfg["number_resnet_before_attn_block"]):         # bottom, punetg.py:378-387
-        x = resnet_block(sd, f"before_block.{r}.", x, te)
+        x = resnet_block(sd, f"before_block.{r}.", x, te, circ)
     xa = x
     nattn = cfg["number_resnet_attn_block"]
     for r in range(nattn):                                           # punetg.py:344-354
-        xa = resnet_block(sd, f"attn_resnet_block.{r}.", xa, te)
+        xa = resnet_block(sd, f"attn_resnet_block.{r}.", xa, te, circ)
         if r < nattn - 1:
             xa = attention_2d(sd, f"attn_block.{r}.", xa, cfg["attn_residual"])
     x = x + xa
     for r in range(cfg["number_resnet_after_attn_block"]):
-        x = resnet_block(sd, f"after_block.{r}.", x, te)
+        x = resnet_block(sd, f"after_block.{r}.", x, te, circ)
     for lv in range(nlev):                                           # decode, punetg.py:367-376
         x = F.interpolate(x, scale_factor=2.0, mode="nearest")
-        x = F.conv2d(x, sd[f"upsamplers.{lv}.conv.weight"],
-                     sd[f"upsamplers.{lv}.conv.bias"], padding="same")
+        x = conv3x3(sd, f"upsamplers.{lv}.conv", x, circ)
         x = x + skips.pop()
         for r in range(cfg["number_resnet_upward_block"]):
-            x = resnet_block(sd, f"upward_blocks.{lv}.{r}.", x, te)
-    return F.conv2d(x, sd["convout.weight"], sd["convout.bias"], padding="same")
+            x = resnet_block(sd, f"upward_blocks.{lv}.{r}.", x, te, circ)
+    return conv3x3(sd, "convout", x, circ)
 
 
 def make_net(sd, cfg, embed=None):

@@ -310,6 +310,46 @@ def vpve():
     npz("vpve8", **arrs)
 
 
+def circular():
+    """PUNetG with convolution_type='circular' (periodic padding in every 3x3 convolution)."""
+    torch.manual_seed(50)
+    cfg = M.nets.PUNetGConfig(model_channels=8, convolution_type="circular")
+    net = M.nets.PUNetG(cfg).eval()
+    with torch.no_grad():
+        for k, v in net.state_dict().items():
+            if "gnorm" in k or k.endswith("in_proj_bias") or k.endswith("out_proj.bias"):
+                v.add_(0.25 * torch.randn_like(v))
+    sd = net.state_dict()
+    torch.manual_seed(51)
+    x = torch.randn(2, 1, 32, 32)
+    t = torch.tensor([0.3, -0.9])
+    arrs = dict(sd_arrays(sd), x=x, t=t)
+    with torch.inference_mode():
+        arrs["out_f32"] = net(x, t)
+        arrs["convin"] = net.convin(x)
+        arrs["down0"] = net.downsamplers[0](arrs["convin"])
+        arrs["up1"] = net.upsamplers[1](net.downsamplers[0](arrs["convin"]))
+    net64 = M.nets.PUNetG(cfg).double().eval()
+    net64.load_state_dict({k: v.double() for k, v in sd.items()})
+    with torch.inference_mode():
+        arrs["out_f64"] = net64(x.double(), t.double())
+    module = M.KarrasModule(net, M.KarrasModuleConfig.from_edm()).eval()
+    wn = torch.randn(2, 1, 32, 32)
+    arrs["white_noise"] = wn
+    arrs["hist_heun_N6_f32"] = module.propagate_white_noise(wn, nsteps=6, record_history=True)
+    npz("punetg8_circular", **arrs)
+    # ADM: the blocks' convolutions become circular, input / output layers stay zero padded
+    torch.manual_seed(52)
+    acfg = M.nets.ADMConfig(model_channels=8, time_embed_dim=8, output_embed_dim=16, convolution_type="circular")
+    anet = M.nets.ADM(acfg).eval()
+    with torch.no_grad():
+        for k, v in anet.state_dict().items():
+            if "norm" in k:
+                v.add_(0.25 * torch.randn_like(v))
+    with torch.inference_mode():
+        npz("adm8_circular", **dict(sd_arrays(anet.state_dict()), x=x, t=t, out_f32=anet(x, t)))
+
+
 def porosity():
     """BASELINE config 5's shape of the path: 4-channel conditional PUNetG with the in-repo dict-style
     PorosityEmbedder (nets/embedder.py:198-229), classifier-free guidance, un-batched dict y."""
@@ -380,6 +420,6 @@ def adm():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["schedule", "toy", "punetg", "porosity", "inpaint", "vpve", "adm"]
+    which = sys.argv[1:] or ["schedule", "toy", "punetg", "porosity", "inpaint", "vpve", "circular", "adm"]
     for name in which:
         globals()[name]()

@@ -148,8 +148,8 @@ def test_adm_against_oracle_on_fresh_inputs(M, dev):
 def test_adm_rejects_unsupported_configurations(M):
     with pytest.raises(NotImplementedError, match="decoder_type"):
         M.ADM(M.ADMConfig(decoder_type=2))
-    with pytest.raises(NotImplementedError, match="convolution_type"):
-        M.ADM(M.ADMConfig(convolution_type="circular"))
+    with pytest.raises(NotImplementedError, match="dimension"):
+        M.ADM(M.ADMConfig(dimension=3))
 
 
 @pytest.mark.parametrize("skip", ["concat", "add"])
@@ -162,3 +162,14 @@ def test_adm_fused_and_standalone_norms_agree(M, dev, skip):
     plain = net(x, t).cpu()
     assert rel_l2(fused, plain) < 2e-6
     assert rel_l2(plain, v["out_f32"]) < REL and rel_l2(fused, v["out_f32"]) < REL
+
+
+def test_adm_circular_convolutions(M, dev):
+    v, sd = load("adm8_circular")
+    net = M.ADM(M.ADMConfig(model_channels=8, time_embed_dim=8, output_embed_dim=16, convolution_type="circular"))
+    r = net.load_state_dict(sd, strict=True)
+    assert not r.missing_keys and not r.unexpected_keys
+    net = net.to(dev)
+    for fuse in (False, True):
+        net.fuse_norm = fuse
+        assert rel_l2(net(v["x"].to(dev), v["t"].to(dev)).cpu(), v["out_f32"]) < REL

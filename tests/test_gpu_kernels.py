@@ -397,3 +397,27 @@ def test_conv_tile_stats_and_fused_prenorm(dev, case):
     tab1 = ops.gnorm1_table(ts, wn.to(dev), bn.to(dev), 0, Cin * Hin * Win).cpu()
     torch.testing.assert_close(tab2[:, :Cin], tab1, rtol=1e-6, atol=1e-7)
     torch.testing.assert_close(tab2[:, Cin:], tab1, rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("case", [(2, 16, 24, 32, 32, 0), (1, 40, 8, 20, 36, 0), (2, 8, 16, 16, 16, 0), (1, 8, 8, 9, 13, 0),
+                                  (1, 16, 32, 16, 32, 1), (1, 24, 12, 16, 32, 2), (1, 4, 4, 8, 8, 0)])
+def test_conv_circular_padding(dev, case):
+    """DS_PAD_CIRCULAR: periodic padding (CircularConv2d) applied to the plain / pooled / upsampled image."""
+    ops = _ops()
+    B, Cin, Cout, H, W, mode = case
+    g = torch.Generator().manual_seed(hash(case) % 1000 + 11)
+    Hin, Win = (2 * H, 2 * W) if mode == 1 else ((H // 2, W // 2) if mode == 2 else (H, W))
+    x = torch.randn(B, Cin, Hin, Win, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)
+    bias = torch.randn(Cout, generator=g)
+    src = F.max_pool2d(x, 2) if mode == 1 else (F.interpolate(x, scale_factor=2.0, mode="nearest") if mode == 2 else x)
+    pad = F.pad(F.pad(src.double(), (1, 1, 0, 0), mode="circular"), (0, 0, 1, 1), mode="circular")
+    want = F.conv2d(pad, w.double(), bias.double())
+    ref32 = F.conv2d(F.pad(F.pad(src, (1, 1, 0, 0), mode="circular"), (0, 0, 1, 1), mode="circular"), w, bias)
+    pw = ops.pack_conv(w.to(dev), "fp16x3")
+    got = ops.conv(x.to(dev), pw, bias=bias.to(dev), load_mode=mode, circular=True).cpu()
+    assert rel_l2(got, want) <= max(3 * rel_l2(ref32, want), 3e-7)
+    zero = ops.conv(x.to(dev), pw, bias=bias.to(dev), load_mode=mode).cpu()
+    assert rel_l2(zero, want) > 1e-3                                    # and it is not the zero-padded result
+    with pytest.raises(NotImplementedError, match="periodic padding"):
+        ops.conv(x.to(dev), ops.pack_conv(w.to(dev), "fp32"), load_mode=mode, circular=True)

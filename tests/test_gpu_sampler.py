@@ -449,3 +449,29 @@ def test_vp_ve_parameterisations(M, net8, dev, tag):
         # and the default fp16x3 mode reports the overflow instead of returning finite garbage
         bad = M.KarrasModule(net8, cfg).propagate_white_noise(wn, nsteps=6).cpu()
         assert not torch.isfinite(bad).all()
+
+
+def test_punetg_circular_convolutions(M, dev, grids):
+    """PUNetGConfig(convolution_type='circular') against the reference."""
+    v, sd = load("punetg8_circular")
+    net = M.PUNetG(M.PUNetGConfig(model_channels=8, convolution_type="circular"))
+    r = net.load_state_dict(sd, strict=True)
+    assert not r.missing_keys and not r.unexpected_keys
+    net = net.to(dev)
+    pk = net.packed_weights()
+    h = net._conv(net.convin, v["x"].to(dev), pk)
+    assert rel_l2(h.cpu(), v["convin"]) < 2e-6
+    d = net._conv(net.downsamplers[0].conv, v["convin"].to(dev), pk, load_mode=1)
+    assert rel_l2(d.cpu(), v["down0"]) < 2e-6
+    u = net._conv(net.upsamplers[1].conv, v["down0"].to(dev), pk, load_mode=2)
+    assert rel_l2(u.cpu(), v["up1"]) < 2e-6
+    out = net(v["x"].to(dev), v["t"].to(dev)).cpu()
+    assert rel_l2(out, v["out_f32"]) < REL
+    assert rel_l2(out, v["out_f64"]) < max(4 * rel_l2(v["out_f32"], v["out_f64"]), 2e-6)
+    module = M.KarrasModule(net, M.KarrasModuleConfig.from_edm())
+    _pin_grid(module, grids)
+    hist = module.propagate_white_noise(v["white_noise"].to(dev), nsteps=6, record_history=True).cpu()
+    assert rel_l2(hist, v["hist_heun_N6_f32"]) < REL
+    net.conv_precision = "bf16x6"
+    with pytest.raises(NotImplementedError, match="periodic padding"):
+        net(v["x"].to(dev), v["t"].to(dev))

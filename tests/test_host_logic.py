@@ -165,7 +165,9 @@ def test_punetg_config_roundtrip_and_unsupported_options():
     c2 = M.PUNetGConfig.from_description(d)
     assert c2.export_description() == d and c2.extended_channel_expansion == [1, 2, 2, 4]
     with pytest.raises(NotImplementedError, match="convolution_type"):
-        M.PUNetG(M.PUNetGConfig(convolution_type="circular"))
+        M.PUNetG(M.PUNetGConfig(convolution_type="mp"))
+    circ = M.PUNetG(M.PUNetGConfig(model_channels=8, convolution_type="circular"))
+    assert "convin.conv.weight" in circ.state_dict() and "downsamplers.0.conv.conv.bias" in circ.state_dict()
     with pytest.raises(NotImplementedError, match="dimension"):
         M.PUNetG(M.PUNetGConfig(dimension=3))
     with pytest.raises(TypeError):

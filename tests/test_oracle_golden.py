@@ -297,3 +297,28 @@ def test_vp_ve_parameterisations(tag):
             h = V.propagate(fns, steps(5), v["white_noise"] * scale, score_fn, "karras", record_history=True,
                             eps=v["ve_punetg_karras_eps"])
             assert_exact_or_rel(h, v["ve_punetg_karras_N4"], "VE PUNetG sigma-churn", 2e-6)
+
+
+def test_punetg_circular_convolutions():
+    """convolution_type='circular' -- periodic padding, parameters under `.conv`."""
+    v, sd = load("punetg8_circular")
+    cfg = punetg_ref.default_config(model_channels=8, convolution_type="circular")
+    with torch.inference_mode():
+        h = punetg_ref.conv3x3(sd, "convin", v["x"], True)
+        assert_exact_or_ulp(h, v["convin"], "circular convin")
+        import torch.nn.functional as F
+        d = punetg_ref.conv3x3(sd, "downsamplers.0.conv", F.max_pool2d(h, 2), True)
+        assert_exact_or_ulp(d, v["down0"], "circular DownSampler")
+        u = punetg_ref.conv3x3(sd, "upsamplers.1.conv", F.interpolate(d, scale_factor=2.0, mode="nearest"), True)
+        assert_exact_or_ulp(u, v["up1"], "circular UpSampler")
+        assert_exact_or_rel(punetg_ref.punetg_forward(sd, cfg, v["x"], v["t"]), v["out_f32"], "out_f32", 2e-6)
+        hist = K.propagate_white_noise(punetg_ref.make_net(sd, cfg), v["white_noise"], 6, record_history=True)
+        assert_exact_or_rel(hist, v["hist_heun_N6_f32"], "hist_heun_N6_f32", 2e-6)
+
+
+def test_adm_circular_convolutions():
+    from oracle import adm_ref
+    v, sd = load("adm8_circular")
+    cfg = adm_ref.default_config(model_channels=8, time_embed_dim=8, output_embed_dim=16, convolution_type="circular")
+    with torch.inference_mode():
+        assert_exact_or_rel(adm_ref.adm_forward(sd, cfg, v["x"], v["t"]), v["out_f32"], "ADM circular", 2e-6)
