@@ -475,3 +475,29 @@ def test_punetg_circular_convolutions(M, dev, grids):
     net.conv_precision = "bf16x6"
     with pytest.raises(NotImplementedError, match="periodic padding"):
         net(v["x"].to(dev), v["t"].to(dev))
+
+
+@pytest.mark.parametrize("shape", [(2, 1, 20, 28), (1, 1, 36, 40), (3, 1, 64, 16)])
+def test_odd_field_sizes_against_oracle(M, dev, shape):
+    """Ragged tiles everywhere: widths that are not multiples of 32, 16 or 4 (element-wise epilogue and
+    its statistics path, 16x16 tile geometry, odd pooled sizes) through the fused-norm network."""
+    torch.manual_seed(9)
+    over = dict(model_channels=8, number_resnet_attn_block=1)          # no attention block: L need not divide by 32
+    cfg = punetg_ref.default_config(**over)
+    sd = punetg_ref.random_state_dict(cfg, seed=3)
+    for k in sd:
+        if "gnorm" in k:
+            sd[k] = sd[k] + 0.2 * torch.randn_like(sd[k])
+    net = M.PUNetG(M.PUNetGConfig(**over))
+    net.load_state_dict(sd)
+    net = net.to(dev)
+    x = torch.randn(*shape)
+    t = torch.linspace(-1.0, 1.5, shape[0])
+    with torch.inference_mode():
+        want = punetg_ref.punetg_forward(sd, cfg, x, t)
+        want64 = punetg_ref.punetg_forward({k: w.double() for k, w in sd.items()}, cfg, x.double(), t.double())
+    for fuse in (True, False):
+        net.fuse_norm = fuse
+        got = net(x.to(dev), t.to(dev)).cpu()
+        assert rel_l2(got, want) < REL, (fuse, rel_l2(got, want))
+        assert rel_l2(got, want64) < max(4 * rel_l2(want, want64), 2e-6)
