@@ -57,6 +57,7 @@ def parse():
     ap.add_argument("--channels", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-direct-out", action="store_true", help="output layer on the MFMA kernel (Cout padded to 64)")
     ap.add_argument("--no-fuse-norm", action="store_true", help="standalone norm kernels instead of norms folded into the convolutions")
     ap.add_argument("--roofline-only", action="store_true",
                     help="only run the dominant kernel's launch set (for rocprofv3 --pmc passes)")
@@ -75,6 +76,7 @@ def build_module(args, dev):
     net.load_state_dict(sd)
     net.conv_precision = args.precision
     net.fuse_norm = not args.no_fuse_norm
+    net.direct_out = not args.no_direct_out
     module = M.KarrasModule(net, M.KarrasModuleConfig.from_edm()).to(dev).eval()
     module.use_graph = not args.no_graph
     return module, sd, cfg

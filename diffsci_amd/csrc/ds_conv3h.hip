@@ -104,7 +104,7 @@ __device__ __forceinline__ float fast_silu(float v) {
   return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.44269504088896341f));
 }
 
-template <int MODE, bool W16, bool PRE>
+template <int MODE, bool W16, bool PRE, bool CIRC>
 __global__ __launch_bounds__(NT, 2) void k_conv3h(const Conv3hArgs a) {
   constexpr int TH = Geo<W16>::TH, TW = Geo<W16>::TW, PW = Geo<W16>::PW, NPOS = Geo<W16>::NPOS;
   constexpr int XITEMS = Geo<W16>::XITEMS, XI = Geo<W16>::XI;
@@ -146,11 +146,14 @@ __global__ __launch_bounds__(NT, 2) void k_conv3h(const Conv3hArgs a) {
     const int r = pos / PW;
     const int col = pos - r * PW;
     int gy = y0 + r - 1, gx = x0 + col - 1;
-    if (a.circular) {                                  // wrap instead of zero padding (also keeps ragged tiles in bounds)
-      gy = gy < 0 ? gy + a.H : gy;
-      gx = gx < 0 ? gx + a.W : gx;
-      gy = gy % a.H;
-      gx = gx % a.W;
+    if (CIRC) {
+      // wrap instead of zero padding: one halo pixel on either side, so a compare-and-add per edge
+      // (no integer division: that cost 2-3 % of the whole kernel in the prologue); rows / columns
+      // further outside only feed outputs of a ragged tile that are never stored -- clamp them
+      gy = gy < 0 ? gy + a.H : (gy >= a.H ? gy - a.H : gy);
+      gx = gx < 0 ? gx + a.W : (gx >= a.W ? gx - a.W : gx);
+      gy = gy >= a.H ? a.H - 1 : gy;
+      gx = gx >= a.W ? a.W - 1 : gx;
     }
     const bool ok = live && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
     int off;
@@ -391,20 +394,25 @@ __global__ void k_pack3h(_Float16* packed, const float* __restrict__ w, int Cout
   packed[i] = piece == 0 ? hi : lo;
 }
 
-template <int MODE, bool W16, bool PRE>
-int launch_conv3h(const Conv3hArgs& a, hipStream_t s) {
+template <int MODE, bool W16, bool PRE, bool CIRC>
+int launch_conv3h_c(const Conv3hArgs& a, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3h<MODE, W16, PRE>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3h<MODE, W16, PRE, CIRC>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (e != hipSuccess) return ds::hip_fail(e, "hipFuncSetAttribute(conv3h)");
     attr_set = true;
   }
   const long long blocks = (long long)a.B * a.tiles_y * a.tiles_x * a.n_cot;
   DS_REQUIRE(blocks > 0 && blocks < (1ll << 31), DS_ERR_SHAPE, "ds_conv2d_h3: grid of %lld workgroups is out of range", blocks);
-  hipLaunchKernelGGL((k_conv3h<MODE, W16, PRE>), dim3((unsigned)blocks), dim3(NT), LDS_BYTES, s, a);
+  hipLaunchKernelGGL((k_conv3h<MODE, W16, PRE, CIRC>), dim3((unsigned)blocks), dim3(NT), LDS_BYTES, s, a);
   DS_CHECK_LAUNCH("ds_conv2d_h3");
   return DS_OK;
+}
+
+template <int MODE, bool W16, bool PRE>
+int launch_conv3h(const Conv3hArgs& a, hipStream_t s) {
+  return a.circular ? launch_conv3h_c<MODE, W16, PRE, true>(a, s) : launch_conv3h_c<MODE, W16, PRE, false>(a, s);
 }
 
 }  // namespace

@@ -414,6 +414,10 @@ class ADM(torch.nn.Module):
         for s_, ss in skips:                                                     # the stem copy is never consumed
             if s_ is not h:
                 give(s_, ss)
-        y = self._conv(self.output_layer, h, pk, out=out)
+        m = self.output_layer
+        if m.out_channels <= 4:                              # see PUNetG._out_conv
+            y = ops.conv_direct(h, m.weight, m.bias, out=out)
+        else:
+            y = self._conv(m, h, pk, out=out)
         give(h, hs)
         return y

@@ -257,6 +257,13 @@ class PUNetG(torch.nn.Module):
     def _conv(self, m, x, pk, **kw):
         return ops.conv(x, pk[id(m)], bias=m.bias, circular=self.circular, **kw)
 
+    def _out_conv(self, m, h, pk, out, circular):
+        """The output layer: Cout <= 4 streams the input once through the direct fp32 kernel instead of
+        padding Cout to a 64-channel MFMA tile."""
+        if m.out_channels <= 4 and getattr(self, "direct_out", True):
+            return ops.conv_direct(h, m.weight, m.bias, circular=circular, out=out)
+        return ops.conv(h, pk[id(m)], bias=m.bias, circular=circular, out=out)
+
     def _fused(self):
         return self.fuse_norm and self.conv_precision == "fp16x3"
 
@@ -375,7 +382,7 @@ class PUNetG(torch.nn.Module):
                 h2, hs2 = self._res(blk, h, sh(), pk, ws, xs=hs, want_stats=not final)
                 give(h, hs)
                 h, hs = h2, hs2
-        y = self._conv(self.convout, h, pk, out=out)
+        y = self._out_conv(self.convout, h, pk, out, self.circular)
         give(h, hs)
         return y
 

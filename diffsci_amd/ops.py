@@ -277,6 +277,21 @@ def conv(x, pw, **kw):
     return conv2d(x, pw.data, pw.Cout, pw.ks, kind=pw.kind, wshift=pw.wshift, **kw)
 
 
+def conv_direct(x, w, bias=None, circular=False, out=None):
+    """3x3 'same' convolution with Cout <= 4, exact fp32, raw torch weight layout (output layers)."""
+    B, Cin, H, W = x.shape
+    Cout = w.shape[0]
+    if tuple(w.shape) != (Cout, Cin, 3, 3):
+        raise ValueError("conv_direct: weight must be [Cout, Cin, 3, 3]")
+    if out is None:
+        out = torch.empty((B, Cout, H, W), dtype=torch.float32, device=x.device)
+    elif tuple(out.shape) != (B, Cout, H, W):
+        raise ValueError(f"out has shape {tuple(out.shape)}, expected {(B, Cout, H, W)}")
+    N.check(N.lib().ds_conv2d_direct(_p(out), _p(x), _p(w), _p(bias), B, Cin, Cout, H, W, 1 if circular else 0,
+                                     _stream()), "ds_conv2d_direct")
+    return out
+
+
 def conv_tile_count(H, W):
     """Pixel tiles per channel plane in the fp16x3 kernels' tile_stats layout."""
     return N.lib().ds_conv_tile_count(int(H), int(W))

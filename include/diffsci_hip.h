@@ -197,6 +197,12 @@ int ds_gnorm1_table(float* table, const float* stats_a, int Ca, int ntiles_a, co
                     int ntiles_b, const float* w, const float* b, const float* film_scale, const float* film_shift,
                     int film_stride, int B, long long count, float eps, int kind, void* stream);
 
+/* 3x3 "same" convolution for Cout <= 4 (the networks' output layers: punetg.py:415, adm.py:193-215) as an
+ * exact-fp32 FMA chain, streaming the input once (HBM-bound) instead of padding Cout to a 64-channel MFMA
+ * tile.  w: torch layout [Cout, Cin, 3, 3] (no repacking).  circular != 0: periodic padding. */
+int ds_conv2d_direct(float* out, const float* in, const float* w, const float* bias, int B, int Cin, int Cout,
+                     int H, int W, int circular, void* stream);
+
 /* 1x1 convolution in the fp16x3 scheme of ds_conv2d_h3 (same epilogue terms, same domain
  * |in| < 65504).  ADM's residual projection convresidual(resample(x)) (adm.py:345-349) with the
  * resampling folded into the load: load_mode PLAIN, UPSAMPLE2 (nearest x2, in is [B,Cin,H/2,W/2])

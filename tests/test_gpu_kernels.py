@@ -421,3 +421,29 @@ def test_conv_circular_padding(dev, case):
     assert rel_l2(zero, want) > 1e-3                                    # and it is not the zero-padded result
     with pytest.raises(NotImplementedError, match="periodic padding"):
         ops.conv(x.to(dev), ops.pack_conv(w.to(dev), "fp32"), load_mode=mode, circular=True)
+
+
+@pytest.mark.parametrize("case", [(2, 64, 1, 32, 32, False), (1, 13, 3, 20, 36, False), (2, 8, 4, 9, 13, False),
+                                  (1, 128, 3, 64, 128, False), (2, 16, 2, 16, 16, True), (1, 5, 4, 18, 70, True)])
+def test_conv_direct_small_cout(dev, case):
+    """ds_conv2d_direct (output layers, Cout <= 4): exact fp32 FMA chains."""
+    ops = _ops()
+    B, Cin, Cout, H, W, circ = case
+    g = torch.Generator().manual_seed(hash(case) % 1000 + 13)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)
+    bias = torch.randn(Cout, generator=g)
+    if circ:
+        pad = lambda t: F.pad(F.pad(t, (1, 1, 0, 0), mode="circular"), (0, 0, 1, 1), mode="circular")   # noqa: E731
+        want, ref32 = F.conv2d(pad(x.double()), w.double(), bias.double()), F.conv2d(pad(x), w, bias)
+    else:
+        want, ref32 = F.conv2d(x.double(), w.double(), bias.double(), padding="same"), F.conv2d(x, w, bias, padding="same")
+    got = ops.conv_direct(x.to(dev), w.to(dev), bias.to(dev), circular=circ).cpu()
+    err, err32 = (got.double() - want).abs().max().item(), (ref32.double() - want).abs().max().item()
+    assert err <= max(8 * err32, 1e-5), (err, err32)
+    assert rel_l2(got, want) <= max(4 * rel_l2(ref32, want), 3e-7)
+    got = ops.conv_direct(x.to(dev), w.to(dev), None, circular=circ).cpu()
+    nb64, nb32 = want - bias.double()[None, :, None, None], ref32 - bias[None, :, None, None]
+    assert rel_l2(got, nb64) <= max(4 * rel_l2(nb32, nb64), 6e-7)
+    with pytest.raises(RuntimeError, match="1..4 supported"):
+        ops.conv_direct(x.to(dev), torch.randn(5, Cin, 3, 3, device=dev))
