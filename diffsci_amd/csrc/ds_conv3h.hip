@@ -29,7 +29,7 @@
 
 #ifdef DS_STAMP
 unsigned long long* g_stamps = nullptr;
-#define STAMP(slot) do { if (threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define STAMP(slot) do { if (threadIdx.x == 0) a.stamps[((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define STAMP(slot) do {} while (0)
 #endif
@@ -75,6 +75,7 @@ struct Conv3hArgs {
   int circular;           // periodic padding in both dimensions (CircularConv2d, commonlayers.py:918-971)
   int B, Cin, Cout, H, W, Hin, Win;
   int tiles_x, tiles_y, n_cot, n_chunks;
+  unsigned tiles_x_magic;   // floor(2^32 / tiles_x) + 1
 #ifdef DS_STAMP
   unsigned long long* stamps;   // diagnostic build only (tools/conv3h_stamp.hip)
 #endif
@@ -121,11 +122,13 @@ __global__ __launch_bounds__(NT, 2) void k_conv3h(const Conv3hArgs a) {
   const int wave_row = W16 ? 4 * wv : 2 * wv;
   constexpr int ROWS_PER_R = W16 ? 2 : 1;
 
-  int bid = blockIdx.x;
-  const int cot = bid % a.n_cot; bid /= a.n_cot;
-  const int tx = bid % a.tiles_x; bid /= a.tiles_x;
-  const int ty = bid % a.tiles_y; bid /= a.tiles_y;
-  const int b = bid;
+  // grid = (channel tiles, pixel tiles, samples): no runtime integer division in the prologue except one
+  // multiply-high by the precomputed reciprocal of tiles_x (exact: tile * tiles_x < 2^32)
+  const int cot = blockIdx.x;
+  const int tile_id = blockIdx.y;
+  const int b = blockIdx.z;
+  const int ty = a.tiles_x == 1 ? tile_id : (int)__umulhi((unsigned)tile_id, a.tiles_x_magic);
+  const int tx = tile_id - ty * a.tiles_x;
   const int x0 = tx * TW, y0 = ty * TH;
   const int HWin = a.Hin * a.Win;
   const int n_steps = a.n_chunks * 3;
@@ -403,9 +406,11 @@ int launch_conv3h_c(const Conv3hArgs& a, hipStream_t s) {
     if (e != hipSuccess) return ds::hip_fail(e, "hipFuncSetAttribute(conv3h)");
     attr_set = true;
   }
-  const long long blocks = (long long)a.B * a.tiles_y * a.tiles_x * a.n_cot;
-  DS_REQUIRE(blocks > 0 && blocks < (1ll << 31), DS_ERR_SHAPE, "ds_conv2d_h3: grid of %lld workgroups is out of range", blocks);
-  hipLaunchKernelGGL((k_conv3h<MODE, W16, PRE, CIRC>), dim3((unsigned)blocks), dim3(NT), LDS_BYTES, s, a);
+  const long long tiles = (long long)a.tiles_y * a.tiles_x;
+  DS_REQUIRE(tiles > 0 && tiles < 65536 && a.B < 65536, DS_ERR_SHAPE,
+             "ds_conv2d_h3: %lld pixel tiles x %d samples exceed the grid limits (65535 each)", tiles, a.B);
+  hipLaunchKernelGGL((k_conv3h<MODE, W16, PRE, CIRC>), dim3((unsigned)a.n_cot, (unsigned)tiles, (unsigned)a.B), dim3(NT),
+                     LDS_BYTES, s, a);
   DS_CHECK_LAUNCH("ds_conv2d_h3");
   return DS_OK;
 }
@@ -475,6 +480,7 @@ int ds_conv2d_h3(float* out, const float* in, const void* w_packed, int wshift, 
   a.tiles_x = (W + TW - 1) / TW; a.tiles_y = (H + TH - 1) / TH;
   a.n_cot = (Cout + COT - 1) / COT;
   a.n_chunks = (Cin + KC - 1) / KC;
+  a.tiles_x_magic = a.tiles_x == 1 ? 0u : (unsigned)((1ull << 32) / (unsigned)a.tiles_x) + 1u;   // tiles_x = 1 is special-cased in the kernel
 #ifdef DS_STAMP
   a.stamps = g_stamps;
 #endif
