@@ -10,7 +10,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_longlong, c_s
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DIFFSCI_HIP_LIB") or os.path.join(_HERE, "_lib", "libdiffsci_hip.so")
 
-DS_IN_NETWORK, DS_IN_SCORE, DS_IN_DRIFT = 0, 1, 2
+DS_IN_NETWORK, DS_IN_SCORE, DS_IN_DRIFT, DS_IN_FLOW = 0, 1, 2, 3
 DS_LOAD_PLAIN, DS_LOAD_MAXPOOL2, DS_LOAD_UPSAMPLE2, DS_LOAD_AVGPOOL2 = 0, 1, 2, 3
 DS_PAD_CIRCULAR = 16
 

@@ -24,6 +24,11 @@ __device__ __forceinline__ float score_of(float x, float f, float fu, bool has_u
 
 __device__ __forceinline__ float drift(float x, float f, float fu, bool has_u, const ds_eval_coef& k) {
   if (k.input_kind == DS_IN_DRIFT) return f;
+  if (k.input_kind == DS_IN_FLOW) {              // f is a flow field v(x, t) (flowfield.py:441-458)
+    float F = f;
+    if (has_u) F = k.one_minus_guidance * fu + k.guidance * f;
+    return k.neg_mult * (F / k.sigma_sq);
+  }
   float score = (k.input_kind == DS_IN_SCORE) ? f : score_of(x, f, fu, has_u, k);
   float d = k.neg_mult * score;
   if (k.stochastic) d = d + k.neg_lang * score;
@@ -244,6 +249,7 @@ __global__ __launch_bounds__(kThreads) void k_add(float* out, const float* __res
   if (t < n) out[t] = a[t] + b[t];
 }
 
+inline bool blends(int input_kind) { return input_kind == DS_IN_NETWORK || input_kind == DS_IN_FLOW; }
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 }  // namespace
@@ -270,7 +276,7 @@ int ds_karras_euler(float* x_out, float* xin_out, const float* x, const float* f
   DS_REQUIRE(DS_ALIGN_OK(x_out) && DS_ALIGN_OK(xin_out) && aligned16(x) && aligned16(f) && DS_ALIGN_OK(fu) &&
                  DS_ALIGN_OK(eps),
              DS_ERR_SHAPE, "ds_karras_euler: pointers must be 16-byte aligned");
-  DS_REQUIRE(!(k->input_kind != 0 && fu), DS_ERR_SHAPE, "ds_karras_euler: guidance blend needs network outputs");
+  DS_REQUIRE(!(!blends(k->input_kind) && fu), DS_ERR_SHAPE, "ds_karras_euler: guidance blend needs network outputs or flow fields");
   if (n == 0) return DS_OK;
   size_t n4 = n / 4;
   dim3 g(grid_for(n4 ? n4 : 1)), b(kThreads);
@@ -295,8 +301,8 @@ int ds_karras_heun(float* x_out, float* xin_out, const float* x, const float* f1
   DS_REQUIRE(aligned16(x_out) && DS_ALIGN_OK(xin_out) && aligned16(x) && aligned16(f1) && aligned16(f2) &&
                  DS_ALIGN_OK(f1u) && DS_ALIGN_OK(f2u),
              DS_ERR_SHAPE, "ds_karras_heun: pointers must be 16-byte aligned");
-  DS_REQUIRE(!((k1->input_kind != 0 || k2->input_kind != 0) && f1u), DS_ERR_SHAPE,
-             "ds_karras_heun: guidance blend needs network outputs");
+  DS_REQUIRE(!((!blends(k1->input_kind) || !blends(k2->input_kind)) && f1u), DS_ERR_SHAPE,
+             "ds_karras_heun: guidance blend needs network outputs or flow fields");
   if (n == 0) return DS_OK;
   size_t n4 = n / 4;
   dim3 g(grid_for(n4 ? n4 : 1)), b(kThreads);
@@ -313,7 +319,7 @@ static int launch_drift(float* out, const float* x, const float* f, const float*
                         size_t n, void* stream, bool score_only, const char* who) {
   DS_REQUIRE(out && f && k, DS_ERR_NULL, "%s: NULL pointer", who);
   DS_REQUIRE(x || k->input_kind != DS_IN_NETWORK, DS_ERR_NULL, "%s: x is required for network outputs", who);
-  DS_REQUIRE(!(k->input_kind != 0 && fu), DS_ERR_SHAPE, "%s: guidance blend needs network outputs", who);
+  DS_REQUIRE(!(!blends(k->input_kind) && fu), DS_ERR_SHAPE, "%s: guidance blend needs network outputs or flow fields", who);
   DS_REQUIRE(!(score_only && k->input_kind != DS_IN_NETWORK), DS_ERR_SHAPE, "%s: input is not a network output", who);
   if (n == 0) return DS_OK;
   dim3 g(grid_for((n + 3) / 4)), b(kThreads);

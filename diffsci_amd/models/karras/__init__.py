@@ -8,3 +8,4 @@ from .noisesamplers import NoiseSampler, EDMNoiseSampler, VPNoiseSampler, VENois
 from .schedulingfunctions import (SchedulingFunctions, EDMSchedulingFunctions,  # noqa: F401
                                   VPSchedulingFunctions, VESchedulingFunctions,
                                   name_to_scheduling_functions)
+from .flowfield import SIModule, SIModuleConfig, SIScheduler  # noqa: F401

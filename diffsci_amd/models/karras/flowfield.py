@@ -1,0 +1,333 @@
+"""Stochastic-interpolant / flow-matching sampler with the reference's surface
+(diffsci/models/karras/flowfield.py:21-170, 233-345, 441-544, 704-795): SIScheduler, Preconditioner,
+SIModuleConfig, SIModule.sample / integrate_flow_field / integration_step / get_flow_field /
+get_score_field.  Sampling only (loss, optimisers, latent autoencoders, batch-norm statistics and
+SIModule.inpaint are outside the HIP path and raise).
+
+The Heun / Euler loop over ``linspace(1, 0, nsteps)`` runs on the same fused HIP stepper and hipGraph
+machinery as KarrasModule: per evaluation the host tabulates (c_in, c_noise, c_out, c_skip, the
+flow multiplier) in fp32 with the reference's operation order, the kernels turn network outputs into
+the flow field v, apply classifier-free guidance and the update in one pass.
+  precondition 'identity':  v = model(x, t, y=y)                              DS_IN_FLOW
+  precondition 'edm':       v = sigma'/sigma * (x - (c_skip x + c_out F))     DS_IN_NETWORK with sigma^2 := 1
+"""
+import warnings
+from typing import Any, Callable
+
+import numpy as np
+import torch
+
+from ... import ops
+from ..._native import DS_IN_FLOW, DS_IN_NETWORK
+from .engine import Loop, ModuleSource
+from .karrasmodule import dict_to, dict_unsqueeze
+from .steptable import EvalRow, StepRow, StepTable
+
+
+class SIScheduler(object):
+    """flowfield.py:21-111 -- scalar functions alpha(t), sigma(t) and derivatives, evaluated on the host."""
+
+    def __init__(self, alpha_fn, sigma_fn, alpha_fn_dot, sigma_fn_dot, sigma_fn_inv):
+        self.alpha_fn = alpha_fn
+        self.sigma_fn = sigma_fn
+        self.alpha_fn_dot = alpha_fn_dot
+        self.sigma_fn_dot = sigma_fn_dot
+        self.sigma_fn_inv = sigma_fn_inv
+
+    @classmethod
+    def linear(cls):
+        return cls(alpha_fn=lambda t: 1 - t, sigma_fn=lambda t: t,
+                   alpha_fn_dot=lambda t: -1 * torch.ones_like(t), sigma_fn_dot=lambda t: torch.ones_like(t),
+                   sigma_fn_inv=lambda s: s)
+
+    @classmethod
+    def cosine(cls):
+        return cls(alpha_fn=lambda t: torch.cos(t * np.pi / 2), sigma_fn=lambda t: torch.sin(t * np.pi / 2),
+                   alpha_fn_dot=lambda t: -1 * torch.pi / 2 * torch.sin(t * np.pi / 2),
+                   sigma_fn_dot=lambda t: torch.pi / 2 * torch.cos(t * np.pi / 2),
+                   sigma_fn_inv=lambda s: (2 / np.pi) * torch.arcsin(s))
+
+    @classmethod
+    def finterpolation(cls, f, finv, fdot, sigma_min: float, sigma_max: float):
+        def sigma_fn(t):
+            return f((1 - t) * finv(sigma_min) + t * finv(sigma_max))
+
+        def sigma_fn_inv(s):
+            return (finv(s) - finv(sigma_min)) / (finv(sigma_max) - finv(sigma_min))
+
+        def sigma_fn_dot(t):
+            return fdot((1 - t) * finv(sigma_min) + t * finv(sigma_max)) * (finv(sigma_max) - finv(sigma_min))
+        return cls(alpha_fn=lambda t: 0.0 * t + 1.0, sigma_fn=sigma_fn, alpha_fn_dot=lambda t: 0.0 * t,
+                   sigma_fn_dot=sigma_fn_dot, sigma_fn_inv=sigma_fn_inv)
+
+    @classmethod
+    def edm(cls, expoent: float = 7.0, sigma_min: float = 0.02, sigma_max: float = 80.0):
+        return cls.finterpolation(lambda x: x ** expoent, lambda x: x ** (1 / expoent),
+                                  lambda x: expoent * x ** (expoent - 1), sigma_min, sigma_max)
+
+    @classmethod
+    def get_interpolator(cls, name, *args, **kwargs):
+        if name not in cls.named_interpolators():
+            raise ValueError(f"Invalid interpolator: {name}")
+        return getattr(cls, name)(*args, **kwargs)
+
+    @classmethod
+    def named_interpolators(cls):
+        return ['linear', 'cosine', 'edm', 'finterpolation']
+
+
+class Preconditioner(object):
+    """flowfield.py:114-169.  Only the named parameterisations ('identity', 'edm', None) of a
+    time-dependent network are on the HIP path."""
+
+    def __init__(self, scheduler: SIScheduler, precondition_fn='identity', is_autonomous: bool = False, **kwargs):
+        if is_autonomous:
+            raise NotImplementedError("autonomous flows (model(x, y=y) without time) are not on the HIP path")
+        if precondition_fn is not None and not isinstance(precondition_fn, str):
+            raise NotImplementedError("user precondition callables are not on the HIP path; use 'identity' or 'edm'")
+        if precondition_fn not in (None, 'identity', 'edm'):
+            raise ValueError(f"Invalid condition function: {precondition_fn}")
+        self.scheduler = scheduler
+        self.precondition_fn = precondition_fn
+        self.is_autonomous = is_autonomous
+        self.kwargs = kwargs
+
+    @property
+    def kind(self):
+        return 'edm' if self.precondition_fn == 'edm' else 'identity'
+
+    def eval_row(self, t, integrate_on_sigma=False):
+        """Scalars of one flow-field evaluation at time t (0-dim fp32 CPU tensor), reference order."""
+        sch = self.scheduler
+        sigma_dot = sch.sigma_fn_dot(t)
+        if self.kind == 'identity':
+            # v = F [/ sigma']: DS_IN_FLOW, d = neg_mult*(F/sigma_sq)
+            return EvalRow(t=t, sigma=float(sch.sigma_fn(t)), sigma_sq=float(sigma_dot) if integrate_on_sigma else 1.0,
+                           neg_mult=1.0, c_skip=0.0, c_out=1.0, c_in=1.0, c_noise=float(t))
+        sigma_data = self.kwargs.get("sigma_data", 0.5)
+        sigma = sch.sigma_fn(t)
+        cin = 1 / torch.sqrt(sigma_data ** 2 + sigma ** 2)
+        cout = sigma * sigma_data / torch.sqrt(sigma_data ** 2 + sigma ** 2)
+        cskip = sigma_data ** 2 / (sigma_data ** 2 + sigma ** 2)
+        cnoise = 0.5 * torch.log(sch.sigma_fn(t))
+        mult = sigma_dot / sigma                                   # v = mult*(x - D) = (-mult)*((D - x)/1)
+        if integrate_on_sigma:
+            mult = mult / sigma_dot
+        return EvalRow(t=t, sigma=float(sigma), sigma_sq=1.0, neg_mult=float(-mult), c_skip=float(cskip),
+                       c_out=float(cout), c_in=float(cin), c_noise=float(cnoise))
+
+
+class SIModuleConfig(torch.nn.Module):
+    """flowfield.py:233-286 (sampling-side fields; the loss configuration is stored, not used)."""
+
+    def __init__(self, scheduler: SIScheduler | str = 'linear', scheduler_args: dict[str, Any] = {},
+                 num_channels: int | None = None, initial_norm: bool | float = False,
+                 autonomous_flow: bool = False, precondition_fn: Callable | str | None = None,
+                 loss_weighting='uniform', loss_metric='huber', autoencoder_is_conditional: bool = False,
+                 encode_condition: bool = False):
+        super().__init__()
+        if isinstance(scheduler, str):
+            scheduler = SIScheduler.get_interpolator(scheduler, **scheduler_args)
+        self.scheduler = scheduler
+        self.num_channels = num_channels
+        self.initial_norm = initial_norm
+        self.autonomous_flow = autonomous_flow
+        self.loss_weighting = loss_weighting
+        self.loss_metric = loss_metric
+        self.precondition_fn = precondition_fn
+        self.autoencoder_is_conditional = autoencoder_is_conditional
+        self.encode_condition = encode_condition
+        self.alpha_fn, self.sigma_fn = scheduler.alpha_fn, scheduler.sigma_fn
+        self.alpha_fn_dot, self.sigma_fn_dot = scheduler.alpha_fn_dot, scheduler.sigma_fn_dot
+        self.sigma_fn_inv = scheduler.sigma_fn_inv
+        self.preconditioner = Preconditioner(scheduler, precondition_fn, autonomous_flow)
+
+
+class _Adapter:
+    """What engine.ModuleSource needs from a module: the network and whether a condition is present."""
+
+    def __init__(self, model, conditional):
+        self.model, self.conditional = model, conditional
+
+
+class SIModule(torch.nn.Module):
+    def __init__(self, config: SIModuleConfig, model: torch.nn.Module, autoencoder: torch.nn.Module | None = None):
+        super().__init__()
+        if autoencoder is not None:
+            raise NotImplementedError("latent autoencoders are outside the HIP sampling path")
+        if isinstance(config.initial_norm, bool) and config.initial_norm:
+            raise NotImplementedError("DimensionAgnosticBatchNorm (initial_norm=True) is outside the HIP sampling path")
+        object.__setattr__(self, "config", config)
+        self.model = model
+        self.autoencoder = None
+        self.norm_sigma = None if isinstance(config.initial_norm, bool) else float(config.initial_norm)
+        self.use_graph = True
+        self._plans = {}
+        self._stream = None
+
+    @property
+    def device(self):
+        try:
+            return next(self.parameters()).device
+        except StopIteration:
+            return torch.device("cpu")
+
+    def _apply(self, fn, *a, **k):
+        self._plans.clear()
+        return super()._apply(fn, *a, **k)
+
+    # ------------------------------------------------------------------ fields
+    def _eval_scalars(self, t):
+        tt = torch.as_tensor(t, dtype=torch.float32).detach().cpu()
+        if tt.numel() != 1 and not bool((tt == tt.reshape(-1)[0]).all()):
+            raise NotImplementedError("per-sample times in get_flow_field (the sampler uses one time per step)")
+        return tt.reshape(-1)[0].reshape(())
+
+    def get_flow_field(self, x_noised, t, guidance: float = 1.0, y=None, integrate_on_sigma: bool = False):
+        """flowfield.py:441-458 for a batch at one time t."""
+        ops.require_device(x_noised, "x_noised")
+        row = self.config.preconditioner.eval_row(self._eval_scalars(t), integrate_on_sigma)
+        src = self._source(y, guidance, x_noised)
+        table = StepTable(kind="euler", t=torch.zeros(2), rows=[StepRow(row, None, 0.0)])
+        src.prepare(table)
+        xin = ops.scale(x_noised.contiguous(), row.c_in)
+        f, fu = src.evaluate(x_noised, xin, row, 0, 0)
+        return ops.drift(x_noised.contiguous(), f, row.coef(src.input_kind, src.guidance), fu=fu)
+
+    def get_score_field_from_flow_field(self, flow_field, x_noised, t):
+        """flowfield.py:483-501: (alpha v - alpha' x) / (sigma (alpha' sigma - alpha sigma'))."""
+        tt = self._eval_scalars(t)
+        c = self.config
+        alpha, sigma, alpha_dot, sigma_dot = c.alpha_fn(tt), c.sigma_fn(tt), c.alpha_fn_dot(tt), c.sigma_fn_dot(tt)
+        den = sigma * (alpha_dot * sigma - alpha * sigma_dot)
+        num = ops.axpby(flow_field.contiguous(), float(alpha), x_noised.contiguous(), -float(alpha_dot))
+        return ops.div_scalar(num, float(den), out=num)
+
+    def get_score_field(self, x_noised, t, y=None, guidance: float = 1.0, integrate_on_sigma: bool = False):
+        """flowfield.py:460-481."""
+        v = self.get_flow_field(x_noised, t, y=y, guidance=guidance, integrate_on_sigma=integrate_on_sigma)
+        return self.get_score_field_from_flow_field(v, x_noised, t)
+
+    # ------------------------------------------------------------------ sampling
+    def _source(self, y, guidance, like):
+        src = ModuleSource(_Adapter(self.model, y is not None), y, guidance, like.shape[0], like)
+        # guidance == 0 with a condition: the reference forms 0*v_c + 1*v_u; ModuleSource evaluates the
+        # unconditional branch alone, which is the same field
+        src.input_kind = DS_IN_FLOW if self.config.preconditioner.kind == 'identity' else DS_IN_NETWORK
+        return src
+
+    def _table(self, time_schedule, integrate_on_sigma):
+        ts = torch.as_tensor(time_schedule, dtype=torch.float32).detach().cpu()
+        pc = self.config.preconditioner
+        n = ts.numel()
+        rows = []
+        for i in range(n - 1):
+            t_curr, t_next = ts[i], ts[i + 1]
+            dt = (self.config.sigma_fn(t_next) - self.config.sigma_fn(t_curr)) if integrate_on_sigma else (t_next - t_curr)
+            first = pc.eval_row(t_curr, integrate_on_sigma)
+            second = None if i == n - 2 else pc.eval_row(t_next, integrate_on_sigma)   # last step: Euler (flowfield.py:724)
+            rows.append(StepRow(first, second, float(dt)))
+        return StepTable(kind="heun", t=ts, rows=rows)
+
+    def sample(self, nsamples: int, shape: list[int], y=None, guidance: float = 1.0, nsteps: int = 30,
+               is_latent_shape: bool = False, integrate_on_sigma: bool = False, noise_injection: bool = False,
+               return_latents: bool = False, orig_noise=None):
+        """flowfield.py:503-544."""
+        with torch.inference_mode():
+            if orig_noise is None:
+                x = torch.randn(nsamples, *shape).to(self.device)
+            else:
+                assert orig_noise.shape[0] == nsamples, "Number of samples must match"
+                assert list(orig_noise.shape[1:]) == list(shape), "Shape of noise must match"
+                x = orig_noise.to(self.device)
+            if y is not None:
+                warnings.warn("Moving y to device: {}".format(self.device))
+                y = dict_to(y, self.device)
+                y = dict_unsqueeze(y, 0)
+            time_schedule = torch.linspace(1, 0, nsteps)
+            sigma_init = self.config.sigma_fn(time_schedule[0])
+            return self._integrate(x, time_schedule, y, guidance, False, integrate_on_sigma, noise_injection,
+                                   scale=float(sigma_init))
+
+    def integrate_flow_field(self, x, time_schedule, y=None, guidance: float = 1.0, return_history: bool = False,
+                             integrate_on_sigma: bool = False, noise_injection: bool = False):
+        """flowfield.py:704-747: Heun steps, the last one Euler; history = [(t_i, x_i)]."""
+        with torch.inference_mode():
+            return self._integrate(x, time_schedule, y, guidance, return_history, integrate_on_sigma, noise_injection)
+
+    def _integrate(self, x, time_schedule, y, guidance, return_history, integrate_on_sigma, noise_injection, scale=None):
+        ops.require_device(x, "x")
+        if noise_injection:
+            return self._integrate_em(x, time_schedule, y, guidance, return_history, integrate_on_sigma, scale)
+        table = self._table(time_schedule, integrate_on_sigma)
+        src = self._source(y, guidance, x)
+        if src.planned and self.use_graph:
+            out = self._run_planned(table, src, x, y, guidance, return_history, integrate_on_sigma, scale)
+        else:
+            loop = Loop(table, src, x, return_history)
+            loop.load(x, scale)
+            loop.launch()
+            out = loop.result()
+        if self.norm_sigma is not None:
+            out = ops.scale(out.contiguous(), self.norm_sigma)                    # initial_norm.unnorm
+        if return_history:
+            return [(table.t[i].to(x.device), out[i]) for i in range(out.shape[0])]
+        return out
+
+    def _run_planned(self, table, src, x, y, guidance, return_history, integrate_on_sigma, scale):
+        """Capture the whole run once per (shape, schedule, guidance, condition) and replay it."""
+        ykey = None if y is None else repr({k: (tuple(v.shape), v.flatten()[:8].tolist()) for k, v in y.items()}
+                                           if isinstance(y, dict) else (tuple(y.shape), y.flatten()[:8].tolist()))
+        key = (tuple(x.shape), tuple(float(v) for v in table.t), float(guidance), ykey, bool(return_history),
+               bool(integrate_on_sigma), getattr(self.model, "conv_precision", None), getattr(self.model, "fuse_norm", None))
+        key = key + (str(x.device), tuple((p.data_ptr(), p._version) for p in self.model.parameters()))
+        # hipGraph capture needs a non-default stream (see KarrasModule._run_planned)
+        if self._stream is None or self._stream.device != x.device:
+            self._stream = torch.cuda.Stream(device=x.device)
+        caller = torch.cuda.current_stream(x.device)
+        self._stream.wait_stream(caller)
+        with torch.cuda.stream(self._stream):
+            plan = self._plans.get(key)
+            if plan is None:
+                loop = Loop(table, src, x, return_history)
+                loop.load(x, scale)
+                loop.launch()                  # eager pass: allocates the workspace, validates shapes
+                self._stream.synchronize()
+                with ops.Graph() as g:
+                    loop.launch()
+                plan = (loop, g)
+                if len(self._plans) >= 4:
+                    self._plans.pop(next(iter(self._plans)))
+                self._plans[key] = plan
+            plan[0].load(x, scale)
+            plan[1].launch()
+            out = plan[0].result().clone()
+        caller.wait_stream(self._stream)
+        return out
+
+    def _integrate_em(self, x, time_schedule, y, guidance, return_history, integrate_on_sigma, scale):
+        """Euler-Maruyama with noise injection (flowfield.py:783-793), one HIP pass per operation group."""
+        ts = torch.as_tensor(time_schedule, dtype=torch.float32).detach().cpu()
+        c = self.config
+        x = ops.scale(x.contiguous(), scale) if scale is not None else x.contiguous()
+        history = [(ts[0], x)] if return_history else None
+        for i in range(ts.numel() - 1):
+            t_curr, t_next = ts[i], ts[i + 1]
+            dt = (c.sigma_fn(t_next) - c.sigma_fn(t_curr)) if integrate_on_sigma else (t_next - t_curr)
+            v = self.get_flow_field(x, t_curr, y=y, guidance=guidance, integrate_on_sigma=integrate_on_sigma)
+            score = self.get_score_field_from_flow_field(v, x, t_curr)
+            omega = c.sigma_fn(t_curr)
+            d = ops.axpby(v, 1.0, score, -float(0.5 * omega))            # v - 0.5*omega*score
+            x = ops.axpby(x, 1.0, d, float(dt))                           # x + dt*(...)
+            x = ops.axpby(x, 1.0, torch.randn_like(x), float(torch.sqrt(omega * torch.abs(dt))), out=x)
+            if return_history:
+                history.append((ts[i + 1], x))
+        if self.norm_sigma is not None:
+            if return_history:
+                history = [(t, ops.scale(h, self.norm_sigma)) for t, h in history]
+            else:
+                x = ops.scale(x, self.norm_sigma)
+        return history if return_history else x
+
+    def inpaint(self, *a, **k):
+        raise NotImplementedError("SIModule.inpaint is outside the HIP path (use KarrasModule.inpaint)")

@@ -63,7 +63,8 @@ typedef struct ds_eval_coef {
   int   stochastic; /* 1: add neg_lang*score to the drift                                 */
 } ds_eval_coef;
 
-enum { DS_IN_NETWORK = 0, DS_IN_SCORE = 1, DS_IN_DRIFT = 2 };
+enum { DS_IN_NETWORK = 0, DS_IN_SCORE = 1, DS_IN_DRIFT = 2,
+       DS_IN_FLOW = 3 /* f is a flow field (SIModule, flowfield.py:441-458): d = neg_mult*(blend(f, fu)/sigma_sq) */ };
 
 /* out = s * x.  karrasmodule.py:881 (x * maximum_scale) and :702 (c_in * x). */
 int ds_karras_scale(float* out, const float* x, float s, size_t n, void* stream);

@@ -350,6 +350,52 @@ def circular():
         npz("adm8_circular", **dict(sd_arrays(anet.state_dict()), x=x, t=t, out_f32=anet(x, t)))
 
 
+def si():
+    """SIModule (stochastic interpolants / flow matching) sampler."""
+    z = np.load(os.path.join(OUT, "punetg8_forward.npz"))
+    sd = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd/")}
+    zc = np.load(os.path.join(OUT, "punetg8_cfg.npz"))
+    torch.manual_seed(60)
+    noise = torch.randn(2, 1, 32, 32)
+    arrs = dict(noise=noise)
+
+    def make(cond=False):
+        emb = None
+        if cond:
+            emb = torch.nn.Embedding(4, 8)
+            emb.weight.data.copy_(torch.from_numpy(zc["emb_weight"]))
+        net = M.nets.PUNetG(M.nets.PUNetGConfig(model_channels=8), conditional_embedding=emb).eval()
+        net.load_state_dict(sd, strict=False)
+        return net
+    ts = torch.linspace(1, 0, 6)
+    for tag, kw in (("linear_identity", dict(scheduler="linear")),
+                    ("edm_edm", dict(scheduler="edm", precondition_fn="edm")),
+                    ("cosine_edm_norm2", dict(scheduler="cosine", precondition_fn="edm", initial_norm=2.0))):
+        mod = M.SIModule(M.SIModuleConfig(**kw), make()).eval()
+        with torch.inference_mode():
+            arrs[f"{tag}_sample_N6"] = mod.sample(2, [1, 32, 32], nsteps=6, orig_noise=noise)
+            h = mod.integrate_flow_field(noise * mod.config.sigma_fn(ts[0]), ts, return_history=True)
+            arrs[f"{tag}_hist_N6"] = torch.stack([x for _, x in h])
+            tt = torch.tensor([0.4, 0.4])
+            arrs[f"{tag}_flow"] = mod.get_flow_field(noise, tt)
+            arrs[f"{tag}_score"] = mod.get_score_field(noise, tt)
+            # (integrate_on_sigma=True raises in the reference for image batches: flow_field / sigma_dot, flowfield.py:455-457,
+            #  divides [B,C,H,W] by [B] without broadcasting)
+    cmod = M.SIModule(M.SIModuleConfig(scheduler="linear"), make(cond=True)).eval()
+    y = torch.tensor(2)
+    import warnings
+    with torch.inference_mode(), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        arrs["cfg_y"] = y
+        arrs["cfg_g2_sample_N6"] = cmod.sample(2, [1, 32, 32], y=y, guidance=2.0, nsteps=6, orig_noise=noise)
+        arrs["cfg_g1_sample_N6"] = cmod.sample(2, [1, 32, 32], y=y, guidance=1.0, nsteps=6, orig_noise=noise)
+    cmod2 = M.SIModule(M.SIModuleConfig(scheduler="edm", precondition_fn="edm"), make(cond=True)).eval()
+    with torch.inference_mode(), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        arrs["cfg_edm_g2_sample_N6"] = cmod2.sample(2, [1, 32, 32], y=y, guidance=2.0, nsteps=6, orig_noise=noise)
+    npz("si8", **arrs)
+
+
 def porosity():
     """BASELINE config 5's shape of the path: 4-channel conditional PUNetG with the in-repo dict-style
     PorosityEmbedder (nets/embedder.py:198-229), classifier-free guidance, un-batched dict y."""
@@ -420,6 +466,6 @@ def adm():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["schedule", "toy", "punetg", "porosity", "inpaint", "vpve", "circular", "adm"]
+    which = sys.argv[1:] or ["schedule", "toy", "punetg", "porosity", "inpaint", "vpve", "circular", "si", "adm"]
     for name in which:
         globals()[name]()

@@ -322,3 +322,38 @@ def test_adm_circular_convolutions():
     cfg = adm_ref.default_config(model_channels=8, time_embed_dim=8, output_embed_dim=16, convolution_type="circular")
     with torch.inference_mode():
         assert_exact_or_rel(adm_ref.adm_forward(sd, cfg, v["x"], v["t"]), v["out_f32"], "ADM circular", 2e-6)
+
+
+def _si_cases():
+    return (("linear_identity", "linear", "identity", None), ("edm_edm", "edm", "edm", None),
+            ("cosine_edm_norm2", "cosine", "edm", 2.0))
+
+
+def test_si_flow_matching_sampler():
+    """SIModule sampling (three interpolants, identity / EDM parameterisation, CFG)."""
+    from oracle import si_ref as S
+    v, _ = load("si8")
+    _, sd = load("punetg8_forward")
+    vc, _ = load("punetg8_cfg")
+    cfg = punetg_ref.default_config(model_channels=8)
+    base = punetg_ref.make_net(sd, cfg)
+    model = lambda x, t, y=None: base(x, t, y)                                  # noqa: E731
+    W = vc["emb_weight"]
+    cbase = punetg_ref.make_net(sd, cfg, embed=lambda y: W[y])
+    cmodel = lambda x, t, y=None: cbase(x, t, y)                                # noqa: E731
+    noise = v["noise"]
+    ts = torch.linspace(1, 0, 6)
+    with torch.inference_mode():
+        for tag, sname, kind, ns in _si_cases():
+            sch = S.scheduler(sname)
+            assert_exact_or_rel(S.sample(sch, kind, model, noise, 6, norm_sigma=ns), v[f"{tag}_sample_N6"], tag, 2e-6)
+            h = S.integrate(sch, kind, model, noise * sch["sigma"](ts[0]), ts, return_history=True)
+            assert_exact_or_rel(h if ns is None else h * ns, v[f"{tag}_hist_N6"], tag + " history", 2e-6)
+            tt = torch.tensor([0.4, 0.4])
+            assert_exact_or_rel(S.flow_field(sch, kind, model, noise, tt), v[f"{tag}_flow"], tag + " flow", 2e-6)
+            assert_exact_or_rel(S.score_field(sch, kind, model, noise, tt), v[f"{tag}_score"], tag + " score", 2e-6)
+        y = v["cfg_y"].unsqueeze(0)
+        lin, edm = S.scheduler("linear"), S.scheduler("edm")
+        assert_exact_or_rel(S.sample(lin, "identity", cmodel, noise, 6, y=y, guidance=2.0), v["cfg_g2_sample_N6"], "cfg g2", 2e-6)
+        assert_exact_or_rel(S.sample(lin, "identity", cmodel, noise, 6, y=y, guidance=1.0), v["cfg_g1_sample_N6"], "cfg g1", 2e-6)
+        assert_exact_or_rel(S.sample(edm, "edm", cmodel, noise, 6, y=y, guidance=2.0), v["cfg_edm_g2_sample_N6"], "cfg edm", 2e-6)
