@@ -60,6 +60,7 @@ _PROTOS = {
     "ds_conv1x1_h3_pack_weights": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     "ds_conv1x1_h3": (c_int, [_P, _P, _P, c_int, _P, _P, c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "ds_attention": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
+    "ds_attention_generic": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     "ds_attention_h3": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     "ds_linear": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "ds_fourier_features": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P]),

@@ -82,3 +82,60 @@ int ds_fourier_features(float* out, const float* t, const float* W, const float*
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// Generic single-head attention for sequence lengths the MFMA kernels do not take (L not a multiple
+// of 32: odd or tiny bottlenecks such as 4x4 or 5x7).  One wave per (sample, query), exact fp32 FMA
+// chains, softmax in fp32 -- a correctness path: these shapes are a few thousand MACs per query.
+//   qkv [B, 3E, L] channel-major, out [B, E, L]   (same contract as ds_attention)
+namespace {
+
+__global__ __launch_bounds__(64) void k_attn_generic(float* out, const float* __restrict__ qkv, int E, int L, float scale) {
+  extern __shared__ float sm[];            // [E] scaled query, then [L] probabilities
+  float* qs = sm;
+  float* ps = sm + E;
+  const int q = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+  const float* Qt = qkv + (size_t)b * 3 * E * L;
+  const float* Kt = Qt + (size_t)E * L;
+  const float* Vt = Kt + (size_t)E * L;
+  for (int d = lane; d < E; d += 64) qs[d] = Qt[(size_t)d * L + q] * scale;
+  __syncthreads();
+  float mx = -INFINITY;
+  for (int k = lane; k < L; k += 64) {
+    float s = 0.f;
+    for (int d = 0; d < E; ++d) s = fmaf(qs[d], Kt[(size_t)d * L + k], s);
+    ps[k] = s;
+    mx = fmaxf(mx, s);
+  }
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  float sum = 0.f;
+  for (int k = lane; k < L; k += 64) {
+    const float p = expf(ps[k] - mx);
+    ps[k] = p;
+    sum += p;
+  }
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+  __syncthreads();
+  const float inv = 1.0f / sum;
+  for (int d = lane; d < E; d += 64) {
+    const float* v = Vt + (size_t)d * L;
+    float acc = 0.f;
+    for (int k = 0; k < L; ++k) acc = fmaf(ps[k], v[k], acc);
+    out[((size_t)b * E + d) * L + q] = acc * inv;
+  }
+}
+
+}  // namespace
+
+extern "C" int ds_attention_generic(float* out, const float* qkv, int B, int E, int L, void* stream) {
+  DS_REQUIRE(out && qkv, DS_ERR_NULL, "ds_attention_generic: NULL pointer");
+  DS_REQUIRE(B >= 0 && E > 0 && L > 0, DS_ERR_SHAPE, "ds_attention_generic: bad shape B=%d E=%d L=%d", B, E, L);
+  DS_REQUIRE(B < 65536, DS_ERR_SHAPE, "ds_attention_generic: B=%d exceeds grid.y", B);
+  const size_t lds = (size_t)(E + L) * sizeof(float);
+  DS_REQUIRE(lds <= 64 * 1024, DS_ERR_UNSUPPORTED, "ds_attention_generic: E + L = %d is too large for the generic path", E + L);
+  if (B == 0) return DS_OK;
+  const float scale = (float)sqrt(1.0 / (double)E);
+  hipLaunchKernelGGL(k_attn_generic, dim3(L, B), dim3(64), lds, ds::as_stream(stream), out, qkv, E, L, scale);
+  DS_CHECK_LAUNCH("ds_attention_generic");
+  return DS_OK;
+}

@@ -397,7 +397,9 @@ def attention(qkv, E, out=None, precision="fp32"):
         raise ValueError("qkv must be [B, 3E, L]")
     if out is None:
         out = torch.empty((B, E, L), dtype=torch.float32, device=qkv.device)
-    if precision == "fp16x3" and E <= 256:
+    if L % 32 != 0 or E not in (32, 64, 128, 256, 384, 512):
+        N.check(N.lib().ds_attention_generic(_p(out), _p(qkv), B, E, L, _stream()), "ds_attention_generic")
+    elif precision == "fp16x3" and E <= 256:
         N.check(N.lib().ds_attention_h3(_p(out), _p(qkv), B, E, L, _stream()), "ds_attention_h3")
     else:
         N.check(N.lib().ds_attention(_p(out), _p(qkv), B, E, L, _stream()), "ds_attention")

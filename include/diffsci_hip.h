@@ -220,6 +220,10 @@ int ds_conv1x1_h3(float* out, const float* in, const void* w_packed, int wshift,
  * nn.MultiheadAttention(E, num_heads=1) core, attention.py:41-43,67.  L a multiple of 32; E in {32, 64, 128, 256, 384, 512}. */
 int ds_attention(float* out, const float* qkv, int B, int E, int L, void* stream);
 
+/* The same contract for any E and L (one wave per query, exact fp32 FMA chains): the path for sequence
+ * lengths that are not a multiple of 32 (tiny or odd bottlenecks, e.g. the reference's own 16x16 ADM test). */
+int ds_attention_generic(float* out, const float* qkv, int B, int E, int L, void* stream);
+
 /* The same attention with both matrix products on the fp16 matrix cores in the fp16x3 scheme of
  * ds_conv2d_h3 (operands split into fp16 hi + lo, three products, fp32 accumulation and fp32
  * softmax statistics): fp32-level accuracy for |q|, |k|, |v| < 65504. Same layouts; E <= 256. */

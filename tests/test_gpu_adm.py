@@ -173,3 +173,18 @@ def test_adm_circular_convolutions(M, dev):
     for fuse in (False, True):
         net.fuse_norm = fuse
         assert rel_l2(net(v["x"].to(dev), v["t"].to(dev)).cpu(), v["out_f32"]) < REL
+
+
+def test_reference_adm_test_shape(M, dev):
+    """The reference's own ADM test (tests/test_adm.py): default ADM(skip='add') on [4, 1, 16, 16] -- the
+    middle-block attention then runs over 4 x 4 = 16 positions (generic attention path), 16 x 16 tiles."""
+    torch.manual_seed(5)
+    net = M.ADM(M.ADMConfig(skip_integration_type="add"))
+    sd = {k: w.clone() for k, w in net.state_dict().items()}
+    x, t = torch.randn(4, 1, 16, 16), torch.rand(4)
+    cfg = adm_ref.default_config(skip_integration_type="add")
+    with torch.inference_mode():
+        want = adm_ref.adm_forward(sd, cfg, x, t)
+    got = net.to(dev)(x.to(dev), t.to(dev)).cpu()
+    assert got.shape == x.shape
+    assert rel_l2(got, want) < REL
