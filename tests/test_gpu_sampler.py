@@ -558,3 +558,22 @@ def test_si_flow_matching_sampler(M, dev):
 def ops_scale(x, s):
     from diffsci_amd import ops
     return ops.scale(x.contiguous(), s)
+
+
+def test_reference_punetg_test_shape(M, dev):
+    """The reference's own tests/test_punetg.py: PUNetG(model_channels=4) on [16, 1, 32, 32] (attention with
+    E = 16: generic attention path; 4/8/16-channel convolutions: one ragged 16-channel chunk)."""
+    torch.manual_seed(4)
+    cfg = punetg_ref.default_config(model_channels=4)
+    sd = punetg_ref.random_state_dict(cfg, seed=11)
+    net = M.PUNetG(M.PUNetGConfig(model_channels=4))
+    net.load_state_dict(sd)
+    net = net.to(dev)
+    x, t = torch.randn(16, 1, 32, 32), torch.rand(16)
+    with torch.inference_mode():
+        want = punetg_ref.punetg_forward(sd, cfg, x, t)
+    pk = net.packed_weights()
+    assert net._conv(net.convin, x.to(dev), pk).shape == (16, 4, 32, 32)
+    assert net.embed_time(t.to(dev)).shape == (16, 4)
+    got = net(x.to(dev), t.to(dev)).cpu()
+    assert got.shape == x.shape and rel_l2(got, want) < REL
