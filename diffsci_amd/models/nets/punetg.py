@@ -45,9 +45,9 @@ class _TimeBlock(torch.nn.Module):
 class _CircConv(torch.nn.Module):
     """CircularConv2d parameters (commonlayers.py:918-971): the weights live one level down, in .conv."""
 
-    def __init__(self, cin, cout, k):
+    def __init__(self, cin, cout, k, bias=True):
         super().__init__()
-        self.conv = torch.nn.Conv2d(cin, cout, k)
+        self.conv = torch.nn.Conv2d(cin, cout, k, bias=bias)
         self.in_channels, self.out_channels = cin, cout
 
     @property
@@ -59,26 +59,26 @@ class _CircConv(torch.nn.Module):
         return self.conv.bias
 
 
-def make_conv(cin, cout, k, circular):
-    return _CircConv(cin, cout, k) if circular else torch.nn.Conv2d(cin, cout, k, padding="same")
+def make_conv(cin, cout, k, circular, bias=True):
+    return _CircConv(cin, cout, k, bias) if circular else torch.nn.Conv2d(cin, cout, k, padding="same", bias=bias)
 
 
 class _ResBlock(torch.nn.Module):
     """ResnetBlockC parameters (commonlayers.py:766-807)."""
 
-    def __init__(self, C, embed, circular=False):
+    def __init__(self, C, embed, circular=False, bias=True):
         super().__init__()
         self.gnorm1 = torch.nn.GroupNorm(C, C)
         self.gnorm2 = _AffineHolder(C)
-        self.conv1 = make_conv(C, C, 3, circular)
-        self.conv2 = make_conv(C, C, 3, circular)
+        self.conv1 = make_conv(C, C, 3, circular, bias)
+        self.conv2 = make_conv(C, C, 3, circular, bias)
         self.timeblock = _TimeBlock(embed, C)
 
 
 class _Sampler(torch.nn.Module):
-    def __init__(self, cin, cout, circular=False):
+    def __init__(self, cin, cout, circular=False, bias=True):
         super().__init__()
-        self.conv = make_conv(cin, cout, 3, circular)
+        self.conv = make_conv(cin, cout, 3, circular, bias)
 
 
 class _Attn(torch.nn.Module):
@@ -134,21 +134,23 @@ class PUNetG(torch.nn.Module):
         self.time_projection = _Fourier(mc, config.time_projection_scale)
         self.conditional_embedding = conditional_embedding
         circ = self.circular = config.convolution_type == "circular"
-        self.convin = make_conv(config.input_channels, mc, 3, circ)
-        self.convout = make_conv(mc, config.output_channels, 3, circ)
+        hb = bool(config.bias)
+        # bias=False: no convolution biases; a constant-one input channel is appended instead (punetg.py:190-191,390-394)
+        self.convin = make_conv(config.input_channels + (0 if hb else 1), mc, 3, circ, hb)
+        self.convout = make_conv(mc, config.output_channels, 3, circ, hb)
 
         def blocks(m, n):
-            return torch.nn.ModuleList([_ResBlock(m * mc, mc, circ) for _ in range(n)])
+            return torch.nn.ModuleList([_ResBlock(m * mc, mc, circ, hb) for _ in range(n)])
 
         self.downward_blocks = torch.nn.ModuleList(
             [blocks(mult[i], config.number_resnet_downward_block) for i in range(len(mult) - 1)])
         self.downsamplers = torch.nn.ModuleList(
-            [_Sampler(mult[i] * mc, mult[i + 1] * mc, circ) for i in range(len(mult) - 1)])
+            [_Sampler(mult[i] * mc, mult[i + 1] * mc, circ, hb) for i in range(len(mult) - 1)])
         rmult = list(reversed(mult))
         self.upward_blocks = torch.nn.ModuleList(
             [blocks(rmult[i + 1], config.number_resnet_upward_block) for i in range(len(mult) - 1)])
         self.upsamplers = torch.nn.ModuleList(
-            [_Sampler(rmult[i] * mc, rmult[i + 1] * mc, circ) for i in range(len(mult) - 1)])
+            [_Sampler(rmult[i] * mc, rmult[i + 1] * mc, circ, hb) for i in range(len(mult) - 1)])
         self.before_block = blocks(mult[-1], config.number_resnet_before_attn_block)
         self.after_block = blocks(mult[-1], config.number_resnet_after_attn_block)
         self.attn_resnet_block = blocks(mult[-1], config.number_resnet_attn_block)
@@ -324,8 +326,17 @@ class PUNetG(torch.nn.Module):
                 ws.give(ts)
 
         H, W = x.shape[2:]
+        xe = None
+        if not cfg.bias:                                                         # punetg.py:390-394
+            ones = ws.take((B, 1, H, W), dev)
+            ones.fill_(1.0)
+            xe = ops.concat2(x, ones, out=ws.take((B, x.shape[1] + 1, H, W), dev))
+            ws.give(ones)
+            x = xe
         hs = self._stats_buf(ws, B, cfg.model_channels, H, W, dev)
         h = self._conv(self.convin, x, pk, tile_stats=hs, out=ws.take((B, cfg.model_channels, H, W), dev))
+        if xe is not None:
+            ws.give(xe)
         skips = []
         for lv, blocks in enumerate(self.downward_blocks):                      # punetg.py:356-365
             for blk in blocks:

@@ -54,8 +54,8 @@ def conv3x3(sd, name, x, circular=False):
     if circular:
         x = F.pad(x, (1, 1, 0, 0), mode="circular")
         x = F.pad(x, (0, 0, 1, 1), mode="circular")
-        return F.conv2d(x, sd[name + ".conv.weight"], sd[name + ".conv.bias"])
-    return F.conv2d(x, sd[name + ".weight"], sd[name + ".bias"], padding="same")
+        return F.conv2d(x, sd[name + ".conv.weight"], sd.get(name + ".conv.bias"))
+    return F.conv2d(x, sd[name + ".weight"], sd.get(name + ".bias"), padding="same")      # bias=False: no bias keys
 
 
 def time_shift(sd, prefix, te):
@@ -99,6 +99,10 @@ def punetg_forward(sd, cfg, x, t, ye=None):
     (conditional_embedding(y), shape [B or 1, model_channels]) or None."""
     nlev = len(cfg["channel_expansion"])
     circ = cfg.get("convolution_type", "default") == "circular"
+    if not cfg.get("bias", True):                                    # punetg.py:390-394: constant-one input channel
+        xe_shape = list(x.shape)
+        xe_shape[1] = 1
+        x = torch.cat([x, torch.ones(xe_shape).to(x)], dim=1)
     x = conv3x3(sd, "convin", x, circ)
     te = fourier_features(t, sd["time_projection.W"])
     if ye is not None:

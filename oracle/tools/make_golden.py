@@ -338,6 +338,15 @@ def circular():
     arrs["white_noise"] = wn
     arrs["hist_heun_N6_f32"] = module.propagate_white_noise(wn, nsteps=6, record_history=True)
     npz("punetg8_circular", **arrs)
+    # bias=False: no convolution biases, a constant-one channel appended to the input (punetg.py:390-394)
+    torch.manual_seed(53)
+    bnet = M.nets.PUNetG(M.nets.PUNetGConfig(model_channels=8, bias=False)).eval()
+    with torch.no_grad():
+        for k, v in bnet.state_dict().items():
+            if "gnorm" in k:
+                v.add_(0.25 * torch.randn_like(v))
+    with torch.inference_mode():
+        npz("punetg8_nobias", **dict(sd_arrays(bnet.state_dict()), x=x, t=t, out_f32=bnet(x, t)))
     # ADM: the blocks' convolutions become circular, input / output layers stay zero padded
     torch.manual_seed(52)
     acfg = M.nets.ADMConfig(model_channels=8, time_embed_dim=8, output_embed_dim=16, convolution_type="circular")

@@ -577,3 +577,19 @@ def test_reference_punetg_test_shape(M, dev):
     assert net.embed_time(t.to(dev)).shape == (16, 4)
     got = net(x.to(dev), t.to(dev)).cpu()
     assert got.shape == x.shape and rel_l2(got, want) < REL
+
+
+def test_punetg_without_biases(M, dev):
+    """PUNetGConfig(bias=False): bias-free convolutions and a constant-one input channel (punetg.py:390-394)."""
+    v, sd = load("punetg8_nobias")
+    net = M.PUNetG(M.PUNetGConfig(model_channels=8, bias=False))
+    r = net.load_state_dict(sd, strict=True)
+    assert not r.missing_keys and not r.unexpected_keys
+    net = net.to(dev)
+    for fuse in (True, False):
+        net.fuse_norm = fuse
+        assert rel_l2(net(v["x"].to(dev), v["t"].to(dev)).cpu(), v["out_f32"]) < REL
+    module = M.KarrasModule(net, M.KarrasModuleConfig.from_edm())
+    a = module.propagate_white_noise(v["x"].to(dev), nsteps=3)
+    module.use_graph = False
+    assert torch.equal(a, module.propagate_white_noise(v["x"].to(dev), nsteps=3))

@@ -357,3 +357,11 @@ def test_si_flow_matching_sampler():
         assert_exact_or_rel(S.sample(lin, "identity", cmodel, noise, 6, y=y, guidance=2.0), v["cfg_g2_sample_N6"], "cfg g2", 2e-6)
         assert_exact_or_rel(S.sample(lin, "identity", cmodel, noise, 6, y=y, guidance=1.0), v["cfg_g1_sample_N6"], "cfg g1", 2e-6)
         assert_exact_or_rel(S.sample(edm, "edm", cmodel, noise, 6, y=y, guidance=2.0), v["cfg_edm_g2_sample_N6"], "cfg edm", 2e-6)
+
+
+def test_punetg_without_biases():
+    v, sd = load("punetg8_nobias")
+    assert not any(k.endswith("conv1.bias") or k.startswith("convin.bias") for k in sd)
+    cfg = punetg_ref.default_config(model_channels=8, bias=False)
+    with torch.inference_mode():
+        assert_exact_or_rel(punetg_ref.punetg_forward(sd, cfg, v["x"], v["t"]), v["out_f32"], "bias=False", 2e-6)
