@@ -41,7 +41,9 @@ __global__ __launch_bounds__(NT) void k_conv_direct(float* out, const float* __r
   for (int c0 = 0; c0 < Cin; c0 += KCH) {
     const int nch = Cin - c0 < KCH ? Cin - c0 : KCH;
     __syncthreads();                                   // previous chunk fully consumed
-    // staging: thread -> (column tid % 64 [and the two halo columns 64, 65 for tid % 64 < 2], rows tid/64 + 4k)
+    // staging: thread -> (column tid % 64 [and the two halo columns 64, 65 for tid % 64 < 2], rows tid/64 + 4k).
+    // All loads of the chunk are issued before the first LDS write (40 + 10 in flight per thread): issued one
+    // at a time the kernel was latency-bound at 4x the time of the MFMA path it replaces.
     {
       const int col = tid & 63, r0 = tid >> 6;
       int gx0 = x0 + col - 1, gx1 = x0 + 64 + col - 1;
@@ -49,16 +51,33 @@ __global__ __launch_bounds__(NT) void k_conv_direct(float* out, const float* __r
         gx0 = (gx0 < 0 ? gx0 + W : gx0) % W;
         gx1 = gx1 % W;
       }
-      const bool okx0 = gx0 >= 0 && gx0 < W, okx1 = col < 2 && gx1 < W;
-      for (int r = r0; r < PH; r += 4) {
+      const bool okx0 = gx0 >= 0 && gx0 < W, okx1 = col < 2 && gx1 >= 0 && gx1 < W;
+      constexpr int NR = (PH + 3) / 4;                                  // 5 row slots per thread
+      float v0[NR][KCH], v1[NR][KCH];
+#pragma unroll
+      for (int k = 0; k < NR; ++k) {
+        const int r = r0 + 4 * k;
         int gy = y0 + r - 1;
         if (circular) gy = (gy < 0 ? gy + H : gy) % H;
-        const bool oky = gy >= 0 && gy < H;
+        const bool oky = r < PH && gy >= 0 && gy < H;
         const float* src = in_b + (size_t)c0 * HW + (size_t)(oky ? gy : 0) * W;
-        for (int ch = 0; ch < nch; ++ch) {
-          float* dst = &patch[ch * PATCH + r * PSTR];
-          dst[col] = (oky && okx0) ? src[(size_t)ch * HW + gx0] : 0.f;
-          if (col < 2) dst[64 + col] = (oky && okx1) ? src[(size_t)ch * HW + gx1] : 0.f;
+#pragma unroll
+        for (int ch = 0; ch < KCH; ++ch) {
+          const bool okc = ch < nch;
+          v0[k][ch] = (oky && okx0 && okc) ? src[(size_t)ch * HW + gx0] : 0.f;
+          v1[k][ch] = (oky && okx1 && okc) ? src[(size_t)ch * HW + gx1] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < NR; ++k) {
+        const int r = r0 + 4 * k;
+        if (r < PH) {
+#pragma unroll
+          for (int ch = 0; ch < KCH; ++ch) {
+            float* dst = &patch[ch * PATCH + r * PSTR];
+            dst[col] = v0[k][ch];
+            if (col < 2) dst[64 + col] = v1[k][ch];
+          }
         }
       }
     }
