@@ -120,8 +120,8 @@ def dominant_kernel_roofline(module, args, dev, reps=40):
     if fused:
         for m, cin, cout, s in launches:
             if (cin, s) not in tabs:
-                t = torch.zeros(B, cin, 4, device=dev)
-                t[..., 1] = 1.0                       # (M, A, C) = (0, 1, 0): the loader computes SiLU(x)
+                t = torch.zeros(B, ops.table_channels(cin), 4, device=dev)
+                t[:, :cin, 1] = 1.0                       # (M, A, C) = (0, 1, 0): the loader computes SiLU(x)
                 tabs[(cin, s)] = t
             stats[(cout, s)] = torch.empty(B, cout, ops.conv_tile_count(s, s), 4, device=dev)
 

@@ -68,7 +68,7 @@ struct Conv3hArgs {
   const float* shift;
   const float* res1;
   const float* res2;
-  const float* prenorm;   // [B][Cin][4] = (M, A, C, -) or NULL: the loader applies SiLU((x - M)*A + C)
+  const float* prenorm;   // [B][ceil16(Cin)][4] = (M, A, C, -), zero rows past Cin, or NULL: the loader applies SiLU((x - M)*A + C)
   float* tile_stats;      // see ds_conv_epilogue.h, or NULL
   float unscale;        // 2^-wshift
   int shift_stride;
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(NT, 2) void k_conv3h(const Conv3hArgs a) {
       if (MODE == DS_LOAD_MAXPOOL2) __builtin_amdgcn_sched_barrier(0);   // one item at a time (registers)
     }
   };
-  const float* pre_b = PRE ? a.prenorm + (size_t)b * a.Cin * 4 : nullptr;
+  const float* pre_b = PRE ? a.prenorm + (size_t)b * a.n_chunks * KC * 4 : nullptr;   // [B][n_chunks*16][4]
   // PRE: normalise + SiLU one staging item in registers, right before its fp16 split.  (Slotting this
   // VALU / transcendental work between the MFMAs of the same wave was measured 2-3 % SLOWER than
   // leaving it in one block: the co-resident workgroup's waves already fill the matrix pipe then.)
@@ -208,12 +208,13 @@ __global__ __launch_bounds__(NT, 2) void k_conv3h(const Conv3hArgs a) {
     typedef const __attribute__((address_space(4))) f32x4* cptr;
     cptr pp = (cptr)(reinterpret_cast<const f32x4*>(pre_b) + xchunk * KC);
     const int h = i == 0 ? 0 : (i == 1 ? 1 : tail_h);
+    // the table is padded to whole 16-channel chunks (zeros), so the 8 rows of this item are one contiguous
+    // 128-byte scalar load: one s_load + one wait per item instead of one dependent round trip per channel pair
+    f32x4 p[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int c = 8 * h + k < xnch ? 8 * h + k : 0;                         // ragged last chunk: stay inside the table
-      const f32x4 p = pp[c];
-      xr[i][k] = fast_silu((xr[i][k] - p[0]) * p[1] + p[2]);
-    }
+    for (int k = 0; k < 8; ++k) p[k] = pp[8 * h + k];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) xr[i][k] = fast_silu((xr[i][k] - p[k][0]) * p[k][1] + p[k][2]);
   };
   auto x_store = [&](int buf) __attribute__((always_inline)) {                       // [normalise + SiLU,] split to fp16 pieces, write the LDS image
     u32x4* xb = Xs + buf * XBUF_VEC;

@@ -2,7 +2,7 @@
 // convolution's epilogue leaves per-(sample, channel, pixel tile) shifted partial sums (`tile_stats`:
 // float4 (K, S = sum(x-K), Q = sum((x-K)^2), n), ds_conv_epilogue.h); the tiny kernels here
 // recombine them in fp64 (sum x = nK + S, sum x^2 = Q + 2KS + nK^2), in a fixed order, to the table
-//   table[b][c] = (M, A, C, 0)   with   activation(x) = SiLU((x - M) * A + C)
+//   table[b][c] = (M, A, C, 0)   with   activation(x) = SiLU((x - M) * A + C)     (c < ceil16(C); zero rows past C)
 // that the next convolution's loader applies while it stages its input -- the normalised tensor is
 // never written to or read from HBM.
 //   ds_inorm_table   PUNetG: GroupNorm(C,C) / GroupRMSNorm(C,C) per (sample, channel) plane
@@ -28,19 +28,23 @@ __device__ __forceinline__ void acc_tile(const float4 v, double& s, double& q) {
 
 // 16 lanes per (b, c) plane
 __global__ __launch_bounds__(256) void k_inorm_table(float* table, const float* __restrict__ ts, const float* __restrict__ w,
-                                                     const float* __restrict__ bias, int planes, int C, int ntiles,
+                                                     const float* __restrict__ bias, int planes, int C, int Cpad, int ntiles,
                                                      double inv_n, float eps, int kind) {
-  const int plane = blockIdx.x * 16 + (threadIdx.x >> 4);
+  // planes = B * Cpad table rows; rows with c >= C are the zero padding of the last 16-channel chunk
+  const int row = blockIdx.x * 16 + (threadIdx.x >> 4);
   const int l = threadIdx.x & 15;
+  const int bb = row / Cpad, c = row - bb * Cpad;
+  const bool real = row < planes && c < C;
+  const int plane = bb * C + c;
   double s = 0.0, q = 0.0;
-  if (plane < planes) {
+  if (real) {
     const float4* p = reinterpret_cast<const float4*>(ts) + (size_t)plane * ntiles;
     for (int t = l; t < ntiles; t += 16) acc_tile(p[t], s, q);
   }
   s = group_sum_d(s, 16);
   q = group_sum_d(q, 16);
-  if (plane < planes && l == 0) {
-    const int c = plane % C;
+  if (row < planes && !real && l == 0) reinterpret_cast<float4*>(table)[row] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (real && l == 0) {
     float M, rs;
     if (kind == 0) {
       const double mean = s * inv_n;
@@ -54,7 +58,7 @@ __global__ __launch_bounds__(256) void k_inorm_table(float* table, const float* 
     }
     float4 o;
     o.x = M; o.y = rs * (w ? w[c] : 1.f); o.z = bias ? bias[c] : 0.f; o.w = 0.f;
-    reinterpret_cast<float4*>(table)[plane] = o;
+    reinterpret_cast<float4*>(table)[row] = o;
   }
 }
 
@@ -96,6 +100,8 @@ __global__ __launch_bounds__(256) void k_gnorm1_table(float* table, const float*
   }
   __syncthreads();
   const float M = st[0], rs = st[1];
+  const int Cpad = (C + 15) / 16 * 16;
+  for (int c = C + threadIdx.x; c < Cpad; c += 256) reinterpret_cast<float4*>(table)[(size_t)b * Cpad + c] = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int c = threadIdx.x; c < C; c += 256) {
     const float wc = w ? w[c] : 1.f, bc = bias ? bias[c] : 0.f;
     float4 o;
@@ -106,7 +112,7 @@ __global__ __launch_bounds__(256) void k_gnorm1_table(float* table, const float*
       o.x = 0.f; o.y = rs * wc * t1; o.z = bc * t1 + t2;
     }
     o.w = 0.f;
-    reinterpret_cast<float4*>(table)[(size_t)b * C + c] = o;
+    reinterpret_cast<float4*>(table)[(size_t)b * Cpad + c] = o;
   }
 }
 
@@ -123,9 +129,10 @@ int ds_inorm_table(float* table, const float* tile_stats, const float* w, const 
   DS_REQUIRE((reinterpret_cast<uintptr_t>(table) & 15u) == 0 && (reinterpret_cast<uintptr_t>(tile_stats) & 15u) == 0,
              DS_ERR_SHAPE, "ds_inorm_table: misaligned pointer");
   if (B == 0) return DS_OK;
-  const int planes = B * C;
+  const int Cpad = (C + 15) / 16 * 16;
+  const int planes = B * Cpad;
   hipLaunchKernelGGL(k_inorm_table, dim3((planes + 15) / 16), dim3(256), 0, ds::as_stream(stream), table, tile_stats, w,
-                     b, planes, C, ntiles, 1.0 / (double)count, eps, kind);
+                     b, planes, C, Cpad, ntiles, 1.0 / (double)count, eps, kind);
   DS_CHECK_LAUNCH("ds_inorm_table");
   return DS_OK;
 }

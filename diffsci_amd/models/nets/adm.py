@@ -282,7 +282,7 @@ class ADM(torch.nn.Module):
         # first_block: norm1 -> act -> resample -> conv1                          (adm.py:312-323)
         if fused and xs is not None and not down:
             sa, sb = xs if isinstance(xs, tuple) else (xs, None)
-            tab = ws.take((B, Ci, 4), dev)
+            tab = ws.take((B, ops.table_channels(Ci), 4), dev)
             ops.gnorm1_table(sa, blk.norm1.weight, blk.norm1.bias, 0, Ci * H * W, stats_b=sb, eps=blk.norm1.eps, out=tab)
             y = self._conv(blk.conv1, x, pk, load_mode=mode, prenorm=tab, tile_stats=ys,
                            out=ws.take((B, blk.cout, Ho, Wo), dev))
@@ -311,7 +311,7 @@ class ADM(torch.nn.Module):
         has_attn = hasattr(blk, "attn")
         os_ = self._stats_buf(ws, B, blk.cout, Ho, Wo, dev) if (want_stats and not has_attn) else None
         if fused:
-            tab = ws.take((B, blk.cout, 4), dev)
+            tab = ws.take((B, ops.table_channels(blk.cout), 4), dev)
             ops.gnorm1_table(ys, blk.norm2.weight, blk.norm2.bias, 1, blk.cout * Ho * Wo, film=film, eps=1e-5, out=tab)
             out = self._conv(blk.conv2, y, pk, res1=r, prenorm=tab, tile_stats=os_, out=ws.take((B, blk.cout, Ho, Wo), dev))
             ws.give(tab)

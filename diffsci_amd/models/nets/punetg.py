@@ -281,7 +281,7 @@ class PUNetG(torch.nn.Module):
         B, C, H, W = x.shape
         dev = x.device
         if self._fused() and xs is not None:
-            tab = ws.take((B, C, 4), dev)
+            tab = ws.take((B, ops.table_channels(C), 4), dev)
             ops.inorm_table(xs, blk.gnorm1.weight, blk.gnorm1.bias, 0, H * W, eps=blk.gnorm1.eps, out=tab)
             ys = self._stats_buf(ws, B, C, H, W, dev)
             y = self._conv(blk.conv1, x, pk, shift=shift, prenorm=tab, tile_stats=ys, out=ws.take(x.shape, dev))

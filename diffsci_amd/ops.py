@@ -297,23 +297,32 @@ def conv_tile_count(H, W):
     return N.lib().ds_conv_tile_count(int(H), int(W))
 
 
+def table_channels(C):
+    """Rows per sample of a prenorm table: channels padded to whole 16-channel chunks."""
+    return (C + 15) // 16 * 16
+
+
 def inorm_table(tile_stats, w, b, kind, count, eps=1e-5, out=None):
-    """PUNetG norm table [B, C, 4] from a convolution's tile statistics [B, C, ntiles, 4]."""
+    """PUNetG norm table [B, ceil16(C), 4] from a convolution's tile statistics [B, C, ntiles, 4]."""
     B, C, nt, _ = tile_stats.shape
     if out is None:
-        out = torch.empty((B, C, 4), dtype=torch.float32, device=tile_stats.device)
+        out = torch.empty((B, table_channels(C), 4), dtype=torch.float32, device=tile_stats.device)
+    elif tuple(out.shape) != (B, table_channels(C), 4):
+        raise ValueError(f"table must be {(B, table_channels(C), 4)}")
     N.check(N.lib().ds_inorm_table(_p(out), _p(tile_stats), _p(w), _p(b), B, C, nt, int(count), float(eps), int(kind),
                                    _stream()), "ds_inorm_table")
     return out
 
 
 def gnorm1_table(stats_a, w, b, kind, count, stats_b=None, film=None, eps=1e-5, out=None):
-    """ADM norm table [B, Ca+Cb, 4] from tile statistics of one tensor or of the two halves of a concat."""
+    """ADM norm table [B, ceil16(Ca+Cb), 4] from tile statistics of one tensor or of the two halves of a concat."""
     B, Ca, nta, _ = stats_a.shape
     Cb, ntb = (0, 0) if stats_b is None else (stats_b.shape[1], stats_b.shape[2])
     C = Ca + Cb
     if out is None:
-        out = torch.empty((B, C, 4), dtype=torch.float32, device=stats_a.device)
+        out = torch.empty((B, table_channels(C), 4), dtype=torch.float32, device=stats_a.device)
+    elif tuple(out.shape) != (B, table_channels(C), 4):
+        raise ValueError(f"table must be {(B, table_channels(C), 4)}")
     f1 = f2 = None
     stride = 0
     if kind == 1:
@@ -330,7 +339,7 @@ def gnorm1_table(stats_a, w, b, kind, count, stats_b=None, film=None, eps=1e-5, 
 def conv2d(x, w_packed, Cout, ks, bias=None, shift=None, res1=None, res2=None,
            load_mode=N.DS_LOAD_PLAIN, out=None, kind="fp32", wshift=0, prenorm=None, tile_stats=None, circular=False):
     """'same' zero-padded conv; x [B, Cin, Hin, Win]; shift [1 or B, Cout] or None.
-    fp16x3 kernels only: prenorm [B, Cin, 4] (3x3) applies SiLU((x-M)*A+C) in the loader; tile_stats
+    fp16x3 kernels only: prenorm [B, ceil16(Cin), 4] (3x3) applies SiLU((x-M)*A+C) in the loader; tile_stats
     [B, Cout, conv_tile_count(H, W), 4] receives per-tile (K, sum(x-K), sum((x-K)^2), n) of the output."""
     B, Cin, Hin, Win = x.shape
     if load_mode in (N.DS_LOAD_MAXPOOL2, N.DS_LOAD_AVGPOOL2):
@@ -367,8 +376,8 @@ def conv2d(x, w_packed, Cout, ks, bias=None, shift=None, res1=None, res2=None,
         raise ValueError("prenorm / tile_stats are features of the fp16x3 kernels")
     if circular and ks == 3 and kind != "fp16x3":
         raise NotImplementedError("periodic padding is implemented in the fp16x3 convolution only")
-    if prenorm is not None and (ks != 3 or tuple(prenorm.shape) != (B, Cin, 4)):
-        raise ValueError(f"prenorm must be [B, Cin, 4] on a 3x3 convolution; got {tuple(prenorm.shape)}")
+    if prenorm is not None and (ks != 3 or tuple(prenorm.shape) != (B, table_channels(Cin), 4)):
+        raise ValueError(f"prenorm must be [B, ceil16(Cin), 4] on a 3x3 convolution; got {tuple(prenorm.shape)}")
     if tile_stats is not None and tuple(tile_stats.shape) != (B, Cout, conv_tile_count(H, W), 4):
         raise ValueError(f"tile_stats must be {(B, Cout, conv_tile_count(H, W), 4)}; got {tuple(tile_stats.shape)}")
     if kind == "fp16x3" and ks == 1:

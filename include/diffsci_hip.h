@@ -175,7 +175,7 @@ int ds_conv2d_h3(float* out, const float* in, const void* w_packed, int wshift, 
                  int B, int Cin, int Cout, int H, int W, int load_mode,
                  const float* prenorm, float* tile_stats, void* stream);
 /* Two optional fusions of the normalisation around the convolution (NULL = off):
- *   prenorm    [B, Cin, 4] = (M, A, C, -): the loader applies SiLU((x - M)*A + C) to every input element
+ *   prenorm    [B, ceil16(Cin), 4] = (M, A, C, -), rows past Cin zero: the loader applies SiLU((x - M)*A + C) to every input element
  *              before the convolution (zero padding stays zero) -- the norm -> act of ResnetBlockC /
  *              ADMBaseBlock (commonlayers.py:824-829, adm.py:312-337) without materialising its output.
  *              Not with MAXPOOL2.  Tables come from ds_inorm_table / ds_gnorm1_table.
@@ -185,7 +185,7 @@ int ds_conv2d_h3(float* out, const float* in, const void* w_packed, int wshift, 
  *              which recombine the tiles in fp64.  16-byte aligned. */
 int ds_conv_tile_count(int H, int W);
 
-/* PUNetG norms from tile statistics: table[b,c] = (mean | 0, rstd*w[c], b[c], 0) for GroupNorm(C,C)
+/* PUNetG norms from tile statistics: table [B, ceil16(C), 4]; table[b,c] = (mean | 0, rstd*w[c], b[c], 0) for GroupNorm(C,C)
  * (kind 0) / GroupRMSNorm(C,C) (kind 1); count = H*W.  commonlayers.py:766-770, 372-384. */
 int ds_inorm_table(float* table, const float* tile_stats, const float* w, const float* b, int B, int C, int ntiles,
                    int count, float eps, int kind, void* stream);
