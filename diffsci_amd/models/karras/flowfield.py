@@ -20,7 +20,7 @@ import torch
 from ... import ops
 from ..._native import DS_IN_FLOW, DS_IN_NETWORK
 from .engine import Loop, ModuleSource
-from .karrasmodule import dict_to, dict_unsqueeze
+from .karrasmodule import _condition_key, dict_map, dict_to, dict_unsqueeze
 from .steptable import EvalRow, StepRow, StepTable
 
 
@@ -276,8 +276,7 @@ class SIModule(torch.nn.Module):
 
     def _run_planned(self, table, src, x, y, guidance, return_history, integrate_on_sigma, scale):
         """Capture the whole run once per (shape, schedule, guidance, condition) and replay it."""
-        ykey = None if y is None else repr({k: (tuple(v.shape), v.flatten()[:8].tolist()) for k, v in y.items()}
-                                           if isinstance(y, dict) else (tuple(y.shape), y.flatten()[:8].tolist()))
+        ykey = None if y is None else repr(dict_map(_condition_key, y))
         key = (tuple(x.shape), tuple(float(v) for v in table.t), float(guidance), ykey, bool(return_history),
                bool(integrate_on_sigma), getattr(self.model, "conv_precision", None), getattr(self.model, "fuse_norm", None))
         key = key + (str(x.device), tuple((p.data_ptr(), p._version) for p in self.model.parameters()))

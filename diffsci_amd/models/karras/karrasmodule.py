@@ -36,6 +36,14 @@ def dict_unsqueeze(d, dim):
     return dict_map(lambda x: torch.unsqueeze(x, dim), d)
 
 
+def _condition_key(t):
+    """Identity of a condition tensor for the plan cache: small tensors by value, fields by storage (the
+    captured graph reads them in place, so a different tensor means a different plan)."""
+    if t.numel() <= 64:
+        return (tuple(t.shape), t.flatten().tolist())
+    return (tuple(t.shape), t.data_ptr(), t._version)
+
+
 def dict_to(d, device):
     """diffsci/torchutils.py:85-87."""
     return dict_map(lambda x: x.to(device), d)
@@ -273,7 +281,7 @@ class KarrasModule(torch.nn.Module):
 
     def _run_planned(self, table, src, x, y, guidance, nsteps, record_history, integ, eps, scale, i0, i1):
         sch = self.config.noisescheduler
-        ykey = None if y is None else repr(dict_map(lambda t: (tuple(t.shape), t.flatten()[:8].tolist()), y))
+        ykey = None if y is None else repr(dict_map(_condition_key, y))
         key = (tuple(x.shape), str(x.device), nsteps, i0, i1, record_history, table.kind,
                (integ.s_schurn, integ.s_tmin, integ.s_tmax, integ.s_noise) if table.kind == "karras" else None,
                float(guidance), ykey, float(sch.langevin_const), repr(sch.langevin_interval),

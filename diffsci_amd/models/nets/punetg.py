@@ -414,8 +414,55 @@ class PUNetG(torch.nn.Module):
 
 
 class PUNetGCond(PUNetG):
-    def __init__(self, *a, **k):
-        raise NotImplementedError(
-            "PUNetGCond (channel-concatenated conditioning, punetg.py:719-735) is outside the HIP "
-            "path's scope; use PUNetG(config, conditional_embedding=...) as the reference's CFG "
-            "path requires (PUNetGCond cannot run the unconditional branch).")
+    """PUNetG with channel-concatenated conditioning (punetg.py:706-735): the fields y[item] for item in
+    ``channel_conditional_items`` are appended to x as input channels (config.input_channels counts them);
+    the remaining entries of y go to the conditional embedding.  Like the reference it needs y on every call,
+    so it cannot run the unconditional branch of classifier-free guidance (guidance must be 1)."""
+
+    def __init__(self, config: PUNetGConfig, conditional_embedding: torch.nn.Module | None = None,
+                 channel_conditional_items: list[str] | None = False, extra_residual: torch.nn.Module | None = None):
+        super().__init__(config, conditional_embedding, extra_residual=extra_residual)
+        self.channel_conditional_items = channel_conditional_items
+        self._ycat = None
+
+    def export_description(self) -> dict[str, Any]:
+        args = super().export_description()
+        args["channel_conditional_items"] = self.channel_conditional_items
+        return args
+
+    def _split_condition(self, y):
+        if y is None:
+            raise TypeError("PUNetGCond needs the condition dictionary y on every call (punetg.py:721-723)")
+        fields = [y[item] for item in self.channel_conditional_items]
+        rest = {k: v for k, v in y.items() if k not in self.channel_conditional_items}
+        ycat = fields[0] if len(fields) == 1 else torch.cat(fields, dim=1)
+        ops.require_device(ycat, "channel condition")
+        return (rest if len(rest) else None), ycat.to(torch.float32).contiguous()
+
+    def _with_condition(self, x, ycat, ws):
+        B = x.shape[0]
+        if ycat.shape[0] == 1 and B > 1:
+            ycat = ycat.expand(B, *ycat.shape[1:]).contiguous()
+        elif ycat.shape[0] != B:
+            raise ValueError("channel condition batch must be 1 or match x")
+        return ops.concat2(x, ycat, out=ws.take((B, x.shape[1] + ycat.shape[1]) + tuple(x.shape[2:]), x.device))
+
+    def forward(self, x, t, y=None):
+        ops.require_device(x, "x")
+        rest, self._ycat = self._split_condition(y)
+        te = self.embed_time(t.reshape(-1).to(x), PUNetG.embed_condition(self, rest))
+        return self.forward_with_shifts(x.contiguous(), self.time_shifts(te), row=None)
+
+    def embed_condition(self, y):
+        """Planned sampler entry: remember the channel fields, embed what is left of y."""
+        rest, self._ycat = self._split_condition(y)
+        return PUNetG.embed_condition(self, rest)
+
+    def forward_with_shifts(self, x, shifts, row=None, out=None):
+        if self._ycat is None:
+            raise TypeError("PUNetGCond needs the condition dictionary y on every call (punetg.py:721-723)")
+        xc = self._with_condition(x, self._ycat, self._ws)
+        try:
+            return super().forward_with_shifts(xc, shifts, row=row, out=out)
+        finally:
+            self._ws.give(xc)

@@ -216,6 +216,29 @@ def punetg():
 
 
 # ---------------------------------------------------------------- 4. ADM (config 3 family, tiny)
+def punetgcond():
+    """PUNetGCond: channel-concatenated field conditioning (punetg.py:706-735), guidance 1."""
+    torch.manual_seed(70)
+    cfg = M.nets.PUNetGConfig(model_channels=8, input_channels=3, output_channels=1)
+    net = M.nets.PUNetGCond(cfg, channel_conditional_items=["field"]).eval()
+    with torch.no_grad():
+        for k, v in net.state_dict().items():
+            if "gnorm" in k:
+                v.add_(0.25 * torch.randn_like(v))
+    torch.manual_seed(71)
+    x, t = torch.randn(2, 1, 32, 32), torch.tensor([0.2, -0.7])
+    field = torch.randn(1, 2, 32, 32)
+    arrs = dict(sd_arrays(net.state_dict()), x=x, t=t, field=field)
+    with torch.inference_mode():
+        arrs["out_f32"] = net(x, t, {"field": field})
+    module = M.KarrasModule(net, M.KarrasModuleConfig.from_edm(), conditional=True).eval()
+    wn = torch.randn(2, 1, 32, 32)
+    arrs["white_noise"] = wn
+    # un-batched y (the module unsqueezes it): [2, 32, 32]
+    arrs["hist_heun_N4_f32"] = module.propagate_white_noise(wn, y={"field": field[0]}, nsteps=4, record_history=True)
+    npz("punetg8_cond", **arrs)
+
+
 def inpaint():
     """inpaint / repaint / forward propagation / image interpolation."""
     import diffsci.data
@@ -475,6 +498,6 @@ def adm():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["schedule", "toy", "punetg", "porosity", "inpaint", "vpve", "circular", "si", "adm"]
+    which = sys.argv[1:] or ["schedule", "toy", "punetg", "porosity", "inpaint", "vpve", "circular", "si", "punetgcond", "adm"]
     for name in which:
         globals()[name]()

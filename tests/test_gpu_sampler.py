@@ -593,3 +593,30 @@ def test_punetg_without_biases(M, dev):
     a = module.propagate_white_noise(v["x"].to(dev), nsteps=3)
     module.use_graph = False
     assert torch.equal(a, module.propagate_white_noise(v["x"].to(dev), nsteps=3))
+
+
+def test_punetgcond_channel_conditioning(M, dev, grids):
+    """PUNetGCond: field conditioning by channel concatenation, eager and hipGraph; a second field reuses
+    nothing from the first one's plan."""
+    v, sd = load("punetg8_cond")
+    net = M.nets.PUNetGCond(M.PUNetGConfig(model_channels=8, input_channels=3, output_channels=1),
+                            channel_conditional_items=["field"])
+    r = net.load_state_dict(sd, strict=True)
+    assert not r.missing_keys and not r.unexpected_keys
+    net = net.to(dev)
+    out = net(v["x"].to(dev), v["t"].to(dev), {"field": v["field"].to(dev)}).cpu()
+    assert rel_l2(out, v["out_f32"]) < REL
+    module = M.KarrasModule(net, M.KarrasModuleConfig.from_edm(), conditional=True)
+    _pin_grid(module, grids)
+    wn = v["white_noise"].to(dev)
+    y = {"field": v["field"][0].to(dev)}
+    for use_graph in (False, True, True):
+        module.use_graph = use_graph
+        h = module.propagate_white_noise(wn, y=y, nsteps=4, record_history=True).cpu()
+        assert rel_l2(h, v["hist_heun_N4_f32"]) < REL
+    y2 = {"field": (v["field"][0] * 0.5).to(dev)}
+    y2["field"][0, 0, :8] = y["field"][0, 0, :8]                     # same leading values, different field
+    h2 = module.propagate_white_noise(wn, y=y2, nsteps=4, record_history=True).cpu()
+    assert rel_l2(h2, v["hist_heun_N4_f32"]) > 1e-3
+    with pytest.raises(TypeError, match="needs the condition"):
+        net(v["x"].to(dev), v["t"].to(dev))

@@ -365,3 +365,21 @@ def test_punetg_without_biases():
     cfg = punetg_ref.default_config(model_channels=8, bias=False)
     with torch.inference_mode():
         assert_exact_or_rel(punetg_ref.punetg_forward(sd, cfg, v["x"], v["t"]), v["out_f32"], "bias=False", 2e-6)
+
+
+def test_punetgcond_channel_conditioning():
+    """PUNetGCond (punetg.py:706-735): y['field'] concatenated to x as input channels."""
+    v, sd = load("punetg8_cond")
+    cfg = punetg_ref.default_config(model_channels=8, input_channels=3, output_channels=1)
+    base = punetg_ref.make_net(sd, cfg)
+
+    def net(x, t, y=None):
+        ycat = y["field"]
+        if ycat.shape[0] == 1 and x.shape[0] > 1:
+            ycat = torch.cat([ycat] * x.shape[0], dim=0)
+        return base(torch.cat([x, ycat], dim=1), t)
+    with torch.inference_mode():
+        assert_exact_or_rel(net(v["x"], v["t"], {"field": v["field"]}), v["out_f32"], "PUNetGCond forward", 2e-6)
+        h = K.propagate_white_noise(net, v["white_noise"], 4, y={"field": v["field"][0]}, guidance=1.0, conditional=True,
+                                    record_history=True)
+        assert_exact_or_rel(h, v["hist_heun_N4_f32"], "PUNetGCond trajectory", 2e-6)
