@@ -216,6 +216,21 @@ def punetg():
 
 
 # ---------------------------------------------------------------- 4. ADM (config 3 family, tiny)
+def langevin():
+    """Euler-Maruyama with the runtime knobs langevin_const / langevin_interval (schedulers.py:219-245)."""
+    import diffsci.data
+    torch.manual_seed(80)
+    gs = diffsci.data.ZeroMeanGaussianDataset(num_samples=8, shape=[2], scale=0.7)
+    sch = M.EDMScheduler()
+    sch.langevin_const = 0.6
+    sch.langevin_interval = (0.3, 25.0)
+    x = torch.randn(8, 2) * 80.0
+    with RandnRecorder() as rec:
+        h = sch.propagate_backward(x, gs.gradlogprob, 12, record_history=True, stochastic=True)
+    npz("em_interval", x=x, hist=h, eps=torch.stack(rec.draws), langevin_const=np.array(0.6),
+        langevin_interval=np.array([0.3, 25.0]))
+
+
 def punetgcond():
     """PUNetGCond: channel-concatenated field conditioning (punetg.py:706-735), guidance 1."""
     torch.manual_seed(70)
@@ -498,6 +513,6 @@ def adm():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["schedule", "toy", "punetg", "porosity", "inpaint", "vpve", "circular", "si", "punetgcond", "adm"]
+    which = sys.argv[1:] or ["schedule", "toy", "punetg", "porosity", "inpaint", "vpve", "circular", "si", "punetgcond", "langevin", "adm"]
     for name in which:
         globals()[name]()

@@ -620,3 +620,16 @@ def test_punetgcond_channel_conditioning(M, dev, grids):
     assert rel_l2(h2, v["hist_heun_N4_f32"]) > 1e-3
     with pytest.raises(TypeError, match="needs the condition"):
         net(v["x"].to(dev), v["t"].to(dev))
+
+
+def test_euler_maruyama_langevin_interval(M, dev):
+    """The runtime knobs langevin_const / langevin_interval of the stochastic sampler (schedulers.py:219-245)."""
+    v, _ = load("em_interval")
+    sch = M.EDMScheduler()
+    sch.langevin_const = float(v["langevin_const"])
+    sch.langevin_interval = tuple(float(t) for t in v["langevin_interval"])
+    h = sch.propagate_backward(v["x"].to(dev), K.gaussian_target_score(0.7), 12, record_history=True, stochastic=True,
+                               eps=v["eps"].to(dev)).cpu()
+    torch.testing.assert_close(h, v["hist"], rtol=2e-6, atol=2e-5)
+    # outside the interval no noise is injected: those steps equal the deterministic Euler update
+    assert (h[1] - v["x"]).abs().max() > 0

@@ -383,3 +383,11 @@ def test_punetgcond_channel_conditioning():
         h = K.propagate_white_noise(net, v["white_noise"], 4, y={"field": v["field"][0]}, guidance=1.0, conditional=True,
                                     record_history=True)
         assert_exact_or_rel(h, v["hist_heun_N4_f32"], "PUNetGCond trajectory", 2e-6)
+
+
+def test_euler_maruyama_langevin_interval():
+    v, _ = load("em_interval")
+    h = K.propagate_backward(v["x"], K.gaussian_target_score(0.7), 12, integrator="euler-maruyama", record_history=True,
+                             eps=v["eps"], langevin_const=float(v["langevin_const"]),
+                             langevin_interval=tuple(float(t) for t in v["langevin_interval"]))
+    assert_exact_or_ulp(h, v["hist"], "EM with a Langevin interval")
