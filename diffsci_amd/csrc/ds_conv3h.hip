@@ -124,9 +124,26 @@ __global__ __launch_bounds__(NT, 2) void k_conv3h(const Conv3hArgs a) {
 
   // grid = (channel tiles, pixel tiles, samples): no runtime integer division in the prologue except one
   // multiply-high by the precomputed reciprocal of tiles_x (exact: tile * tiles_x < 2^32)
-  const int cot = blockIdx.x;
-  const int tile_id = blockIdx.y;
-  const int b = blockIdx.z;
+  // XCD-aware tile order.  The dispatcher deals workgroups round-robin over the 8 XCDs (linear id % 8), each with
+  // its own L2; renumbering so that every XCD owns one contiguous run of (channel tile, pixel tile, sample) work
+  // lets the Cout/64 workgroups that read the same input patch, and the neighbouring tiles that share its halo,
+  // hit in one L2 instead of fetching the patch once per XCD.
+  unsigned cot_u, tile_u, b_u;
+  {
+    const unsigned nx = gridDim.x, ny = gridDim.y;
+    const unsigned id = blockIdx.x + nx * (blockIdx.y + ny * blockIdx.z);
+    const unsigned total = nx * ny * gridDim.z;
+    const unsigned per = total >> 3, rem = total & 7u;
+    const unsigned xcd = id & 7u, k = id >> 3;
+    const unsigned logical = xcd * per + (xcd < rem ? xcd : rem) + k;
+    cot_u = logical % nx;
+    const unsigned rest = logical / nx;
+    tile_u = rest % ny;
+    b_u = rest / ny;
+  }
+  const int cot = (int)cot_u;
+  const int tile_id = (int)tile_u;
+  const int b = (int)b_u;
   const int ty = a.tiles_x == 1 ? tile_id : (int)__umulhi((unsigned)tile_id, a.tiles_x_magic);
   const int tx = tile_id - ty * a.tiles_x;
   const int x0 = tx * TW, y0 = ty * TH;
