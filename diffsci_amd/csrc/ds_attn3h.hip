@@ -71,8 +71,21 @@ __global__ __launch_bounds__(NT) void k_attn3h(float* out, const float* __restri
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lh = lane >> 5;
-  const int b = blockIdx.y;
-  const int q0_raw = (blockIdx.x * 4 + wv) * 32;
+  // XCD-aware order (see ds_conv3h.hip): the query blocks of one sample stream the same K / V tiles; keep them on
+  // one XCD so that after the first block the tiles come from its L2
+  unsigned qblk, b_u;
+  {
+    const unsigned nx = gridDim.x;
+    const unsigned id = blockIdx.x + nx * blockIdx.y;
+    const unsigned total = nx * gridDim.y;
+    const unsigned per = total >> 3, rem = total & 7u;
+    const unsigned xcd = id & 7u, k = id >> 3;
+    const unsigned logical = xcd * per + (xcd < rem ? xcd : rem) + k;
+    qblk = logical % nx;
+    b_u = logical / nx;
+  }
+  const int b = (int)b_u;
+  const int q0_raw = ((int)qblk * 4 + wv) * 32;
   const bool active = q0_raw < L;                    // a wave past the last query block recomputes
   const int q0 = active ? q0_raw : L - 32;           // the last block and does not store (no branches
                                                      // around the MFMA pipeline: they cost registers)
