@@ -57,6 +57,7 @@ def parse():
     ap.add_argument("--channels", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--fuse-max-cot", type=int, default=None, help="fuse norms only in layers with Cout/64 <= this")
     ap.add_argument("--no-direct-out", action="store_true", help="output layer on the MFMA kernel (Cout padded to 64)")
     ap.add_argument("--no-fuse-norm", action="store_true", help="standalone norm kernels instead of norms folded into the convolutions")
     ap.add_argument("--roofline-only", action="store_true",
@@ -77,6 +78,8 @@ def build_module(args, dev):
     net.conv_precision = args.precision
     net.fuse_norm = not args.no_fuse_norm
     net.direct_out = not args.no_direct_out
+    if args.fuse_max_cot is not None:
+        net.fuse_max_cot = args.fuse_max_cot
     module = M.KarrasModule(net, M.KarrasModuleConfig.from_edm()).to(dev).eval()
     module.use_graph = not args.no_graph
     return module, sd, cfg
@@ -127,7 +130,7 @@ def dominant_kernel_roofline(module, args, dev, reps=40):
 
     def run():      # the same loaders / epilogues as in the network
         for m, cin, cout, s in launches:
-            block = id(m) in conv1s or id(m) in conv2s
+            block = (id(m) in conv1s or id(m) in conv2s) and (cin + 63) // 64 <= net.fuse_max_cot
             ops.conv(buf(cin, s), pk[id(m)], bias=m.bias,
                      shift=shift[cout] if id(m) in conv1s else None,
                      res1=buf(cout, s, "res") if id(m) in conv2s else None,

@@ -278,7 +278,8 @@ class SIModule(torch.nn.Module):
         """Capture the whole run once per (shape, schedule, guidance, condition) and replay it."""
         ykey = None if y is None else repr(dict_map(_condition_key, y))
         key = (tuple(x.shape), tuple(float(v) for v in table.t), float(guidance), ykey, bool(return_history),
-               bool(integrate_on_sigma), getattr(self.model, "conv_precision", None), getattr(self.model, "fuse_norm", None))
+               bool(integrate_on_sigma), getattr(self.model, "conv_precision", None), getattr(self.model, "fuse_norm", None),
+               getattr(self.model, "fuse_max_cot", None))
         key = key + (str(x.device), tuple((p.data_ptr(), p._version) for p in self.model.parameters()))
         # hipGraph capture needs a non-default stream (see KarrasModule._run_planned)
         if self._stream is None or self._stream.device != x.device:

@@ -165,6 +165,10 @@ class PUNetG(torch.nn.Module):
         # around them (statistics from the producer's epilogue, normalise + SiLU in the consumer's
         # loader): the normalised tensors never touch HBM.  False: standalone ds_inorm_silu kernels.
         self.fuse_norm = True
+        # ... but only where one workgroup column covers all output channels: with Cout/64 > fuse_max_cot channel
+        # tiles every tile's workgroup would redo the activation of the same input patch (5.3x the transcendental
+        # work of a standalone pass at Cout = 256), and the standalone kernel wins
+        self.fuse_max_cot = 2
         self._packed = None
         self._packed_sig = None
         self._ws = _Workspace()
@@ -280,7 +284,7 @@ class PUNetG(torch.nn.Module):
         x untouched.  xs = tile statistics of x (from the convolution that produced it) or None."""
         B, C, H, W = x.shape
         dev = x.device
-        if self._fused() and xs is not None:
+        if self._fused() and xs is not None and (C + 63) // 64 <= self.fuse_max_cot:
             tab = ws.take((B, ops.table_channels(C), 4), dev)
             ops.inorm_table(xs, blk.gnorm1.weight, blk.gnorm1.bias, 0, H * W, eps=blk.gnorm1.eps, out=tab)
             ys = self._stats_buf(ws, B, C, H, W, dev)

@@ -5,16 +5,25 @@
 #include <vector>
 #include <algorithm>
 int main(int argc, char** argv) {
-  int B = argc > 1 ? atoi(argv[1]) : 64, Cin = argc > 2 ? atoi(argv[2]) : 64, Cout = 64, S = 128;
+  int B = argc > 1 ? atoi(argv[1]) : 64, Cin = argc > 2 ? atoi(argv[2]) : 64, Cout = Cin, S = argc > 3 ? atoi(argv[3]) : 128;
+  const bool pre = argc > 4 && atoi(argv[4]) != 0;     // fused norm+SiLU loader and tile statistics
   size_t nin = (size_t)B * Cin * S * S, nout = (size_t)B * Cout * S * S;
   float *in, *out, *w; void* wp;
   hipMalloc(&in, nin * 4); hipMalloc(&out, nout * 4); hipMalloc(&w, (size_t)Cout * Cin * 9 * 4);
   hipMemset(in, 0, nin * 4); hipMemset(w, 0, (size_t)Cout * Cin * 36);
   hipMalloc(&wp, ds_conv2d_h3_packed_bytes(Cout, Cin));
   ds_conv2d_h3_pack_weights(wp, w, Cout, Cin, 0, nullptr);
-  int blocks = B * (S / 8) * (S / 32);
+  int blocks = B * (S / 8) * (S / 32) * ((Cout + 63) / 64);
+  float *tab = nullptr, *stats = nullptr;
+  if (pre) {
+    const size_t nt = (size_t)B * ((Cin + 15) / 16 * 16) * 4;
+    std::vector<float> ht(nt, 0.f);
+    for (size_t i = 1; i < nt; i += 4) ht[i] = 1.f;                       // (M, A, C) = (0, 1, 0)
+    hipMalloc(&tab, nt * 4); hipMemcpy(tab, ht.data(), nt * 4, hipMemcpyHostToDevice);
+    hipMalloc(&stats, (size_t)B * Cout * ds_conv_tile_count(S, S) * 16);
+  }
   hipMalloc(&g_stamps, (size_t)blocks * 8 * 8);
-  for (int it = 0; it < 3; ++it) ds_conv2d_h3(out, in, wp, 0, nullptr, nullptr, 0, nullptr, nullptr, B, Cin, Cout, S, S, 0, nullptr);
+  for (int it = 0; it < 3; ++it) ds_conv2d_h3(out, in, wp, 0, nullptr, nullptr, 0, nullptr, nullptr, B, Cin, Cout, S, S, 0, tab, stats, nullptr);
   hipDeviceSynchronize();
   std::vector<unsigned long long> h((size_t)blocks * 8);
   hipMemcpy(h.data(), g_stamps, h.size() * 8, hipMemcpyDeviceToHost);
@@ -22,7 +31,7 @@ int main(int argc, char** argv) {
   for (int b = 0; b < blocks; ++b) { t0 = std::min(t0, h[b * 8]); t1 = std::max(t1, h[b * 8 + 5]); }
   double seg[5] = {0, 0, 0, 0, 0};
   for (int b = 0; b < blocks; ++b) for (int k = 0; k < 5; ++k) seg[k] += (double)(h[b * 8 + k + 1] - h[b * 8 + k]);
-  printf("B=%d Cin=%d blocks=%d: kernel span %.1f us\n", B, Cin, blocks, (t1 - t0) / 100.0);
+  printf("B=%d C=%d S=%d pre=%d blocks=%d: kernel span %.1f us\n", B, Cin, S, (int)pre, blocks, (t1 - t0) / 100.0);
   const char* names[5] = {"plan+issue loads", "x_store+barrier (load latency)", "main loop", "epilogue issue", "store drain"};
   for (int k = 0; k < 5; ++k) printf("  %-32s avg %.2f us\n", names[k], seg[k] / blocks / 100.0);
   // start-time distribution
