@@ -176,9 +176,12 @@ class ADM(torch.nn.Module):
         self.input_layer = torch.nn.Conv2d(config.input_channels, mc, 3, padding="same")
         self.output_layer = torch.nn.Conv2d(mc, config.output_channels, 3, padding="same")
         self.conv_precision = "fp16x3"       # see PUNetG.conv_precision
-        # see PUNetG.fuse_norm; measured on MI355X at config 3 the folded norms are 1-2 % slower than the
-        # standalone two-phase kernels (per-sample table reductions, large-Cin loaders), so off by default
-        self.fuse_norm = False
+        # see PUNetG.fuse_norm / fuse_max_cot.  Measured on MI355X at config 3: folding the norms of the layers with
+        # up to 256 channels (1 GiB .. 134 MB tensors: the standalone pass is HBM-bound) gives 8.28 samples/s against
+        # 8.05 with standalone kernels everywhere and 8.22 with a 128-channel limit; folding every layer is slower
+        # (the 512-1024-channel layers would redo the activation once per 64-channel tile).
+        self.fuse_norm = True
+        self.fuse_max_cot = 4
         self._packed = None
         self._packed_sig = None
         self._ws = _Workspace()
@@ -278,9 +281,11 @@ class ADM(torch.nn.Module):
         Ho, Wo = (H // 2, W // 2) if down else ((2 * H, 2 * W) if up else (H, W))
         mode = DS_LOAD_UPSAMPLE2 if up else DS_LOAD_PLAIN
         fused = self._fused()
+        fuse1 = fused and (Ci + 63) // 64 <= self.fuse_max_cot            # per layer: see PUNetG.fuse_max_cot
+        fuse2 = fused and (blk.cout + 63) // 64 <= self.fuse_max_cot
         ys = self._stats_buf(ws, B, blk.cout, Ho, Wo, dev)
         # first_block: norm1 -> act -> resample -> conv1                          (adm.py:312-323)
-        if fused and xs is not None and not down:
+        if fuse1 and xs is not None and not down:
             sa, sb = xs if isinstance(xs, tuple) else (xs, None)
             tab = ws.take((B, ops.table_channels(Ci), 4), dev)
             ops.gnorm1_table(sa, blk.norm1.weight, blk.norm1.bias, 0, Ci * H * W, stats_b=sb, eps=blk.norm1.eps, out=tab)
@@ -310,7 +315,7 @@ class ADM(torch.nn.Module):
         # norm2 -> FiLM -> act -> conv2, + residual                               (adm.py:325-337)
         has_attn = hasattr(blk, "attn")
         os_ = self._stats_buf(ws, B, blk.cout, Ho, Wo, dev) if (want_stats and not has_attn) else None
-        if fused:
+        if fuse2:
             tab = ws.take((B, ops.table_channels(blk.cout), 4), dev)
             ops.gnorm1_table(ys, blk.norm2.weight, blk.norm2.bias, 1, blk.cout * Ho * Wo, film=film, eps=1e-5, out=tab)
             out = self._conv(blk.conv2, y, pk, res1=r, prenorm=tab, tile_stats=os_, out=ws.take((B, blk.cout, Ho, Wo), dev))
@@ -323,10 +328,12 @@ class ADM(torch.nn.Module):
             ops.gnorm1_stats(y, 1, eps=1e-5, stats=stats, workspace=scratch)
             a2 = ops.gnorm1_apply(y, stats, blk.norm2.weight, blk.norm2.bias, 1, film=film,
                                   out=ws.take((B, blk.cout, Ho, Wo), dev))
-            out = self._conv(blk.conv2, a2, pk, res1=r, out=y)
+            out = self._conv(blk.conv2, a2, pk, res1=r, tile_stats=os_, out=y)
             ws.give(a2)
             ws.give(stats)
             ws.give(scratch)
+            if ys is not None:
+                ws.give(ys)
         ws.give(r)
         if has_attn:
             os_ = self._stats_buf(ws, B, blk.cout, Ho, Wo, dev) if want_stats else None

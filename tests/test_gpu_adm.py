@@ -156,8 +156,10 @@ def test_adm_rejects_unsupported_configurations(M):
 def test_adm_fused_and_standalone_norms_agree(M, dev, skip):
     net, v, _ = _net(M, dev, skip)
     x, t = v["x"].to(dev), v["t"].to(dev)
-    net.fuse_norm = True
+    net.fuse_norm, net.fuse_max_cot = True, 99           # every layer folded
     fused = net(x, t).cpu()
+    net.fuse_max_cot = 0                                  # tables built, no layer folded
+    assert rel_l2(net(x, t).cpu(), fused) < 2e-6
     net.fuse_norm = False
     plain = net(x, t).cpu()
     assert rel_l2(fused, plain) < 2e-6

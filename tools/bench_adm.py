@@ -26,7 +26,8 @@ def main():
     ap.add_argument("--integrator", default="karras")
     ap.add_argument("--precision", default="fp16x3")
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--fuse-norm", action="store_true")
+    ap.add_argument("--no-fuse-norm", action="store_true")
+    ap.add_argument("--fuse-max-cot", type=int, default=None)
     a = ap.parse_args()
     import diffsci_amd.models as M
     dev = torch.device("cuda:0")
@@ -35,7 +36,9 @@ def main():
     net = M.ADM(M.ADMConfig(input_channels=3, output_channels=3, model_channels=c, time_embed_dim=c,
                             output_embed_dim=4 * c, channel_expansion=[1, 2, 4, 4], skip_integration_type=a.skip))
     net.conv_precision = a.precision
-    net.fuse_norm = a.fuse_norm
+    net.fuse_norm = not a.no_fuse_norm
+    if a.fuse_max_cot is not None:
+        net.fuse_max_cot = a.fuse_max_cot
     nparam = sum(p.numel() for p in net.parameters())
     module = M.KarrasModule(net, M.KarrasModuleConfig.from_edm()).to(dev).eval()
     module.use_graph = not a.no_graph
