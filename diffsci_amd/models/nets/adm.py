@@ -285,7 +285,9 @@ class ADM(torch.nn.Module):
         fuse2 = fused and (blk.cout + 63) // 64 <= self.fuse_max_cot
         ys = self._stats_buf(ws, B, blk.cout, Ho, Wo, dev)
         # first_block: norm1 -> act -> resample -> conv1                          (adm.py:312-323)
-        if fuse1 and xs is not None and not down:
+        # not for 'down' (pooling follows the activation) nor 'up' blocks (the loader would activate every source
+        # pixel four times, once per upsampled copy)
+        if fuse1 and xs is not None and not down and not up:
             sa, sb = xs if isinstance(xs, tuple) else (xs, None)
             tab = ws.take((B, ops.table_channels(Ci), 4), dev)
             ops.gnorm1_table(sa, blk.norm1.weight, blk.norm1.bias, 0, Ci * H * W, stats_b=sb, eps=blk.norm1.eps, out=tab)
