@@ -17,7 +17,7 @@ import torch
 
 from ... import ops
 from ..._native import DS_IN_NETWORK
-from . import integrators, noisesamplers, preconditioners, schedulers
+from . import noisesamplers, preconditioners, schedulers
 from .engine import Loop, ModuleSource
 from .steptable import build_step_table
 

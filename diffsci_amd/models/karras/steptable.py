@@ -11,7 +11,7 @@ Only the constant-scaling (EDM) branch of Scheduler.rhs (schedulers.py:259-274) 
 """
 import math
 from dataclasses import dataclass, field
-from typing import Callable, List, Optional
+from typing import List, Optional
 
 import torch
 

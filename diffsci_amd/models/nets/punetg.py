@@ -18,7 +18,7 @@ from typing import Any
 import torch
 
 from ... import ops
-from ..._native import DS_LOAD_MAXPOOL2, DS_LOAD_PLAIN, DS_LOAD_UPSAMPLE2
+from ..._native import DS_LOAD_MAXPOOL2, DS_LOAD_UPSAMPLE2
 from .punetg_config import PUNetGConfig
 
 
