@@ -466,3 +466,15 @@ def test_conv_direct_small_cout(dev, case):
     assert rel_l2(got, nb64) <= max(4 * rel_l2(nb32, nb64), 6e-7)
     with pytest.raises(RuntimeError, match="1..4 supported"):
         ops.conv_direct(x.to(dev), torch.randn(5, Cin, 3, 3, device=dev))
+
+
+def test_convolution_family_fuzz():
+    """A short run of tools/conv_fuzz.py: random shapes through every load / padding / fusion combination."""
+    import subprocess
+    import sys
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "conv_fuzz.py"), "--n", "80", "--seed", "7"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "all 80 cases passed" in r.stdout

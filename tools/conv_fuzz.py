@@ -1,0 +1,112 @@
+"""Randomised cross-check of the fp16x3 convolution family (3x3 with every load mode, padding mode, fused
+loader and tile statistics; 1x1 with its load modes; direct output layer) against fp64 torch on random shapes.
+
+    python tools/conv_fuzz.py [--n 200] [--seed 0]
+"""
+import argparse
+import math
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import torch.nn.functional as F
+
+from diffsci_amd import ops
+
+
+def rel(a, b):
+    return float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=200)
+    ap.add_argument("--seed", type=int, default=0)
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(a.seed)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))       # noqa: E731
+    worst = 0.0
+    for it in range(a.n):
+        kind = ["3x3", "3x3", "3x3", "1x1", "direct"][ri(0, 4)]
+        B, Cin, Cout = ri(1, 3), ri(1, 80), ri(1, 140)
+        H, W = ri(1, 12) * 2, ri(1, 20) * 2
+        if ri(0, 3) == 0:
+            W += 1 if kind != "1x1" else 0                                       # odd width: scalar epilogue path
+        circ = kind != "1x1" and ri(0, 2) == 0
+        mode = ri(0, 2) if kind == "3x3" else (ri(0, 2) * 0 if kind == "direct" else [0, 2, 3][ri(0, 2)])
+        if mode in (1, 3):
+            Hin, Win = 2 * H, 2 * W
+        elif mode == 2:
+            if W % 2:
+                W += 1
+            Hin, Win = H // 2, W // 2
+        else:
+            Hin, Win = H, W
+        x = torch.randn(B, Cin, Hin, Win, generator=g) * 2 + 0.3
+        src = x
+        if mode == 1:
+            src = F.max_pool2d(x, 2)
+        elif mode == 3:
+            src = F.avg_pool2d(x, 2)
+        elif mode == 2:
+            src = F.interpolate(x, scale_factor=2.0, mode="nearest")
+        bias = torch.randn(Cout, generator=g)
+        pad = (lambda t: F.pad(F.pad(t, (1, 1, 0, 0), mode="circular"), (0, 0, 1, 1), mode="circular")) if circ else None
+        if kind == "direct":
+            Cout = ri(1, 4)
+            bias = torch.randn(Cout, generator=g)
+            w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)
+            want = F.conv2d(pad(src.double()), w.double(), bias.double()) if circ else F.conv2d(src.double(), w.double(), bias.double(), padding="same")
+            got = ops.conv_direct(x.to(dev), w.to(dev), bias.to(dev), circular=circ).cpu()
+            e = rel(got, want)
+        elif kind == "1x1":
+            w = torch.randn(Cout, Cin, 1, 1, generator=g) / math.sqrt(Cin)
+            r1 = torch.randn(B, Cout, H, W, generator=g)
+            want = F.conv2d(src.double(), w.double(), bias.double()) + r1.double()
+            nt = ops.conv_tile_count(H, W)
+            ts = torch.zeros(B, Cout, nt, 4, device=dev) if W % 4 == 0 or True else None
+            got = ops.conv(x.to(dev), ops.pack_conv(w.to(dev), "fp16x3"), bias=bias.to(dev), res1=r1.to(dev), load_mode=mode,
+                           tile_stats=ts).cpu()
+            e = rel(got, want)
+            K, S, Q, n = ts.cpu().double().unbind(-1)
+            sx = (n * K + S).sum(-1)
+            e = max(e, float((sx - want.sum(dim=(2, 3))).abs().max() / (want.abs().sum(dim=(2, 3)).max() + 1e-30)))
+        else:
+            w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)
+            pre = mode != 1 and ri(0, 1) == 1
+            shift = torch.randn(B, Cout, generator=g)
+            r1 = torch.randn(B, Cout, H, W, generator=g)
+            s64 = src.double()
+            tab = None
+            if pre:
+                M, A, C = torch.randn(B, Cin, generator=g) * 0.3, torch.rand(B, Cin, generator=g) + 0.5, torch.randn(B, Cin, generator=g) * 0.3
+                tab = torch.zeros(B, ops.table_channels(Cin), 4)
+                tab[:, :Cin, 0], tab[:, :Cin, 1], tab[:, :Cin, 2] = M, A, C
+                xin = x.double()
+                act = F.silu((xin - M.double()[..., None, None]) * A.double()[..., None, None] + C.double()[..., None, None])
+                s64 = F.interpolate(act, scale_factor=2.0, mode="nearest") if mode == 2 else act
+            want = (F.conv2d(pad(s64), w.double(), bias.double()) if circ else F.conv2d(s64, w.double(), bias.double(), padding="same"))
+            want = want + shift.double()[..., None, None] + r1.double()
+            nt = ops.conv_tile_count(H, W)
+            ts = torch.full((B, Cout, nt, 4), float("nan"), device=dev)
+            got = ops.conv(x.to(dev), ops.pack_conv(w.to(dev), "fp16x3"), bias=bias.to(dev), shift=shift.to(dev), res1=r1.to(dev),
+                           load_mode=mode, circular=circ, prenorm=None if tab is None else tab.to(dev), tile_stats=ts).cpu()
+            e = rel(got, want)
+            K, S, Q, n = ts.cpu().double().unbind(-1)
+            assert torch.isfinite(ts).all(), "tile statistics not fully written"
+            assert torch.equal(n.sum(-1), torch.full_like(n.sum(-1), H * W)), "tile pixel counts"
+            sxx = (Q + 2 * K * S + n * K * K).sum(-1)
+            e = max(e, float(((sxx - (want * want).sum(dim=(2, 3))).abs() / (want * want).sum(dim=(2, 3)).clamp_min(1e-30)).max()))
+        worst = max(worst, e)
+        if e > 3e-6:
+            print(f"FAIL it={it} kind={kind} B={B} Cin={Cin} Cout={Cout} H={H} W={W} mode={mode} circ={circ} err={e:.3e}")
+            sys.exit(1)
+        if it % 25 == 0:
+            print(f"it {it}: ok (worst so far {worst:.2e})", flush=True)
+    print(f"all {a.n} cases passed; worst relative error {worst:.2e}")
+
+
+if __name__ == "__main__":
+    main()
