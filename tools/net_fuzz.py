@@ -1,0 +1,94 @@
+"""Randomised structural cross-check: random PUNetG / ADM configurations (depths, widths, attention residual,
+skip type, field size) on the GPU against the CPU oracle, with folded and standalone norms.
+
+    python tools/net_fuzz.py [--n 30] [--seed 0]
+"""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+import diffsci_amd.models as M
+from oracle import adm_ref, punetg_ref
+
+
+def rel(a, b):
+    return float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=30)
+    ap.add_argument("--seed", type=int, default=0)
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(a.seed)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))       # noqa: E731
+    pick = lambda xs: xs[ri(0, len(xs) - 1)]                                      # noqa: E731
+    worst = 0.0
+    for it in range(a.n):
+        torch.manual_seed(1000 + it)
+        family = "punetg" if it % 2 == 0 else "adm"
+        exp = pick([[2], [2, 4], [1, 2], [2, 2, 2]])
+        lev = len(exp)
+        B, cin = ri(1, 3), ri(1, 3)
+        unit = 2 ** lev
+        H, W = unit * ri(1, 4), unit * ri(1, 6)
+        x = torch.randn(B, cin, H, W)
+        t = torch.rand(B) * 3 - 1.5
+        if family == "punetg":
+            over = dict(model_channels=pick([4, 8, 16]), channel_expansion=exp, input_channels=cin, output_channels=ri(1, 5),
+                        number_resnet_downward_block=ri(1, 2), number_resnet_upward_block=ri(1, 2),
+                        number_resnet_attn_block=ri(1, 3), number_resnet_before_attn_block=ri(0, 2),
+                        number_resnet_after_attn_block=ri(0, 2), attn_residual=bool(ri(0, 1)))
+            cfg = punetg_ref.default_config(**over)
+            sd = punetg_ref.random_state_dict(cfg, seed=it)
+            for k in sd:
+                if "gnorm" in k or k.endswith("bias"):
+                    sd[k] = sd[k] + 0.2 * torch.randn_like(sd[k])
+            net = M.PUNetG(M.PUNetGConfig(**over))
+            net.load_state_dict(sd)
+            with torch.inference_mode():
+                want = punetg_ref.punetg_forward(sd, cfg, x, t)
+                want64 = punetg_ref.punetg_forward({k: w.double() for k, w in sd.items()}, cfg, x.double(), t.double())
+        else:
+            over = dict(model_channels=pick([8, 16]), time_embed_dim=8, output_embed_dim=16, channel_expansion=exp,
+                        input_channels=cin, output_channels=ri(1, 5), number_resnet_downward_block=ri(1, 2),
+                        number_resnet_upward_block=ri(1, 3), number_resnet_attn_block=ri(1, 2),
+                        number_resnet_before_attn_block=ri(0, 1), number_resnet_after_attn_block=ri(0, 1),
+                        skip_integration_type=pick(["concat", "add"]), attn_residual=bool(ri(0, 1)))
+            net = M.ADM(M.ADMConfig(**over))
+            with torch.no_grad():
+                for k, w in net.state_dict().items():
+                    if "norm" in k or k.endswith("bias"):
+                        w.add_(0.2 * torch.randn_like(w))
+            sd = {k: w.clone() for k, w in net.state_dict().items()}
+            cfg = adm_ref.default_config(**over)
+            with torch.inference_mode():
+                want = adm_ref.adm_forward(sd, cfg, x, t)
+                want64 = adm_ref.adm_forward({k: w.double() for k, w in sd.items()}, cfg, x.double(), t.double())
+        net = net.to(dev)
+        # the usual bound: 1e-5, or 4x the reference's own fp32-vs-fp64 error where tiny planes (a few pixels per
+        # instance norm) make the configuration ill-conditioned for fp32 itself
+        tol = max(1e-5, 4 * rel(want, want64))
+        errs = []
+        for fuse, cot in ((True, 99), (True, 1), (False, 0)):
+            net.fuse_norm, net.fuse_max_cot = fuse, cot
+            got = net(x.to(dev), t.to(dev)).cpu()
+            got2 = net(x.to(dev), t.to(dev)).cpu()                 # second pass: workspace reuse
+            assert torch.equal(got, got2), "second pass through the workspace differs"
+            errs.append(max(rel(got, want), rel(got, want64)))
+        e = max(errs)
+        worst = max(worst, e)
+        tag = f"{family} exp={exp} B={B} cin={cin} {H}x{W} " + " ".join(f"{k}={v}" for k, v in over.items() if k.startswith("number") or k in ("model_channels", "skip_integration_type"))
+        if e > tol:
+            print("FAIL", tag, errs, tol)
+            sys.exit(1)
+        print(f"it {it}: ok {e:.2e}  {tag}", flush=True)
+    print(f"all {a.n} networks passed; worst relative error {worst:.2e}")
+
+
+if __name__ == "__main__":
+    main()
