@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get("DIFFSCI_HIP_LIB") or os.path.join(_HERE, "_lib", "lib
 DS_IN_NETWORK, DS_IN_SCORE, DS_IN_DRIFT, DS_IN_FLOW = 0, 1, 2, 3
 DS_LOAD_PLAIN, DS_LOAD_MAXPOOL2, DS_LOAD_UPSAMPLE2, DS_LOAD_AVGPOOL2 = 0, 1, 2, 3
 DS_PAD_CIRCULAR = 16
+DS_RES1_UPSAMPLED = 32
 
 
 class EvalCoef(Structure):

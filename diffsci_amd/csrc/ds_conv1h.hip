@@ -46,6 +46,7 @@ struct Conv1hArgs {
   const float* res1;
   const float* res2;
   float* tile_stats;      // see ds_conv_epilogue.h, or NULL
+  int res1_up;
   float unscale;
   int shift_stride;
   int B, Cin, Cout, H, W, Hin, Win;
@@ -220,7 +221,7 @@ __global__ __launch_bounds__(NT, 2) void k_conv1h(const Conv1hArgs a) {
 
   {
     ds_epi::Args e;
-    e.out = a.out; e.bias = a.bias; e.shift = a.shift; e.res1 = a.res1; e.res2 = a.res2;
+    e.out = a.out; e.bias = a.bias; e.shift = a.shift; e.res1 = a.res1; e.res2 = a.res2; e.res1_up = a.res1_up;
     e.unscale = a.unscale; e.shift_stride = a.shift_stride;
     e.b = b; e.co_base = cot * COT; e.y0 = y0 + (W16 ? 4 : 2) * wv; e.x0 = x0;
     e.Cout = a.Cout; e.H = a.H; e.W = a.W;
@@ -309,7 +310,7 @@ int ds_conv1x1_h3(float* out, const float* in, const void* w_packed, int wshift,
   if (B == 0) return DS_OK;
   Conv1hArgs a;
   a.out = out; a.in = in; a.wp = reinterpret_cast<const u32x4*>(w_packed); a.bias = bias; a.shift = shift;
-  a.res1 = res1; a.res2 = res2; a.shift_stride = shift_stride; a.tile_stats = tile_stats;
+  a.res1 = res1; a.res2 = res2; a.shift_stride = shift_stride; a.tile_stats = tile_stats; a.res1_up = 0;
   a.unscale = ldexpf(1.0f, -wshift);
   a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W;
   a.Hin = load_mode == DS_LOAD_AVGPOOL2 ? 2 * H : (load_mode == DS_LOAD_UPSAMPLE2 ? H / 2 : H);

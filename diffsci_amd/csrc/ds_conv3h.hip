@@ -72,6 +72,7 @@ struct Conv3hArgs {
   float* tile_stats;      // see ds_conv_epilogue.h, or NULL
   float unscale;        // 2^-wshift
   int shift_stride;
+  int res1_up;            // res1 is at half resolution (see ds_conv_epilogue.h)
   int circular;           // periodic padding in both dimensions (CircularConv2d, commonlayers.py:918-971)
   int B, Cin, Cout, H, W, Hin, Win;
   int tiles_x, tiles_y, n_cot, n_chunks;
@@ -374,7 +375,7 @@ __global__ __launch_bounds__(NT, 2) void k_conv3h(const Conv3hArgs a) {
   //      dead after the last step's barrier; each wave takes a private 16 KiB of them. ----
   {
     ds_epi::Args e;
-    e.out = a.out; e.bias = a.bias; e.shift = a.shift; e.res1 = a.res1; e.res2 = a.res2;
+    e.out = a.out; e.bias = a.bias; e.shift = a.shift; e.res1 = a.res1; e.res2 = a.res2; e.res1_up = a.res1_up;
     e.unscale = a.unscale; e.shift_stride = a.shift_stride;
     e.b = b; e.co_base = cot * COT; e.y0 = y0 + wave_row; e.x0 = x0;
     e.Cout = a.Cout; e.H = a.H; e.W = a.W;
@@ -467,7 +468,9 @@ int ds_conv2d_h3(float* out, const float* in, const void* w_packed, int wshift, 
   DS_REQUIRE(B >= 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, DS_ERR_SHAPE,
              "ds_conv2d_h3: bad shape B=%d Cin=%d Cout=%d H=%d W=%d", B, Cin, Cout, H, W);
   const int circular = (load_mode & DS_PAD_CIRCULAR) ? 1 : 0;
-  load_mode &= ~DS_PAD_CIRCULAR;
+  const int res1_up = (load_mode & DS_RES1_UPSAMPLED) ? 1 : 0;
+  load_mode &= ~(DS_PAD_CIRCULAR | DS_RES1_UPSAMPLED);
+  DS_REQUIRE(!res1_up || (res1 && H % 2 == 0 && W % 2 == 0), DS_ERR_SHAPE, "ds_conv2d_h3: RES1_UPSAMPLED needs res1 and even H, W");
   DS_REQUIRE(load_mode >= 0 && load_mode <= 2, DS_ERR_UNSUPPORTED, "ds_conv2d_h3: load_mode %d", load_mode);
   DS_REQUIRE(load_mode != DS_LOAD_UPSAMPLE2 || (H % 2 == 0 && W % 2 == 0), DS_ERR_SHAPE,
              "ds_conv2d_h3: UPSAMPLE2 needs even output H, W (got %d x %d)", H, W);
@@ -482,7 +485,7 @@ int ds_conv2d_h3(float* out, const float* in, const void* w_packed, int wshift, 
   DS_REQUIRE((reinterpret_cast<uintptr_t>(prenorm) & 15u) == 0, DS_ERR_SHAPE, "ds_conv2d_h3: prenorm must be 16-byte aligned");
   if (B == 0) return DS_OK;
   Conv3hArgs a;
-  a.prenorm = prenorm; a.tile_stats = tile_stats; a.circular = circular;
+  a.prenorm = prenorm; a.tile_stats = tile_stats; a.circular = circular; a.res1_up = res1_up;
   a.out = out; a.in = in; a.wp = reinterpret_cast<const u32x4*>(w_packed); a.bias = bias; a.shift = shift;
   a.res1 = res1; a.res2 = res2; a.shift_stride = shift_stride;
   a.unscale = ldexpf(1.0f, -wshift);

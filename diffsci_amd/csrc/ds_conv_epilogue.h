@@ -17,6 +17,7 @@ struct Args {
   const float* shift;     // + b*shift_stride + co
   const float* res1;
   const float* res2;
+  int res1_up;            // res1 is [B, Cout, H/2, W/2] and is added nearest-upsampled (x2): out += res1[.., y/2, x/2]
   float unscale;
   int shift_stride;
   int b, co_base;         // sample, first channel of the workgroup's 64-channel tile
@@ -90,8 +91,21 @@ __device__ __forceinline__ void store_tile(const f32x16 (&acc)[2][2], float* til
         v[k] = *reinterpret_cast<const f32x4*>(&tile[seg * 32 + p4]);
       }
       if (e.res1) {
+        if (e.res1_up) {                              // 4 output columns = 2 low-resolution columns
 #pragma unroll
-        for (int k = 0; k < 4; ++k) r1[k] = *reinterpret_cast<const f32x4*>(e.res1 + idx[k]);
+          for (int k = 0; k < 4; ++k) {
+            const int seg = (half * 4 + k) * 8 + (lane >> 3);
+            const int co = seg >> 1, r = seg & 1;
+            const int gy = e.y0 + (W16 ? 2 * r + yq : r);
+            const size_t lidx = ok[k] ? (((size_t)e.b * e.Cout + e.co_base + co) * (e.H >> 1) + (gy >> 1)) * (e.W >> 1) + (gx >> 1) : (size_t)0;
+            typedef float f32x2_t __attribute__((ext_vector_type(2)));
+            const f32x2_t lo = *reinterpret_cast<const f32x2_t*>(e.res1 + lidx);
+            r1[k] = f32x4{lo[0], lo[0], lo[1], lo[1]};
+          }
+        } else {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) r1[k] = *reinterpret_cast<const f32x4*>(e.res1 + idx[k]);
+        }
       }
       if (e.res2) {
 #pragma unroll
@@ -143,7 +157,8 @@ __device__ __forceinline__ void store_tile(const f32x16 (&acc)[2][2], float* til
       if (okv) {
         const size_t idx = ((size_t)e.b * e.Cout + e.co_base + co) * plane + (size_t)gy * e.W + gxx;
         v = tile[i];
-        if (e.res1) v = v + e.res1[idx];
+        if (e.res1) v = v + (e.res1_up ? e.res1[(((size_t)e.b * e.Cout + e.co_base + co) * (e.H >> 1) + (gy >> 1)) * (e.W >> 1) + (gxx >> 1)]
+                                       : e.res1[idx]);
         if (e.res2) v = v + e.res2[idx];
         e.out[idx] = v;
       }

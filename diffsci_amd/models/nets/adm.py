@@ -306,12 +306,18 @@ class ADM(torch.nn.Module):
             ws.give(stats)
             ws.give(scratch)
         # residual_block: convresidual(resample(x))                               (adm.py:345-349)
+        r_up = False
         if down and pk[id(blk.convresidual)].kind == "fp16x3":
             r = self._conv(blk.convresidual, x, pk, load_mode=DS_LOAD_AVGPOOL2, out=ws.take((B, blk.cout, Ho, Wo), dev))
         elif down:
             a = ops.gnorm1_apply(x, None, None, None, 2, pool=True, out=ws.take((B, Ci, Ho, Wo), dev))
             r = self._conv(blk.convresidual, a, pk, out=ws.take((B, blk.cout, Ho, Wo), dev))
             ws.give(a)
+        elif up and pk[id(blk.convresidual)].kind == "fp16x3" and pk[id(blk.conv2)].kind == "fp16x3":
+            # a 1x1 convolution commutes with nearest upsampling: project at low resolution (a quarter of the
+            # pixels) and let conv2's epilogue add the result upsampled
+            r = self._conv(blk.convresidual, x, pk, out=ws.take((B, blk.cout, H, W), dev))
+            r_up = True
         else:
             r = self._conv(blk.convresidual, x, pk, load_mode=mode, out=ws.take((B, blk.cout, Ho, Wo), dev))
         # norm2 -> FiLM -> act -> conv2, + residual                               (adm.py:325-337)
@@ -320,7 +326,8 @@ class ADM(torch.nn.Module):
         if fuse2:
             tab = ws.take((B, ops.table_channels(blk.cout), 4), dev)
             ops.gnorm1_table(ys, blk.norm2.weight, blk.norm2.bias, 1, blk.cout * Ho * Wo, film=film, eps=1e-5, out=tab)
-            out = self._conv(blk.conv2, y, pk, res1=r, prenorm=tab, tile_stats=os_, out=ws.take((B, blk.cout, Ho, Wo), dev))
+            out = self._conv(blk.conv2, y, pk, res1=r, res1_upsampled=r_up, prenorm=tab, tile_stats=os_,
+                             out=ws.take((B, blk.cout, Ho, Wo), dev))
             ws.give(tab)
             ws.give(ys)
             ws.give(y)
@@ -330,7 +337,7 @@ class ADM(torch.nn.Module):
             ops.gnorm1_stats(y, 1, eps=1e-5, stats=stats, workspace=scratch)
             a2 = ops.gnorm1_apply(y, stats, blk.norm2.weight, blk.norm2.bias, 1, film=film,
                                   out=ws.take((B, blk.cout, Ho, Wo), dev))
-            out = self._conv(blk.conv2, a2, pk, res1=r, tile_stats=os_, out=y)
+            out = self._conv(blk.conv2, a2, pk, res1=r, res1_upsampled=r_up, tile_stats=os_, out=y)
             ws.give(a2)
             ws.give(stats)
             ws.give(scratch)

@@ -337,7 +337,8 @@ def gnorm1_table(stats_a, w, b, kind, count, stats_b=None, film=None, eps=1e-5, 
 
 
 def conv2d(x, w_packed, Cout, ks, bias=None, shift=None, res1=None, res2=None,
-           load_mode=N.DS_LOAD_PLAIN, out=None, kind="fp32", wshift=0, prenorm=None, tile_stats=None, circular=False):
+           load_mode=N.DS_LOAD_PLAIN, out=None, kind="fp32", wshift=0, prenorm=None, tile_stats=None, circular=False,
+           res1_upsampled=False):
     """'same' zero-padded conv; x [B, Cin, Hin, Win]; shift [1 or B, Cout] or None.
     fp16x3 kernels only: prenorm [B, ceil16(Cin), 4] (3x3) applies SiLU((x-M)*A+C) in the loader; tile_stats
     [B, Cout, conv_tile_count(H, W), 4] receives per-tile (K, sum(x-K), sum((x-K)^2), n) of the output."""
@@ -367,7 +368,10 @@ def conv2d(x, w_packed, Cout, ks, bias=None, shift=None, res1=None, res2=None,
         if shift.dim() != 2 or shift.shape[1] != Cout or shift.shape[0] not in (1, B):
             raise ValueError(f"shift must be [1 or B, Cout]; got {tuple(shift.shape)}")
         stride = 0 if shift.shape[0] == 1 else Cout
-    for r in (res1, res2):
+    if res1_upsampled:
+        if kind != "fp16x3" or ks != 3 or res1 is None or H % 2 or W % 2 or tuple(res1.shape) != (B, Cout, H // 2, W // 2):
+            raise ValueError("res1_upsampled: fp16x3 3x3 convolution with res1 of shape [B, Cout, H/2, W/2]")
+    for r in ((res2,) if res1_upsampled else (res1, res2)):
         if r is not None and tuple(r.shape) != (B, Cout, H, W):
             raise ValueError("residual shape mismatch")
     if bias is not None and bias.numel() != Cout:
@@ -387,7 +391,8 @@ def conv2d(x, w_packed, Cout, ks, bias=None, shift=None, res1=None, res2=None,
     elif kind == "fp16x3":
         N.check(N.lib().ds_conv2d_h3(_p(out), _p(x), _p(w_packed), int(wshift), _p(bias), _p(shift), stride,
                                      _p(res1), _p(res2), B, Cin, Cout, H, W,
-                                     load_mode | (N.DS_PAD_CIRCULAR if circular else 0), _p(prenorm), _p(tile_stats),
+                                     load_mode | (N.DS_PAD_CIRCULAR if circular else 0) | (N.DS_RES1_UPSAMPLED if res1_upsampled else 0),
+                                     _p(prenorm), _p(tile_stats),
                                      _stream()), "ds_conv2d_h3")
     elif kind == "bf16x6":
         N.check(N.lib().ds_conv2d_x6(_p(out), _p(x), _p(w_packed), _p(bias), _p(shift), stride, _p(res1),

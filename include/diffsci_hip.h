@@ -133,6 +133,8 @@ size_t ds_conv2d_packed_floats(int Cout, int Cin, int ks);
 int ds_conv2d_pack_weights(float* packed, const float* w, int Cout, int Cin, int ks, void* stream);
 
 enum { DS_LOAD_PLAIN = 0, DS_LOAD_MAXPOOL2 = 1, DS_LOAD_UPSAMPLE2 = 2, DS_LOAD_AVGPOOL2 = 3 /* ds_conv1x1_h3 only */,
+       DS_RES1_UPSAMPLED = 32 /* OR-ed into load_mode of ds_conv2d_h3: res1 is [B, Cout, H/2, W/2] and is added
+                                 nearest-upsampled -- ADM's convresidual(upsample(x)) = upsample(convresidual(x)), adm.py:345-349 */,
        DS_PAD_CIRCULAR = 16 /* OR-ed into load_mode of ds_conv2d_h3: periodic instead of zero padding in H and W
                                (CircularConv2d, commonlayers.py:918-971; applied to the pooled / upsampled image) */ };
 

@@ -478,3 +478,26 @@ def test_convolution_family_fuzz():
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "all 80 cases passed" in r.stdout
+
+
+@pytest.mark.parametrize("case", [(2, 16, 24, 32, 32), (1, 40, 72, 16, 16), (1, 8, 8, 10, 14), (2, 24, 130, 64, 32)])
+def test_conv_upsampled_residual(dev, case):
+    """DS_RES1_UPSAMPLED: the residual is stored at half resolution and added nearest-upsampled
+    (convresidual(upsample(x)) = upsample(convresidual(x)) for ADM's 1x1 residual branch)."""
+    ops = _ops()
+    B, Cin, Cout, H, W = case
+    g = torch.Generator().manual_seed(hash(case) % 1000 + 17)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)
+    bias = torch.randn(Cout, generator=g)
+    rlow = torch.randn(B, Cout, H // 2, W // 2, generator=g)
+    want = F.conv2d(x.double(), w.double(), bias.double(), padding="same") + F.interpolate(rlow.double(), scale_factor=2.0, mode="nearest")
+    ref32 = F.conv2d(x, w, bias, padding="same") + F.interpolate(rlow, scale_factor=2.0, mode="nearest")
+    ts = torch.zeros(B, Cout, ops.conv_tile_count(H, W), 4, device=dev)
+    got = ops.conv(x.to(dev), ops.pack_conv(w.to(dev), "fp16x3"), bias=bias.to(dev), res1=rlow.to(dev), res1_upsampled=True,
+                   tile_stats=ts).cpu()
+    assert rel_l2(got, want) <= max(3 * rel_l2(ref32, want), 3e-7)
+    K, S, Q, n = ts.cpu().double().unbind(-1)
+    torch.testing.assert_close((n * K + S).sum(-1), want.sum(dim=(2, 3)), rtol=1e-5, atol=1e-3)
+    with pytest.raises(ValueError, match="res1_upsampled"):
+        ops.conv(x.to(dev), ops.pack_conv(w.to(dev), "fp16x3"), res1=rlow.to(dev)[:, :, :-1], res1_upsampled=True)
