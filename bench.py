@@ -58,6 +58,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--fuse-max-cot", type=int, default=None, help="fuse norms only in layers with Cout/64 <= this")
+    ap.add_argument("--no-up-parity", action="store_true", help="UpSampler convolutions through the generic gather loader")
     ap.add_argument("--no-direct-out", action="store_true", help="output layer on the MFMA kernel (Cout padded to 64)")
     ap.add_argument("--no-fuse-norm", action="store_true", help="standalone norm kernels instead of norms folded into the convolutions")
     ap.add_argument("--roofline-only", action="store_true",
@@ -78,6 +79,7 @@ def build_module(args, dev):
     net.conv_precision = args.precision
     net.fuse_norm = not args.no_fuse_norm
     net.direct_out = not args.no_direct_out
+    net.upsample_parity = not args.no_up_parity
     if args.fuse_max_cot is not None:
         net.fuse_max_cot = args.fuse_max_cot
     module = M.KarrasModule(net, M.KarrasModuleConfig.from_edm()).to(dev).eval()

@@ -26,6 +26,7 @@
 //     MFMAs of the previous block.  One barrier per step, nothing waits on it.
 #include "ds_common.h"
 #include "ds_conv_epilogue.h"
+#include "ds_h3_common.h"
 
 #ifdef DS_STAMP
 unsigned long long* g_stamps = nullptr;
@@ -38,9 +39,10 @@ namespace {
 
 using ds_epi::f32x16;
 using ds_epi::f32x4;
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+using ds_h3::u32x4;
+using ds_h3::f16x8;
+using ds_h3::split2;
+using ds_h3::fast_silu;
 
 constexpr int COT = 64, NT = 256;
 constexpr int KC = 16;
@@ -82,29 +84,7 @@ struct Conv3hArgs {
 #endif
 };
 
-// Exact-sum split of two fp32 values into packed fp16 hi / lo pairs.  The low piece MUST be the
-// remainder against the very same rounded high piece that is stored: hipcc otherwise rounds the
-// stored pair with v_cvt_pk_f16_f32 and the remainder's reference with v_cvt_f16_f32, and the two
-// disagree on exact ties (measured on gfx950: hi + lo off by one fp16 ulp, 2^-11 relative, for one
-// value in ~8000).  Deriving the reference from the packed bits removes the second rounding.
-__device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned& lo) {
-  f16x2 h = {(_Float16)a, (_Float16)b};
-  unsigned hp = __builtin_bit_cast(unsigned, h);
-  asm volatile("" : "+v"(hp));                       // opaque: both uses below see these exact bits
-  const f16x2 hq = __builtin_bit_cast(f16x2, hp);
-  f16x2 l = {(_Float16)(a - (float)hq[0]), (_Float16)(b - (float)hq[1])};
-  hi = hp;
-  lo = __builtin_bit_cast(unsigned, l);
-}
-
 struct Frags { f16x8 a[2][2]; f16x8 b[2][2]; };   // [piece][m] weights, [piece][r] input
-
-// x * sigmoid(x) with the hardware exp2 / rcp (1 ulp each): the fused-normalisation loader's
-// activation (the standalone norm kernels use expf and an IEEE division; the difference is ~2e-7
-// relative, far inside the path's stated 1e-5 tolerance).
-__device__ __forceinline__ float fast_silu(float v) {
-  return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.44269504088896341f));
-}
 
 template <int MODE, bool W16, bool PRE, bool CIRC>
 __global__ __launch_bounds__(NT, 2) void k_conv3h(const Conv3hArgs a) {

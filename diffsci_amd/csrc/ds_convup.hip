@@ -1,0 +1,426 @@
+// Nearest-neighbour x2 upsampling followed by a 3x3 convolution (UpSampler, commonlayers.py; ADM "up" blocks,
+// adm.py:292-349), evaluated at the LOW resolution with fp32 accuracy on the fp16 matrix cores (the fp16x3
+// split of ds_conv3h.hip).
+//
+// Output pixel (2y + a, 2x + b) reads upsampled rows 2y + a + ky - 1, i.e. low-resolution rows
+// y + floor((a + ky - 1) / 2): only TWO distinct rows (y + a - 1 and y + a), and likewise two columns.  For each
+// of the four output parities (a, b) the 3x3 kernel therefore collapses to a 2x2 kernel on the low-resolution
+// image whose taps are sums of the original ones,
+//     a = 0: rows {ky 0} , {ky 1, 2}        a = 1: rows {ky 0, 1} , {ky 2}          (columns alike with b, kx)
+// 16 multiply-adds per output instead of 36 when the generic kernel gathers the upsampled patch: 2.25x fewer
+// MFMAs.  The tap sums are formed once at pack time (in fp64, rounded to fp32: the reference's
+// w1*x + w2*x and our (w1 + w2)*x differ by one fp32 rounding of the weight).  Zero / periodic padding of the
+// upsampled image is exactly zero / periodic padding of the low-resolution one.
+//
+// One workgroup = one parity x 64 output channels x (8 x 32 | 16 x 16) LOW-resolution pixels; same pipeline as
+// ds_conv3h.hip with a step = (chunk of 16 input channels, row tap s), two column-tap MFMA blocks per step:
+//     X  [2 buffers][piece 2][h 2][9*33 | 17*17 positions][8 ci] fp16
+//     W  [3-slot ring][piece 2][t 2][h 2][64 co][8 ci] fp16            (8 KiB slabs by LDS-DMA)
+// The patch of chunk c+1 is fetched at step (c-1, s=1)... stored at (c, s=0), published by that step's barrier
+// and first read by the operand prefetch at the end of (c, s=1).
+#include "ds_common.h"
+#include "ds_conv_epilogue.h"
+#include "ds_h3_common.h"
+
+namespace {
+
+using ds_epi::f32x16;
+using ds_epi::f32x4;
+using ds_h3::u32x4;
+using ds_h3::f16x8;
+using ds_h3::split2;
+using ds_h3::fast_silu;
+
+constexpr int COT = 64, NT = 256, KC = 16;
+template <bool W16> struct Geo {
+  static constexpr int TH = W16 ? 16 : 8, TW = W16 ? 16 : 32;
+  static constexpr int PH = TH + 1, PW = TW + 1, NPOS = PH * PW;     // 297 / 289: one halo row and column
+};
+constexpr int XBUF_VEC = 2 * 2 * 297;                       // 16-byte vectors per X buffer (larger geometry)
+constexpr int WSLAB_VEC = 2 * 2 * 2 * COT;                  // per (chunk, s) slab: 512
+constexpr int WDMA = WSLAB_VEC / 64 / 4;                    // LDS-DMA wave-instructions per wave: 2
+constexpr int STAGE_BYTES = (2 * XBUF_VEC + 3 * WSLAB_VEC) * 16;   // 62,592
+constexpr int EPI_BYTES = 4 * 64 * 2 * 32 * 4;                     // the epilogue's transpose: 16 KiB per wave
+constexpr int MAIN_BYTES = STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES;
+constexpr int LDS_BYTES = MAIN_BYTES + 128 * 4;
+
+struct UpArgs {
+  float* out;
+  const float* in;        // [B, Cin, Hl, Wl]
+  const u32x4* wp;
+  const float* bias;
+  const float* shift;
+  const float* res1;
+  const float* res2;
+  const float* prenorm;   // as ds_conv2d_h3, over the LOW-resolution input
+  float* tile_stats;
+  float unscale;
+  int shift_stride;
+  int res1_up;
+  int B, Cin, Cout, Hl, Wl;
+  int tiles_x, tiles_y, n_cot, n_chunks;
+  unsigned tiles_x_magic;
+};
+
+struct Frags { f16x8 a[2][2]; f16x8 b[2][2]; };   // [piece][m] weights, [piece][r] input
+
+template <bool W16, bool PRE, bool CIRC>
+__global__ __launch_bounds__(NT, 2) void k_convup(const UpArgs a) {
+  constexpr int TH = Geo<W16>::TH, TW = Geo<W16>::TW, PW = Geo<W16>::PW, NPOS = Geo<W16>::NPOS;
+  constexpr int XI = 3;
+  static_assert(NPOS > NT && NPOS - NT <= NT / 2, "staging plan assumes 256 < NPOS <= 384");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  u32x4* Xs = reinterpret_cast<u32x4*>(smem);                        // [buf][piece][h][pos]
+  u32x4* Ws = Xs + 2 * XBUF_VEC;                                     // [slot][piece][t][h][co]
+  float* BS = reinterpret_cast<float*>(smem + MAIN_BYTES);            // [2][64] bias, shift
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  const int lane_pos = W16 ? (li >> 4) * PW + (li & 15) : li;
+  const int wave_row = W16 ? 4 * wv : 2 * wv;
+  constexpr int ROWS_PER_R = W16 ? 2 : 1;
+
+  // grid = (4 parities x channel tiles, pixel tiles, samples), renumbered so that each XCD owns a contiguous
+  // run (see ds_conv3h.hip): the 4 * Cout/64 workgroups that read one input patch share an L2, and so do the
+  // two column parities whose stores interleave in the same cache lines.
+  unsigned cp_u, tile_u, b_u;
+  {
+    const unsigned nx = gridDim.x, ny = gridDim.y;
+    const unsigned id = blockIdx.x + nx * (blockIdx.y + ny * blockIdx.z);
+    const unsigned total = nx * ny * gridDim.z;
+    const unsigned per = total >> 3, rem = total & 7u;
+    const unsigned xcd = id & 7u, k = id >> 3;
+    const unsigned logical = xcd * per + (xcd < rem ? xcd : rem) + k;
+    cp_u = logical % nx;
+    const unsigned rest = logical / nx;
+    tile_u = rest % ny;
+    b_u = rest / ny;
+  }
+  const int par = (int)(cp_u & 3u), cot = (int)(cp_u >> 2);
+  const int pa = par >> 1, pb = par & 1;
+  const int tile_id = (int)tile_u;
+  const int b = (int)b_u;
+  const int ty = a.tiles_x == 1 ? tile_id : (int)__umulhi((unsigned)tile_id, a.tiles_x_magic);
+  const int tx = tile_id - ty * a.tiles_x;
+  const int x0 = tx * TW, y0 = ty * TH;
+  const int HW = a.Hl * a.Wl;
+  const int n_steps = a.n_chunks * 2;
+
+  // ---- staging plan (as ds_conv3h.hip): items 0 / 1 = position tid of channel half 0 / 1, item 2 = the
+  //      patch's tail with h = wave / 2.  Patch origin: (y0 - 1 + a, x0 - 1 + b). ----
+  const int tail_h = wv >> 1;
+  int xoff[XI], xlds[XI];
+  unsigned xvalid = 0, xlive = 0;
+#pragma unroll
+  for (int i = 0; i < XI; ++i) {
+    const int h = i == 0 ? 0 : (i == 1 ? 1 : tail_h);
+    const int pos = i < 2 ? tid : NT + (tid & (NT / 2 - 1));
+    const bool live = pos < NPOS;
+    const int r = pos / PW;
+    const int col = pos - r * PW;
+    int gy = y0 + r - 1 + pa, gx = x0 + col - 1 + pb;
+    if (CIRC) {                                       // tiles divide the image: at most one pixel outside
+      gy = gy < 0 ? gy + a.Hl : (gy >= a.Hl ? gy - a.Hl : gy);
+      gx = gx < 0 ? gx + a.Wl : (gx >= a.Wl ? gx - a.Wl : gx);
+    }
+    const bool ok = live && gy >= 0 && gy < a.Hl && gx >= 0 && gx < a.Wl;
+    xoff[i] = ok ? gy * a.Wl + gx : 0;
+    xlds[i] = h * NPOS + pos;
+    if (ok) xvalid |= (1u << i);
+    if (live) xlive |= (1u << i);
+  }
+  const float* in_b = a.in + (size_t)b * a.Cin * HW;
+  const u32x4* wp = a.wp + (size_t)(cot * 4 + par) * n_steps * WSLAB_VEC;
+
+  float xr[XI][8];
+  int xnch = KC;
+  int xchunk = 0;
+  auto x_fetch = [&](int chunk) __attribute__((always_inline)) {
+    const int cbase = chunk * KC;
+    const float* src = in_b + (size_t)cbase * HW;
+    xchunk = chunk;
+    xnch = a.Cin - cbase < KC ? a.Cin - cbase : KC;
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+      const int h = i == 0 ? 0 : (i == 1 ? 1 : tail_h);
+      const float* p0 = src + xoff[i];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int c = 8 * h + k;
+        xr[i][k] = p0[(c < xnch ? c : 0) * HW];
+      }
+    }
+  };
+  const float* pre_b = PRE ? a.prenorm + (size_t)b * a.n_chunks * KC * 4 : nullptr;
+  auto x_activate = [&](int i) __attribute__((always_inline)) {
+    typedef const __attribute__((address_space(4))) f32x4* cptr;
+    cptr pp = (cptr)(reinterpret_cast<const f32x4*>(pre_b) + xchunk * KC);
+    const int h = i == 0 ? 0 : (i == 1 ? 1 : tail_h);
+    f32x4 p[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) p[k] = pp[8 * h + k];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) xr[i][k] = fast_silu((xr[i][k] - p[k][0]) * p[k][1] + p[k][2]);
+  };
+  auto x_store = [&](int buf) __attribute__((always_inline)) {
+    u32x4* xb = Xs + buf * XBUF_VEC;
+    if (PRE) { x_activate(0); x_activate(1); x_activate(2); }
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+      if (i < 2 || ((xlive >> i) & 1u)) {
+        const int h = i == 0 ? 0 : (i == 1 ? 1 : tail_h);
+        const bool item_ok = (xvalid >> i) & 1u;
+        u32x4 qh, ql;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float v0 = (item_ok && 8 * h + 2 * k < xnch) ? xr[i][2 * k] : 0.f;
+          const float v1 = (item_ok && 8 * h + 2 * k + 1 < xnch) ? xr[i][2 * k + 1] : 0.f;
+          unsigned ph, pl;
+          split2(v0, v1, ph, pl);
+          qh[k] = ph; ql[k] = pl;
+        }
+        xb[xlds[i]] = qh;
+        xb[2 * NPOS + xlds[i]] = ql;
+      }
+    }
+  };
+  auto w_fetch = [&](int step, int slot) __attribute__((always_inline)) {
+    const u32x4* src = wp + (size_t)step * WSLAB_VEC;
+    u32x4* dst = Ws + slot * WSLAB_VEC;
+#pragma unroll
+    for (int i = 0; i < WDMA; ++i) {
+      const int k = wv + 4 * i;
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)(src + 64 * k + lane),
+          (__attribute__((address_space(3))) void*)(dst + 64 * k), 16, 0, 0);
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[m][r][q] = 0.f;
+
+  auto frag_load = [&](Frags& f, int slot, int xbuf, int s, int t) __attribute__((always_inline)) {
+    const u32x4* wb = Ws + slot * WSLAB_VEC;
+    const u32x4* xb = Xs + xbuf * XBUF_VEC;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+        f.a[p][m] = *reinterpret_cast<const f16x8*>(&wb[((p * 2 + t) * 2 + lh) * COT + 32 * m + li]);
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+        f.b[p][r] = *reinterpret_cast<const f16x8*>(&xb[(p * 2 + lh) * NPOS + (wave_row + ROWS_PER_R * r + s) * PW + lane_pos + t]);
+    }
+  };
+  auto frag_mma = [&](const Frags& f) __attribute__((always_inline)) {               // lo*hi, hi*lo, hi*hi
+    constexpr int PA[3] = {1, 0, 0};
+    constexpr int PB[3] = {0, 1, 0};
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+          acc[m][r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[PA[t]][m], f.b[PB[t]][r], acc[m][r], 0, 0, 0);
+  };
+  auto reads_between_mfmas = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+  };
+
+  // ---- prologue: patch 0 staged, patch 1 in flight, weight slabs 0 and 1 ----
+  ds_epi::load_bias_shift(BS, a.bias, a.shift, a.shift_stride, b, cot * COT, a.Cout);
+  x_fetch(0);
+  w_fetch(0, 0);
+  w_fetch(1, 1);                                                 // n_steps >= 2 always
+  x_store(0);
+  if (a.n_chunks > 1) x_fetch(1);                                // stored at the end of step (0, s = 0)
+  __syncthreads();
+
+  Frags fA, fB;
+  frag_load(fA, 0, 0, 0, 0);
+
+  // One step = (chunk, s).  fA holds the operands of t = 0 on entry and, on exit, those of the next step's t = 0.
+  // slot = g % 3 for step g = 2*chunk + s.
+  auto step = [&](int chunk, int s, int slot) __attribute__((always_inline)) {
+    const int g = chunk * 2 + s;
+    const int xbuf = chunk & 1;
+    if (g + 2 < n_steps) w_fetch(g + 2, slot >= 1 ? slot - 1 : 2);      // (slot + 2) % 3
+    if (s == 1 && chunk + 2 < a.n_chunks) x_fetch(chunk + 2);
+    __builtin_amdgcn_sched_barrier(0);
+    frag_load(fB, slot, xbuf, s, 1);
+    frag_mma(fA);
+    reads_between_mfmas();
+    __builtin_amdgcn_sched_barrier(0);
+    if (g + 1 < n_steps) {
+      const int nslot = slot == 2 ? 0 : slot + 1;
+      frag_load(fA, nslot, s == 1 ? xbuf ^ 1 : xbuf, s ^ 1, 0);
+    }
+    frag_mma(fB);
+    if (g + 1 < n_steps) reads_between_mfmas();
+    __builtin_amdgcn_sched_barrier(0);
+    if (s == 0 && chunk + 1 < a.n_chunks) x_store(xbuf ^ 1);            // published by this step's barrier
+    __syncthreads();
+  };
+
+  // slot pattern repeats every three chunks: (0,1) (2,0) (1,2)
+  int chunk = 0;
+  for (; chunk + 2 < a.n_chunks; chunk += 3) {
+    step(chunk, 0, 0); step(chunk, 1, 1);
+    step(chunk + 1, 0, 2); step(chunk + 1, 1, 0);
+    step(chunk + 2, 0, 1); step(chunk + 2, 1, 2);
+  }
+  if (chunk < a.n_chunks) { step(chunk, 0, 0); step(chunk, 1, 1); ++chunk; }
+  if (chunk < a.n_chunks) { step(chunk, 0, 2); step(chunk, 1, 0); }
+
+  {
+    ds_epi::Args e;
+    e.out = a.out; e.bias = a.bias; e.shift = a.shift; e.res1 = a.res1; e.res2 = a.res2; e.res1_up = a.res1_up;
+    e.unscale = a.unscale; e.shift_stride = a.shift_stride;
+    e.b = b; e.co_base = cot * COT; e.y0 = y0 + wave_row; e.x0 = x0;
+    e.Cout = a.Cout; e.H = 2 * a.Hl; e.W = 2 * a.Wl;
+    e.pa = pa; e.pb = pb;
+    e.tile_stats = a.tile_stats; e.tile = (ty * a.tiles_x + tx) * 4 + par; e.ntiles = a.tiles_x * a.tiles_y * 4;
+    float* tile = reinterpret_cast<float*>(smem) + wv * (64 * 2 * 32);
+    ds_epi::store_tile<W16, true>(acc, tile, BS, e);
+    if (a.tile_stats) {
+      __syncthreads();
+      ds_epi::store_tile_stats(reinterpret_cast<const float*>(smem), 64 * 2 * 32, e);
+    }
+  }
+}
+
+// torch [Cout][Cin][3][3] fp32 -> [cot][parity 4][chunk][s 2][piece 2][t 2][h 2][co 64][ci 8] fp16 of the
+// collapsed 2x2 taps (times 2^wshift)
+__global__ void k_pack_up(_Float16* packed, const float* __restrict__ w, int Cout, int Cin, int n_chunks, float scale,
+                          size_t total) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  size_t t = i;
+  const int c8 = t % 8; t /= 8;
+  const int co64 = t % COT; t /= COT;
+  const int h = t % 2; t /= 2;
+  const int tt = t % 2; t /= 2;
+  const int piece = t % 2; t /= 2;
+  const int s = t % 2; t /= 2;
+  const int chunk = t % n_chunks; t /= n_chunks;
+  const int par = t % 4; t /= 4;
+  const int cot = (int)t;
+  const int pa = par >> 1, pb = par & 1;
+  const int co = cot * COT + co64, ci = chunk * KC + 8 * h + c8;
+  float v = 0.f;
+  if (co < Cout && ci < Cin) {
+    const float* wk = w + ((size_t)co * Cin + ci) * 9;
+    // rows of parity pa: s = 0 -> ky in [0, pa], s = 1 -> ky in [pa + 1, 2]; columns alike
+    const int ky0 = s == 0 ? 0 : pa + 1, ky1 = s == 0 ? pa : 2;
+    const int kx0 = tt == 0 ? 0 : pb + 1, kx1 = tt == 0 ? pb : 2;
+    double acc = 0.0;
+    for (int ky = ky0; ky <= ky1; ++ky)
+      for (int kx = kx0; kx <= kx1; ++kx) acc += (double)wk[ky * 3 + kx];
+    v = (float)acc * scale;
+  }
+  const _Float16 hi = (_Float16)v;
+  const _Float16 lo = (_Float16)(v - (float)hi);
+  packed[i] = piece == 0 ? hi : lo;
+}
+
+template <bool W16, bool PRE, bool CIRC>
+int launch_up(const UpArgs& a, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_convup<W16, PRE, CIRC>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    if (e != hipSuccess) return ds::hip_fail(e, "hipFuncSetAttribute(convup)");
+    attr_set = true;
+  }
+  const long long tiles = (long long)a.tiles_y * a.tiles_x;
+  DS_REQUIRE(tiles > 0 && tiles < 65536 && a.B < 65536, DS_ERR_SHAPE,
+             "ds_conv2d_h3_up: %lld pixel tiles x %d samples exceed the grid limits (65535 each)", tiles, a.B);
+  hipLaunchKernelGGL((k_convup<W16, PRE, CIRC>), dim3((unsigned)a.n_cot * 4u, (unsigned)tiles, (unsigned)a.B), dim3(NT),
+                     LDS_BYTES, s, a);
+  DS_CHECK_LAUNCH("ds_conv2d_h3_up");
+  return DS_OK;
+}
+
+// 0: unsupported, 1: 8 x 32 tiles, 2: 16 x 16 tiles
+int up_geometry(int Hl, int Wl) {
+  if (Hl > 0 && Wl > 0 && Hl % 8 == 0 && Wl % 32 == 0) return 1;
+  if (Hl > 0 && Wl > 0 && Hl % 16 == 0 && Wl % 16 == 0) return 2;
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ds_conv2d_h3_up_supported(int Hl, int Wl) { return up_geometry(Hl, Wl) != 0; }
+
+size_t ds_conv2d_h3_up_packed_bytes(int Cout, int Cin) {
+  if (Cout <= 0 || Cin <= 0) return 0;
+  const size_t n_cot = (Cout + COT - 1) / COT, n_chunks = (Cin + KC - 1) / KC;
+  return n_cot * 4 * n_chunks * 2 * (size_t)WSLAB_VEC * 16;
+}
+
+int ds_conv2d_h3_up_pack_weights(void* packed, const float* w, int Cout, int Cin, int wshift, void* stream) {
+  DS_REQUIRE(packed && w, DS_ERR_NULL, "ds_conv2d_h3_up_pack_weights: NULL pointer");
+  DS_REQUIRE(Cout > 0 && Cin > 0, DS_ERR_SHAPE, "ds_conv2d_h3_up_pack_weights: Cout=%d Cin=%d", Cout, Cin);
+  DS_REQUIRE(wshift >= -40 && wshift <= 40, DS_ERR_SHAPE, "ds_conv2d_h3_up_pack_weights: wshift %d out of range", wshift);
+  const int n_chunks = (Cin + KC - 1) / KC;
+  const size_t total = ds_conv2d_h3_up_packed_bytes(Cout, Cin) / 2;
+  hipLaunchKernelGGL(k_pack_up, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ds::as_stream(stream),
+                     reinterpret_cast<_Float16*>(packed), w, Cout, Cin, n_chunks, ldexpf(1.0f, wshift), total);
+  DS_CHECK_LAUNCH("ds_conv2d_h3_up_pack_weights");
+  return DS_OK;
+}
+
+int ds_conv2d_h3_up(float* out, const float* in, const void* w_packed, int wshift, const float* bias, const float* shift,
+                    int shift_stride, const float* res1, const float* res2, int B, int Cin, int Cout, int Hl, int Wl,
+                    int flags, const float* prenorm, float* tile_stats, void* stream) {
+  DS_REQUIRE(out && in && w_packed, DS_ERR_NULL, "ds_conv2d_h3_up: NULL pointer");
+  DS_REQUIRE(B >= 0 && Cin > 0 && Cout > 0 && Hl > 0 && Wl > 0, DS_ERR_SHAPE,
+             "ds_conv2d_h3_up: bad shape B=%d Cin=%d Cout=%d Hl=%d Wl=%d", B, Cin, Cout, Hl, Wl);
+  DS_REQUIRE((flags & ~(DS_PAD_CIRCULAR | DS_RES1_UPSAMPLED)) == 0, DS_ERR_UNSUPPORTED, "ds_conv2d_h3_up: flags %d", flags);
+  const int geo = up_geometry(Hl, Wl);
+  DS_REQUIRE(geo != 0, DS_ERR_UNSUPPORTED,
+             "ds_conv2d_h3_up: %d x %d input is not a whole number of 8x32 or 16x16 tiles (use ds_conv2d_h3 with DS_LOAD_UPSAMPLE2)",
+             Hl, Wl);
+  const int res1_up = (flags & DS_RES1_UPSAMPLED) ? 1 : 0;
+  DS_REQUIRE(!res1_up || res1, DS_ERR_NULL, "ds_conv2d_h3_up: RES1_UPSAMPLED needs res1");
+  DS_REQUIRE(shift == nullptr || shift_stride == 0 || shift_stride >= Cout, DS_ERR_SHAPE,
+             "ds_conv2d_h3_up: shift_stride %d < Cout %d", shift_stride, Cout);
+  DS_REQUIRE((reinterpret_cast<uintptr_t>(w_packed) & 15u) == 0, DS_ERR_SHAPE, "ds_conv2d_h3_up: w_packed must be 16-byte aligned");
+  DS_REQUIRE((reinterpret_cast<uintptr_t>(prenorm) & 15u) == 0, DS_ERR_SHAPE, "ds_conv2d_h3_up: prenorm must be 16-byte aligned");
+  DS_REQUIRE(!res1_up || (reinterpret_cast<uintptr_t>(res1) & 15u) == 0, DS_ERR_SHAPE, "ds_conv2d_h3_up: low-resolution res1 must be 16-byte aligned");
+  DS_REQUIRE(wshift >= -40 && wshift <= 40, DS_ERR_SHAPE, "ds_conv2d_h3_up: wshift %d out of range", wshift);
+  DS_REQUIRE((long long)Cin * Hl * Wl < (1ll << 31), DS_ERR_SHAPE, "ds_conv2d_h3_up: per-sample input exceeds 2^31 floats");
+  if (B == 0) return DS_OK;
+  UpArgs a;
+  a.out = out; a.in = in; a.wp = reinterpret_cast<const u32x4*>(w_packed); a.bias = bias; a.shift = shift;
+  a.res1 = res1; a.res2 = res2; a.prenorm = prenorm; a.tile_stats = tile_stats;
+  a.unscale = ldexpf(1.0f, -wshift); a.shift_stride = shift_stride; a.res1_up = res1_up;
+  a.B = B; a.Cin = Cin; a.Cout = Cout; a.Hl = Hl; a.Wl = Wl;
+  const bool w16 = geo == 2;
+  const int TW = w16 ? 16 : 32, TH = w16 ? 16 : 8;
+  a.tiles_x = Wl / TW; a.tiles_y = Hl / TH;
+  a.n_cot = (Cout + COT - 1) / COT;
+  a.n_chunks = (Cin + KC - 1) / KC;
+  a.tiles_x_magic = a.tiles_x == 1 ? 0u : (unsigned)((1ull << 32) / (unsigned)a.tiles_x) + 1u;
+  hipStream_t s = ds::as_stream(stream);
+  const bool circ = flags & DS_PAD_CIRCULAR;
+#define DS_LU(W) (prenorm ? (circ ? launch_up<W, true, true>(a, s) : launch_up<W, true, false>(a, s)) \
+                          : (circ ? launch_up<W, false, true>(a, s) : launch_up<W, false, false>(a, s)))
+  return w16 ? DS_LU(true) : DS_LU(false);
+#undef DS_LU
+}
+
+}  // extern "C"

@@ -287,7 +287,7 @@ class KarrasModule(torch.nn.Module):
                float(guidance), ykey, float(sch.langevin_const), repr(sch.langevin_interval),
                tuple(float(v) for v in table.t.tolist()),
                tuple((p.data_ptr(), p._version) for p in self.model.parameters()),
-               tuple(getattr(self.model, a, None) for a in ("conv_precision", "fuse_norm", "fuse_max_cot", "direct_out")))
+               tuple(getattr(self.model, a, None) for a in ("conv_precision", "fuse_norm", "fuse_max_cot", "direct_out", "upsample_parity")))
         # hipGraph capture needs a non-default stream: planned runs live on a side stream that is
         # ordered after the caller's stream on entry and before it on exit.
         if self._stream is None or self._stream.device != x.device:

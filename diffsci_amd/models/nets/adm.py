@@ -243,14 +243,15 @@ class ADM(torch.nn.Module):
         for b in blocks:
             convs += [b.conv1, b.conv2, b.convresidual]
         attns = [b.attn for b in blocks if hasattr(b, "attn")]
-        sig = (self.conv_precision,) + tuple((m.weight.data_ptr(), m.weight._version) for m in convs) + tuple(
+        sig = (self.conv_precision, getattr(self, "upsample_parity", True)) + tuple((m.weight.data_ptr(), m.weight._version) for m in convs) + tuple(
             (a.mhattn.in_proj_weight.data_ptr(), a.mhattn.in_proj_weight._version) for a in attns)
         if self._packed is not None and sig == self._packed_sig:
             return self._packed
         pk = {}
         with torch.no_grad():
+            ups = {id(b.conv1) for b in blocks if b.sample == "up"} if getattr(self, "upsample_parity", True) else set()
             for m in convs:
-                pk[id(m)] = ops.pack_conv(m.weight.detach(), self.conv_precision)
+                pk[id(m)] = ops.pack_conv(m.weight.detach(), self.conv_precision, upsampled=id(m) in ups)
             for a in attns:
                 E = a.mhattn.embed_dim
                 prec = "fp16x3" if self.conv_precision == "fp16x3" else "fp32"

@@ -243,14 +243,15 @@ class PUNetG(torch.nn.Module):
     def packed_weights(self):
         """MFMA-operand repack of every conv / projection weight, cached per parameter version."""
         mods = list(self._conv_modules())
-        sig = (self.conv_precision,) + tuple((m.weight.data_ptr(), m.weight._version) for m in mods) + tuple(
+        sig = (self.conv_precision, getattr(self, "upsample_parity", True)) + tuple((m.weight.data_ptr(), m.weight._version) for m in mods) + tuple(
             (a.mhattn.in_proj_weight.data_ptr(), a.mhattn.in_proj_weight._version) for a in self.attn_block)
         if self._packed is not None and sig == self._packed_sig:
             return self._packed
         pk = {}
         with torch.no_grad():
+            ups = {id(u.conv) for u in self.upsamplers} if getattr(self, "upsample_parity", True) else set()
             for m in mods:
-                pk[id(m)] = ops.pack_conv(m.weight.detach(), self.conv_precision)
+                pk[id(m)] = ops.pack_conv(m.weight.detach(), self.conv_precision, upsampled=id(m) in ups)
             for a in self.attn_block:
                 E = a.mhattn.embed_dim
                 prec = "fp16x3" if self.conv_precision == "fp16x3" else "fp32"

@@ -229,10 +229,12 @@ def pack_conv_weight(w):
 class PackedConv:
     """A convolution weight repacked for one of the MFMA kernels.
     kind: "fp32" (exact-fp32 MFMA), "bf16x6" or "fp16x3" (fp32 emulated on the 16-bit matrix cores)."""
-    __slots__ = ("data", "Cout", "Cin", "ks", "kind", "wshift")
+    __slots__ = ("data", "Cout", "Cin", "ks", "kind", "wshift", "up", "up_wshift")
 
-    def __init__(self, data, Cout, Cin, ks, kind, wshift=0):
+    def __init__(self, data, Cout, Cin, ks, kind, wshift=0, up=None, up_wshift=0):
         self.data, self.Cout, self.Cin, self.ks, self.kind, self.wshift = data, Cout, Cin, ks, kind, wshift
+        # fp16x3 3x3 only: the four 2x2 parity kernels of "upsample x2, then this convolution" and their scale
+        self.up, self.up_wshift = up, up_wshift
 
     @property
     def x6(self):
@@ -242,9 +244,11 @@ class PackedConv:
 CONV_PRECISIONS = ("fp16x3", "bf16x6", "fp32")
 
 
-def pack_conv(w, precision="bf16x6"):
+def pack_conv(w, precision="bf16x6", upsampled=False):
     """Repack a torch conv weight [Cout, Cin, k, k] (device, fp32).  3x3 kernels honour
-    `precision`; 1x1 kernels use the fp16x3 kernel for "fp16x3" and the exact-fp32 MFMA kernel otherwise."""
+    `precision`; 1x1 kernels use the fp16x3 kernel for "fp16x3" and the exact-fp32 MFMA kernel otherwise.
+    upsampled: the convolution follows a nearest x2 upsampling; the fp16x3 packing then also carries the
+    collapsed parity kernels of ds_conv2d_h3_up."""
     require_device(w, "conv weight")
     if precision not in CONV_PRECISIONS:
         raise ValueError(f"unknown conv precision {precision!r}; choose from {CONV_PRECISIONS}")
@@ -268,13 +272,19 @@ def pack_conv(w, precision="bf16x6"):
                             (N.lib().ds_conv1x1_h3_packed_bytes, N.lib().ds_conv1x1_h3_pack_weights))
         data = torch.empty(size_fn(Cout, Cin) // 4, dtype=torch.float32, device=w.device)
         N.check(pack_fn(data.data_ptr(), _p(w), Cout, Cin, wshift, _stream()), "ds_conv*_h3_pack_weights")
-        return PackedConv(data, Cout, Cin, k, "fp16x3", wshift)
+        up, up_wshift = None, 0
+        if upsampled and k == 3:
+            up_wshift = max(-40, wshift - 2)          # a collapsed tap sums up to four weights: two bits of headroom
+            up = torch.empty(N.lib().ds_conv2d_h3_up_packed_bytes(Cout, Cin) // 4, dtype=torch.float32, device=w.device)
+            N.check(N.lib().ds_conv2d_h3_up_pack_weights(up.data_ptr(), _p(w), Cout, Cin, up_wshift, _stream()),
+                    "ds_conv2d_h3_up_pack_weights")
+        return PackedConv(data, Cout, Cin, k, "fp16x3", wshift, up, up_wshift)
     return PackedConv(pack_conv_weight(w), Cout, Cin, k, "fp32")
 
 
 def conv(x, pw, **kw):
     """Dispatch on the packing: ds_conv2d_h3, ds_conv2d_x6 or ds_conv2d."""
-    return conv2d(x, pw.data, pw.Cout, pw.ks, kind=pw.kind, wshift=pw.wshift, **kw)
+    return conv2d(x, pw.data, pw.Cout, pw.ks, kind=pw.kind, wshift=pw.wshift, w_up=pw.up, up_wshift=pw.up_wshift, **kw)
 
 
 def conv_direct(x, w, bias=None, circular=False, out=None):
@@ -338,7 +348,7 @@ def gnorm1_table(stats_a, w, b, kind, count, stats_b=None, film=None, eps=1e-5, 
 
 def conv2d(x, w_packed, Cout, ks, bias=None, shift=None, res1=None, res2=None,
            load_mode=N.DS_LOAD_PLAIN, out=None, kind="fp32", wshift=0, prenorm=None, tile_stats=None, circular=False,
-           res1_upsampled=False):
+           res1_upsampled=False, w_up=None, up_wshift=0):
     """'same' zero-padded conv; x [B, Cin, Hin, Win]; shift [1 or B, Cout] or None.
     fp16x3 kernels only: prenorm [B, ceil16(Cin), 4] (3x3) applies SiLU((x-M)*A+C) in the loader; tile_stats
     [B, Cout, conv_tile_count(H, W), 4] receives per-tile (K, sum(x-K), sum((x-K)^2), n) of the output."""
@@ -388,6 +398,14 @@ def conv2d(x, w_packed, Cout, ks, bias=None, shift=None, res1=None, res2=None,
         N.check(N.lib().ds_conv1x1_h3(_p(out), _p(x), _p(w_packed), int(wshift), _p(bias), _p(shift), stride,
                                       _p(res1), _p(res2), B, Cin, Cout, H, W, load_mode, _p(tile_stats), _stream()),
                 "ds_conv1x1_h3")
+    elif kind == "fp16x3" and load_mode == N.DS_LOAD_UPSAMPLE2 and w_up is not None \
+            and N.lib().ds_conv2d_h3_up_supported(Hin, Win):
+        if w_up.numel() != N.lib().ds_conv2d_h3_up_packed_bytes(Cout, Cin) // 4:
+            raise ValueError("w_up size does not match (Cout, Cin)")
+        N.check(N.lib().ds_conv2d_h3_up(_p(out), _p(x), _p(w_up), int(up_wshift), _p(bias), _p(shift), stride,
+                                        _p(res1), _p(res2), B, Cin, Cout, Hin, Win,
+                                        (N.DS_PAD_CIRCULAR if circular else 0) | (N.DS_RES1_UPSAMPLED if res1_upsampled else 0),
+                                        _p(prenorm), _p(tile_stats), _stream()), "ds_conv2d_h3_up")
     elif kind == "fp16x3":
         N.check(N.lib().ds_conv2d_h3(_p(out), _p(x), _p(w_packed), int(wshift), _p(bias), _p(shift), stride,
                                      _p(res1), _p(res2), B, Cin, Cout, H, W,

@@ -176,6 +176,21 @@ int ds_conv2d_h3(float* out, const float* in, const void* w_packed, int wshift, 
                  const float* shift, int shift_stride, const float* res1, const float* res2,
                  int B, int Cin, int Cout, int H, int W, int load_mode,
                  const float* prenorm, float* tile_stats, void* stream);
+
+/* "Nearest x2 upsampling, then the 3x3 convolution" (UpSampler, commonlayers.py:145; ADM up blocks, adm.py:312-323)
+ * evaluated at the LOW resolution: for each of the four output parities the 3x3 kernel collapses to a 2x2 kernel
+ * on the un-upsampled input (taps summed at pack time), 16 instead of 36 multiply-adds per output.  in is
+ * [B,Cin,Hl,Wl], out [B,Cout,2Hl,2Wl]; same epilogue terms, prenorm and tile_stats (4 tiles per low-resolution
+ * tile: the count equals ds_conv_tile_count(2Hl, 2Wl)) as ds_conv2d_h3.  flags: DS_PAD_CIRCULAR and/or
+ * DS_RES1_UPSAMPLED.  Only for inputs that are whole 8x32 or 16x16 tiles (ds_conv2d_h3_up_supported); other
+ * shapes use ds_conv2d_h3 with DS_LOAD_UPSAMPLE2. */
+int ds_conv2d_h3_up_supported(int Hl, int Wl);
+size_t ds_conv2d_h3_up_packed_bytes(int Cout, int Cin);
+int ds_conv2d_h3_up_pack_weights(void* packed, const float* w, int Cout, int Cin, int wshift, void* stream);
+int ds_conv2d_h3_up(float* out, const float* in, const void* w_packed, int wshift, const float* bias,
+                    const float* shift, int shift_stride, const float* res1, const float* res2,
+                    int B, int Cin, int Cout, int Hl, int Wl, int flags, const float* prenorm, float* tile_stats,
+                    void* stream);
 /* Two optional fusions of the normalisation around the convolution (NULL = off):
  *   prenorm    [B, ceil16(Cin), 4] = (M, A, C, -), rows past Cin zero: the loader applies SiLU((x - M)*A + C) to every input element
  *              before the convolution (zero padding stays zero) -- the norm -> act of ResnetBlockC /

@@ -501,3 +501,85 @@ def test_conv_upsampled_residual(dev, case):
     torch.testing.assert_close((n * K + S).sum(-1), want.sum(dim=(2, 3)), rtol=1e-5, atol=1e-3)
     with pytest.raises(ValueError, match="res1_upsampled"):
         ops.conv(x.to(dev), ops.pack_conv(w.to(dev), "fp16x3"), res1=rlow.to(dev)[:, :, :-1], res1_upsampled=True)
+
+
+@pytest.mark.parametrize("case", [
+    # B, Cin, Cout, Hl, Wl, circular, prenorm, res1 ("hi" | "low" | None)
+    (2, 16, 64, 8, 32, False, False, None),
+    (1, 40, 72, 16, 16, False, False, "hi"),        # 16 x 16 tiles, ragged channel tiles
+    (2, 24, 130, 16, 64, True, False, "low"),       # periodic padding, low-resolution residual
+    (1, 50, 33, 32, 32, False, True, "hi"),         # normalisation + SiLU folded into the loader
+    (1, 16, 16, 48, 16, True, True, None),          # 16 x 16 tiles, three tile rows, one chunk
+    (3, 96, 64, 8, 64, False, False, "hi"),         # six chunks: two rounds of the weight-slot pattern
+])
+def test_conv_upsample_parity_kernel(dev, case):
+    """ds_conv2d_h3_up (upsample x2 + 3x3 conv as four 2x2 parity kernels at low resolution) against the fp64
+    definition, and its tile statistics."""
+    ops = _ops()
+    B, Cin, Cout, Hl, Wl, circ, pre, res = case
+    H, W = 2 * Hl, 2 * Wl
+    g = torch.Generator().manual_seed(sum(int(v or 0) * (i + 3) for i, v in enumerate(case[:5])))
+    x = torch.randn(B, Cin, Hl, Wl, generator=g) * 2 + 0.3
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)
+    bias = torch.randn(Cout, generator=g)
+    shift = torch.randn(B, Cout, generator=g)
+    res2 = torch.randn(B, Cout, H, W, generator=g)
+    r1 = None if res is None else torch.randn(B, Cout, *((H, W) if res == "hi" else (Hl, Wl)), generator=g)
+    assert ops.N.lib().ds_conv2d_h3_up_supported(Hl, Wl)
+
+    def definition(dt):
+        xx = x.to(dt)
+        if pre:
+            tab = table.to(dt)[:, :Cin]
+            xx = F.silu((xx - tab[:, :, 0, None, None]) * tab[:, :, 1, None, None] + tab[:, :, 2, None, None])
+        up = F.interpolate(xx, scale_factor=2.0, mode="nearest")
+        if circ:
+            y = F.conv2d(F.pad(up, (1, 1, 1, 1), mode="circular"), w.to(dt), bias.to(dt))
+        else:
+            y = F.conv2d(up, w.to(dt), bias.to(dt), padding=1)
+        y = y + shift.to(dt)[:, :, None, None]
+        if r1 is not None:
+            y = y + (r1.to(dt) if res == "hi" else F.interpolate(r1.to(dt), scale_factor=2.0, mode="nearest"))
+        return y + res2.to(dt)
+
+    table = None
+    if pre:
+        table = torch.zeros(B, ops.table_channels(Cin), 4)
+        table[:, :Cin, 0] = torch.randn(B, Cin, generator=g) * 0.2
+        table[:, :Cin, 1] = torch.rand(B, Cin, generator=g) + 0.5
+        table[:, :Cin, 2] = torch.randn(B, Cin, generator=g) * 0.2
+    want, ref32 = definition(torch.float64), definition(torch.float32)
+    pw = ops.pack_conv(w.to(dev), "fp16x3", upsampled=True)
+    assert pw.up is not None and pw.up_wshift == pw.wshift - 2
+    ts = torch.zeros(B, Cout, ops.conv_tile_count(H, W), 4, device=dev)
+    kw = dict(bias=bias.to(dev), shift=shift.to(dev), res1=None if r1 is None else r1.to(dev), res1_upsampled=res == "low",
+              res2=res2.to(dev), load_mode=ops.N.DS_LOAD_UPSAMPLE2, circular=circ,
+              prenorm=None if table is None else table.to(dev))
+    got = ops.conv(x.to(dev), pw, tile_stats=ts, **kw).cpu()
+    assert rel_l2(got, want) <= max(3 * rel_l2(ref32, want), 3e-7)
+    K, S, Q, n = ts.cpu().double().unbind(-1)
+    assert torch.equal(n.sum(-1), torch.full((B, Cout), float(H * W), dtype=torch.float64))
+    torch.testing.assert_close((n * K + S).sum(-1), want.sum(dim=(2, 3)), rtol=1e-5, atol=2e-3)
+    mean = (n * K + S).sum(-1) / (H * W)
+    m2 = (Q + 2 * (K - mean[..., None]) * S + n * (K - mean[..., None]) ** 2).sum(-1)
+    torch.testing.assert_close(m2, ((want - want.mean(dim=(2, 3), keepdim=True)) ** 2).sum(dim=(2, 3)), rtol=2e-5, atol=1e-3)
+    # the generic gather kernel (no parity packing) computes the same thing
+    generic = ops.conv(x.to(dev), ops.pack_conv(w.to(dev), "fp16x3"), **kw).cpu()
+    assert rel_l2(got, generic.double()) < 5e-7
+
+
+def test_conv_upsample_parity_fallback_and_errors(dev):
+    """Shapes that are not whole tiles take ds_conv2d_h3's UPSAMPLE2 loader; the raw entry point refuses them."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(1, 16, 12, 20, generator=g)
+    w = torch.randn(8, 16, 3, 3, generator=g) / 12
+    assert not ops.N.lib().ds_conv2d_h3_up_supported(12, 20)
+    pw = ops.pack_conv(w.to(dev), "fp16x3", upsampled=True)
+    got = ops.conv(x.to(dev), pw, load_mode=ops.N.DS_LOAD_UPSAMPLE2).cpu()
+    want = F.conv2d(F.interpolate(x.double(), scale_factor=2.0, mode="nearest"), w.double(), padding=1)
+    assert rel_l2(got, want) < 3e-7
+    out = torch.empty(1, 8, 24, 40, device=dev)
+    rc = ops.N.lib().ds_conv2d_h3_up(out.data_ptr(), x.to(dev).data_ptr(), pw.up.data_ptr(), 0, None, None, 0, None, None,
+                                     1, 16, 8, 12, 20, 0, None, None, None)
+    assert rc != 0 and b"whole number" in ops.N.lib().ds_last_error()

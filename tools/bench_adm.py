@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-fuse-norm", action="store_true")
     ap.add_argument("--fuse-max-cot", type=int, default=None)
+    ap.add_argument("--no-up-parity", action="store_true")
     a = ap.parse_args()
     import diffsci_amd.models as M
     dev = torch.device("cuda:0")
@@ -37,6 +38,7 @@ def main():
                             output_embed_dim=4 * c, channel_expansion=[1, 2, 4, 4], skip_integration_type=a.skip))
     net.conv_precision = a.precision
     net.fuse_norm = not a.no_fuse_norm
+    net.upsample_parity = not a.no_up_parity
     if a.fuse_max_cot is not None:
         net.fuse_max_cot = a.fuse_max_cot
     nparam = sum(p.numel() for p in net.parameters())
