@@ -216,15 +216,45 @@ int launch_inorm(float* out, const float* x, const float* w, const float* b, int
   return DS_OK;
 }
 
+// kinds without a reduction: 2 = no normalisation (torch.nn.Identity: SiLU only), 3 = GroupPixNorm(C, C)
+// (commonlayers.py:387-440 with one channel per group: x / sqrt(x^2 + eps) * w[c] + b[c]), then SiLU
+template <int KIND>
+__global__ __launch_bounds__(256) void k_pointwise_silu(float* out, const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ b, int C, int HW, float eps) {
+  const int plane = blockIdx.y;
+  const int c = plane % C;
+  const float wc = (KIND == 3 && w) ? w[c] : 1.0f, bc = (KIND == 3 && b) ? b[c] : 0.0f;
+  const float* xp = x + (size_t)plane * HW;
+  float* op = out + (size_t)plane * HW;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += gridDim.x * 256) {
+    float v = xp[i];
+    if (KIND == 3) {
+      v = v / sqrtf(v * v + eps);
+      v = v * wc + bc;
+    }
+    op[i] = v / (1.0f + expf(-v));
+  }
+}
+
 }  // namespace
 
 extern "C" int ds_inorm_silu(float* out, const float* x, const float* w, const float* b, int B, int C, int HW,
                              float eps, int kind, void* stream) {
   DS_REQUIRE(out && x, DS_ERR_NULL, "ds_inorm_silu: NULL pointer");
   DS_REQUIRE(B >= 0 && C > 0 && HW > 0, DS_ERR_SHAPE, "ds_inorm_silu: bad shape B=%d C=%d HW=%d", B, C, HW);
-  DS_REQUIRE(kind == 0 || kind == 1, DS_ERR_UNSUPPORTED, "ds_inorm_silu: kind must be 0 (GroupLN) or 1 (GroupRMS)");
+  DS_REQUIRE(kind >= 0 && kind <= 3, DS_ERR_UNSUPPORTED,
+             "ds_inorm_silu: kind must be 0 (GroupLN), 1 (GroupRMS), 2 (none) or 3 (GroupPix)");
   DS_REQUIRE((long long)B * C < (1ll << 31), DS_ERR_SHAPE, "ds_inorm_silu: too many planes");
   if (B == 0) return DS_OK;
   hipStream_t s = ds::as_stream(stream);
+  if (kind >= 2) {
+    const int planes = B * C;
+    DS_REQUIRE(planes < 65536, DS_ERR_SHAPE, "ds_inorm_silu: kind %d supports B*C < 65536 planes", kind);
+    dim3 g((unsigned)((HW + 1023) / 1024 > 64 ? 64 : (HW + 1023) / 1024), (unsigned)planes);
+    if (kind == 2) hipLaunchKernelGGL((k_pointwise_silu<2>), g, dim3(256), 0, s, out, x, w, b, C, HW, eps);
+    else hipLaunchKernelGGL((k_pointwise_silu<3>), g, dim3(256), 0, s, out, x, w, b, C, HW, eps);
+    DS_CHECK_LAUNCH("ds_inorm_silu");
+    return DS_OK;
+  }
   return kind == 0 ? launch_inorm<0>(out, x, w, b, B, C, HW, eps, s) : launch_inorm<1>(out, x, w, b, B, C, HW, eps, s);
 }

@@ -6,7 +6,8 @@
 // that the next convolution's loader applies while it stages its input -- the normalised tensor is
 // never written to or read from HBM.
 //   ds_inorm_table   PUNetG: GroupNorm(C,C) / GroupRMSNorm(C,C) per (sample, channel) plane
-//                    (commonlayers.py:766-770, 372-384):   M = mean | 0,  A = rstd*w[c],  C = b[c]
+//                    (commonlayers.py:766-770, 372-384):   M = mean | 0,  A = rstd*w[c],  C = b[c];
+//                    kind 2 (norm = Identity, commonlayers.py:891-899): (0, 1, 0)
 //   ds_gnorm1_table  ADM: GroupNorm(1,C) / GroupRMSNorm(1,C)+FiLM per sample over (C,H,W), optionally
 //                    over the channel concatenation of two tensors (adm.py:306-343, 385-406, 764-766):
 //                    kind 0: M = mean_b, A = rstd_b*w[c], C = b[c]
@@ -52,12 +53,15 @@ __global__ __launch_bounds__(256) void k_inorm_table(float* table, const float* 
       if (var < 0.0) var = 0.0;
       M = (float)mean;
       rs = 1.0f / sqrtf((float)var + eps);
-    } else {
+    } else if (kind == 1) {
       M = 0.f;
       rs = 1.0f / sqrtf((float)(q * inv_n) + eps);
+    } else {                                   // kind 2: no normalisation, the loader applies SiLU alone
+      M = 0.f;
+      rs = 1.0f;
     }
     float4 o;
-    o.x = M; o.y = rs * (w ? w[c] : 1.f); o.z = bias ? bias[c] : 0.f; o.w = 0.f;
+    o.x = M; o.y = rs * ((w && kind != 2) ? w[c] : 1.f); o.z = (bias && kind != 2) ? bias[c] : 0.f; o.w = 0.f;
     reinterpret_cast<float4*>(table)[row] = o;
   }
 }
@@ -124,7 +128,7 @@ int ds_inorm_table(float* table, const float* tile_stats, const float* w, const 
                    int count, float eps, int kind, void* stream) {
   DS_REQUIRE(table && tile_stats, DS_ERR_NULL, "ds_inorm_table: NULL pointer");
   DS_REQUIRE(B >= 0 && C > 0 && ntiles > 0 && count > 0, DS_ERR_SHAPE, "ds_inorm_table: bad shape");
-  DS_REQUIRE(kind == 0 || kind == 1, DS_ERR_UNSUPPORTED, "ds_inorm_table: kind %d", kind);
+  DS_REQUIRE(kind >= 0 && kind <= 2, DS_ERR_UNSUPPORTED, "ds_inorm_table: kind %d (0 GroupLN, 1 GroupRMS, 2 none)", kind);
   DS_REQUIRE((long long)B * C < (1ll << 31), DS_ERR_SHAPE, "ds_inorm_table: too many planes");
   DS_REQUIRE((reinterpret_cast<uintptr_t>(table) & 15u) == 0 && (reinterpret_cast<uintptr_t>(tile_stats) & 15u) == 0,
              DS_ERR_SHAPE, "ds_inorm_table: misaligned pointer");

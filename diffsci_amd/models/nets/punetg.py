@@ -13,6 +13,7 @@ operation of the forward pass is a launch into libdiffsci_hip.so:
   TwoDimensionalAttention (nn.MultiheadAttention, 1 head)  ds_conv2d (1x1 projections) + ds_attention
   x + xa (punetg.py:385)                                    folded into the preceding conv epilogue
 """
+import math
 from typing import Any
 
 import torch
@@ -23,23 +24,98 @@ from .punetg_config import PUNetGConfig
 
 
 class _AffineHolder(torch.nn.Module):
-    """weight/bias container for GroupRMSNorm (commonlayers.py:332-361)."""
+    """weight/bias container for GroupRMSNorm / GroupPixNorm (commonlayers.py:332-361, 387-414); no parameters
+    when affine=False."""
+
+    def __init__(self, C, affine=True):
+        super().__init__()
+        self.weight = torch.nn.Parameter(torch.ones(C)) if affine else None
+        self.bias = torch.nn.Parameter(torch.zeros(C)) if affine else None
+
+
+NORM_KINDS = {"GroupLN": 0, "GroupRMS": 1, "GroupPix": 3}       # anything else: Identity (kind 2), commonlayers.py:882-899
+
+
+def make_norm(name, C, affine=True):
+    """ResnetBlockC.get_normalization_functions (commonlayers.py:882-899) with num_groups = C."""
+    if name == "GroupLN":
+        return torch.nn.GroupNorm(C, C, affine=affine)
+    if name in ("GroupRMS", "GroupPix"):
+        return _AffineHolder(C, affine)
+    return torch.nn.Identity()
+
+
+def mp_weight(w):
+    """Effective weight of the magnitude-preserving layers in eval mode (normedlayers.py:17-22,46-55,95-99):
+    normalize(w) / sqrt(fan_in) with normalize(x) = x / (eps + ||x_row|| * sqrt(1/fan_in)), eps = 1e-4."""
+    fan_in = w[0].numel()
+    n = torch.linalg.vector_norm(w, dim=list(range(1, w.ndim)), keepdim=True)
+    alpha = math.sqrt(n.numel() / w.numel())
+    return (w / torch.add(1e-4, n, alpha=alpha)) / math.sqrt(fan_in)
+
+
+class _MPConv(torch.nn.Module):
+    """MagnitudePreservingConv2d parameters (normedlayers.py:26-44): N(0,1) weight, zero bias."""
+    mp = True
+
+    def __init__(self, cin, cout, k, bias=True):
+        super().__init__()
+        self.weight = torch.nn.Parameter(torch.randn(cout, cin, k, k))
+        self.bias = torch.nn.Parameter(torch.zeros(cout)) if bias else None
+        self.in_channels, self.out_channels = cin, cout
+
+
+class _MPLinear(torch.nn.Module):
+    """MagnitudePreservingLinear parameters (normedlayers.py:6-15)."""
+    mp = True
+
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.weight = torch.nn.Parameter(torch.randn(cout, cin))
+        self.bias = torch.nn.Parameter(torch.zeros(cout))
+
+
+class _MPAttention(torch.nn.Module):
+    """The in-house MultiHeadAttention the reference substitutes for nn.MultiheadAttention when
+    magnitude_preserving (attention.py:30-41, 110-153): one head, dk = dv = dmodel, no biases."""
 
     def __init__(self, C):
         super().__init__()
-        self.weight = torch.nn.Parameter(torch.ones(C))
-        self.bias = torch.nn.Parameter(torch.zeros(C))
+        for n in ("q", "k", "v", "o"):
+            setattr(self, n + "_proj_matrix", torch.nn.Parameter(torch.randn(1, C, C)))
+        self.embed_dim = C
+
+    @staticmethod
+    def _normalized(weight, kind):
+        """MultiHeadAttention.normalize_weight + the 1/sqrt(fan_in) of forward (attention.py:183-196, 232-247)."""
+        if kind == "wo":
+            norm = torch.linalg.vector_norm(weight, dim=[0, 2], keepdim=True)
+            fan_in = weight.shape[0] * weight.shape[2]
+        else:
+            norm = torch.linalg.vector_norm(weight, dim=1, keepdim=True)
+            fan_in = weight.shape[1]
+        alpha = math.sqrt(norm.numel() / weight.numel())
+        return (weight / (alpha * norm + 1e-4)) / math.sqrt(fan_in)
+
+    def projection_weights(self):
+        """(in_proj [3E, E], out_proj [E, E]) as 1x1-convolution weights: q = x Wq -> rows of Wq^T;
+        out[l] = sum_k a[k] wo[0, l, k]."""
+        wq, wk, wv = (self._normalized(getattr(self, n + "_proj_matrix").detach(), "w" + n)[0].t() for n in "qkv")
+        wo = self._normalized(self.o_proj_matrix.detach(), "wo")[0]
+        return torch.cat([wq, wk, wv], dim=0).contiguous(), wo.contiguous()
 
 
 class _TimeBlock(torch.nn.Module):
-    """ResnetTimeBlock parameters: net.{0,2,4} Linear (commonlayers.py:516-522)."""
+    """ResnetTimeBlock parameters: net.{0,2,4} Linear (commonlayers.py:512-522), magnitude-preserving
+    linears when the convolutions are."""
 
-    def __init__(self, embed, out):
+    def __init__(self, embed, out, mp=False):
         super().__init__()
+        lin = (lambda i, o: _MPLinear(i, o)) if mp else torch.nn.Linear
         self.net = torch.nn.Sequential(
-            torch.nn.Linear(embed, 4 * embed), torch.nn.Identity(),
-            torch.nn.Linear(4 * embed, 4 * embed), torch.nn.Identity(),
-            torch.nn.Linear(4 * embed, out))
+            lin(embed, 4 * embed), torch.nn.Identity(),
+            lin(4 * embed, 4 * embed), torch.nn.Identity(),
+            lin(4 * embed, out))
 
 
 class _CircConv(torch.nn.Module):
@@ -59,32 +135,37 @@ class _CircConv(torch.nn.Module):
         return self.conv.bias
 
 
-def make_conv(cin, cout, k, circular, bias=True):
-    return _CircConv(cin, cout, k, bias) if circular else torch.nn.Conv2d(cin, cout, k, padding="same", bias=bias)
+def make_conv(cin, cout, k, kind="default", bias=True):
+    """choose_conv_cls (punetg.py:217-236): kind = convolution_type ("default" | "circular" | "mp")."""
+    if kind is True or kind == "circular":
+        return _CircConv(cin, cout, k, bias)
+    if kind == "mp":
+        return _MPConv(cin, cout, k, bias)
+    return torch.nn.Conv2d(cin, cout, k, padding="same", bias=bias)
 
 
 class _ResBlock(torch.nn.Module):
     """ResnetBlockC parameters (commonlayers.py:766-807)."""
 
-    def __init__(self, C, embed, circular=False, bias=True):
+    def __init__(self, C, embed, conv_kind="default", bias=True, norms=("GroupLN", "GroupRMS"), affine=True):
         super().__init__()
-        self.gnorm1 = torch.nn.GroupNorm(C, C)
-        self.gnorm2 = _AffineHolder(C)
-        self.conv1 = make_conv(C, C, 3, circular, bias)
-        self.conv2 = make_conv(C, C, 3, circular, bias)
-        self.timeblock = _TimeBlock(embed, C)
+        self.gnorm1 = make_norm(norms[0], C, affine)
+        self.gnorm2 = make_norm(norms[1], C, affine)
+        self.conv1 = make_conv(C, C, 3, conv_kind, bias)
+        self.conv2 = make_conv(C, C, 3, conv_kind, bias)
+        self.timeblock = _TimeBlock(embed, C, mp=conv_kind == "mp")
 
 
 class _Sampler(torch.nn.Module):
-    def __init__(self, cin, cout, circular=False, bias=True):
+    def __init__(self, cin, cout, conv_kind="default", bias=True):
         super().__init__()
-        self.conv = make_conv(cin, cout, 3, circular, bias)
+        self.conv = make_conv(cin, cout, 3, conv_kind, bias)
 
 
 class _Attn(torch.nn.Module):
-    def __init__(self, C):
+    def __init__(self, C, mp=False):
         super().__init__()
-        self.mhattn = torch.nn.MultiheadAttention(C, num_heads=1, batch_first=True)
+        self.mhattn = _MPAttention(C) if mp else torch.nn.MultiheadAttention(C, num_heads=1, batch_first=True)
 
 
 class _Fourier(torch.nn.Module):
@@ -133,14 +214,18 @@ class PUNetG(torch.nn.Module):
         mult = config.extended_channel_expansion
         self.time_projection = _Fourier(mc, config.time_projection_scale)
         self.conditional_embedding = conditional_embedding
-        circ = self.circular = config.convolution_type == "circular"
+        self.circular = config.convolution_type == "circular"
+        circ = config.convolution_type                     # conv kind: "default" | "circular" | "mp"
+        self.mp = config.convolution_type == "mp"
         hb = bool(config.bias)
+        norms = (config.first_resblock_norm, config.second_resblock_norm)
+        self.norm_kinds = tuple(NORM_KINDS.get(n, 2) for n in norms)
         # bias=False: no convolution biases; a constant-one input channel is appended instead (punetg.py:190-191,390-394)
         self.convin = make_conv(config.input_channels + (0 if hb else 1), mc, 3, circ, hb)
         self.convout = make_conv(mc, config.output_channels, 3, circ, hb)
 
         def blocks(m, n):
-            return torch.nn.ModuleList([_ResBlock(m * mc, mc, circ, hb) for _ in range(n)])
+            return torch.nn.ModuleList([_ResBlock(m * mc, mc, circ, hb, norms, bool(config.affine_norm)) for _ in range(n)])
 
         self.downward_blocks = torch.nn.ModuleList(
             [blocks(mult[i], config.number_resnet_downward_block) for i in range(len(mult) - 1)])
@@ -155,7 +240,7 @@ class PUNetG(torch.nn.Module):
         self.after_block = blocks(mult[-1], config.number_resnet_after_attn_block)
         self.attn_resnet_block = blocks(mult[-1], config.number_resnet_attn_block)
         self.attn_block = torch.nn.ModuleList(
-            [_Attn(mult[-1] * mc) for _ in range(config.number_resnet_attn_block - 1)])
+            [_Attn(mult[-1] * mc, self.mp) for _ in range(config.number_resnet_attn_block - 1)])
         # Arithmetic of the 3x3 convolutions -- all three give fp32-level error (tests/test_gpu_kernels.py):
         #   "fp16x3": fp16 hi+lo split, 3 MFMA products (default; inputs must stay below 65504 in magnitude)
         #   "bf16x6": exact 3-way bf16 split, 6 MFMA products (no range limit, half the speed)
@@ -214,11 +299,16 @@ class PUNetG(torch.nn.Module):
     def time_shifts(self, te):
         """Per-block ResnetTimeBlock(te): list of [M, C_block] tensors in block order."""
         out = []
+        pk = self.packed_weights() if self.mp else None
+
+        def wgt(lin):
+            return pk[(id(lin), "eff")] if pk is not None else lin.weight
+
         for blk in self._resblocks():
             n = blk.timeblock.net
-            h = ops.linear(te, n[0].weight, n[0].bias, act=1)
-            h = ops.linear(h, n[2].weight, n[2].bias, act=1)
-            out.append(ops.linear(h, n[4].weight, n[4].bias, act=0))
+            h = ops.linear(te, wgt(n[0]), n[0].bias, act=1)
+            h = ops.linear(h, wgt(n[2]), n[2].bias, act=1)
+            out.append(ops.linear(h, wgt(n[4]), n[4].bias, act=0))
         return out
 
     def _resblocks(self):
@@ -240,23 +330,45 @@ class PUNetG(torch.nn.Module):
         for s in list(self.downsamplers) + list(self.upsamplers):
             yield s.conv
 
+    def _timeblock_linears(self):
+        for blk in self._resblocks():
+            n = blk.timeblock.net
+            yield from (n[0], n[2], n[4])
+
     def packed_weights(self):
-        """MFMA-operand repack of every conv / projection weight, cached per parameter version."""
+        """MFMA-operand repack of every conv / projection weight, cached per parameter version.  Magnitude-preserving
+        layers contribute their eval-mode effective weights (mp_weight), computed here once per weight version."""
         mods = list(self._conv_modules())
-        sig = (self.conv_precision, getattr(self, "upsample_parity", True)) + tuple((m.weight.data_ptr(), m.weight._version) for m in mods) + tuple(
-            (a.mhattn.in_proj_weight.data_ptr(), a.mhattn.in_proj_weight._version) for a in self.attn_block)
+        tracked = [m.weight for m in mods]
+        for a in self.attn_block:
+            tracked += ([a.mhattn.q_proj_matrix, a.mhattn.k_proj_matrix, a.mhattn.v_proj_matrix, a.mhattn.o_proj_matrix]
+                        if self.mp else [a.mhattn.in_proj_weight, a.mhattn.out_proj.weight])
+        if self.mp:
+            tracked += [lin.weight for lin in self._timeblock_linears()]
+        sig = (self.conv_precision, getattr(self, "upsample_parity", True)) + tuple((t.data_ptr(), t._version) for t in tracked)
         if self._packed is not None and sig == self._packed_sig:
             return self._packed
         pk = {}
         with torch.no_grad():
             ups = {id(u.conv) for u in self.upsamplers} if getattr(self, "upsample_parity", True) else set()
             for m in mods:
-                pk[id(m)] = ops.pack_conv(m.weight.detach(), self.conv_precision, upsampled=id(m) in ups)
+                w = m.weight.detach()
+                if getattr(m, "mp", False):
+                    w = mp_weight(w)
+                    pk[(id(m), "eff")] = w                         # the direct output-layer kernel takes the raw layout
+                pk[id(m)] = ops.pack_conv(w, self.conv_precision, upsampled=id(m) in ups)
+            prec = "fp16x3" if self.conv_precision == "fp16x3" else "fp32"
             for a in self.attn_block:
                 E = a.mhattn.embed_dim
-                prec = "fp16x3" if self.conv_precision == "fp16x3" else "fp32"
-                pk[(id(a), "in")] = ops.pack_conv(a.mhattn.in_proj_weight.detach().reshape(3 * E, E, 1, 1), prec)
-                pk[(id(a), "out")] = ops.pack_conv(a.mhattn.out_proj.weight.detach().reshape(E, E, 1, 1), prec)
+                if self.mp:
+                    w_in, w_out = a.mhattn.projection_weights()
+                else:
+                    w_in, w_out = a.mhattn.in_proj_weight.detach(), a.mhattn.out_proj.weight.detach()
+                pk[(id(a), "in")] = ops.pack_conv(w_in.reshape(3 * E, E, 1, 1), prec)
+                pk[(id(a), "out")] = ops.pack_conv(w_out.reshape(E, E, 1, 1), prec)
+            if self.mp:
+                for lin in self._timeblock_linears():
+                    pk[(id(lin), "eff")] = mp_weight(lin.weight.detach()).contiguous()
         self._packed, self._packed_sig = pk, sig
         return pk
 
@@ -268,7 +380,7 @@ class PUNetG(torch.nn.Module):
         """The output layer: Cout <= 4 streams the input once through the direct fp32 kernel instead of
         padding Cout to a 64-channel MFMA tile."""
         if m.out_channels <= 4 and getattr(self, "direct_out", True):
-            return ops.conv_direct(h, m.weight, m.bias, circular=circular, out=out)
+            return ops.conv_direct(h, pk.get((id(m), "eff"), m.weight), m.bias, circular=circular, out=out)
         return ops.conv(h, pk[id(m)], bias=m.bias, circular=circular, out=out)
 
     def _fused(self):
@@ -285,22 +397,24 @@ class PUNetG(torch.nn.Module):
         x untouched.  xs = tile statistics of x (from the convolution that produced it) or None."""
         B, C, H, W = x.shape
         dev = x.device
-        if self._fused() and xs is not None and (C + 63) // 64 <= self.fuse_max_cot:
+        k1, k2 = self.norm_kinds                           # 0 GroupLN, 1 GroupRMS, 2 none, 3 GroupPix (not a table)
+        w1, b1 = getattr(blk.gnorm1, "weight", None), getattr(blk.gnorm1, "bias", None)
+        w2, b2 = getattr(blk.gnorm2, "weight", None), getattr(blk.gnorm2, "bias", None)
+        if self._fused() and xs is not None and (C + 63) // 64 <= self.fuse_max_cot and k1 != 3 and k2 != 3:
             tab = ws.take((B, ops.table_channels(C), 4), dev)
-            ops.inorm_table(xs, blk.gnorm1.weight, blk.gnorm1.bias, 0, H * W, eps=blk.gnorm1.eps, out=tab)
+            ops.inorm_table(xs, w1, b1, k1, H * W, eps=1e-5, out=tab)
             ys = self._stats_buf(ws, B, C, H, W, dev)
             y = self._conv(blk.conv1, x, pk, shift=shift, prenorm=tab, tile_stats=ys, out=ws.take(x.shape, dev))
-            ops.inorm_table(ys, blk.gnorm2.weight, blk.gnorm2.bias, 1, H * W, eps=1e-5, out=tab)
+            ops.inorm_table(ys, w2, b2, k2, H * W, eps=1e-5, out=tab)
             os_ = self._stats_buf(ws, B, C, H, W, dev) if want_stats else None
             out = self._conv(blk.conv2, y, pk, res1=x, res2=res2, prenorm=tab, tile_stats=os_, out=ws.take(x.shape, dev))
             ws.give(y)
             ws.give(ys)
             ws.give(tab)
             return out, os_
-        a = ops.inorm_silu(x, blk.gnorm1.weight, blk.gnorm1.bias, kind=0, eps=blk.gnorm1.eps,
-                           out=ws.take(x.shape, dev))
+        a = ops.inorm_silu(x, w1, b1, kind=k1, eps=1e-5, out=ws.take(x.shape, dev))
         y = self._conv(blk.conv1, a, pk, shift=shift, out=ws.take(x.shape, dev))
-        ops.inorm_silu(y, blk.gnorm2.weight, blk.gnorm2.bias, kind=1, eps=1e-5, out=a)
+        ops.inorm_silu(y, w2, b2, kind=k2, eps=1e-5, out=a)
         os_ = self._stats_buf(ws, B, C, H, W, dev) if want_stats else None
         self._conv(blk.conv2, a, pk, res1=x, res2=res2, tile_stats=os_, out=y)
         ws.give(a)
@@ -407,11 +521,13 @@ class PUNetG(torch.nn.Module):
         B, E, Hh, Ww = x.shape
         L = Hh * Ww
         m = att.mhattn
-        qkv = ops.conv(x, pk[(id(att), "in")], bias=m.in_proj_bias, out=ws.take((B, 3 * E, Hh, Ww), x.device))
+        in_bias = None if self.mp else m.in_proj_bias           # the in-house attention of "mp" has no biases
+        out_bias = None if self.mp else m.out_proj.bias
+        qkv = ops.conv(x, pk[(id(att), "in")], bias=in_bias, out=ws.take((B, 3 * E, Hh, Ww), x.device))
         o = ops.attention(qkv.view(B, 3 * E, L), E, out=ws.take((B, E, L), x.device),
                           precision=self.conv_precision)
         res1 = x if self.config.attn_residual else None
-        y = ops.conv(o.view(B, E, Hh, Ww), pk[(id(att), "out")], bias=m.out_proj.bias,
+        y = ops.conv(o.view(B, E, Hh, Ww), pk[(id(att), "out")], bias=out_bias,
                      res1=res1, res2=res2, tile_stats=tile_stats, out=ws.take(x.shape, x.device))
         ws.give(qkv)
         ws.give(o)

@@ -56,10 +56,7 @@ class PUNetGConfig(object):
         """None if the HIP path implements this configuration, else why not."""
         checks = [
             (self.dimension == 2, "only 2-D fields (dimension=2)"),
-            (self.convolution_type in ("default", "circular"), "convolution_type 'default' or 'circular' (mp is a later scope row)"),
-            (self.first_resblock_norm == "GroupLN" and self.second_resblock_norm == "GroupRMS",
-             "only first_resblock_norm='GroupLN' with second_resblock_norm='GroupRMS'"),
-            (self.affine_norm, "affine_norm=True"),
+            (self.convolution_type in ("default", "circular", "mp"), "convolution_type 'default', 'circular' or 'mp'"),
             (self.kernel_size == 3 and self.in_out_kernel_size == 3 and self.transition_kernel_size == 3,
              "3x3 kernels"),
             (self.transition_scale_factor == 2, "transition_scale_factor=2"),

@@ -122,7 +122,9 @@ int ds_karras_denoiser(float* out, const float* x, const float* f, const float* 
 /* Per-(sample, channel) normalisation over H*W fused with SiLU:
  *   kind 0: GroupNorm(num_groups=C) -- (x-mean)/sqrt(var_biased+eps)*w[c]+b[c]  (commonlayers.py:766-770,824)
  *   kind 1: GroupRMSNorm(C, C)      -- x/sqrt(mean(x^2)+eps)*w[c]+b[c]          (commonlayers.py:372-384,829)
- * followed by x*sigmoid(x).  x, out: [B, C, HW]. out may alias x. */
+ *   kind 2: no normalisation (first/second_resblock_norm other than the named ones -> Identity, commonlayers.py:891-899)
+ *   kind 3: GroupPixNorm(C, C)      -- x/sqrt(x^2+eps)*w[c]+b[c]                (commonlayers.py:387-440)
+ * followed by x*sigmoid(x).  x, out: [B, C, HW]. out may alias x.  w, b may be NULL (affine=False). */
 int ds_inorm_silu(float* out, const float* x, const float* w, const float* b,
                   int B, int C, int HW, float eps, int kind, void* stream);
 
@@ -176,6 +178,16 @@ int ds_conv2d_h3(float* out, const float* in, const void* w_packed, int wshift, 
                  const float* shift, int shift_stride, const float* res1, const float* res2,
                  int B, int Cin, int Cout, int H, int W, int load_mode,
                  const float* prenorm, float* tile_stats, void* stream);
+/* Two optional fusions of the normalisation around the convolution (NULL = off):
+ *   prenorm    [B, ceil16(Cin), 4] = (M, A, C, -), rows past Cin zero: the loader applies SiLU((x - M)*A + C) to every input element
+ *              before the convolution (zero padding stays zero) -- the norm -> act of ResnetBlockC /
+ *              ADMBaseBlock (commonlayers.py:824-829, adm.py:312-337) without materialising its output.
+ *              Not with MAXPOOL2.  Tables come from ds_inorm_table / ds_gnorm1_table.
+ *   tile_stats [B, Cout, ntiles, 4]: per output channel and pixel tile of the stored values, (K, S, Q, n):
+ *              n valid pixels, K one of them, S = sum(x-K), Q = sum((x-K)^2) (shifted sums: no mean^2
+ *              cancellation in fp32); ntiles = ds_conv_tile_count(H, W); consumed by the *_table calls,
+ *              which recombine the tiles in fp64.  16-byte aligned. */
+int ds_conv_tile_count(int H, int W);
 
 /* "Nearest x2 upsampling, then the 3x3 convolution" (UpSampler, commonlayers.py:145; ADM up blocks, adm.py:312-323)
  * evaluated at the LOW resolution: for each of the four output parities the 3x3 kernel collapses to a 2x2 kernel
@@ -191,19 +203,11 @@ int ds_conv2d_h3_up(float* out, const float* in, const void* w_packed, int wshif
                     const float* shift, int shift_stride, const float* res1, const float* res2,
                     int B, int Cin, int Cout, int Hl, int Wl, int flags, const float* prenorm, float* tile_stats,
                     void* stream);
-/* Two optional fusions of the normalisation around the convolution (NULL = off):
- *   prenorm    [B, ceil16(Cin), 4] = (M, A, C, -), rows past Cin zero: the loader applies SiLU((x - M)*A + C) to every input element
- *              before the convolution (zero padding stays zero) -- the norm -> act of ResnetBlockC /
- *              ADMBaseBlock (commonlayers.py:824-829, adm.py:312-337) without materialising its output.
- *              Not with MAXPOOL2.  Tables come from ds_inorm_table / ds_gnorm1_table.
- *   tile_stats [B, Cout, ntiles, 4]: per output channel and pixel tile of the stored values, (K, S, Q, n):
- *              n valid pixels, K one of them, S = sum(x-K), Q = sum((x-K)^2) (shifted sums: no mean^2
- *              cancellation in fp32); ntiles = ds_conv_tile_count(H, W); consumed by the *_table calls,
- *              which recombine the tiles in fp64.  16-byte aligned. */
-int ds_conv_tile_count(int H, int W);
+
 
 /* PUNetG norms from tile statistics: table [B, ceil16(C), 4]; table[b,c] = (mean | 0, rstd*w[c], b[c], 0) for GroupNorm(C,C)
- * (kind 0) / GroupRMSNorm(C,C) (kind 1); count = H*W.  commonlayers.py:766-770, 372-384. */
+ * (kind 0) / GroupRMSNorm(C,C) (kind 1), (0, 1, 0, 0) for no normalisation (kind 2); count = H*W.
+ * commonlayers.py:766-770, 372-384, 891-899. */
 int ds_inorm_table(float* table, const float* tile_stats, const float* w, const float* b, int B, int C, int ntiles,
                    int count, float eps, int kind, void* stream);
 

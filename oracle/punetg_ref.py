@@ -9,9 +9,12 @@ key names, restating
   diffsci/models/nets/commonlayers.py:516-549    (ResnetTimeBlock)
   diffsci/models/nets/commonlayers.py:81,145     (DownSampler / UpSampler forward)
   diffsci/models/nets/attention.py:54-90         (TwoDimensionalAttention, nn.MultiheadAttention, 1 head)
-for the default configuration family (2-D, "default" convolutions, GroupLN +
-GroupRMS norms, bias=True, dropout 0).  Convolution / GroupNorm / attention
-arithmetic is torch's, as in the reference.
+  diffsci/models/nets/normedlayers.py:6-99       (magnitude-preserving conv / linear, convolution_type="mp")
+  diffsci/models/nets/attention.py:110-247       (the in-house one-head attention "mp" substitutes)
+  diffsci/models/nets/commonlayers.py:387-440    (GroupPixNorm), :882-899 (norm selection)
+for the 2-D configuration family ("default" | "circular" | "mp" convolutions, any of GroupLN / GroupRMS /
+GroupPix / none in either norm slot, affine or not, bias on / off, dropout 0).  Convolution / GroupNorm /
+attention arithmetic is torch's, as in the reference.
 """
 import math
 
@@ -48,9 +51,25 @@ def group_rms_norm(x, weight, bias, eps=1e-5):
     return x * w + b
 
 
+def mp_normalize(x, eps=1e-4):
+    """normedlayers.py:95-99."""
+    dim = list(range(1, x.ndim))
+    n = torch.linalg.vector_norm(x, dim=dim, keepdim=True)
+    alpha = math.sqrt(n.numel() / x.numel())
+    return x / torch.add(eps, n, alpha=alpha)
+
+
+def mp_effective(w):
+    """Eval-mode weight of MagnitudePreservingConv2d / Linear (normedlayers.py:17-22, 46-55)."""
+    return mp_normalize(w) / math.sqrt(w[0].numel())
+
+
 def conv3x3(sd, name, x, circular=False):
     """torch.nn.Conv2d(padding='same'), or CircularConv2d (commonlayers.py:918-971: F.pad circular in W,
-    then in H, then an unpadded convolution; parameters one level down, in `<name>.conv`)."""
+    then in H, then an unpadded convolution; parameters one level down, in `<name>.conv`), or -- circular ==
+    "mp" -- MagnitudePreservingConv2d (normedlayers.py:26-55)."""
+    if circular == "mp":
+        return F.conv2d(x, mp_effective(sd[name + ".weight"]), sd.get(name + ".bias"), padding="same")
     if circular:
         x = F.pad(x, (1, 1, 0, 0), mode="circular")
         x = F.pad(x, (0, 0, 1, 1), mode="circular")
@@ -58,25 +77,76 @@ def conv3x3(sd, name, x, circular=False):
     return F.conv2d(x, sd[name + ".weight"], sd.get(name + ".bias"), padding="same")      # bias=False: no bias keys
 
 
-def time_shift(sd, prefix, te):
-    """ResnetTimeBlock: Linear-SiLU-Linear-SiLU-Linear, commonlayers.py:516-522,546-549."""
-    h = F.linear(te, sd[prefix + "net.0.weight"], sd[prefix + "net.0.bias"])
+def time_shift(sd, prefix, te, mp=False):
+    """ResnetTimeBlock: Linear-SiLU-Linear-SiLU-Linear, commonlayers.py:512-522,546-549 (magnitude-preserving
+    linears when mp)."""
+    def w(i):
+        wt = sd[prefix + f"net.{i}.weight"]
+        return mp_effective(wt) if mp else wt
+    h = F.linear(te, w(0), sd[prefix + "net.0.bias"])
     h = F.silu(h)
-    h = F.linear(h, sd[prefix + "net.2.weight"], sd[prefix + "net.2.bias"])
+    h = F.linear(h, w(2), sd[prefix + "net.2.bias"])
     h = F.silu(h)
-    h = F.linear(h, sd[prefix + "net.4.weight"], sd[prefix + "net.4.bias"])
+    h = F.linear(h, w(4), sd[prefix + "net.4.bias"])
     return h.view(*h.shape, 1, 1)
 
 
-def resnet_block(sd, prefix, x, te, circular=False):
-    """ResnetBlockC.forward, commonlayers.py:824-833."""
+def block_norm(kind, sd, prefix, x):
+    """One norm slot of ResnetBlockC with num_groups = C (commonlayers.py:766-774, 882-899); affine_norm=False
+    leaves no weight / bias keys."""
     C = x.shape[1]
-    h = F.group_norm(x, C, sd[prefix + "gnorm1.weight"], sd[prefix + "gnorm1.bias"], 1e-5)
+    w, b = sd.get(prefix + "weight"), sd.get(prefix + "bias")
+    if kind == "GroupLN":
+        return F.group_norm(x, C, w, b, 1e-5)
+    if kind == "GroupRMS":
+        if w is None:
+            w, b = torch.ones(C).to(x), torch.zeros(C).to(x)
+        return group_rms_norm(x, w, b)
+    if kind == "GroupPix":                                   # commonlayers.py:425-440, one channel per group
+        y = x / torch.sqrt(x.pow(2) + 1e-5)
+        if w is not None:
+            shape = (1, C) + (1,) * (x.dim() - 2)
+            y = y * w.view(shape) + b.view(shape)
+        return y
+    return x                                                 # torch.nn.Identity
+
+
+def resnet_block(sd, prefix, x, te, circular=False, norms=("GroupLN", "GroupRMS")):
+    """ResnetBlockC.forward, commonlayers.py:824-833."""
+    h = block_norm(norms[0], sd, prefix + "gnorm1.", x)
     y = conv3x3(sd, prefix + "conv1", F.silu(h), circular)
-    y = y + time_shift(sd, prefix + "timeblock.", te)
-    h = group_rms_norm(y, sd[prefix + "gnorm2.weight"], sd[prefix + "gnorm2.bias"])
+    y = y + time_shift(sd, prefix + "timeblock.", te, mp=circular == "mp")
+    h = block_norm(norms[1], sd, prefix + "gnorm2.", y)
     y = conv3x3(sd, prefix + "conv2", F.silu(h), circular)
     return y + x
+
+
+def mp_attention_2d(sd, prefix, x, attn_residual=False):
+    """TwoDimensionalAttention around the in-house MultiHeadAttention(1 head, dk = dv = C, 'dot',
+    magnitude_preserving=True), attention.py:30-41, 156-247, 250-296."""
+    B, C, Hh, Ww = x.shape
+    xr = x.permute(0, 2, 3, 1).reshape(B, Hh * Ww, C)
+    ws = []
+    for kind in ("q", "k", "v", "o"):
+        weight = sd[prefix + f"mhattn.{kind}_proj_matrix"]
+        if kind == "o":
+            norm = torch.linalg.vector_norm(weight, dim=[0, 2], keepdim=True)
+            fan_in = weight.shape[0] * weight.shape[2]
+        else:
+            norm = torch.linalg.vector_norm(weight, dim=1, keepdim=True)
+            fan_in = weight.shape[1]
+        alpha = math.sqrt(norm.numel() / weight.numel())
+        ws.append((weight / (alpha * norm + 1e-4)) / math.sqrt(fan_in))
+    wq, wk, wv, wo = ws
+    q = torch.einsum('...ij, kjm -> ...kim', xr, wq)
+    k = torch.einsum('...ij, kjm -> ...kim', xr, wk)
+    v = torch.einsum('...ij, kjm -> ...kim', xr, wv)
+    inner = torch.einsum('...ij, ...kj -> ...ik', q, k)
+    inner = inner / math.sqrt(q.shape[-1])
+    a = torch.einsum('...ij, ...jk -> ...ik', torch.softmax(inner, dim=-1), v)
+    out = torch.einsum('...ijk, ilk -> ...jl', a, wo)
+    out = out.reshape(B, Hh, Ww, C).permute(0, 3, 1, 2)
+    return x + out if attn_residual else out
 
 
 def attention_2d(sd, prefix, x, attn_residual=False):
@@ -98,7 +168,9 @@ def punetg_forward(sd, cfg, x, t, ye=None):
     """PUNetG.forward, punetg.py:389-416.  ``ye`` is the already-embedded condition
     (conditional_embedding(y), shape [B or 1, model_channels]) or None."""
     nlev = len(cfg["channel_expansion"])
-    circ = cfg.get("convolution_type", "default") == "circular"
+    ctype = cfg.get("convolution_type", "default")
+    circ = "mp" if ctype == "mp" else ctype == "circular"
+    norms = (cfg.get("first_resblock_norm", "GroupLN"), cfg.get("second_resblock_norm", "GroupRMS"))
     if not cfg.get("bias", True):                                    # punetg.py:390-394: constant-one input channel
         xe_shape = list(x.shape)
         xe_shape[1] = 1
@@ -110,26 +182,26 @@ def punetg_forward(sd, cfg, x, t, ye=None):
     skips = []
     for lv in range(nlev):                                           # encode, punetg.py:356-365
         for r in range(cfg["number_resnet_downward_block"]):
-            x = resnet_block(sd, f"downward_blocks.{lv}.{r}.", x, te, circ)
+            x = resnet_block(sd, f"downward_blocks.{lv}.{r}.", x, te, circ, norms)
         skips.append(x)
         x = conv3x3(sd, f"downsamplers.{lv}.conv", F.max_pool2d(x, 2), circ)
     for r in range(cfg["number_resnet_before_attn_block"]):         # bottom, punetg.py:378-387
-        x = resnet_block(sd, f"before_block.{r}.", x, te, circ)
+        x = resnet_block(sd, f"before_block.{r}.", x, te, circ, norms)
     xa = x
     nattn = cfg["number_resnet_attn_block"]
     for r in range(nattn):                                           # punetg.py:344-354
-        xa = resnet_block(sd, f"attn_resnet_block.{r}.", xa, te, circ)
+        xa = resnet_block(sd, f"attn_resnet_block.{r}.", xa, te, circ, norms)
         if r < nattn - 1:
-            xa = attention_2d(sd, f"attn_block.{r}.", xa, cfg["attn_residual"])
+            xa = (mp_attention_2d if ctype == "mp" else attention_2d)(sd, f"attn_block.{r}.", xa, cfg["attn_residual"])
     x = x + xa
     for r in range(cfg["number_resnet_after_attn_block"]):
-        x = resnet_block(sd, f"after_block.{r}.", x, te, circ)
+        x = resnet_block(sd, f"after_block.{r}.", x, te, circ, norms)
     for lv in range(nlev):                                           # decode, punetg.py:367-376
         x = F.interpolate(x, scale_factor=2.0, mode="nearest")
         x = conv3x3(sd, f"upsamplers.{lv}.conv", x, circ)
         x = x + skips.pop()
         for r in range(cfg["number_resnet_upward_block"]):
-            x = resnet_block(sd, f"upward_blocks.{lv}.{r}.", x, te, circ)
+            x = resnet_block(sd, f"upward_blocks.{lv}.{r}.", x, te, circ, norms)
     return conv3x3(sd, "convout", x, circ)
 
 

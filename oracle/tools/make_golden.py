@@ -512,7 +512,53 @@ def adm():
         npz(f"adm8_{skip}", **arrs)
 
 
+def variants():
+    """PUNetG with magnitude-preserving layers (convolution_type='mp': normedlayers.py, the in-house
+    attention of attention.py:110-247) and with the other norm choices of ResnetBlockC (commonlayers.py:882-899)."""
+    import warnings
+    cases = {
+        "mp": dict(convolution_type="mp"),
+        "pix_ln": dict(first_resblock_norm="GroupPix", second_resblock_norm="GroupLN"),
+        "none_rms_noaffine": dict(first_resblock_norm="none", second_resblock_norm="GroupRMS", affine_norm=False),
+    }
+    for i, (tag, over) in enumerate(cases.items()):
+        torch.manual_seed(70 + i)
+        cfg = M.nets.PUNetGConfig(model_channels=8, **over)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            net = M.nets.PUNetG(cfg).eval()
+        with torch.no_grad():
+            for k, v in net.state_dict().items():
+                if "gnorm" in k or k.endswith(".bias"):
+                    v.add_(0.25 * torch.randn_like(v))
+        sd = net.state_dict()
+        torch.manual_seed(80 + i)
+        x = torch.randn(2, 1, 32, 32)
+        t = torch.tensor([0.3, -1.1])
+        arrs = dict(sd_arrays(sd), x=x, t=t)
+        with torch.inference_mode():
+            arrs["out_f32"] = net(x, t)
+            h = net.convin(x)
+            arrs["convin"] = h
+            blk = net.downward_blocks[0][0]
+            arrs["resblock"] = blk(h, net.time_projection(t))
+            hb = torch.randn(2, 32, 8, 8)
+            arrs["attn_in"] = hb
+            arrs["attn_out"] = net.attn_block[0](hb)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            net64 = M.nets.PUNetG(cfg).double().eval()
+        net64.load_state_dict({k: v.double() for k, v in sd.items()})
+        with torch.inference_mode():
+            arrs["out_f64"] = net64(x.double(), t.double())
+        module = M.KarrasModule(net, M.KarrasModuleConfig.from_edm()).eval()
+        wn = torch.randn(2, 1, 32, 32)
+        arrs["white_noise"] = wn
+        arrs["hist_heun_N6_f32"] = module.propagate_white_noise(wn, nsteps=6, record_history=True)
+        npz(f"punetg8_{tag}", **arrs)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["schedule", "toy", "punetg", "porosity", "inpaint", "vpve", "circular", "si", "punetgcond", "langevin", "adm"]
+    which = sys.argv[1:] or ["schedule", "toy", "punetg", "porosity", "inpaint", "vpve", "circular", "si", "punetgcond", "langevin", "adm", "variants"]
     for name in which:
         globals()[name]()

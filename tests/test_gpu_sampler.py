@@ -477,6 +477,55 @@ def test_punetg_circular_convolutions(M, dev, grids):
         net(v["x"].to(dev), v["t"].to(dev))
 
 
+@pytest.mark.parametrize("fuse", [True, False])
+@pytest.mark.parametrize("tag,over", [
+    ("mp", dict(convolution_type="mp")),
+    ("pix_ln", dict(first_resblock_norm="GroupPix", second_resblock_norm="GroupLN")),
+    ("none_rms_noaffine", dict(first_resblock_norm="none", second_resblock_norm="GroupRMS", affine_norm=False)),
+])
+def test_punetg_layer_variants(M, dev, grids, tag, over, fuse):
+    """magnitude-preserving convolutions / linears / attention (weights folded when packed)
+    and the GroupPix / none / non-affine norm choices, against the reference's outputs; reference checkpoints
+    load by key name."""
+    v, sd = load("punetg8_" + tag)
+    net = M.PUNetG(M.PUNetGConfig(model_channels=8, **over))
+    r = net.load_state_dict(sd, strict=True)
+    assert not r.missing_keys and not r.unexpected_keys
+    net = net.to(dev)
+    net.fuse_norm = fuse
+    pk = net.packed_weights()
+    h = net._conv(net.convin, v["x"].to(dev), pk)
+    assert rel_l2(h.cpu(), v["convin"]) < 2e-6
+    ws = net._ws
+    y = net._attention(net.attn_block[0], v["attn_in"].to(dev), pk, ws)
+    assert rel_l2(y.cpu(), v["attn_out"]) < 5e-6
+    shifts = net.time_shifts(net.embed_time(v["t"].to(dev)))
+    r_, _ = net._res(net.downward_blocks[0][0], v["convin"].to(dev), shifts[0], pk, ws)
+    assert rel_l2(r_.cpu(), v["resblock"]) < 2e-6
+    out = net(v["x"].to(dev), v["t"].to(dev)).cpu()
+    # GroupPix is x / sqrt(x^2 + 1e-5): slope 316 at zero.  With random weights the whole network amplifies rounding
+    # so much that the reference's OWN fp32 and fp64 outputs differ by 8 % (pix_ln fixture); end to end such a case
+    # is held to the reference's own conditioning, and to the usual 1e-5 layer by layer (above).
+    ref_err = rel_l2(v["out_f32"], v["out_f64"])
+    assert rel_l2(out, v["out_f32"]) < max(REL, 4 * ref_err)
+    assert rel_l2(out, v["out_f64"]) < max(4 * ref_err, 2e-6)
+    module = M.KarrasModule(net, M.KarrasModuleConfig.from_edm())
+    _pin_grid(module, grids)
+    hist = module.propagate_white_noise(v["white_noise"].to(dev), nsteps=6, record_history=True).cpu()
+    if ref_err < REL:
+        assert rel_l2(hist, v["hist_heun_N6_f32"]) < REL
+    else:
+        # no fp64 trajectory to measure the reference's own divergence against: shape, start and finiteness only
+        assert tag == "pix_ln" and torch.isfinite(hist).all() and hist.shape == v["hist_heun_N6_f32"].shape
+        assert torch.equal(hist[0], v["hist_heun_N6_f32"][0])
+    if tag == "mp":
+        # a weight update re-derives the effective weights (the reference renormalises on every forward)
+        with torch.no_grad():
+            net.convin.weight.mul_(3.0)              # normalize() makes the layer scale-invariant up to its eps
+        out2 = net(v["x"].to(dev), v["t"].to(dev)).cpu()
+        assert rel_l2(out2, out) < 1e-3 and net.packed_weights() is not pk
+
+
 @pytest.mark.parametrize("shape", [(2, 1, 20, 28), (1, 1, 36, 40), (3, 1, 64, 16)])
 def test_odd_field_sizes_against_oracle(M, dev, shape):
     """Ragged tiles everywhere: widths that are not multiples of 32, 16 or 4 (element-wise epilogue and

@@ -165,7 +165,18 @@ def test_punetg_config_roundtrip_and_unsupported_options():
     c2 = M.PUNetGConfig.from_description(d)
     assert c2.export_description() == d and c2.extended_channel_expansion == [1, 2, 2, 4]
     with pytest.raises(NotImplementedError, match="convolution_type"):
-        M.PUNetG(M.PUNetGConfig(convolution_type="mp"))
+        M.PUNetG(M.PUNetGConfig(convolution_type="spherical"))
+    # the layer variants keep the reference's state_dict keys and shapes (checkpoints load strictly)
+    for tag, over in (("mp", dict(convolution_type="mp")),
+                      ("pix_ln", dict(first_resblock_norm="GroupPix", second_resblock_norm="GroupLN")),
+                      ("none_rms_noaffine", dict(first_resblock_norm="none", second_resblock_norm="GroupRMS", affine_norm=False))):
+        _, sd = load("punetg8_" + tag)
+        net = M.PUNetG(M.PUNetGConfig(model_channels=8, **over))
+        mine = net.state_dict()
+        assert set(mine) == set(sd) and all(tuple(mine[k].shape) == tuple(sd[k].shape) for k in sd), tag
+        net.load_state_dict(sd)
+    mp = M.PUNetG(M.PUNetGConfig(model_channels=8, convolution_type="mp"))
+    assert "attn_block.0.mhattn.q_proj_matrix" in mp.state_dict() and float(mp.convin.weight.std()) > 0.5   # N(0,1) init
     circ = M.PUNetG(M.PUNetGConfig(model_channels=8, convolution_type="circular"))
     assert "convin.conv.weight" in circ.state_dict() and "downsamplers.0.conv.conv.bias" in circ.state_dict()
     with pytest.raises(NotImplementedError, match="dimension"):

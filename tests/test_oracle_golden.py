@@ -316,6 +316,37 @@ def test_punetg_circular_convolutions():
         assert_exact_or_rel(hist, v["hist_heun_N6_f32"], "hist_heun_N6_f32", 2e-6)
 
 
+VARIANTS = {
+    "mp": dict(convolution_type="mp"),
+    "pix_ln": dict(first_resblock_norm="GroupPix", second_resblock_norm="GroupLN"),
+    "none_rms_noaffine": dict(first_resblock_norm="none", second_resblock_norm="GroupRMS", affine_norm=False),
+}
+
+
+@pytest.mark.parametrize("tag", sorted(VARIANTS))
+def test_punetg_layer_variants(tag):
+    """magnitude-preserving layers (normedlayers.py, the in-house attention) and the other
+    norm choices of ResnetBlockC (GroupPix, none, affine_norm=False) against the reference's outputs."""
+    v, sd = load("punetg8_" + tag)
+    over = VARIANTS[tag]
+    cfg = punetg_ref.default_config(model_channels=8, **over)
+    kind = "mp" if tag == "mp" else False
+    norms = (over.get("first_resblock_norm", "GroupLN"), over.get("second_resblock_norm", "GroupRMS"))
+    if not over.get("affine_norm", True):
+        assert not any("gnorm" in k for k in sd)
+    with torch.inference_mode():
+        h = punetg_ref.conv3x3(sd, "convin", v["x"], kind)
+        assert_exact_or_ulp(h, v["convin"], tag + " convin")
+        te = punetg_ref.fourier_features(v["t"], sd["time_projection.W"])
+        r = punetg_ref.resnet_block(sd, "downward_blocks.0.0.", v["convin"], te, kind, norms)
+        assert_exact_or_rel(r, v["resblock"], tag + " resblock", 1e-6)
+        att = punetg_ref.mp_attention_2d if tag == "mp" else punetg_ref.attention_2d
+        assert_exact_or_rel(att(sd, "attn_block.0.", v["attn_in"]), v["attn_out"], tag + " attention", 2e-6)
+        assert_exact_or_rel(punetg_ref.punetg_forward(sd, cfg, v["x"], v["t"]), v["out_f32"], tag + " out_f32", 2e-6)
+        hist = K.propagate_white_noise(punetg_ref.make_net(sd, cfg), v["white_noise"], 6, record_history=True)
+        assert_exact_or_rel(hist, v["hist_heun_N6_f32"], tag + " hist_heun_N6_f32", 2e-6)
+
+
 def test_adm_circular_convolutions():
     from oracle import adm_ref
     v, sd = load("adm8_circular")
