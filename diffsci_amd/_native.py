@@ -77,6 +77,7 @@ _PROTOS = {
     "ds_mask_blend": (c_int, [_P, _P, _P, _P, c_size_t, c_int, _P]),
     "ds_axpby": (c_int, [_P, _P, c_float, _P, c_float, c_size_t, _P]),
     "ds_div_scalar": (c_int, [_P, _P, c_float, c_size_t, _P]),
+    "ds_batchnorm_eval": (c_int, [_P, _P, _P, _P, _P, _P, c_float, c_float, c_int, c_int, c_int, c_int, c_size_t, _P]),
     "ds_lerp_stack": (c_int, [_P, _P, _P, c_int, c_size_t, _P]),
     "ds_add": (c_int, [_P, _P, _P, c_size_t, _P]),
     "ds_graph_begin_capture": (c_int, [_P]),

@@ -223,6 +223,37 @@ __global__ __launch_bounds__(kThreads) void k_div_scalar(float* out, const float
   for (; i < n; i += stride) out[i] = x[i] / s;
 }
 
+// DimensionAgnosticBatchNorm in eval mode (aux_scripts/batchnorm.py:111-170), the reference's operation order:
+//   FORWARD:  x = (x - mean) / sqrt(var + eps);  [x = x*w + b;]  x = x*sigma
+//   inverse:  x = x / sigma;  [x = (x - b) / w;]  x = x*sqrt(var + eps) + mean
+// statistics / affine hold nc = 1 (broadcast) or C entries; grid.y = B*C planes
+template <bool FORWARD>
+__global__ __launch_bounds__(kThreads) void k_batchnorm(float* out, const float* __restrict__ x, const float* __restrict__ mean,
+                                                        const float* __restrict__ var, const float* __restrict__ w,
+                                                        const float* __restrict__ b, float eps, float sigma, int C, int nc,
+                                                        size_t HW) {
+  const int plane = blockIdx.y;
+  const int c = nc == 1 ? 0 : plane % C;
+  const float m = mean[c], sd = sqrtf(var[c] + eps);
+  const float wc = w ? w[c] : 1.0f, bc = b ? b[c] : 0.0f;
+  const bool affine = w != nullptr;
+  const float* xp = x + (size_t)plane * HW;
+  float* op = out + (size_t)plane * HW;
+  for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < HW; i += (size_t)gridDim.x * kThreads) {
+    float v = xp[i];
+    if (FORWARD) {
+      v = (v - m) / sd;
+      if (affine) v = v * wc + bc;
+      v = v * sigma;
+    } else {
+      v = v / sigma;
+      if (affine) v = (v - bc) / wc;
+      v = v * sd + m;
+    }
+    op[i] = v;
+  }
+}
+
 // out[i] = x1 + ((x2 - x1) * i) / (n - 1), i = 0..n-1  (torchutils.py:64-65, same operation order)
 __global__ __launch_bounds__(kThreads) void k_lerp_stack(float* out, const float* __restrict__ x1,
                                                          const float* __restrict__ x2, int n, size_t numel) {
@@ -396,6 +427,23 @@ int ds_div_scalar(float* out, const float* x, float s, size_t n, void* stream) {
   if (n == 0) return DS_OK;
   hipLaunchKernelGGL(k_div_scalar, dim3(grid_for((n + 3) / 4)), dim3(kThreads), 0, ds::as_stream(stream), out, x, s, n);
   DS_CHECK_LAUNCH("ds_div_scalar");
+  return DS_OK;
+}
+
+int ds_batchnorm_eval(float* out, const float* x, const float* mean, const float* var, const float* weight,
+                      const float* bias, float eps, float sigma, int inverse, int B, int C, int nc, size_t HW, void* stream) {
+  DS_REQUIRE(out && x && mean && var, DS_ERR_NULL, "ds_batchnorm_eval: NULL pointer");
+  DS_REQUIRE((weight == nullptr) == (bias == nullptr), DS_ERR_NULL, "ds_batchnorm_eval: weight and bias go together");
+  DS_REQUIRE(B >= 0 && C > 0 && HW > 0 && (nc == 1 || nc == C), DS_ERR_SHAPE,
+             "ds_batchnorm_eval: bad shape B=%d C=%d nc=%d (1 or C)", B, C, nc);
+  DS_REQUIRE((long long)B * C < 65536, DS_ERR_SHAPE, "ds_batchnorm_eval: B*C must stay below 65536 planes");
+  DS_REQUIRE(sigma != 0.0f, DS_ERR_SHAPE, "ds_batchnorm_eval: sigma = 0");
+  if (B == 0) return DS_OK;
+  const size_t per = (HW + 4 * kThreads - 1) / (4 * kThreads);
+  dim3 g((unsigned)(per > 256 ? 256 : per), (unsigned)(B * C));
+  if (inverse) hipLaunchKernelGGL((k_batchnorm<false>), g, dim3(kThreads), 0, ds::as_stream(stream), out, x, mean, var, weight, bias, eps, sigma, C, nc, HW);
+  else hipLaunchKernelGGL((k_batchnorm<true>), g, dim3(kThreads), 0, ds::as_stream(stream), out, x, mean, var, weight, bias, eps, sigma, C, nc, HW);
+  DS_CHECK_LAUNCH("ds_batchnorm_eval");
   return DS_OK;
 }
 

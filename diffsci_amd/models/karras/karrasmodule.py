@@ -4,9 +4,9 @@
 Kept: ``KarrasModuleConfig.from_edm`` (+ the plain constructor), ``KarrasModule(model, config,
 conditional=...)`` with ``sample``, ``propagate_white_noise``, ``propagate_toward_sample``,
 ``propagate_partial_toward_sample``, ``get_denoiser``, ``get_score``, ``encode`` / ``decode``
-(non-latent: identity up to ``norm``), ``device``, ``.to()`` / ``.eval()``, and the model protocol
-``model(c_in*x, c_noise[, y])``.  Training (loss_fn, training_step, optimisers), latent
-autoencoders and EDM batch-norm are outside this path and raise if requested.
+(``norm``, the EDM batch-norm map of ``has_edm_batch_norm`` -- one HIP launch each way -- and a user
+autoencoder run as given), ``device``, ``.to()`` / ``.eval()``, and the model protocol
+``model(c_in*x, c_noise[, y])``.  Training (loss_fn, training_step, optimisers) is outside this path.
 
 For a HIP-native score network (``PUNetG``) the whole N-step loop -- ~85 launches per network
 evaluation -- is captured once per (batch shape, nsteps, integrator, guidance) into a hipGraph
@@ -17,7 +17,7 @@ import torch
 
 from ... import ops
 from ..._native import DS_IN_NETWORK
-from . import noisesamplers, preconditioners, schedulers
+from . import edmbatchnorm, noisesamplers, preconditioners, schedulers
 from .engine import Loop, ModuleSource
 from .steptable import build_step_table
 
@@ -54,8 +54,6 @@ class KarrasModuleConfig(object):
                  tag: str = "custom", has_edm_batch_norm: bool = False,
                  dynamic_loss_weight: int | None = None, extra_args: None | dict[str, Any] = None,
                  **legacy):
-        if has_edm_batch_norm:
-            raise NotImplementedError("has_edm_batch_norm is outside the HIP sampling path")
         self.preconditioner = preconditioner
         self.noisesampler = noisesampler
         self.noisescheduler = noisescheduler
@@ -118,17 +116,20 @@ class KarrasModule(torch.nn.Module):
                  autoencoder_conditional: bool = False, encode_y: bool = False,
                  decode_original_y: bool = False):
         super().__init__()
-        if autoencoder is not None or encode_y or decode_original_y:
-            raise NotImplementedError("latent (autoencoder) models are outside the HIP sampling path")
         self.model = model
         self.config = config
         self.conditional = conditional
         self.masked = masked
-        self.autoencoder = None
+        # latent models (karrasmodule.py:443-450): the autoencoder is a user module, run as given (its encode /
+        # decode are ordinary torch code on whatever device it lives on); the loop between them is the HIP path
+        self.autoencoder = autoencoder
         self.autoencoder_conditional = autoencoder_conditional
-        self.encode_y = False
-        self.decode_original_y = False
+        self.encode_y = encode_y
+        self.decode_original_y = decode_original_y
         self.norm = 1.0
+        # karrasmodule.py:1236-1241
+        self.edm_batch_norm = (edmbatchnorm.DimensionAgnosticBatchNorm(sigma=config.extra_args.get("sigma_data", 0.5))
+                               if config.has_edm_batch_norm else None)
         self.use_graph = True          # capture the loop as a hipGraph for HIP-native networks
         self._plans = {}
         self._stream = None
@@ -143,7 +144,7 @@ class KarrasModule(torch.nn.Module):
 
     @property
     def latent_model(self):
-        return False
+        return self.autoencoder is not None
 
     def _apply(self, fn, *a, **k):
         self._plans = {}
@@ -209,30 +210,49 @@ class KarrasModule(torch.nn.Module):
                record_history: bool = False, maximum_batch_size: None | int = None,
                integrator=None, move_to_cpu: bool = False, is_latent_shape: bool = False,
                squeeze_memory_efficiency: bool = False, return_in_latent_space: bool = False):
-        """karrasmodule.py:801-865: CPU-generator white noise, optional minibatching."""
+        """karrasmodule.py:801-865: CPU-generator white noise, optional minibatching.  Latent models given a
+        data-space `shape` encode a dummy batch to learn the latent shape and redraw the noise there, as the
+        reference does (karrasmodule.py:842-851)."""
         with torch.inference_mode():
             if maximum_batch_size is not None:
                 result = [self.sample(b, shape, y, guidance, nsteps, record_history, maximum_batch_size=None,
-                                      integrator=integrator, move_to_cpu=move_to_cpu)
+                                      integrator=integrator, move_to_cpu=move_to_cpu, is_latent_shape=is_latent_shape,
+                                      squeeze_memory_efficiency=squeeze_memory_efficiency,
+                                      return_in_latent_space=return_in_latent_space)
                           for b in get_minibatch_sizes(nsamples, maximum_batch_size)]
                 return torch.cat(result, dim=1 if record_history else 0)
             white_noise = torch.randn(*([nsamples] + list(shape))).to(self.device)
             if y is not None:
                 y = dict_to(y, self.device)
+            original_y = None
+            if self.latent_model and not is_latent_shape:
+                if self.encode_y:
+                    if self.decode_original_y:
+                        original_y = y.copy()
+                    white_noise, y = self.encode(white_noise, y)
+                    y['y'] = y['y'].squeeze(0)
+                else:
+                    white_noise = self.encode(white_noise, y)
+                white_noise = torch.randn_like(white_noise)
             return self.propagate_white_noise(white_noise, y, guidance, nsteps, record_history,
-                                              integrator=integrator, move_to_cpu=move_to_cpu)
+                                              integrator=integrator,
+                                              original_y=original_y if self.decode_original_y else None,
+                                              move_to_cpu=move_to_cpu, latent_shape=is_latent_shape,
+                                              squeeze_memory_efficiency=squeeze_memory_efficiency,
+                                              return_in_latent_space=return_in_latent_space)
 
     def propagate_white_noise(self, x, y=None, guidance: float = 1.0, nsteps: int = 100,
                               record_history: bool = False, integrator=None, original_y=None,
                               move_to_cpu: bool = False, latent_shape: bool = False,
                               squeeze_memory_efficiency: bool = False, return_in_latent_space: bool = False,
                               eps=None):
-        """karrasmodule.py:867-905: x*maximum_scale, the N-step loop, decode."""
+        """karrasmodule.py:867-905: x*maximum_scale, the N-step loop, decode (unless return_in_latent_space)."""
         with torch.inference_mode():
             result = self.propagate_toward_sample(x, y, guidance, nsteps, record_history,
                                                   integrator=integrator, eps=eps,
                                                   _scale=self.config.noisescheduler.maximum_scale)
-            result = self.decode(result, y, record_history)
+            if not return_in_latent_space:
+                result = self.decode(result, original_y if original_y is not None else y, record_history)
         if move_to_cpu:
             result = result.detach().cpu()
         return result
@@ -384,9 +404,29 @@ class KarrasModule(torch.nn.Module):
         return self.propagate_toward_sample(x_interp, y=y, nsteps=nsteps, record_history=record_history)
 
     def encode(self, x, y=None, record_history=False):
-        """karrasmodule.py:1192-1214 for a non-latent module."""
-        return x / self.norm
+        """karrasmodule.py:1192-1214: [autoencoder.encode] -> [edm_batch_norm.normalize] -> / norm."""
+        if record_history:
+            return torch.stack([self.encode(xx, y, record_history=False) for xx in x], dim=0)
+        if self.latent_model:
+            if self.autoencoder_conditional:
+                if self.encode_y:
+                    x, y = self.autoencoder.encode(x, y)
+                else:
+                    x = self.autoencoder.encode(x, y)
+            else:
+                x = self.autoencoder.encode(x)
+        if self.edm_batch_norm is not None:
+            x = self.edm_batch_norm.normalize(x)
+        x = x if self.norm == 1.0 else ops.div_scalar(x.contiguous(), self.norm)
+        return (x, y) if self.encode_y else x
 
     def decode(self, x, y=None, record_history=False):
-        """karrasmodule.py:1216-1234 for a non-latent module: x*norm (norm = 1.0 -> identity)."""
-        return x if self.norm == 1.0 else ops.scale(x.contiguous(), self.norm)
+        """karrasmodule.py:1216-1234: * norm (1.0 -> identity) -> [edm_batch_norm.unnormalize] -> [autoencoder.decode]."""
+        if record_history:
+            return torch.stack([self.decode(xx, y, record_history=False) for xx in x], dim=0)
+        x = x if self.norm == 1.0 else ops.scale(x.contiguous(), self.norm)
+        if self.edm_batch_norm is not None:
+            x = self.edm_batch_norm.unnormalize(x)
+        if self.latent_model:
+            x = self.autoencoder.decode(x, y) if self.autoencoder_conditional else self.autoencoder.decode(x)
+        return x

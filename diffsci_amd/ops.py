@@ -84,6 +84,21 @@ def div_scalar(x, s, out=None):
     return out
 
 
+def batchnorm_eval(x, mean, var, weight=None, bias=None, eps=1e-5, sigma=1.0, inverse=False, out=None):
+    """DimensionAgnosticBatchNorm.forward / .unnorm with running statistics; x [B, C, *spatial]."""
+    require_device(x, "x")
+    out = torch.empty_like(x) if out is None else out
+    _same_numel(x, out)
+    B, C = x.shape[0], x.shape[1]
+    HW = x.numel() // max(B * C, 1)
+    nc = mean.numel()
+    if var.numel() != nc or nc not in (1, C) or (weight is not None and (weight.numel() != nc or bias.numel() != nc)):
+        raise ValueError("batch-norm statistics / affine must hold 1 or C entries")
+    N.check(N.lib().ds_batchnorm_eval(_p(out), _p(x), _p(mean), _p(var), _p(weight), _p(bias), float(eps), float(sigma),
+                                      1 if inverse else 0, B, C, nc, HW, _stream()), "ds_batchnorm_eval")
+    return out
+
+
 def lerp_stack(x1, x2, n):
     """stack([x1 + (x2 - x1)*i/(n-1) for i in range(n)])."""
     out = torch.empty((n,) + tuple(x1.shape), dtype=torch.float32, device=x1.device)

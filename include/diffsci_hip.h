@@ -302,6 +302,15 @@ int ds_mask_blend(float* out, const float* x, const float* y, const float* mask,
 int ds_axpby(float* out, const float* x, float a, const float* y, float b, size_t n, void* stream);
 int ds_div_scalar(float* out, const float* x, float s, size_t n, void* stream);
 
+/* DimensionAgnosticBatchNorm with its running statistics (eval mode), around the sampling loop when
+ * KarrasModuleConfig.has_edm_batch_norm (karrasmodule.py:1209-1210,1225-1226; aux_scripts/batchnorm.py:111-170):
+ *   inverse = 0 (normalize):   ((x - mean)/sqrt(var + eps) [*weight + bias]) * sigma
+ *   inverse = 1 (unnormalize): ((x/sigma [- bias)/weight]) * sqrt(var + eps) + mean
+ * x, out [B, C, HW]; mean/var (and weight/bias, or both NULL) have nc = 1 or C entries. out may alias x. */
+int ds_batchnorm_eval(float* out, const float* x, const float* mean, const float* var, const float* weight,
+                      const float* bias, float eps, float sigma, int inverse, int B, int C, int nc, size_t HW,
+                      void* stream);
+
 /* out[i] = x1 + ((x2 - x1)*i)/(n - 1), i = 0..n-1, each of numel floats: linear_interpolation
  * (torchutils.py:64-65) used by KarrasModule.interpolate_images (karrasmodule.py:1136-1138). */
 int ds_lerp_stack(float* out, const float* x1, const float* x2, int n, size_t numel, void* stream);

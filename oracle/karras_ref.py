@@ -330,6 +330,45 @@ def propagate_white_noise(net, white_noise, nsteps, integrator="heun", precond=e
         return out * 1.0  # decode(): x * self.norm with norm = 1.0 (karrasmodule.py:1224)
 
 
+def batchnorm_eval(x, mean, var, sigma=1.0, eps=1e-5, weight=None, bias=None, inverse=False):
+    """DimensionAgnosticBatchNorm.forward / .unnorm with running statistics (aux_scripts/batchnorm.py:123-170);
+    mean / var / weight / bias hold 1 or C entries."""
+    shape = [1, mean.numel()] + [1] * (x.dim() - 2)
+    mean, var = mean.view(shape), var.view(shape)
+    if inverse:
+        x = x / sigma
+        if weight is not None:
+            x = (x - bias.view(shape)) / weight.view(shape)
+        return x * torch.sqrt(var + eps) + mean
+    x = (x - mean) / torch.sqrt(var + eps)
+    if weight is not None:
+        x = x * weight.view(shape) + bias.view(shape)
+    return x * sigma
+
+
+def encode(x, autoencoder=None, bn=None, norm=1.0):
+    """KarrasModule.encode (karrasmodule.py:1192-1214) without y-encoding: autoencoder.encode -> batch-norm
+    normalize -> / norm.  bn = dict(mean=, var=, sigma=) or None."""
+    if autoencoder is not None:
+        x = autoencoder.encode(x)
+    if bn is not None:
+        x = batchnorm_eval(x, **bn)
+    return x / norm
+
+
+def decode(x, autoencoder=None, bn=None, norm=1.0, record_history=False):
+    """KarrasModule.decode (karrasmodule.py:1216-1234): * norm -> batch-norm unnormalize -> autoencoder.decode;
+    histories are decoded slice by slice."""
+    if record_history:
+        return torch.stack([decode(xx, autoencoder, bn, norm) for xx in x], dim=0)
+    x = x * norm
+    if bn is not None:
+        x = batchnorm_eval(x, inverse=True, **bn)
+    if autoencoder is not None:
+        x = autoencoder.decode(x)
+    return x
+
+
 # --------------------------------------------------------------------------- closed-form KATs
 def gaussian_target_score(scale):
     """grad log p(x; sigma) for data ~ N(0, scale^2 I).  data/toy_datasets.py:259-279."""

@@ -558,7 +558,67 @@ def variants():
         npz(f"punetg8_{tag}", **arrs)
 
 
+class ToyAutoencoder(torch.nn.Module):
+    """Parameter-free stand-in for a latent autoencoder (ours, not the reference's): 2x2 pixel-unshuffle with a gain.
+    tests/test_gpu_sampler.py defines the same three lines."""
+
+    def encode(self, x):
+        return torch.nn.functional.pixel_unshuffle(x, 2) * 0.5
+
+    def decode(self, z):
+        return torch.nn.functional.pixel_shuffle(z * 2.0, 2)
+
+
+def latent():
+    """the latent boundary of KarrasModule -- autoencoder.encode/decode and the EDM batch-norm
+    map around the loop (karrasmodule.py:842-851, 867-905, 1192-1241; aux_scripts/batchnorm.py:86-170)."""
+    torch.manual_seed(90)
+    cfg = M.nets.PUNetGConfig(input_channels=4, output_channels=4, model_channels=8)
+    net = M.nets.PUNetG(cfg).eval()
+    with torch.no_grad():
+        for k, v in net.state_dict().items():
+            if "gnorm" in k:
+                v.add_(0.25 * torch.randn_like(v))
+    arrs = dict(sd_arrays(net.state_dict()))
+    torch.manual_seed(91)
+    x = torch.randn(2, 1, 32, 32) * 0.7 + 0.2
+    wn = torch.randn(2, 4, 16, 16)
+    arrs.update(x=x, white_noise=wn)
+    # the layer on its own, per-channel statistics and affine (the KarrasModule instance is DimensionAgnosticBatchNorm(
+    # sigma=sigma_data): one broadcast statistic)
+    from diffsci.models.karras import edmbatchnorm
+    bn = edmbatchnorm.DimensionAgnosticBatchNorm(num_channels=4, affine=True, sigma=0.5).eval()
+    bn.running_mean = torch.tensor([0.3, -0.2, 0.05, 1.1])
+    bn.running_var = torch.tensor([2.5, 0.4, 1.0, 0.09])
+    with torch.no_grad():
+        bn.weight.copy_(torch.tensor([1.5, 0.7, -1.2, 0.9]))
+        bn.bias.copy_(torch.tensor([0.1, -0.3, 0.0, 0.4]))
+        arrs["bnC_in"] = wn
+        arrs["bnC_normalize"] = bn.normalize(wn)
+        arrs["bnC_unnormalize"] = bn.unnormalize(wn)
+    for tag, mean, var in (("bn1", torch.tensor([0.3]), torch.tensor([2.5])),):
+        module = M.KarrasModule(net, M.KarrasModuleConfig.from_edm(has_edm_batch_norm=True),
+                                autoencoder=ToyAutoencoder()).eval()
+        module.edm_batch_norm.running_mean = mean.clone()
+        module.edm_batch_norm.running_var = var.clone()
+        arrs[tag + "_mean"], arrs[tag + "_var"] = mean, var
+        with torch.inference_mode():
+            z = module.encode(x)
+            arrs[tag + "_encode"] = z
+            arrs[tag + "_decode_encode"] = module.decode(z)
+        arrs[tag + "_sample_N4"] = module.propagate_white_noise(wn, nsteps=4, latent_shape=True)
+        arrs[tag + "_latent_N4"] = module.propagate_white_noise(wn, nsteps=4, latent_shape=True, return_in_latent_space=True)
+        arrs[tag + "_hist_N3"] = module.propagate_white_noise(wn, nsteps=3, latent_shape=True, record_history=True)
+    # batch-norm only (no autoencoder)
+    module = M.KarrasModule(net, M.KarrasModuleConfig.from_edm(has_edm_batch_norm=True)).eval()
+    module.edm_batch_norm.running_mean = torch.tensor([-0.4])
+    module.edm_batch_norm.running_var = torch.tensor([0.6])
+    arrs["plain_sample_N4"] = module.propagate_white_noise(wn, nsteps=4)
+    arrs["plain_sd_keys"] = np.array(sorted(k for k in module.state_dict() if not k.startswith("model.")))
+    npz("latent8", **arrs)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["schedule", "toy", "punetg", "porosity", "inpaint", "vpve", "circular", "si", "punetgcond", "langevin", "adm", "variants"]
+    which = sys.argv[1:] or ["schedule", "toy", "punetg", "porosity", "inpaint", "vpve", "circular", "si", "punetgcond", "langevin", "adm", "variants", "latent"]
     for name in which:
         globals()[name]()

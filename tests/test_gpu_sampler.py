@@ -526,6 +526,65 @@ def test_punetg_layer_variants(M, dev, grids, tag, over, fuse):
         assert rel_l2(out2, out) < 1e-3 and net.packed_weights() is not pk
 
 
+class ToyAutoencoder(torch.nn.Module):
+    """The parameter-free autoencoder the latent8 fixture was generated with (oracle/tools/make_golden.py)."""
+
+    def encode(self, x):
+        return torch.nn.functional.pixel_unshuffle(x, 2) * 0.5
+
+    def decode(self, z):
+        return torch.nn.functional.pixel_shuffle(z * 2.0, 2)
+
+
+def test_latent_boundary_and_edm_batch_norm(M, dev, grids):
+    """KarrasModule(autoencoder=..., config.has_edm_batch_norm) -- the user autoencoder runs as
+    given, the batch-norm map is ds_batchnorm_eval, the loop between them is the captured HIP path."""
+    from diffsci_amd.models.karras.edmbatchnorm import DimensionAgnosticBatchNorm
+    v, sd = load("latent8")
+    bn = DimensionAgnosticBatchNorm(num_channels=4, affine=True, sigma=0.5).to(dev).eval()
+    with torch.no_grad():
+        bn.running_mean.copy_(torch.tensor([0.3, -0.2, 0.05, 1.1]))
+        bn.running_var.copy_(torch.tensor([2.5, 0.4, 1.0, 0.09]))
+        bn.weight.copy_(torch.tensor([1.5, 0.7, -1.2, 0.9]))
+        bn.bias.copy_(torch.tensor([0.1, -0.3, 0.0, 0.4]))
+    assert rel_l2(bn.normalize(v["bnC_in"].to(dev)).cpu(), v["bnC_normalize"]) < 3e-7
+    assert rel_l2(bn.unnormalize(v["bnC_in"].to(dev)).cpu(), v["bnC_unnormalize"]) < 3e-7
+    with pytest.raises(NotImplementedError, match="training"):
+        bn.train()(v["bnC_in"].to(dev))
+
+    net = M.PUNetG(M.PUNetGConfig(input_channels=4, output_channels=4, model_channels=8))
+    net.load_state_dict(sd)
+    module = M.KarrasModule(net, M.KarrasModuleConfig.from_edm(has_edm_batch_norm=True), autoencoder=ToyAutoencoder())
+    assert module.latent_model and sorted(k for k in module.state_dict() if not k.startswith("model.")) == [
+        "edm_batch_norm.running_mean", "edm_batch_norm.running_var"]
+    module.load_state_dict({"edm_batch_norm.running_mean": v["bn1_mean"], "edm_batch_norm.running_var": v["bn1_var"]},
+                           strict=False)
+    module = module.to(dev).eval()
+    _pin_grid(module, grids)
+    x, wn = v["x"].to(dev), v["white_noise"].to(dev)
+    z = module.encode(x)
+    assert rel_l2(z.cpu(), v["bn1_encode"]) < 3e-7
+    assert rel_l2(module.decode(z).cpu(), v["bn1_decode_encode"]) < 3e-7
+    out = module.propagate_white_noise(wn, nsteps=4, latent_shape=True).cpu()
+    assert out.shape == (2, 1, 32, 32) and rel_l2(out, v["bn1_sample_N4"]) < REL
+    lat = module.propagate_white_noise(wn, nsteps=4, latent_shape=True, return_in_latent_space=True).cpu()
+    assert lat.shape == (2, 4, 16, 16) and rel_l2(lat, v["bn1_latent_N4"]) < REL
+    hist = module.propagate_white_noise(wn, nsteps=3, latent_shape=True, record_history=True).cpu()
+    assert rel_l2(hist, v["bn1_hist_N3"]) < REL
+    # sample(): a data-space shape is encoded once to find the latent shape (karrasmodule.py:842-851)
+    s = module.sample(3, [1, 32, 32], nsteps=2)
+    assert s.shape == (3, 1, 32, 32) and torch.isfinite(s).all()
+    s = module.sample(3, [4, 16, 16], nsteps=2, is_latent_shape=True, return_in_latent_space=True, maximum_batch_size=2)
+    assert s.shape == (3, 4, 16, 16)
+
+    plain = M.KarrasModule(net, M.KarrasModuleConfig.from_edm(has_edm_batch_norm=True)).to(dev).eval()
+    with torch.no_grad():
+        plain.edm_batch_norm.running_mean.fill_(-0.4)
+        plain.edm_batch_norm.running_var.fill_(0.6)
+    _pin_grid(plain, grids)
+    assert rel_l2(plain.propagate_white_noise(wn, nsteps=4).cpu(), v["plain_sample_N4"]) < REL
+
+
 @pytest.mark.parametrize("shape", [(2, 1, 20, 28), (1, 1, 36, 40), (3, 1, 64, 16)])
 def test_odd_field_sizes_against_oracle(M, dev, shape):
     """Ragged tiles everywhere: widths that are not multiples of 32, 16 or 4 (element-wise epilogue and

@@ -347,6 +347,41 @@ def test_punetg_layer_variants(tag):
         assert_exact_or_rel(hist, v["hist_heun_N6_f32"], tag + " hist_heun_N6_f32", 2e-6)
 
 
+class ToyAutoencoder(torch.nn.Module):
+    """The parameter-free autoencoder the latent8 fixture was generated with (oracle/tools/make_golden.py)."""
+
+    def encode(self, x):
+        return torch.nn.functional.pixel_unshuffle(x, 2) * 0.5
+
+    def decode(self, z):
+        return torch.nn.functional.pixel_shuffle(z * 2.0, 2)
+
+
+def test_latent_boundary_and_edm_batch_norm():
+    """autoencoder + DimensionAgnosticBatchNorm around the loop (karrasmodule.py:1192-1241)."""
+    v, sd = load("latent8")
+    cfg = punetg_ref.default_config(model_channels=8, input_channels=4, output_channels=4)
+    net = punetg_ref.make_net(sd, cfg)
+    ae = ToyAutoencoder()
+    with torch.inference_mode():
+        stats = dict(mean=torch.tensor([0.3, -0.2, 0.05, 1.1]), var=torch.tensor([2.5, 0.4, 1.0, 0.09]), sigma=0.5,
+                     weight=torch.tensor([1.5, 0.7, -1.2, 0.9]), bias=torch.tensor([0.1, -0.3, 0.0, 0.4]))
+        assert_exact_or_ulp(K.batchnorm_eval(v["bnC_in"], **stats), v["bnC_normalize"], "per-channel normalize")
+        assert_exact_or_ulp(K.batchnorm_eval(v["bnC_in"], inverse=True, **stats), v["bnC_unnormalize"], "per-channel unnorm")
+        bn = dict(mean=v["bn1_mean"], var=v["bn1_var"], sigma=0.5)
+        z = K.encode(v["x"], ae, bn)
+        assert_exact_or_ulp(z, v["bn1_encode"], "encode")
+        assert_exact_or_ulp(K.decode(z, ae, bn), v["bn1_decode_encode"], "decode(encode)")
+        lat = K.propagate_white_noise(net, v["white_noise"], 4)
+        assert_exact_or_rel(lat, v["bn1_latent_N4"], "latent sample", 2e-6)
+        assert_exact_or_rel(K.decode(lat, ae, bn), v["bn1_sample_N4"], "decoded sample", 2e-6)
+        hist = K.propagate_white_noise(net, v["white_noise"], 3, record_history=True)
+        assert_exact_or_rel(K.decode(hist, ae, bn, record_history=True), v["bn1_hist_N3"], "decoded history", 2e-6)
+        plain = dict(mean=torch.tensor([-0.4]), var=torch.tensor([0.6]), sigma=0.5)
+        assert_exact_or_rel(K.decode(lat, None, plain), v["plain_sample_N4"], "batch-norm only", 2e-6)
+    assert str(v["plain_sd_keys"]) == "['edm_batch_norm.running_mean' 'edm_batch_norm.running_var']"
+
+
 def test_adm_circular_convolutions():
     from oracle import adm_ref
     v, sd = load("adm8_circular")
