@@ -91,11 +91,14 @@ __global__ void k_g1_final(float* stats, const double* __restrict__ part, int ch
 
 __device__ __forceinline__ float silu(float v) { return v / (1.0f + expf(-v)); }
 
+// KIND 0: GroupNorm(1, C), stats = (mean, rstd); KIND 1: GroupRMSNorm(1, C), stats = (0, rms denominator);
+// either may be followed by FiLM (the second norm of an ADM block, adm.py:306-307,331-333); KIND 2: copy
 template <int KIND>
-__device__ __forceinline__ float apply1(float x, float mean, float sd, float w, float b, float f1, float f2) {
-  if (KIND == 0) return silu((x - mean) * sd * w + b);
-  if (KIND == 1) return silu((x / sd * w + b) * f1 + f2);
-  return x;
+__device__ __forceinline__ float apply1(float x, float mean, float sd, float w, float b, bool film, float f1, float f2) {
+  if (KIND == 2) return x;
+  float v = KIND == 0 ? (x - mean) * sd * w + b : x / sd * w + b;
+  if (film) v = v * f1 + f2;
+  return silu(v);
 }
 
 // one thread = VEC (4 or 1) consecutive output pixels of one (b, c) row
@@ -115,11 +118,12 @@ __global__ __launch_bounds__(NT) void k_g1_apply(float* out, const float* __rest
   const float mean = KIND == 2 ? 0.f : stats[2 * b], sd = KIND == 2 ? 1.f : stats[2 * b + 1];
   const float wc = (KIND == 2 || !w) ? 1.f : w[c], bc = (KIND == 2 || !bias) ? 0.f : bias[c];
   float f1 = 1.f, f2 = 0.f;
-  if (KIND == 1) {
+  const bool film = KIND != 2 && film1 != nullptr;
+  if (film) {
     f1 = film1[(size_t)b * film_stride + c];
     f2 = film2[(size_t)b * film_stride + c];
   }
-#define DS_A(v) apply1<KIND>(v, mean, sd, wc, bc, f1, f2)
+#define DS_A(v) apply1<KIND>(v, mean, sd, wc, bc, film, f1, f2)
   // torch avg_pool2d: running sum over (kh, kw) in row-major order, then one division
 #define DS_P(p, q, r, s) ((((DS_A(p) + DS_A(q)) + DS_A(r)) + DS_A(s)) / 4.0f)
   float* dst = out + (((size_t)b * C + c) * Ho + y) * Wo + VEC * xq;
@@ -207,7 +211,7 @@ int ds_gnorm1_apply(float* out, const float* x, const float* stats, const float*
   DS_REQUIRE(out && x, DS_ERR_NULL, "ds_gnorm1_apply: NULL pointer");
   DS_REQUIRE(kind >= 0 && kind <= 2 && (pool == 0 || pool == 1), DS_ERR_UNSUPPORTED, "ds_gnorm1_apply: kind %d pool %d", kind, pool);
   DS_REQUIRE(kind == 2 || stats, DS_ERR_NULL, "ds_gnorm1_apply: stats is NULL");
-  DS_REQUIRE(kind != 1 || (film_scale && film_shift), DS_ERR_NULL, "ds_gnorm1_apply: FiLM tensors are NULL");
+  DS_REQUIRE((film_scale == nullptr) == (film_shift == nullptr), DS_ERR_NULL, "ds_gnorm1_apply: FiLM scale and shift go together");
   DS_REQUIRE(B >= 0 && C > 0 && H > 0 && W > 0, DS_ERR_SHAPE, "ds_gnorm1_apply: bad shape");
   const int Ho = pool ? H / 2 : H, Wo = pool ? W / 2 : W;
   DS_REQUIRE(!pool || (H % 2 == 0 && W % 2 == 0), DS_ERR_SHAPE, "ds_gnorm1_apply: pooling needs even H, W");

@@ -10,8 +10,8 @@
 //                    kind 2 (norm = Identity, commonlayers.py:891-899): (0, 1, 0)
 //   ds_gnorm1_table  ADM: GroupNorm(1,C) / GroupRMSNorm(1,C)+FiLM per sample over (C,H,W), optionally
 //                    over the channel concatenation of two tensors (adm.py:306-343, 385-406, 764-766):
-//                    kind 0: M = mean_b, A = rstd_b*w[c], C = b[c]
-//                    kind 1: M = 0, A = w[c]/d_b*te1[b,c], C = b[c]*te1[b,c] + te2[b,c]
+//                    kind 0: M = mean_b, A = rstd_b*w[c], C = b[c];  kind 1: M = 0, A = w[c]/d_b, C = b[c];
+//                    with FiLM rows (the block's second norm): A *= te1[b,c], C = C*te1[b,c] + te2[b,c]
 #include "ds_common.h"
 
 namespace {
@@ -109,11 +109,10 @@ __global__ __launch_bounds__(256) void k_gnorm1_table(float* table, const float*
   for (int c = threadIdx.x; c < C; c += 256) {
     const float wc = w ? w[c] : 1.f, bc = bias ? bias[c] : 0.f;
     float4 o;
-    if (kind == 0) {
-      o.x = M; o.y = rs * wc; o.z = bc;
-    } else {
+    o.x = M; o.y = rs * wc; o.z = bc;                       // M = 0 for the RMS norm
+    if (f1) {                                               // FiLM: (n*w + b)*t1 + t2 = n*(w*t1) + (b*t1 + t2)
       const float t1 = f1[(size_t)b * film_stride + c], t2 = f2[(size_t)b * film_stride + c];
-      o.x = 0.f; o.y = rs * wc * t1; o.z = bc * t1 + t2;
+      o.y = rs * wc * t1; o.z = bc * t1 + t2;
     }
     o.w = 0.f;
     reinterpret_cast<float4*>(table)[(size_t)b * Cpad + c] = o;
@@ -148,7 +147,7 @@ int ds_gnorm1_table(float* table, const float* stats_a, int Ca, int ntiles_a, co
   DS_REQUIRE(B >= 0 && Ca > 0 && ntiles_a > 0 && Cb >= 0 && count > 0, DS_ERR_SHAPE, "ds_gnorm1_table: bad shape");
   DS_REQUIRE(Cb == 0 || (stats_b && ntiles_b > 0), DS_ERR_NULL, "ds_gnorm1_table: second source missing");
   DS_REQUIRE(kind == 0 || kind == 1, DS_ERR_UNSUPPORTED, "ds_gnorm1_table: kind %d", kind);
-  DS_REQUIRE(kind != 1 || (film_scale && film_shift), DS_ERR_NULL, "ds_gnorm1_table: FiLM rows are NULL");
+  DS_REQUIRE((film_scale == nullptr) == (film_shift == nullptr), DS_ERR_NULL, "ds_gnorm1_table: FiLM scale and shift go together");
   DS_REQUIRE(((reinterpret_cast<uintptr_t>(table) | reinterpret_cast<uintptr_t>(stats_a) | reinterpret_cast<uintptr_t>(stats_b)) & 15u) == 0,
              DS_ERR_SHAPE, "ds_gnorm1_table: pointers must be 16-byte aligned");
   if (B == 0) return DS_OK;

@@ -83,10 +83,9 @@ class ADMConfig(object):
         checks = [
             (self.dimension == 2, "only 2-D fields (dimension=2)"),
             (self.convolution_type in ("default", "circular"), "convolution_type 'default' or 'circular'"),
-            (self.first_resblock_norm == "GroupLN" and self.second_resblock_norm == "GroupRMS",
-             "only first_resblock_norm='GroupLN' with second_resblock_norm='GroupRMS'"),
+            (self.first_resblock_norm in ("GroupLN", "GroupRMS") and self.second_resblock_norm in ("GroupLN", "GroupRMS"),
+             "first/second_resblock_norm 'GroupLN' or 'GroupRMS' (the reference raises on anything else, adm.py:395,406)"),
             (self.num_groups == 1, "num_groups=1"),
-            (self.affine_norm, "affine_norm=True"),
             (self.kernel_size == 3, "kernel_size=3"),
             (self.transition_scale_factor == 2, "transition_scale_factor=2"),
             (self.decoder_type == 1, "decoder_type=1"),
@@ -102,11 +101,14 @@ class ADMConfig(object):
 class _Block(torch.nn.Module):
     """ADMBaseBlock parameters (adm.py:262-287); sample in {None, 'down', 'up'}."""
 
-    def __init__(self, cin, cout, cembed, sample=None, has_attn=False, circular=False):
+    def __init__(self, cin, cout, cembed, sample=None, has_attn=False, circular=False,
+                 norms=("GroupLN", "GroupRMS"), affine=True):
         super().__init__()
         self.cin, self.cout, self.sample = cin, cout, sample
-        self.norm1 = torch.nn.GroupNorm(1, cin)
-        self.norm2 = _AffineHolder(cout)
+        # make_norm_layers, adm.py:385-406 (num_groups = 1): GroupNorm(1, C) or GroupRMSNorm(1, C) in either slot
+        self.norm1 = torch.nn.GroupNorm(1, cin, affine=affine) if norms[0] == "GroupLN" else _AffineHolder(cin, affine)
+        self.norm2 = torch.nn.GroupNorm(1, cout, affine=affine) if norms[1] == "GroupLN" else _AffineHolder(cout, affine)
+        self.kinds = tuple(0 if n == "GroupLN" else 1 for n in norms)
         self.conv1 = make_conv(cin, cout, 3, circular)          # conv_fn, adm.py:427-443
         self.conv2 = make_conv(cout, cout, 3, circular)
         self.embed_linear = torch.nn.Linear(cembed, 2 * cout)
@@ -155,23 +157,26 @@ class ADM(torch.nn.Module):
         mult = config.extended_channel_expansion
         self.time_embedding = _TimeEmbedding(config.time_embed_dim, ce, config.time_projection_scale)
         circ = config.convolution_type == "circular"           # the blocks' convolutions; input/output layers stay zero-padded
+        # ADMConfig.affine_norm never reaches the blocks in the reference (ADMEncoder / ADMMiddleBlock / ADMDecoder do
+        # not forward it, adm.py:455-520,540-834): the norms are always affine, and checkpoints carry their weights
+        nk = dict(norms=(config.first_resblock_norm, config.second_resblock_norm))
         nb = config.number_resnet_downward_block
         enc = []
         for i in range(len(mult) - 1):                                   # adm.py:566-592
             cin, cout = mc * mult[i], mc * mult[i + 1]
-            enc.append(_Layer([_Block(cin, cin, ce, circular=circ) for _ in range(nb - 1)] +
-                              [_Block(cin, cout, ce, "down", circular=circ)]))
+            enc.append(_Layer([_Block(cin, cin, ce, circular=circ, **nk) for _ in range(nb - 1)] +
+                              [_Block(cin, cout, ce, "down", circular=circ, **nk)]))
         self.encoder = _Layers(enc)
         cm = config.middle_channel
-        self.middle_block = _Middle([_Block(cm, cm, ce, None, a, circular=circ) for a in config.middle_block_attn_config])
+        self.middle_block = _Middle([_Block(cm, cm, ce, None, a, circular=circ, **nk) for a in config.middle_block_attn_config])
         rmult = mult[::-1]
         nb = config.number_resnet_upward_block
         dec = []
         for i in range(len(mult) - 1):                                   # adm.py:731-762
             cin, cout = mc * rmult[i], mc * rmult[i + 1]
             cb = 2 * cin if config.skip_integration_type == "concat" else cin
-            dec.append(_Layer([_Block(cb, cb, ce, circular=circ) for _ in range(nb - 1)] +
-                              [_Block(cb, cout, ce, "up", circular=circ)]))
+            dec.append(_Layer([_Block(cb, cb, ce, circular=circ, **nk) for _ in range(nb - 1)] +
+                              [_Block(cb, cout, ce, "up", circular=circ, **nk)]))
         self.decoder = _Layers(dec)
         self.input_layer = torch.nn.Conv2d(config.input_channels, mc, 3, padding="same")
         self.output_layer = torch.nn.Conv2d(mc, config.output_channels, 3, padding="same")
@@ -279,6 +284,7 @@ class ADM(torch.nn.Module):
         B, Ci, H, W = x.shape
         dev = x.device
         down, up = blk.sample == "down", blk.sample == "up"
+        k1, k2 = blk.kinds                                     # 0 GroupNorm(1, C), 1 GroupRMSNorm(1, C)
         Ho, Wo = (H // 2, W // 2) if down else ((2 * H, 2 * W) if up else (H, W))
         mode = DS_LOAD_UPSAMPLE2 if up else DS_LOAD_PLAIN
         fused = self._fused()
@@ -291,7 +297,7 @@ class ADM(torch.nn.Module):
         if fuse1 and xs is not None and not down and not up:
             sa, sb = xs if isinstance(xs, tuple) else (xs, None)
             tab = ws.take((B, ops.table_channels(Ci), 4), dev)
-            ops.gnorm1_table(sa, blk.norm1.weight, blk.norm1.bias, 0, Ci * H * W, stats_b=sb, eps=blk.norm1.eps, out=tab)
+            ops.gnorm1_table(sa, blk.norm1.weight, blk.norm1.bias, k1, Ci * H * W, stats_b=sb, eps=1e-5, out=tab)
             y = self._conv(blk.conv1, x, pk, load_mode=mode, prenorm=tab, tile_stats=ys,
                            out=ws.take((B, blk.cout, Ho, Wo), dev))
             ws.give(tab)
@@ -299,8 +305,8 @@ class ADM(torch.nn.Module):
             Hm, Wm = (Ho, Wo) if down else (H, W)
             stats = ws.take((B, 2), dev)
             scratch = ws.take((ops.N.lib().ds_gnorm1_workspace_bytes(B) // 4,), dev)
-            ops.gnorm1_stats(x, 0, eps=blk.norm1.eps, stats=stats, workspace=scratch)
-            a = ops.gnorm1_apply(x, stats, blk.norm1.weight, blk.norm1.bias, 0, pool=down,
+            ops.gnorm1_stats(x, k1, eps=1e-5, stats=stats, workspace=scratch)
+            a = ops.gnorm1_apply(x, stats, blk.norm1.weight, blk.norm1.bias, k1, pool=down,
                                  out=ws.take((B, Ci, Hm, Wm), dev))
             y = self._conv(blk.conv1, a, pk, load_mode=mode, tile_stats=ys, out=ws.take((B, blk.cout, Ho, Wo), dev))
             ws.give(a)
@@ -326,7 +332,7 @@ class ADM(torch.nn.Module):
         os_ = self._stats_buf(ws, B, blk.cout, Ho, Wo, dev) if (want_stats and not has_attn) else None
         if fuse2:
             tab = ws.take((B, ops.table_channels(blk.cout), 4), dev)
-            ops.gnorm1_table(ys, blk.norm2.weight, blk.norm2.bias, 1, blk.cout * Ho * Wo, film=film, eps=1e-5, out=tab)
+            ops.gnorm1_table(ys, blk.norm2.weight, blk.norm2.bias, k2, blk.cout * Ho * Wo, film=film, eps=1e-5, out=tab)
             out = self._conv(blk.conv2, y, pk, res1=r, res1_upsampled=r_up, prenorm=tab, tile_stats=os_,
                              out=ws.take((B, blk.cout, Ho, Wo), dev))
             ws.give(tab)
@@ -335,8 +341,8 @@ class ADM(torch.nn.Module):
         else:
             stats = ws.take((B, 2), dev)
             scratch = ws.take((ops.N.lib().ds_gnorm1_workspace_bytes(B) // 4,), dev)
-            ops.gnorm1_stats(y, 1, eps=1e-5, stats=stats, workspace=scratch)
-            a2 = ops.gnorm1_apply(y, stats, blk.norm2.weight, blk.norm2.bias, 1, film=film,
+            ops.gnorm1_stats(y, k2, eps=1e-5, stats=stats, workspace=scratch)
+            a2 = ops.gnorm1_apply(y, stats, blk.norm2.weight, blk.norm2.bias, k2, film=film,
                                   out=ws.take((B, blk.cout, Ho, Wo), dev))
             out = self._conv(blk.conv2, a2, pk, res1=r, res1_upsampled=r_up, tile_stats=os_, out=y)
             ws.give(a2)

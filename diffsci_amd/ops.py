@@ -188,16 +188,16 @@ def gnorm1_stats(x, kind, eps=1e-5, stats=None, workspace=None):
 
 
 def gnorm1_apply(x, stats, w, b, kind, pool=False, film=None, out=None):
-    """kind 0: SiLU(GroupNorm1(x)); kind 1: SiLU(FiLM(GroupRMSNorm1(x))); kind 2: identity;
-    then optional 2x2 average pooling.  film: [1 or B, 2C] rows of embed_linear(te)."""
+    """kind 0: GroupNorm(1, C), kind 1: GroupRMSNorm(1, C), each followed by FiLM when `film` is given, then SiLU;
+    kind 2: identity; then optional 2x2 average pooling.  film: [1 or B, 2C] rows of embed_linear(te)."""
     B, C, H, W = x.shape
     Ho, Wo = (H // 2, W // 2) if pool else (H, W)
     if out is None:
         out = torch.empty((B, C, Ho, Wo), dtype=torch.float32, device=x.device)
     f1 = f2 = None
     stride = 0
-    if kind == 1:
-        if film is None or film.dim() != 2 or film.shape[1] != 2 * C or film.shape[0] not in (1, B):
+    if film is not None:
+        if film.dim() != 2 or film.shape[1] != 2 * C or film.shape[0] not in (1, B):
             raise ValueError("film must be [1 or B, 2C]")
         require_device(film, "film")
         stride = 0 if film.shape[0] == 1 else 2 * C
@@ -350,8 +350,8 @@ def gnorm1_table(stats_a, w, b, kind, count, stats_b=None, film=None, eps=1e-5, 
         raise ValueError(f"table must be {(B, table_channels(C), 4)}")
     f1 = f2 = None
     stride = 0
-    if kind == 1:
-        if film is None or film.dim() != 2 or film.shape[1] != 2 * C or film.shape[0] not in (1, B):
+    if film is not None:
+        if film.dim() != 2 or film.shape[1] != 2 * C or film.shape[0] not in (1, B):
             raise ValueError("film must be [1 or B, 2C]")
         require_device(film, "film")
         stride = 0 if film.shape[0] == 1 else 2 * C

@@ -213,7 +213,8 @@ int ds_inorm_table(float* table, const float* tile_stats, const float* w, const 
 
 /* ADM norms from tile statistics, per sample over (C, H, W), optionally over the channel concatenation
  * of two tensors (Cb = 0: one source): kind 0 GroupNorm(1,C): (mean_b, rstd_b*w[c], b[c]); kind 1
- * GroupRMSNorm(1,C) + FiLM: (0, w[c]/d_b*scale[b,c], b[c]*scale[b,c] + shift[b,c]).  count = C*H*W.
+ * GroupRMSNorm(1,C): (0, w[c]/d_b, b[c]); with FiLM rows (both or neither NULL; the block's second norm, whichever
+ * kind): A *= scale[b,c], C = C*scale[b,c] + shift[b,c].  count = C*H*W.
  * adm.py:306-343, 385-406, 764-766. */
 int ds_gnorm1_table(float* table, const float* stats_a, int Ca, int ntiles_a, const float* stats_b, int Cb,
                     int ntiles_b, const float* w, const float* b, const float* film_scale, const float* film_shift,
@@ -273,8 +274,10 @@ int ds_gnorm1_stats(float* stats, void* workspace, const float* x, int B, int C,
                     void* stream);
 
 /* One elementwise pass fusing the normalisation with what follows it in ADMBaseBlock (adm.py:306-343):
- *   kind 0: SiLU((x-mean)*rstd*w[c]+b[c])                        norm1 -> act          (adm.py:327-328)
- *   kind 1: SiLU((x/denom*w[c]+b[c])*scale[b,c] + shift[b,c])    norm2 -> FiLM -> act  (adm.py:331,307,335)
+ *   kind 0: SiLU(n) or SiLU(n*scale[b,c] + shift[b,c]), n = (x-mean)*rstd*w[c]+b[c]     GroupNorm(1, C)
+ *   kind 1: likewise with n = x/denom*w[c]+b[c]                                          GroupRMSNorm(1, C)
+ *           (FiLM when scale/shift are given: norm1 -> act, adm.py:327-328; norm2 -> FiLM -> act, adm.py:331,307,335;
+ *           ADM's defaults are kind 0 without and kind 1 with FiLM, make_norm_layers adm.py:385-406 allows either)
  *   kind 2: x                                                    residual-branch input (adm.py:345-347)
  * then, pool = 1, the block's AvgPool2d(2) (adm.py:316-319).  x [B,C,H,W] -> out [B,C,H(/2),W(/2)].
  * scale/shift: rows of embed_linear(te), film_stride floats between samples (0 = shared row). */

@@ -46,7 +46,18 @@ def time_embedding(sd, t, ye=None):
     return F.silu(te)
 
 
-def block(sd, p, x, te, sample=None, has_attn=False, attn_residual=True, circular=False):
+def block_norm(kind, sd, p, x):
+    """make_norm_layers (adm.py:385-406), num_groups = 1; affine_norm=False leaves no weight / bias keys."""
+    C = x.shape[1]
+    w, b = sd.get(p + "weight"), sd.get(p + "bias")
+    if kind == "GroupLN":
+        return F.group_norm(x, 1, w, b, 1e-5)
+    if w is None:
+        w, b = torch.ones(C).to(x), torch.zeros(C).to(x)
+    return group1_rms_norm(x, w, b)
+
+
+def block(sd, p, x, te, sample=None, has_attn=False, attn_residual=True, circular=False, norms=("GroupLN", "GroupRMS")):
     """ADMBaseBlock.forward for a block without its own skip input (adm.py:292-349).  circular: the block's
     convolutions are CircularConv2d (conv_fn, adm.py:427-443; parameters under `.conv`)."""
     def resample(v):
@@ -55,9 +66,9 @@ def block(sd, p, x, te, sample=None, has_attn=False, attn_residual=True, circula
         if sample == "up":
             return F.interpolate(v, scale_factor=2.0, mode="nearest")
         return v
-    y = F.silu(F.group_norm(x, 1, sd[p + "norm1.weight"], sd[p + "norm1.bias"], 1e-5))
+    y = F.silu(block_norm(norms[0], sd, p + "norm1.", x))
     y = conv3x3(sd, p + "conv1", resample(y), circular)
-    y = group1_rms_norm(y, sd[p + "norm2.weight"], sd[p + "norm2.bias"])
+    y = block_norm(norms[1], sd, p + "norm2.", y)
     e = F.linear(te, sd[p + "embed_linear.weight"], sd[p + "embed_linear.bias"])
     te1, te2 = torch.chunk(e, 2, dim=-1)
     y = y * te1[:, :, None, None] + te2[:, :, None, None]
@@ -73,13 +84,14 @@ def adm_forward(sd, cfg, x, t, ye=None):
     """ADM.forward, adm.py:199-216 (ye = conditional_embedding(y) or None)."""
     nl = len(cfg["channel_expansion"])
     circ = cfg.get("convolution_type", "default") == "circular"
+    norms = (cfg.get("first_resblock_norm", "GroupLN"), cfg.get("second_resblock_norm", "GroupRMS"))
     te = time_embedding(sd, t, ye)
     x = F.conv2d(x, sd["input_layer.weight"], sd["input_layer.bias"], padding="same")
     skips = [x]
     for i in range(nl):
         nb = cfg["number_resnet_downward_block"]
         for j in range(nb):
-            x = block(sd, f"encoder.layers.{i}.input_blocks.{j}.", x, te, sample="down" if j == nb - 1 else None, circular=circ)
+            x = block(sd, f"encoder.layers.{i}.input_blocks.{j}.", x, te, sample="down" if j == nb - 1 else None, circular=circ, norms=norms)
         skips.append(x)
     nmid = (cfg["number_resnet_before_attn_block"] + cfg["number_resnet_attn_block"] +
             cfg["number_resnet_after_attn_block"])
@@ -88,13 +100,13 @@ def adm_forward(sd, cfg, x, t, ye=None):
              [False] * cfg["number_resnet_after_attn_block"])
     for j in range(nmid):
         x = block(sd, f"middle_block.middle_blocks.{j}.", x, te, has_attn=flags[j],
-                  attn_residual=cfg["attn_residual"], circular=circ)
+                  attn_residual=cfg["attn_residual"], circular=circ, norms=norms)
     for i in range(nl):
         h = skips.pop()
         x = torch.cat([x, h], dim=1) if cfg["skip_integration_type"] == "concat" else x + h
         nb = cfg["number_resnet_upward_block"]
         for j in range(nb):
-            x = block(sd, f"decoder.layers.{i}.input_blocks.{j}.", x, te, sample="up" if j == nb - 1 else None, circular=circ)
+            x = block(sd, f"decoder.layers.{i}.input_blocks.{j}.", x, te, sample="up" if j == nb - 1 else None, circular=circ, norms=norms)
     return F.conv2d(x, sd["output_layer.weight"], sd["output_layer.bias"], padding="same")
 
 

@@ -558,6 +558,37 @@ def variants():
         npz(f"punetg8_{tag}", **arrs)
 
 
+def adm_norms():
+    """ADM with the other norm choices of make_norm_layers (adm.py:385-406): RMS first / LN second (+FiLM), and LN / LN
+    with affine_norm=False -- which the reference's ADM silently ignores (the flag is not forwarded to the blocks)."""
+    for i, (tag, over) in enumerate((("rms_ln", dict(first_resblock_norm="GroupRMS", second_resblock_norm="GroupLN")),
+                                     ("ln_ln_noaffine", dict(first_resblock_norm="GroupLN", second_resblock_norm="GroupLN",
+                                                             affine_norm=False)))):
+        torch.manual_seed(100 + i)
+        cfg = M.nets.ADMConfig(model_channels=8, time_embed_dim=8, output_embed_dim=16, **over)
+        net = M.nets.ADM(cfg).eval()
+        with torch.no_grad():
+            for k, v in net.state_dict().items():
+                if "norm" in k:
+                    v.add_(0.25 * torch.randn_like(v))
+        sd = net.state_dict()
+        torch.manual_seed(110 + i)
+        x = torch.randn(2, 1, 32, 32)
+        t = torch.tensor([0.4, -1.1])
+        arrs = dict(sd_arrays(sd), x=x, t=t)
+        with torch.inference_mode():
+            arrs["out_f32"] = net(x, t)
+            te = net.time_embedding(t, None)
+            h = net.input_layer(x)
+            arrs["stem"] = h
+            arrs["enc00"] = net.encoder.layers[0].input_blocks[0](h, te)
+        net64 = M.nets.ADM(cfg).double().eval()
+        net64.load_state_dict({k: v.double() for k, v in sd.items()})
+        with torch.inference_mode():
+            arrs["out_f64"] = net64(x.double(), t.double())
+        npz(f"adm8_{tag}", **arrs)
+
+
 class ToyAutoencoder(torch.nn.Module):
     """Parameter-free stand-in for a latent autoencoder (ours, not the reference's): 2x2 pixel-unshuffle with a gain.
     tests/test_gpu_sampler.py defines the same three lines."""
@@ -619,6 +650,6 @@ def latent():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["schedule", "toy", "punetg", "porosity", "inpaint", "vpve", "circular", "si", "punetgcond", "langevin", "adm", "variants", "latent"]
+    which = sys.argv[1:] or ["schedule", "toy", "punetg", "porosity", "inpaint", "vpve", "circular", "si", "punetgcond", "langevin", "adm", "variants", "latent", "adm_norms"]
     for name in which:
         globals()[name]()

@@ -111,6 +111,30 @@ def test_adm_trajectories_vs_reference(M, dev, skip, use_graph):
     assert rel_l2(h, v["hist_karras_N4_f32"]) < REL
 
 
+ADM_NORMS = {"rms_ln": dict(first_resblock_norm="GroupRMS", second_resblock_norm="GroupLN"),
+             "ln_ln_noaffine": dict(first_resblock_norm="GroupLN", second_resblock_norm="GroupLN", affine_norm=False)}
+
+
+@pytest.mark.parametrize("fuse", [True, False])
+@pytest.mark.parametrize("tag", sorted(ADM_NORMS))
+def test_adm_norm_choices(M, dev, tag, fuse):
+    """make_norm_layers (adm.py:385-406): GroupNorm(1, C) or GroupRMSNorm(1, C) in either slot (FiLM follows the
+    second); affine_norm=False is ignored by the reference's ADM, so the norms stay affine -- folded into the convolutions and as standalone kernels."""
+    v, sd = load("adm8_" + tag)
+    net = M.ADM(M.ADMConfig(model_channels=8, time_embed_dim=8, output_embed_dim=16, **ADM_NORMS[tag]))
+    r = net.load_state_dict(sd, strict=True)
+    assert not r.missing_keys and not r.unexpected_keys
+    net = net.to(dev)
+    net.fuse_norm = fuse
+    pk = net.packed_weights()
+    films = net.time_shifts(net.embed_time(v["t"].to(dev)))
+    b0, _ = net._block(net.encoder.layers[0].input_blocks[0], v["stem"].to(dev), films[0], pk, net._ws)
+    assert rel_l2(b0.cpu(), v["enc00"]) < 5e-6
+    out = net(v["x"].to(dev), v["t"].to(dev)).cpu()
+    assert rel_l2(out, v["out_f32"]) < REL
+    assert rel_l2(out, v["out_f64"]) < max(4 * rel_l2(v["out_f32"], v["out_f64"]), 2e-6)
+
+
 @pytest.mark.parametrize("precision", ["bf16x6", "fp32"])
 def test_adm_other_precisions(M, dev, precision):
     net, v, _ = _net(M, dev, "concat")
