@@ -19,6 +19,49 @@ def rel(a, b):
     return float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
 
 
+def fuzz_up(ri, g, dev):
+    """ds_conv2d_h3_up: whole-tile low-resolution shapes, every epilogue / loader option."""
+    B, Cin, Cout = ri(1, 3), ri(1, 70), ri(1, 140)
+    if ri(0, 1):
+        Hl, Wl = 8 * ri(1, 4), 32 * ri(1, 2)
+    else:
+        Hl, Wl = 16 * ri(1, 2), 16 * ri(1, 3)
+    assert ops.N.lib().ds_conv2d_h3_up_supported(Hl, Wl)
+    H, W = 2 * Hl, 2 * Wl
+    circ, pre, res = ri(0, 2) == 0, ri(0, 1) == 1, ri(0, 2)
+    x = torch.randn(B, Cin, Hl, Wl, generator=g) * 2 + 0.3
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)
+    bias, shift = torch.randn(Cout, generator=g), torch.randn(B, Cout, generator=g)
+    r1 = None if res == 0 else torch.randn(B, Cout, *((H, W) if res == 1 else (Hl, Wl)), generator=g)
+    xin = x.double()
+    tab = None
+    if pre:
+        M, A, C = torch.randn(B, Cin, generator=g) * 0.3, torch.rand(B, Cin, generator=g) + 0.5, torch.randn(B, Cin, generator=g) * 0.3
+        tab = torch.zeros(B, ops.table_channels(Cin), 4)
+        tab[:, :Cin, 0], tab[:, :Cin, 1], tab[:, :Cin, 2] = M, A, C
+        xin = F.silu((xin - M.double()[..., None, None]) * A.double()[..., None, None] + C.double()[..., None, None])
+    up = F.interpolate(xin, scale_factor=2.0, mode="nearest")
+    if circ:
+        up = F.pad(F.pad(up, (1, 1, 0, 0), mode="circular"), (0, 0, 1, 1), mode="circular")
+        want = F.conv2d(up, w.double(), bias.double())
+    else:
+        want = F.conv2d(up, w.double(), bias.double(), padding=1)
+    want = want + shift.double()[..., None, None]
+    if r1 is not None:
+        want = want + (r1.double() if res == 1 else F.interpolate(r1.double(), scale_factor=2.0, mode="nearest"))
+    ts = torch.full((B, Cout, ops.conv_tile_count(H, W), 4), float("nan"), device=dev)
+    pw = ops.pack_conv(w.to(dev), "fp16x3", upsampled=True)
+    got = ops.conv(x.to(dev), pw, bias=bias.to(dev), shift=shift.to(dev), res1=None if r1 is None else r1.to(dev),
+                   res1_upsampled=res == 2, load_mode=2, circular=circ, prenorm=None if tab is None else tab.to(dev),
+                   tile_stats=ts).cpu()
+    e = rel(got, want)
+    assert torch.isfinite(ts).all(), "tile statistics not fully written"
+    K, S, Q, n = ts.cpu().double().unbind(-1)
+    assert torch.equal(n.sum(-1), torch.full_like(n.sum(-1), H * W)), "tile pixel counts"
+    sxx = (Q + 2 * K * S + n * K * K).sum(-1)
+    return max(e, float(((sxx - (want * want).sum(dim=(2, 3))).abs() / (want * want).sum(dim=(2, 3)).clamp_min(1e-30)).max()))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=200)
@@ -29,7 +72,16 @@ def main():
     ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))       # noqa: E731
     worst = 0.0
     for it in range(a.n):
-        kind = ["3x3", "3x3", "3x3", "1x1", "direct"][ri(0, 4)]
+        kind = ["3x3", "3x3", "3x3", "1x1", "direct", "up"][ri(0, 5)]
+        if kind == "up":
+            e = fuzz_up(ri, g, dev)
+            worst = max(worst, e)
+            if e > 3e-6:
+                print(f"FAIL it={it} kind=up err={e:.3e}")
+                sys.exit(1)
+            if it % 25 == 0:
+                print(f"it {it}: ok (worst so far {worst:.2e})", flush=True)
+            continue
         B, Cin, Cout = ri(1, 3), ri(1, 80), ri(1, 140)
         H, W = ri(1, 12) * 2, ri(1, 20) * 2
         if ri(0, 3) == 0:

@@ -43,13 +43,18 @@ def main():
                         number_resnet_downward_block=ri(1, 2), number_resnet_upward_block=ri(1, 2),
                         number_resnet_attn_block=ri(1, 3), number_resnet_before_attn_block=ri(0, 2),
                         number_resnet_after_attn_block=ri(0, 2), attn_residual=bool(ri(0, 1)))
+            # layer variants: periodic / magnitude-preserving convolutions, the other norm choices, bias-free
+            over.update(convolution_type=pick(["default", "default", "circular", "mp"]),
+                        first_resblock_norm=pick(["GroupLN", "GroupLN", "GroupRMS", "none"]),
+                        second_resblock_norm=pick(["GroupRMS", "GroupRMS", "GroupLN", "none"]),
+                        affine_norm=bool(ri(0, 3)), bias=bool(ri(0, 3)))
             cfg = punetg_ref.default_config(**over)
-            sd = punetg_ref.random_state_dict(cfg, seed=it)
-            for k in sd:
-                if "gnorm" in k or k.endswith("bias"):
-                    sd[k] = sd[k] + 0.2 * torch.randn_like(sd[k])
             net = M.PUNetG(M.PUNetGConfig(**over))
-            net.load_state_dict(sd)
+            with torch.no_grad():
+                for k, w in net.state_dict().items():
+                    if "gnorm" in k or k.endswith("bias"):
+                        w.add_(0.2 * torch.randn_like(w))
+            sd = {k: w.clone() for k, w in net.state_dict().items()}
             with torch.inference_mode():
                 want = punetg_ref.punetg_forward(sd, cfg, x, t)
                 want64 = punetg_ref.punetg_forward({k: w.double() for k, w in sd.items()}, cfg, x.double(), t.double())
@@ -58,7 +63,10 @@ def main():
                         input_channels=cin, output_channels=ri(1, 5), number_resnet_downward_block=ri(1, 2),
                         number_resnet_upward_block=ri(1, 3), number_resnet_attn_block=ri(1, 2),
                         number_resnet_before_attn_block=ri(0, 1), number_resnet_after_attn_block=ri(0, 1),
-                        skip_integration_type=pick(["concat", "add"]), attn_residual=bool(ri(0, 1)))
+                        skip_integration_type=pick(["concat", "add"]), attn_residual=bool(ri(0, 1)),
+                        convolution_type=pick(["default", "default", "circular"]),
+                        first_resblock_norm=pick(["GroupLN", "GroupLN", "GroupRMS"]),
+                        second_resblock_norm=pick(["GroupRMS", "GroupRMS", "GroupLN"]))
             net = M.ADM(M.ADMConfig(**over))
             with torch.no_grad():
                 for k, w in net.state_dict().items():
@@ -82,7 +90,7 @@ def main():
             errs.append(max(rel(got, want), rel(got, want64)))
         e = max(errs)
         worst = max(worst, e)
-        tag = f"{family} exp={exp} B={B} cin={cin} {H}x{W} " + " ".join(f"{k}={v}" for k, v in over.items() if k.startswith("number") or k in ("model_channels", "skip_integration_type"))
+        tag = f"{family} exp={exp} B={B} cin={cin} {H}x{W} " + " ".join(f"{k}={v}" for k, v in over.items() if k.startswith("number") or k in ("model_channels", "skip_integration_type", "convolution_type", "first_resblock_norm", "second_resblock_norm", "affine_norm", "bias"))
         if e > tol:
             print("FAIL", tag, errs, tol)
             sys.exit(1)
