@@ -66,31 +66,33 @@ __global__ __launch_bounds__(256) void k_inorm_table(float* table, const float* 
   }
 }
 
-// one workgroup per sample
-__global__ __launch_bounds__(256) void k_gnorm1_table(float* table, const float* __restrict__ sa, int Ca, int nta,
+// one workgroup of 1024 threads per sample: the tile statistics of one sample are up to 1 MiB (256 channels x 256
+// tiles x 16 B at 256 x 256) and are read exactly once -- 256 threads took 30 us on them
+constexpr int G1T = 1024;
+__global__ __launch_bounds__(G1T) void k_gnorm1_table(float* table, const float* __restrict__ sa, int Ca, int nta,
                                                       const float* __restrict__ sb, int Cb, int ntb,
                                                       const float* __restrict__ w, const float* __restrict__ bias,
                                                       const float* __restrict__ f1, const float* __restrict__ f2,
                                                       int film_stride, double inv_n, float eps, int kind) {
-  __shared__ double red[2][4];
+  __shared__ double red[2][G1T / 64];
   __shared__ float st[2];
   const int b = blockIdx.x, C = Ca + Cb;
   double s = 0.0, q = 0.0;
   {
     const float4* p = reinterpret_cast<const float4*>(sa) + (size_t)b * Ca * nta;
-    for (int i = threadIdx.x; i < Ca * nta; i += 256) acc_tile(p[i], s, q);
+    for (int i = threadIdx.x; i < Ca * nta; i += G1T) acc_tile(p[i], s, q);
   }
   if (Cb > 0) {
     const float4* p = reinterpret_cast<const float4*>(sb) + (size_t)b * Cb * ntb;
-    for (int i = threadIdx.x; i < Cb * ntb; i += 256) acc_tile(p[i], s, q);
+    for (int i = threadIdx.x; i < Cb * ntb; i += G1T) acc_tile(p[i], s, q);
   }
   s = group_sum_d(s, 64);
   q = group_sum_d(q, 64);
   if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s; red[1][threadIdx.x >> 6] = q; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    const double ts = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
-    const double tq = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    double ts = 0.0, tq = 0.0;                             // fixed order: deterministic
+    for (int k = 0; k < G1T / 64; ++k) { ts += red[0][k]; tq += red[1][k]; }
     if (kind == 0) {
       const double mean = ts * inv_n;
       double var = tq * inv_n - mean * mean;
@@ -105,8 +107,8 @@ __global__ __launch_bounds__(256) void k_gnorm1_table(float* table, const float*
   __syncthreads();
   const float M = st[0], rs = st[1];
   const int Cpad = (C + 15) / 16 * 16;
-  for (int c = C + threadIdx.x; c < Cpad; c += 256) reinterpret_cast<float4*>(table)[(size_t)b * Cpad + c] = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int c = threadIdx.x; c < C; c += 256) {
+  for (int c = C + threadIdx.x; c < Cpad; c += G1T) reinterpret_cast<float4*>(table)[(size_t)b * Cpad + c] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int c = threadIdx.x; c < C; c += G1T) {
     const float wc = w ? w[c] : 1.f, bc = bias ? bias[c] : 0.f;
     float4 o;
     o.x = M; o.y = rs * wc; o.z = bc;                       // M = 0 for the RMS norm
@@ -151,7 +153,7 @@ int ds_gnorm1_table(float* table, const float* stats_a, int Ca, int ntiles_a, co
   DS_REQUIRE(((reinterpret_cast<uintptr_t>(table) | reinterpret_cast<uintptr_t>(stats_a) | reinterpret_cast<uintptr_t>(stats_b)) & 15u) == 0,
              DS_ERR_SHAPE, "ds_gnorm1_table: pointers must be 16-byte aligned");
   if (B == 0) return DS_OK;
-  hipLaunchKernelGGL(k_gnorm1_table, dim3(B), dim3(256), 0, ds::as_stream(stream), table, stats_a, Ca, ntiles_a, stats_b,
+  hipLaunchKernelGGL(k_gnorm1_table, dim3(B), dim3(G1T), 0, ds::as_stream(stream), table, stats_a, Ca, ntiles_a, stats_b,
                      Cb, ntiles_b, w, b, film_scale, film_shift, film_stride, 1.0 / (double)count, eps, kind);
   DS_CHECK_LAUNCH("ds_gnorm1_table");
   return DS_OK;
