@@ -18,6 +18,7 @@ import torch
 from ... import ops
 from ..._native import DS_IN_NETWORK
 from . import edmbatchnorm, noisesamplers, preconditioners, schedulers
+from .autoregressivesample import LatentSpaceAutoregressive
 from .engine import Loop, ModuleSource
 from .steptable import build_step_table
 
@@ -41,6 +42,10 @@ def _condition_key(t):
     captured graph reads them in place, so a different tensor means a different plan)."""
     if t.numel() <= 64:
         return (tuple(t.shape), t.flatten().tolist())
+    if getattr(t, "_ds_static", False):                  # a plan-owned copy of a channel field: refreshed before replay
+        return (tuple(t.shape), t.data_ptr(), "static")
+    if t.is_inference():                                 # no version counter: a checksum stands in for it
+        return (tuple(t.shape), t.data_ptr(), float(t.double().sum()), float(t.double().abs().sum()))
     return (tuple(t.shape), t.data_ptr(), t._version)
 
 
@@ -110,7 +115,7 @@ class _Plan:
         self.loop, self.graph = loop, graph
 
 
-class KarrasModule(torch.nn.Module):
+class KarrasModule(torch.nn.Module, LatentSpaceAutoregressive):
     def __init__(self, model: torch.nn.Module, config: KarrasModuleConfig, conditional: bool = False,
                  masked: bool = False, autoencoder: None | torch.nn.Module = None,
                  autoencoder_conditional: bool = False, encode_y: bool = False,
@@ -132,6 +137,7 @@ class KarrasModule(torch.nn.Module):
                                if config.has_edm_batch_norm else None)
         self.use_graph = True          # capture the loop as a hipGraph for HIP-native networks
         self._plans = {}
+        self._static_fields = {}
         self._stream = None
 
     # ---------------------------------------------------------------- bookkeeping
@@ -148,6 +154,7 @@ class KarrasModule(torch.nn.Module):
 
     def _apply(self, fn, *a, **k):
         self._plans = {}
+        self._static_fields = {}
         return super()._apply(fn, *a, **k)
 
     # ---------------------------------------------------------------- denoiser / score (public API)
@@ -289,6 +296,8 @@ class KarrasModule(torch.nn.Module):
         finally:
             if integrator is not None:
                 sch.unset_temporary_integrator()
+        if self.use_graph and y is not None:
+            y = self._static_channel_fields(y)
         src = ModuleSource(self, y, guidance, x.shape[0], x)
         if src.planned and self.use_graph:
             return self._run_planned(table, src, x, y, guidance, nsteps, record_history, integ, eps, scale,
@@ -298,6 +307,31 @@ class KarrasModule(torch.nn.Module):
         loop.set_noise(eps)
         loop.launch()
         return loop.result()
+
+    def _static_channel_fields(self, y):
+        """Channel-concatenated condition fields (PUNetGCond.channel_conditional_items) are read in place by the
+        captured graph.  Callers such as autoregressive_sample pass a NEW field tensor on every call; keying the plan
+        on its storage would re-capture the whole loop each time.  The module therefore keeps one buffer per (item,
+        shape), copies the caller's values into it, and hands that buffer to the plan."""
+        items = getattr(self.model, "channel_conditional_items", None)
+        if not items or not isinstance(y, dict):
+            return y
+        y = dict(y)
+        for item in items:
+            t = y.get(item)
+            if not torch.is_tensor(t) or t.numel() <= 64 or not t.is_cuda:
+                continue
+            key = (item, tuple(t.shape), str(t.device))
+            buf = self._static_fields.get(key)
+            if buf is None:
+                if len(self._static_fields) >= 8:
+                    self._static_fields.pop(next(iter(self._static_fields)))
+                buf = torch.empty(t.shape, dtype=torch.float32, device=t.device)
+                buf._ds_static = True
+                self._static_fields[key] = buf
+            buf.copy_(t)                                   # on the caller's stream; the plan's stream waits on it
+            y[item] = buf
+        return y
 
     def _run_planned(self, table, src, x, y, guidance, nsteps, record_history, integ, eps, scale, i0, i1):
         sch = self.config.noisescheduler

@@ -562,11 +562,19 @@ class PUNetGCond(PUNetG):
 
     def _with_condition(self, x, ycat, ws):
         B = x.shape[0]
+        yexp = None
         if ycat.shape[0] == 1 and B > 1:
-            ycat = ycat.expand(B, *ycat.shape[1:]).contiguous()
+            # broadcast into a WORKSPACE buffer: a temporary from torch's allocator would be freed right after the
+            # capture while the graph keeps writing to its address on every replay
+            yexp = ws.take((B,) + tuple(ycat.shape[1:]), x.device)
+            yexp.copy_(ycat.expand(B, *ycat.shape[1:]))
+            ycat = yexp
         elif ycat.shape[0] != B:
             raise ValueError("channel condition batch must be 1 or match x")
-        return ops.concat2(x, ycat, out=ws.take((B, x.shape[1] + ycat.shape[1]) + tuple(x.shape[2:]), x.device))
+        out = ops.concat2(x, ycat, out=ws.take((B, x.shape[1] + ycat.shape[1]) + tuple(x.shape[2:]), x.device))
+        if yexp is not None:
+            ws.give(yexp)
+        return out
 
     def forward(self, x, t, y=None):
         ops.require_device(x, "x")

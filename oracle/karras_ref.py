@@ -369,6 +369,33 @@ def decode(x, autoencoder=None, bn=None, norm=1.0, record_history=False):
     return x
 
 
+def autoregressive_forecast(sample_fn, y0, nsamples, latent_shape, nsteps_forecast, cond_time):
+    """LatentSpaceAutoregressive.autoregressive_sample in latent space (autoregressivesample.py:83-183), written
+    the way the reference runs it: a prediction buffer, and a condition dict whose 'y' entry is overwritten in place
+    and read back on the next step.  sample_fn(nsamples, y_dict) -> [nsamples, C, h, w].  Returns the stacked
+    forecasts [nsteps_forecast, nsamples, C, h, w]."""
+    C, h, w = latent_shape
+    y = {"y": y0}
+    buf = torch.zeros((max(cond_time, nsteps_forecast + 1), nsamples, C, h, w))
+    out = [sample_fn(nsamples, y)]
+    buf[0] = out[0]
+    for step in range(nsteps_forecast - 1):
+        count = step + 1
+        if count >= cond_time:
+            y["y"] = buf[count - cond_time:count][:, 0].reshape(cond_time * C, h, w)      # sample 0 of each frame
+        else:
+            initial = y["y"].reshape(cond_time, C, h, w)              # the window written on the previous step
+            need = cond_time - count
+            combined = torch.zeros((cond_time, C, h, w))
+            combined[:need] = initial[cond_time - need:]
+            combined[need:] = buf[:count, 0]
+            y["y"] = combined.reshape(cond_time * C, h, w)
+        pred = sample_fn(nsamples, y)
+        buf[(step + 1) % buf.shape[0]] = pred
+        out.append(pred)
+    return torch.stack(out, dim=0)
+
+
 # --------------------------------------------------------------------------- closed-form KATs
 def gaussian_target_score(scale):
     """grad log p(x; sigma) for data ~ N(0, scale^2 I).  data/toy_datasets.py:259-279."""

@@ -589,6 +589,60 @@ def adm_norms():
         npz(f"adm8_{tag}", **arrs)
 
 
+def autoregressive():
+    """KarrasModule.autoregressive_sample (LatentSpaceAutoregressive mixin,
+    autoregressivesample.py:27-203): a forecast loop that calls sample() once per step with a sliding window of its own
+    predictions as the channel condition y['y'].  Weights: the punetg8_cond fixture's network (same seed)."""
+    torch.manual_seed(70)
+    cfg = M.nets.PUNetGConfig(model_channels=8, input_channels=3, output_channels=1)
+    net = M.nets.PUNetGCond(cfg, channel_conditional_items=["y"]).eval()
+    with torch.no_grad():
+        for k, v in net.state_dict().items():
+            if "gnorm" in k:
+                v.add_(0.25 * torch.randn_like(v))
+    ref = np.load(os.path.join(OUT, "punetg8_cond.npz"))
+    assert all(np.array_equal(ref["sd/" + k], v.numpy()) for k, v in net.state_dict().items())
+    module = M.KarrasModule(net, M.KarrasModuleConfig.from_edm(), conditional=True).eval()
+    torch.manual_seed(120)
+    y0 = torch.randn(2, 16, 16)                      # cond_time = 2 frames of 1 channel
+    arrs = dict(y0=y0)
+    import contextlib, io
+    for tag, kw in (("plain", dict(nsamples=2)), ("batched", dict(nsamples=3, maximum_batch_size=2))):
+        torch.manual_seed(121)                       # sample() draws its white noise from the CPU generator
+        with contextlib.redirect_stdout(io.StringIO()):
+            res = module.autoregressive_sample(latent_shape=[1, 16, 16], nsteps_forecast=5, cond_time=2,
+                                               nsteps_diffusion=3, y={"y": y0.clone()}, y_already_encoded=True,
+                                               return_intermediate=True, **kw)
+        for k, v in res.items():
+            arrs[f"{tag}_{k}"] = v
+    # cond_time = 3 pins how the window is assembled while fewer than cond_time predictions exist (the loop re-reads
+    # the window it wrote on the previous step as "initial conditions", autoregressivesample.py:147-161), with a
+    # parameter-light stand-in network (ours; tests define the same class)
+    tiny = M.KarrasModule(TinyCondNet(), M.KarrasModuleConfig.from_edm(), conditional=True).eval()
+    y3 = torch.randn(6, 8, 8)                        # 3 frames x 2 channels
+    arrs["tiny_y0"] = y3
+    torch.manual_seed(122)
+    with contextlib.redirect_stdout(io.StringIO()):
+        res = tiny.autoregressive_sample(nsamples=2, latent_shape=[2, 8, 8], nsteps_forecast=6, cond_time=3,
+                                         nsteps_diffusion=3, y={"y": y3.clone()}, y_already_encoded=True)
+    arrs["tiny_forecasts"] = res["forecasts"]
+    arrs["tiny_final_forecast"] = res["final_forecast"]
+    npz("autoreg8", **arrs)
+
+
+class TinyCondNet(torch.nn.Module):
+    """model(x, c_noise, y): mixes x with a weighted sum of the condition frames, so every frame of the window matters."""
+
+    def __init__(self):
+        super().__init__()
+        self.gain = torch.nn.Parameter(torch.tensor(0.3))
+
+    def forward(self, x, t, y=None):
+        f = y["y"].reshape(y["y"].shape[0], 3, 2, *y["y"].shape[2:])
+        wts = torch.tensor([0.2, -0.5, 0.9]).view(1, 3, 1, 1, 1).to(x)
+        return self.gain * x + (f * wts).sum(dim=1) + 0.1 * t.view(-1, 1, 1, 1)
+
+
 class ToyAutoencoder(torch.nn.Module):
     """Parameter-free stand-in for a latent autoencoder (ours, not the reference's): 2x2 pixel-unshuffle with a gain.
     tests/test_gpu_sampler.py defines the same three lines."""
@@ -650,6 +704,6 @@ def latent():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["schedule", "toy", "punetg", "porosity", "inpaint", "vpve", "circular", "si", "punetgcond", "langevin", "adm", "variants", "latent", "adm_norms"]
+    which = sys.argv[1:] or ["schedule", "toy", "punetg", "porosity", "inpaint", "vpve", "circular", "si", "punetgcond", "langevin", "adm", "variants", "latent", "adm_norms", "autoregressive"]
     for name in which:
         globals()[name]()

@@ -730,6 +730,56 @@ def test_punetgcond_channel_conditioning(M, dev, grids):
         net(v["x"].to(dev), v["t"].to(dev))
 
 
+class TinyCondNet(torch.nn.Module):
+    """The stand-in network of the autoreg8 fixture's cond_time = 3 case (oracle/tools/make_golden.py)."""
+
+    def __init__(self):
+        super().__init__()
+        self.gain = torch.nn.Parameter(torch.tensor(0.3))
+
+    def forward(self, x, t, y=None):
+        f = y["y"].reshape(y["y"].shape[0], 3, 2, *y["y"].shape[2:])
+        wts = torch.tensor([0.2, -0.5, 0.9]).view(1, 3, 1, 1, 1).to(x)
+        return self.gain * x + (f * wts).sum(dim=1) + 0.1 * t.view(-1, 1, 1, 1)
+
+
+def test_autoregressive_forecast_loop(M, dev, grids):
+    """KarrasModule.autoregressive_sample -- one captured HIP sampling run per forecast step,
+    conditioned on a sliding window of sample 0's predictions -- against the reference's forecasts.  Every forecast
+    feeds the next one's condition, so per-step differences compound: the first forecast is held to 1e-5, the whole
+    sequence to 2e-4."""
+    v, sd = load("autoreg8")
+    _, sd = load("punetg8_cond")
+    net = M.nets.PUNetGCond(M.PUNetGConfig(model_channels=8, input_channels=3, output_channels=1),
+                            channel_conditional_items=["y"])
+    net.load_state_dict(sd)
+    module = M.KarrasModule(net, M.KarrasModuleConfig.from_edm(), conditional=True).to(dev).eval()
+    _pin_grid(module, grids)
+    kw = dict(latent_shape=[1, 16, 16], nsteps_forecast=5, cond_time=2, nsteps_diffusion=3, y_already_encoded=True)
+    torch.manual_seed(121)                                          # sample() draws white noise from the CPU generator
+    res = module.autoregressive_sample(nsamples=2, y={"y": v["y0"].clone()}, return_intermediate=True, **kw)
+    assert sorted(res) == ["final_forecast", "forecasts", "intermediate_latent"]
+    f = res["forecasts"].cpu()
+    assert f.shape == v["plain_forecasts"].shape
+    assert rel_l2(f[0], v["plain_forecasts"][0]) < REL and rel_l2(f, v["plain_forecasts"]) < 2e-4
+    assert torch.equal(res["final_forecast"], res["forecasts"][-1])
+    torch.manual_seed(121)
+    res = module.autoregressive_sample(nsamples=3, maximum_batch_size=2, y={"y": v["y0"].clone()}, **kw)
+    assert rel_l2(res["forecasts"].cpu(), v["batched_forecasts"]) < 2e-4
+    torch.manual_seed(121)
+    lat = module.autoregressive_sample(nsamples=2, y={"y": v["y0"].clone()}, return_in_latent=True, **kw)
+    assert sorted(lat) == ["final_forecast_latent", "forecasts"] and torch.equal(lat["forecasts"].cpu(), f)
+    with pytest.raises(ValueError, match="must be provided"):
+        module.autoregressive_sample(nsamples=1, y={}, **kw)
+    # cond_time = 3: the head of the window while fewer than three predictions exist (reference quirk, see the module)
+    tiny = M.KarrasModule(TinyCondNet(), M.KarrasModuleConfig.from_edm(), conditional=True).to(dev).eval()
+    _pin_grid(tiny, grids)
+    torch.manual_seed(122)
+    res = tiny.autoregressive_sample(nsamples=2, latent_shape=[2, 8, 8], nsteps_forecast=6, cond_time=3, nsteps_diffusion=3,
+                                     y={"y": v["tiny_y0"].clone()}, y_already_encoded=True)
+    assert rel_l2(res["forecasts"].cpu(), v["tiny_forecasts"]) < REL
+
+
 def test_euler_maruyama_langevin_interval(M, dev):
     """The runtime knobs langevin_const / langevin_interval of the stochastic sampler (schedulers.py:219-245)."""
     v, _ = load("em_interval")

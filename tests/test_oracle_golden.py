@@ -347,6 +347,56 @@ def test_punetg_layer_variants(tag):
         assert_exact_or_rel(hist, v["hist_heun_N6_f32"], tag + " hist_heun_N6_f32", 2e-6)
 
 
+class TinyCondNet(torch.nn.Module):
+    """The stand-in network of the autoreg8 fixture's cond_time = 3 case (oracle/tools/make_golden.py)."""
+
+    def __init__(self):
+        super().__init__()
+        self.gain = torch.nn.Parameter(torch.tensor(0.3))
+
+    def forward(self, x, t, y=None):
+        f = y["y"].reshape(y["y"].shape[0], 3, 2, *y["y"].shape[2:])
+        wts = torch.tensor([0.2, -0.5, 0.9]).view(1, 3, 1, 1, 1).to(x)
+        return self.gain * x + (f * wts).sum(dim=1) + 0.1 * t.view(-1, 1, 1, 1)
+
+
+def test_autoregressive_forecast_loop():
+    """KarrasModule.autoregressive_sample (autoregressivesample.py:27-203) -- window assembly,
+    sample-0 conditioning, minibatching -- with the white noise drawn from the CPU generator as sample() does."""
+    v, _ = load("autoreg8")
+    _, sd = load("punetg8_cond")
+    cfg = punetg_ref.default_config(model_channels=8, input_channels=3, output_channels=1)
+
+    def cond_net(x, t, y=None):                                   # PUNetGCond.forward, punetg.py:719-735
+        f = y["y"].expand(x.shape[0], *y["y"].shape[1:])
+        return punetg_ref.punetg_forward(sd, cfg, torch.cat([x, f], dim=1), t)
+
+    def sampler(net, shape, nsteps):
+        def fn(n, y):
+            wn = torch.randn(n, *shape)
+            return K.propagate_white_noise(net, wn, nsteps, y=dict(y), conditional=True)
+        return fn
+
+    with torch.inference_mode():
+        torch.manual_seed(121)
+        f = K.autoregressive_forecast(sampler(cond_net, (1, 16, 16), 3), v["y0"].clone(), 2, (1, 16, 16), 5, 2)
+        assert_exact_or_rel(f, v["plain_forecasts"], "autoregressive forecasts", 2e-6)
+        assert_exact_or_rel(f, v["plain_intermediate_latent"], "latent == pixel without an autoencoder", 2e-6)
+        assert_exact_or_rel(f[-1], v["plain_final_forecast"], "final forecast", 2e-6)
+        torch.manual_seed(121)                                     # maximum_batch_size = 2 on 3 samples: runs of 2 and 1
+        parts = [K.autoregressive_forecast(sampler(cond_net, (1, 16, 16), 3), v["y0"].clone(), b, (1, 16, 16), 5, 2)
+                 for b in (2, 1)]
+        assert_exact_or_rel(parts[0], v["batched_forecasts"][:, :2], "minibatched forecasts, first run", 2e-6)
+        # the single-sample run takes other convolution code paths in torch's CPU backend than the fixture's run did
+        # (thread count / blocking), and five forecasts fed back into the condition amplify that last-ulp difference
+        assert rel_l2(parts[1], v["batched_forecasts"][:, 2:]) < 1e-4
+        tiny = TinyCondNet()
+        torch.manual_seed(122)
+        f3 = K.autoregressive_forecast(sampler(lambda x, t, y=None: tiny(x, t, y), (2, 8, 8), 3), v["tiny_y0"].clone(),
+                                       2, (2, 8, 8), 6, 3)
+        assert_exact_or_rel(f3, v["tiny_forecasts"], "cond_time = 3 window assembly", 2e-6)
+
+
 class ToyAutoencoder(torch.nn.Module):
     """The parameter-free autoencoder the latent8 fixture was generated with (oracle/tools/make_golden.py)."""
 
