@@ -484,8 +484,13 @@ class Graph:
         self._h = ctypes.c_void_p()
         self.nodes = 0
 
+    @staticmethod
+    def _allocations():
+        return torch.cuda.memory_stats().get("allocation.all.allocated", 0)
+
     def __enter__(self):
         self._stream = _stream()
+        self._alloc0 = self._allocations()
         N.check(N.lib().ds_graph_begin_capture(self._stream), "ds_graph_begin_capture")
         return self
 
@@ -494,6 +499,13 @@ class Graph:
         rc = N.lib().ds_graph_end_capture(self._stream, ctypes.byref(self._h), ctypes.byref(n))
         if et is None:
             N.check(rc, "ds_graph_end_capture")
+            # The graph bakes device addresses.  A tensor allocated inside the captured region belongs to torch's
+            # caching allocator, which hands its block to someone else once the Python object dies -- while every
+            # replay keeps writing there.  Captured code must take its buffers from a pre-filled workspace.
+            made = self._allocations() - self._alloc0
+            if made:
+                raise RuntimeError(f"{made} device allocation(s) happened inside a captured region; the graph would "
+                                   "write to memory it does not own on replay")
         self.nodes = n.value
         return False
 

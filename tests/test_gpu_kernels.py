@@ -583,3 +583,23 @@ def test_conv_upsample_parity_fallback_and_errors(dev):
     rc = ops.N.lib().ds_conv2d_h3_up(out.data_ptr(), x.to(dev).data_ptr(), pw.up.data_ptr(), 0, None, None, 0, None, None,
                                      1, 16, 8, 12, 20, 0, None, None, None)
     assert rc != 0 and b"whole number" in ops.N.lib().ds_last_error()
+
+
+def test_graph_capture_refuses_allocations(dev):
+    """A captured region must not allocate: the graph bakes addresses that torch's allocator would hand to someone
+    else after the capture (this once corrupted replays of the channel-conditioned network)."""
+    ops = _ops()
+    x = torch.randn(4096, device=dev)
+    out = torch.empty_like(x)
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        with ops.Graph() as g:                       # pre-allocated output: fine
+            ops.scale(x, 2.0, out=out)
+        g.launch()
+        side.synchronize()
+        assert torch.equal(out, x * 2.0)
+        with pytest.raises(RuntimeError, match="allocation"):
+            with ops.Graph():
+                ops.scale(x, 3.0)                    # allocates its result inside the capture
+    torch.cuda.current_stream(dev).wait_stream(side)
