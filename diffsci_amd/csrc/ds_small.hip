@@ -139,3 +139,38 @@ extern "C" int ds_attention_generic(float* out, const float* qkv, int B, int E, 
   DS_CHECK_LAUNCH("ds_attention_generic");
   return DS_OK;
 }
+
+// ---- cosine attention (attention.py:300-372): queries and keys are L2-normalised per token before the product ----
+namespace {
+
+// x: [B, Ctot, L] channel-major; channels [c0, c0 + C) of every token are divided by (their L2 norm + eps) and
+// multiplied by `gain`.  One thread per token: loads are coalesced along L; the C values are read twice (L2 hits).
+__global__ __launch_bounds__(256) void k_token_l2norm(float* x, int Ctot, int c0, int C, int L, float eps, float gain) {
+  const int l = blockIdx.x * 256 + threadIdx.x;
+  if (l >= L) return;
+  float* p = x + ((size_t)blockIdx.y * Ctot + c0) * L + l;
+  float ss = 0.f;
+  for (int c = 0; c < C; ++c) {
+    const float v = p[(size_t)c * L];
+    ss += v * v;
+  }
+  const float den = sqrtf(ss) + eps;
+  for (int c = 0; c < C; ++c) {
+    float v = p[(size_t)c * L] / den;
+    p[(size_t)c * L] = v * gain;
+  }
+}
+
+}  // namespace
+
+extern "C" int ds_token_l2_normalize(float* x, int B, int Ctot, int c0, int C, int L, float eps, float gain, void* stream) {
+  DS_REQUIRE(x, DS_ERR_NULL, "ds_token_l2_normalize: NULL pointer");
+  DS_REQUIRE(B >= 0 && Ctot > 0 && c0 >= 0 && C > 0 && c0 + C <= Ctot && L > 0, DS_ERR_SHAPE,
+             "ds_token_l2_normalize: bad shape B=%d Ctot=%d c0=%d C=%d L=%d", B, Ctot, c0, C, L);
+  DS_REQUIRE(B < 65536, DS_ERR_SHAPE, "ds_token_l2_normalize: B must stay below 65536");
+  if (B == 0) return DS_OK;
+  hipLaunchKernelGGL(k_token_l2norm, dim3((unsigned)((L + 255) / 256), (unsigned)B), dim3(256), 0, ds::as_stream(stream), x,
+                     Ctot, c0, C, L, eps, gain);
+  DS_CHECK_LAUNCH("ds_token_l2_normalize");
+  return DS_OK;
+}

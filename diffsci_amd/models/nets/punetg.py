@@ -75,27 +75,29 @@ class _MPLinear(torch.nn.Module):
         self.bias = torch.nn.Parameter(torch.zeros(cout))
 
 
-class _MPAttention(torch.nn.Module):
-    """The in-house MultiHeadAttention the reference substitutes for nn.MultiheadAttention when
-    magnitude_preserving (attention.py:30-41, 110-153): one head, dk = dv = dmodel, no biases."""
+class _InHouseAttention(torch.nn.Module):
+    """The reference's own MultiHeadAttention (attention.py:110-153), used instead of nn.MultiheadAttention when the
+    network is magnitude preserving or attn_type == "cosine" (attention.py:29-52): one head, dk = dv = dmodel, no
+    biases; N(0,1) weights renormalised on the fly when magnitude preserving, Xavier-uniform otherwise."""
 
-    def __init__(self, C):
+    def __init__(self, C, magnitude_preserving, cosine):
         super().__init__()
         for n in ("q", "k", "v", "o"):
-            setattr(self, n + "_proj_matrix", torch.nn.Parameter(torch.randn(1, C, C)))
+            w = torch.empty(1, C, C)
+            (torch.nn.init.normal_ if magnitude_preserving else torch.nn.init.xavier_uniform_)(w)
+            setattr(self, n + "_proj_matrix", torch.nn.Parameter(w))
         self.embed_dim = C
+        self.magnitude_preserving, self.cosine = magnitude_preserving, cosine
 
-    @staticmethod
-    def _normalized(weight, kind):
-        """MultiHeadAttention.normalize_weight + the 1/sqrt(fan_in) of forward (attention.py:183-196, 232-247)."""
-        if kind == "wo":
-            norm = torch.linalg.vector_norm(weight, dim=[0, 2], keepdim=True)
-            fan_in = weight.shape[0] * weight.shape[2]
-        else:
-            norm = torch.linalg.vector_norm(weight, dim=1, keepdim=True)
-            fan_in = weight.shape[1]
-        alpha = math.sqrt(norm.numel() / weight.numel())
-        return (weight / (alpha * norm + 1e-4)) / math.sqrt(fan_in)
+    def _normalized(self, weight, kind):
+        """MultiHeadAttention.normalize_weight (magnitude preserving only) + the unconditional 1/sqrt(fan_in) of
+        forward (attention.py:183-196, 232-247)."""
+        fan_in = weight.shape[0] * weight.shape[2] if kind == "wo" else weight.shape[1]
+        if self.magnitude_preserving:
+            norm = torch.linalg.vector_norm(weight, dim=[0, 2] if kind == "wo" else 1, keepdim=True)
+            alpha = math.sqrt(norm.numel() / weight.numel())
+            weight = weight / (alpha * norm + 1e-4)
+        return weight / math.sqrt(fan_in)
 
     def projection_weights(self):
         """(in_proj [3E, E], out_proj [E, E]) as 1x1-convolution weights: q = x Wq -> rows of Wq^T;
@@ -163,9 +165,10 @@ class _Sampler(torch.nn.Module):
 
 
 class _Attn(torch.nn.Module):
-    def __init__(self, C, mp=False):
+    def __init__(self, C, mp=False, cosine=False):
         super().__init__()
-        self.mhattn = _MPAttention(C) if mp else torch.nn.MultiheadAttention(C, num_heads=1, batch_first=True)
+        self.mhattn = (_InHouseAttention(C, mp, cosine) if (mp or cosine)
+                       else torch.nn.MultiheadAttention(C, num_heads=1, batch_first=True))
 
 
 class _Fourier(torch.nn.Module):
@@ -217,6 +220,8 @@ class PUNetG(torch.nn.Module):
         self.circular = config.convolution_type == "circular"
         circ = config.convolution_type                     # conv kind: "default" | "circular" | "mp"
         self.mp = config.convolution_type == "mp"
+        self.cosine_attn = config.attn_type == "cosine"
+        self.inhouse_attn = self.mp or self.cosine_attn        # attention.py:29-52
         hb = bool(config.bias)
         norms = (config.first_resblock_norm, config.second_resblock_norm)
         self.norm_kinds = tuple(NORM_KINDS.get(n, 2) for n in norms)
@@ -240,7 +245,7 @@ class PUNetG(torch.nn.Module):
         self.after_block = blocks(mult[-1], config.number_resnet_after_attn_block)
         self.attn_resnet_block = blocks(mult[-1], config.number_resnet_attn_block)
         self.attn_block = torch.nn.ModuleList(
-            [_Attn(mult[-1] * mc, self.mp) for _ in range(config.number_resnet_attn_block - 1)])
+            [_Attn(mult[-1] * mc, self.mp, self.cosine_attn) for _ in range(config.number_resnet_attn_block - 1)])
         # Arithmetic of the 3x3 convolutions -- all three give fp32-level error (tests/test_gpu_kernels.py):
         #   "fp16x3": fp16 hi+lo split, 3 MFMA products (default; inputs must stay below 65504 in magnitude)
         #   "bf16x6": exact 3-way bf16 split, 6 MFMA products (no range limit, half the speed)
@@ -342,7 +347,7 @@ class PUNetG(torch.nn.Module):
         tracked = [m.weight for m in mods]
         for a in self.attn_block:
             tracked += ([a.mhattn.q_proj_matrix, a.mhattn.k_proj_matrix, a.mhattn.v_proj_matrix, a.mhattn.o_proj_matrix]
-                        if self.mp else [a.mhattn.in_proj_weight, a.mhattn.out_proj.weight])
+                        if self.inhouse_attn else [a.mhattn.in_proj_weight, a.mhattn.out_proj.weight])
         if self.mp:
             tracked += [lin.weight for lin in self._timeblock_linears()]
         sig = (self.conv_precision, getattr(self, "upsample_parity", True)) + tuple((t.data_ptr(), t._version) for t in tracked)
@@ -360,7 +365,7 @@ class PUNetG(torch.nn.Module):
             prec = "fp16x3" if self.conv_precision == "fp16x3" else "fp32"
             for a in self.attn_block:
                 E = a.mhattn.embed_dim
-                if self.mp:
+                if self.inhouse_attn:
                     w_in, w_out = a.mhattn.projection_weights()
                 else:
                     w_in, w_out = a.mhattn.in_proj_weight.detach(), a.mhattn.out_proj.weight.detach()
@@ -521,9 +526,14 @@ class PUNetG(torch.nn.Module):
         B, E, Hh, Ww = x.shape
         L = Hh * Ww
         m = att.mhattn
-        in_bias = None if self.mp else m.in_proj_bias           # the in-house attention of "mp" has no biases
-        out_bias = None if self.mp else m.out_proj.bias
+        in_bias = None if self.inhouse_attn else m.in_proj_bias    # the in-house attention has no biases
+        out_bias = None if self.inhouse_attn else m.out_proj.bias
         qkv = ops.conv(x, pk[(id(att), "in")], bias=in_bias, out=ws.take((B, 3 * E, Hh, Ww), x.device))
+        if self.cosine_attn:
+            # cosine_similarity (attention.py:362-372): unit queries and keys, logits without 1/sqrt(E) -- the
+            # attention kernels scale by 1/sqrt(E), which the queries' gain cancels
+            ops.token_l2_normalize(qkv.view(B, 3 * E, L), 0, E, eps=1e-8, gain=math.sqrt(E))
+            ops.token_l2_normalize(qkv.view(B, 3 * E, L), E, E, eps=1e-8, gain=1.0)
         o = ops.attention(qkv.view(B, 3 * E, L), E, out=ws.take((B, E, L), x.device),
                           precision=self.conv_precision)
         res1 = x if self.config.attn_residual else None

@@ -61,7 +61,7 @@ class PUNetGConfig(object):
              "3x3 kernels"),
             (self.transition_scale_factor == 2, "transition_scale_factor=2"),
             (not self.in_embedding, "in_embedding=False"),
-            (self.attn_type == "default", "attn_type='default'"),
+            (self.attn_type in ("default", "cosine"), "attn_type 'default' or 'cosine'"),
             (self.dropout == 0.0 and self.cond_dropout == 0.0, "dropout=0 (sampling path)"),
             (not self.cond_drop, "cond_drop=0 (sampling path)"),
         ]

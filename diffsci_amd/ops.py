@@ -436,6 +436,15 @@ def conv2d(x, w_packed, Cout, ks, bias=None, shift=None, res1=None, res2=None,
     return out
 
 
+def token_l2_normalize(x, c0, C, eps=1e-8, gain=1.0):
+    """In place: channels [c0, c0+C) of x [B, Ctot, L] divided by (per-token L2 norm + eps), times gain."""
+    require_device(x, "x")
+    B, Ctot, L = x.shape
+    N.check(N.lib().ds_token_l2_normalize(_p(x), B, Ctot, int(c0), int(C), L, float(eps), float(gain), _stream()),
+            "ds_token_l2_normalize")
+    return x
+
+
 def attention(qkv, E, out=None, precision="fp32"):
     """qkv [B, 3E, L] channel-major -> out [B, E, L].  precision "fp16x3": split-fp16 MFMA
     (fp32-level accuracy, |operands| < 65504, E <= 256); anything else, or wider heads: exact-fp32 MFMA."""

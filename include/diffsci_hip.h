@@ -246,6 +246,12 @@ int ds_attention(float* out, const float* qkv, int B, int E, int L, void* stream
  * lengths that are not a multiple of 32 (tiny or odd bottlenecks, e.g. the reference's own 16x16 ADM test). */
 int ds_attention_generic(float* out, const float* qkv, int B, int E, int L, void* stream);
 
+/* Cosine attention (attn_type="cosine": cosine_product_attn / cosine_similarity, attention.py:300-372): queries and
+ * keys are divided by (their per-token L2 norm over the channels + eps) before the product, and the logits carry no
+ * 1/sqrt(E).  In place on x [B, Ctot, L], channels [c0, c0+C): x = x/(||x_token|| + eps)*gain.  Call it on the q
+ * block of qkv with gain = sqrt(E) (cancelling the attention kernels' 1/sqrt(E)) and on the k block with gain = 1. */
+int ds_token_l2_normalize(float* x, int B, int Ctot, int c0, int C, int L, float eps, float gain, void* stream);
+
 /* The same attention with both matrix products on the fp16 matrix cores in the fp16x3 scheme of
  * ds_conv2d_h3 (operands split into fp16 hi + lo, three products, fp32 accumulation and fp32
  * softmax statistics): fp32-level accuracy for |q|, |k|, |v| < 65504. Same layouts; E <= 256. */

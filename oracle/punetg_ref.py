@@ -121,28 +121,32 @@ def resnet_block(sd, prefix, x, te, circular=False, norms=("GroupLN", "GroupRMS"
     return y + x
 
 
-def mp_attention_2d(sd, prefix, x, attn_residual=False):
-    """TwoDimensionalAttention around the in-house MultiHeadAttention(1 head, dk = dv = C, 'dot',
-    magnitude_preserving=True), attention.py:30-41, 156-247, 250-296."""
+def mp_attention_2d(sd, prefix, x, attn_residual=False, magnitude_preserving=True, cosine=False):
+    """TwoDimensionalAttention around the in-house MultiHeadAttention(1 head, dk = dv = C), attention.py:29-52,
+    156-247: 'dot' (250-296) or 'cosine' (300-372) logits; weights renormalised only when magnitude preserving,
+    always divided by sqrt(fan_in)."""
     B, C, Hh, Ww = x.shape
     xr = x.permute(0, 2, 3, 1).reshape(B, Hh * Ww, C)
     ws = []
     for kind in ("q", "k", "v", "o"):
         weight = sd[prefix + f"mhattn.{kind}_proj_matrix"]
-        if kind == "o":
-            norm = torch.linalg.vector_norm(weight, dim=[0, 2], keepdim=True)
-            fan_in = weight.shape[0] * weight.shape[2]
-        else:
-            norm = torch.linalg.vector_norm(weight, dim=1, keepdim=True)
-            fan_in = weight.shape[1]
-        alpha = math.sqrt(norm.numel() / weight.numel())
-        ws.append((weight / (alpha * norm + 1e-4)) / math.sqrt(fan_in))
+        fan_in = weight.shape[0] * weight.shape[2] if kind == "o" else weight.shape[1]
+        if magnitude_preserving:
+            norm = torch.linalg.vector_norm(weight, dim=[0, 2] if kind == "o" else 1, keepdim=True)
+            alpha = math.sqrt(norm.numel() / weight.numel())
+            weight = weight / (alpha * norm + 1e-4)
+        ws.append(weight / math.sqrt(fan_in))
     wq, wk, wv, wo = ws
     q = torch.einsum('...ij, kjm -> ...kim', xr, wq)
     k = torch.einsum('...ij, kjm -> ...kim', xr, wk)
     v = torch.einsum('...ij, kjm -> ...kim', xr, wv)
-    inner = torch.einsum('...ij, ...kj -> ...ik', q, k)
-    inner = inner / math.sqrt(q.shape[-1])
+    if cosine:                                                # cosine_similarity, attention.py:362-372
+        qn = q / (torch.linalg.vector_norm(q, dim=-1, keepdim=True) + 1e-8)
+        kn = k / (torch.linalg.vector_norm(k, dim=-1, keepdim=True) + 1e-8)
+        inner = torch.einsum('...nd,...md->...nm', qn, kn)
+    else:
+        inner = torch.einsum('...ij, ...kj -> ...ik', q, k)
+        inner = inner / math.sqrt(q.shape[-1])
     a = torch.einsum('...ij, ...jk -> ...ik', torch.softmax(inner, dim=-1), v)
     out = torch.einsum('...ijk, ilk -> ...jl', a, wo)
     out = out.reshape(B, Hh, Ww, C).permute(0, 3, 1, 2)
@@ -192,7 +196,11 @@ def punetg_forward(sd, cfg, x, t, ye=None):
     for r in range(nattn):                                           # punetg.py:344-354
         xa = resnet_block(sd, f"attn_resnet_block.{r}.", xa, te, circ, norms)
         if r < nattn - 1:
-            xa = (mp_attention_2d if ctype == "mp" else attention_2d)(sd, f"attn_block.{r}.", xa, cfg["attn_residual"])
+            cosine = cfg.get("attn_type", "default") == "cosine"
+            if ctype == "mp" or cosine:
+                xa = mp_attention_2d(sd, f"attn_block.{r}.", xa, cfg["attn_residual"], ctype == "mp", cosine)
+            else:
+                xa = attention_2d(sd, f"attn_block.{r}.", xa, cfg["attn_residual"])
     x = x + xa
     for r in range(cfg["number_resnet_after_attn_block"]):
         x = resnet_block(sd, f"after_block.{r}.", x, te, circ, norms)

@@ -520,8 +520,12 @@ def variants():
         "mp": dict(convolution_type="mp"),
         "pix_ln": dict(first_resblock_norm="GroupPix", second_resblock_norm="GroupLN"),
         "none_rms_noaffine": dict(first_resblock_norm="none", second_resblock_norm="GroupRMS", affine_norm=False),
+        "cosine": dict(attn_type="cosine"),
     }
+    only = os.environ.get("VARIANTS_ONLY")
     for i, (tag, over) in enumerate(cases.items()):
+        if only and tag not in only.split(","):
+            continue
         torch.manual_seed(70 + i)
         cfg = M.nets.PUNetGConfig(model_channels=8, **over)
         with warnings.catch_warnings():

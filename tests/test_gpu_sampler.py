@@ -482,6 +482,7 @@ def test_punetg_circular_convolutions(M, dev, grids):
     ("mp", dict(convolution_type="mp")),
     ("pix_ln", dict(first_resblock_norm="GroupPix", second_resblock_norm="GroupLN")),
     ("none_rms_noaffine", dict(first_resblock_norm="none", second_resblock_norm="GroupRMS", affine_norm=False)),
+    ("cosine", dict(attn_type="cosine")),
 ])
 def test_punetg_layer_variants(M, dev, grids, tag, over, fuse):
     """magnitude-preserving convolutions / linears / attention (weights folded when packed)

@@ -169,7 +169,8 @@ def test_punetg_config_roundtrip_and_unsupported_options():
     # the layer variants keep the reference's state_dict keys and shapes (checkpoints load strictly)
     for tag, over in (("mp", dict(convolution_type="mp")),
                       ("pix_ln", dict(first_resblock_norm="GroupPix", second_resblock_norm="GroupLN")),
-                      ("none_rms_noaffine", dict(first_resblock_norm="none", second_resblock_norm="GroupRMS", affine_norm=False))):
+                      ("none_rms_noaffine", dict(first_resblock_norm="none", second_resblock_norm="GroupRMS", affine_norm=False)),
+                      ("cosine", dict(attn_type="cosine"))):
         _, sd = load("punetg8_" + tag)
         net = M.PUNetG(M.PUNetGConfig(model_channels=8, **over))
         mine = net.state_dict()

@@ -320,6 +320,7 @@ VARIANTS = {
     "mp": dict(convolution_type="mp"),
     "pix_ln": dict(first_resblock_norm="GroupPix", second_resblock_norm="GroupLN"),
     "none_rms_noaffine": dict(first_resblock_norm="none", second_resblock_norm="GroupRMS", affine_norm=False),
+    "cosine": dict(attn_type="cosine"),
 }
 
 
@@ -340,8 +341,11 @@ def test_punetg_layer_variants(tag):
         te = punetg_ref.fourier_features(v["t"], sd["time_projection.W"])
         r = punetg_ref.resnet_block(sd, "downward_blocks.0.0.", v["convin"], te, kind, norms)
         assert_exact_or_rel(r, v["resblock"], tag + " resblock", 1e-6)
-        att = punetg_ref.mp_attention_2d if tag == "mp" else punetg_ref.attention_2d
-        assert_exact_or_rel(att(sd, "attn_block.0.", v["attn_in"]), v["attn_out"], tag + " attention", 2e-6)
+        if tag in ("mp", "cosine"):
+            a = punetg_ref.mp_attention_2d(sd, "attn_block.0.", v["attn_in"], False, tag == "mp", tag == "cosine")
+        else:
+            a = punetg_ref.attention_2d(sd, "attn_block.0.", v["attn_in"])
+        assert_exact_or_rel(a, v["attn_out"], tag + " attention", 2e-6)
         assert_exact_or_rel(punetg_ref.punetg_forward(sd, cfg, v["x"], v["t"]), v["out_f32"], tag + " out_f32", 2e-6)
         hist = K.propagate_white_noise(punetg_ref.make_net(sd, cfg), v["white_noise"], 6, record_history=True)
         assert_exact_or_rel(hist, v["hist_heun_N6_f32"], tag + " hist_heun_N6_f32", 2e-6)
