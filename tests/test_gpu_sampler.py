@@ -277,6 +277,60 @@ def test_against_oracle_on_fresh_inputs(M, dev):
     assert rel_l2(got, want) < REL
 
 
+def test_full_size_config2_properties(M, dev):
+    """BASELINE config 2 at its full size -- PUNetG(PUNetGConfig()) 64 channels / 11.3 M parameters, x = [64, 1, 128,
+    128], 50-step Heun (99 evaluations) -- through properties that do not need the (minutes-long) CPU oracle run of
+    the whole workload:
+      * the oracle itself on two of the 64 samples for a short schedule and a single evaluation (per-sample work is
+        batch independent in the reference: all norms and the attention are per sample);
+      * samples are independent: permuting the batch permutes the result, halves of the batch give the same rows;
+      * replay determinism; finite, non-degenerate output;
+      * the stepper alone at the full tensor size against the closed-form Heun gain product of a Gaussian target."""
+    cfg = punetg_ref.default_config()
+    sd = punetg_ref.random_state_dict(cfg, seed=0)
+    net = M.PUNetG(M.PUNetGConfig())
+    net.load_state_dict(sd)
+    assert sum(p.numel() for p in net.parameters()) == 11_314_689
+    module = M.KarrasModule(net, M.KarrasModuleConfig.from_edm()).to(dev).eval()
+    torch.manual_seed(1)
+    wn = torch.randn(64, 1, 128, 128)
+    x = wn.to(dev)
+    out = module.propagate_white_noise(x, nsteps=50)
+    assert out.shape == (64, 1, 128, 128) and torch.isfinite(out).all() and float(out.std()) > 1e-3
+    assert torch.equal(module.propagate_white_noise(x, nsteps=50), out)                  # replay of the captured graph
+    perm = torch.randperm(64)
+    outp = module.propagate_white_noise(x[perm.to(dev)].contiguous(), nsteps=50)
+    assert torch.equal(outp, out[perm.to(dev)])                                          # batch-position independent
+    half = module.propagate_white_noise(x[32:].contiguous(), nsteps=50)
+    assert rel_l2(half.cpu(), out[32:].cpu()) < 1e-6                                     # other tile -> XCD assignment only
+    # oracle on samples 5 and 41: one evaluation at sigma = 2.5, and a 3-step Heun run
+    rows = [5, 41]
+    onet = punetg_ref.make_net(sd, cfg)
+    sig = torch.full((2,), 2.5)
+    xs = wn[rows] * 2.5
+    with torch.inference_mode():
+        want_d = K.denoiser(onet, xs, sig)
+        grid = module.config.noisescheduler.create_steps(4)
+        want_t = K.propagate_white_noise(onet, wn[rows], 3, sigma_grid=grid)
+        onet64 = punetg_ref.make_net({k: w.double() for k, w in sd.items()}, cfg)
+        want_t64 = K.propagate_white_noise(onet64, wn[rows].double(), 3, sigma_grid=grid.double())
+    got_d = module.get_denoiser((x * 2.5).contiguous(), torch.full((64,), 2.5, device=dev))
+    got_d = (got_d[0] if isinstance(got_d, tuple) else got_d)[rows].cpu()
+    assert rel_l2(got_d, want_d) < REL
+    got_t = module.propagate_white_noise(x, nsteps=3)[rows].cpu()
+    # three giant steps (80 -> 2.5 -> 0.002 -> 0) through a random-init network: held to the stated tolerance's
+    # second clause, the reference arithmetic's own fp32-vs-fp64 distance on this very input
+    ref_err = rel_l2(want_t, want_t64)
+    assert rel_l2(got_t, want_t) < max(REL, 4 * ref_err) and rel_l2(got_t, want_t64) < max(REL, 4 * ref_err)
+    # the stepper at full size: linear score -> x_N = x_0 * prod(g_i) exactly (SURVEY 8c)
+    sch = M.EDMScheduler()
+    t = sch.create_steps(51)
+    xn = sch.propagate_backward((x * 80.0).contiguous(), K.gaussian_target_score(0.5), 50)
+    gain = K.heun_gain_product(t, 0.5)
+    # 50 fp32 steps against the fp64 product: a few 1e-7 per step
+    assert rel_l2(xn.cpu().double(), (wn.double() * 80.0) * gain) < 5e-6
+
+
 def test_get_score_and_denoiser_per_sample_sigma(M, net8, dev):
     v, sd = load("punetg8_forward")
     module = M.KarrasModule(net8, M.KarrasModuleConfig.from_edm())
