@@ -89,7 +89,7 @@ struct Frags { f16x8 a[2][2]; f16x8 b[2][2]; };   // [piece][m] weights, [piece]
 template <int MODE, bool W16, bool PRE, bool CIRC>
 __global__ __launch_bounds__(NT, 2) void k_conv3h(const Conv3hArgs a) {
   constexpr int TH = Geo<W16>::TH, TW = Geo<W16>::TW, PW = Geo<W16>::PW, NPOS = Geo<W16>::NPOS;
-  constexpr int XITEMS = Geo<W16>::XITEMS, XI = Geo<W16>::XI;
+  constexpr int XI = Geo<W16>::XI;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   u32x4* Xs = reinterpret_cast<u32x4*>(smem);                        // [buf][piece][h][pos]
   u32x4* Ws = Xs + 2 * XBUF_VEC;                                     // [slot][piece][kx][h][co]

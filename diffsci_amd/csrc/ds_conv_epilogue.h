@@ -29,8 +29,8 @@ struct Args {
   // mean^2 cancellation; the table kernels (ds_normtab.hip) combine the tiles in fp64.
   float* tile_stats;
   int tile, ntiles;
-  // UP epilogue (ds_convup.hip): the tile is in LOW-resolution coordinates (y0, x0, and H, W are the output's)
-  // and covers output pixels (2y + pa, 2x + pb)
+  // ds_convup.hip only: the tile is in LOW-resolution coordinates (y0, x0; H, W are the output's) and covers output
+  // rows 2y + pa
   int pa, pb;
 };
 
@@ -52,7 +52,7 @@ __device__ __forceinline__ float row16_first(float v) {
 // tile:  wave-private LDS scratch of 64*2*32 floats (16 KiB), 16-byte aligned.
 // bs:    LDS array [2][64]: bias and shift of the workgroup's 64 channels (zeros where absent),
 //        written by the caller before the last barrier of the main loop.
-template <bool W16 = false, bool UP = false>
+template <bool W16 = false>
 __device__ __forceinline__ void store_tile(const f32x16 (&acc)[2][2], float* tile, const float* bs, const Args& e) {
   const int lane = threadIdx.x & 63;
   const int li = lane & 31, lh = lane >> 5;
@@ -77,17 +77,7 @@ __device__ __forceinline__ void store_tile(const f32x16 (&acc)[2][2], float* til
   const int yq = W16 ? (p4 >> 4) : 0;
   const size_t plane = (size_t)e.H * e.W;
   const bool stats = e.tile_stats != nullptr;
-  // UP: a lane's four values are low-resolution columns gx .. gx+3 = output columns 2gx+pb, +2, +4, +6 of output
-  // row 2gy+pa (the host only selects this epilogue for tiles that divide the low-resolution image)
-  auto ld4 = [&](const float* p, size_t i) __attribute__((always_inline)) -> f32x4 {
-    if (UP) return f32x4{p[i], p[i + 2], p[i + 4], p[i + 6]};
-    return *reinterpret_cast<const f32x4*>(p + i);
-  };
-  auto st4 = [&](float* p, size_t i, const f32x4& v) __attribute__((always_inline)) {
-    if (UP) { p[i] = v.x; p[i + 2] = v.y; p[i + 4] = v.z; p[i + 6] = v.w; }
-    else *reinterpret_cast<f32x4*>(p + i) = v;
-  };
-  if (UP || (e.W & 3) == 0) {
+  if ((e.W & 3) == 0) {
     float sK[16], ssum[16], ssq[16], scnt[16];        // per (half, k): channel 4*(4*half+k) + lane/16, valid in every lane of the row
 #pragma unroll
     for (int half = 0; half < 4; ++half) {            // 4 batches of 4 wave-instructions
@@ -99,13 +89,8 @@ __device__ __forceinline__ void store_tile(const f32x16 (&acc)[2][2], float* til
         const int seg = (half * 4 + k) * 8 + (lane >> 3);
         const int co = seg >> 1, r = seg & 1;
         const int gy = e.y0 + (W16 ? 2 * r + yq : r);
-        if (UP) {
-          ok[k] = (e.co_base + co < e.Cout) && 2 * gy < e.H && 2 * gx < e.W;
-          idx[k] = ok[k] ? ((size_t)e.b * e.Cout + e.co_base + co) * plane + (size_t)(2 * gy + e.pa) * e.W + 2 * gx + e.pb : (size_t)0;
-        } else {
-          ok[k] = (e.co_base + co < e.Cout) && gy < e.H && gx < e.W;
-          idx[k] = ok[k] ? ((size_t)e.b * e.Cout + e.co_base + co) * plane + (size_t)gy * e.W + gx : (size_t)0;
-        }
+        ok[k] = (e.co_base + co < e.Cout) && gy < e.H && gx < e.W;
+        idx[k] = ok[k] ? ((size_t)e.b * e.Cout + e.co_base + co) * plane + (size_t)gy * e.W + gx : (size_t)0;
         v[k] = *reinterpret_cast<const f32x4*>(&tile[seg * 32 + p4]);
       }
       if (e.res1) {
@@ -115,24 +100,19 @@ __device__ __forceinline__ void store_tile(const f32x16 (&acc)[2][2], float* til
             const int seg = (half * 4 + k) * 8 + (lane >> 3);
             const int co = seg >> 1, r = seg & 1;
             const int gy = e.y0 + (W16 ? 2 * r + yq : r);
-            if (UP) {                                 // the tile IS in low-resolution coordinates
-              const size_t lidx = ok[k] ? (((size_t)e.b * e.Cout + e.co_base + co) * (e.H >> 1) + gy) * (e.W >> 1) + gx : (size_t)0;
-              r1[k] = *reinterpret_cast<const f32x4*>(e.res1 + lidx);
-            } else {
-              const size_t lidx = ok[k] ? (((size_t)e.b * e.Cout + e.co_base + co) * (e.H >> 1) + (gy >> 1)) * (e.W >> 1) + (gx >> 1) : (size_t)0;
-              typedef float f32x2_t __attribute__((ext_vector_type(2)));
-              const f32x2_t lo = *reinterpret_cast<const f32x2_t*>(e.res1 + lidx);
-              r1[k] = f32x4{lo[0], lo[0], lo[1], lo[1]};
-            }
+            const size_t lidx = ok[k] ? (((size_t)e.b * e.Cout + e.co_base + co) * (e.H >> 1) + (gy >> 1)) * (e.W >> 1) + (gx >> 1) : (size_t)0;
+            typedef float f32x2_t __attribute__((ext_vector_type(2)));
+            const f32x2_t lo = *reinterpret_cast<const f32x2_t*>(e.res1 + lidx);
+            r1[k] = f32x4{lo[0], lo[0], lo[1], lo[1]};
           }
         } else {
 #pragma unroll
-          for (int k = 0; k < 4; ++k) r1[k] = ld4(e.res1, idx[k]);
+          for (int k = 0; k < 4; ++k) r1[k] = *reinterpret_cast<const f32x4*>(e.res1 + idx[k]);
         }
       }
       if (e.res2) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) r2[k] = ld4(e.res2, idx[k]);
+        for (int k = 0; k < 4; ++k) r2[k] = *reinterpret_cast<const f32x4*>(e.res2 + idx[k]);
       }
       if (e.res1) {
 #pragma unroll
@@ -144,7 +124,7 @@ __device__ __forceinline__ void store_tile(const f32x16 (&acc)[2][2], float* til
       }
 #pragma unroll
       for (int k = 0; k < 4; ++k)
-        if (ok[k]) st4(e.out, idx[k], v[k]);
+        if (ok[k]) *reinterpret_cast<f32x4*>(e.out + idx[k]) = v[k];
       if (stats) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {

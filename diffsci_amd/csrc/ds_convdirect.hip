@@ -12,7 +12,7 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int NT = 256, TH = 16, TW = 64, KCH = 8;
-constexpr int PH = TH + 2, PWD = TW + 2, PSTR = 68;       // row stride padded to a multiple of 4 floats
+constexpr int PH = TH + 2, PSTR = 68;                   // row stride padded to a multiple of 4 floats
 constexpr int PATCH = PH * PSTR;
 
 template <int COUT>

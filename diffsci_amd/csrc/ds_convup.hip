@@ -12,12 +12,16 @@
 // w1*x + w2*x and our (w1 + w2)*x differ by one fp32 rounding of the weight).  Zero / periodic padding of the
 // upsampled image is exactly zero / periodic padding of the low-resolution one.
 //
-// One workgroup = one parity x 64 output channels x (8 x 32 | 16 x 16) LOW-resolution pixels; same pipeline as
-// ds_conv3h.hip with a step = (chunk of 16 input channels, row tap s), two column-tap MFMA blocks per step:
-//     X  [2 buffers][piece 2][h 2][9*33 | 17*17 positions][8 ci] fp16
-//     W  [3-slot ring][piece 2][t 2][h 2][64 co][8 ci] fp16            (8 KiB slabs by LDS-DMA)
-// The patch of chunk c+1 is fetched at step (c-1, s=1)... stored at (c, s=0), published by that step's barrier
-// and first read by the operand prefetch at the end of (c, s=1).
+// One workgroup = one ROW parity a x 64 output channels x (8 x 32 | 16 x 16) LOW-resolution pixels, BOTH column
+// parities (two accumulator sets, 128 registers): the two share the staged patch (columns x-1, x, x+1) and their
+// outputs interleave along a row, so the epilogue writes whole 16-byte vectors of contiguous output columns.  (A first
+// version ran one workgroup per (a, b): its stride-2 dword stores and residual loads cost 1.7 % of config 2 end to
+// end, measured by pointing them at contiguous addresses.)  Same pipeline as ds_conv3h.hip with a step =
+// (chunk of 16 input channels, row tap s, column parity b), two column-tap MFMA blocks per step:
+//     X  [2 buffers][piece 2][h 2][9*34 | 17*18 positions][8 ci] fp16                  2 x 19,584 B
+//     W  [3-slot ring][piece 2][t 2][h 2][64 co][8 ci] fp16  (8 KiB slabs by LDS-DMA)   3 x  8,192 B
+// The patch of chunk c+1 is fetched at step (c, 0), split and stored at the end of (c, 2), published by that step's
+// barrier and first read by the operand prefetch at the end of (c, 3).
 #include "ds_common.h"
 #include "ds_conv_epilogue.h"
 #include "ds_h3_common.h"
@@ -34,15 +38,16 @@ using ds_h3::fast_silu;
 constexpr int COT = 64, NT = 256, KC = 16;
 template <bool W16> struct Geo {
   static constexpr int TH = W16 ? 16 : 8, TW = W16 ? 16 : 32;
-  static constexpr int PH = TH + 1, PW = TW + 1, NPOS = PH * PW;     // 297 / 289: one halo row and column
+  static constexpr int PH = TH + 1, PW = TW + 2, NPOS = PH * PW;     // 306 either way: one halo row, two halo columns
 };
-constexpr int XBUF_VEC = 2 * 2 * 297;                       // 16-byte vectors per X buffer (larger geometry)
-constexpr int WSLAB_VEC = 2 * 2 * 2 * COT;                  // per (chunk, s) slab: 512
+constexpr int XBUF_VEC = 2 * 2 * 306;                       // 16-byte vectors per X buffer
+constexpr int WSLAB_VEC = 2 * 2 * 2 * COT;                  // per (chunk, s, b) slab: 512
 constexpr int WDMA = WSLAB_VEC / 64 / 4;                    // LDS-DMA wave-instructions per wave: 2
-constexpr int STAGE_BYTES = (2 * XBUF_VEC + 3 * WSLAB_VEC) * 16;   // 62,592
+constexpr int STAGE_BYTES = (2 * XBUF_VEC + 3 * WSLAB_VEC) * 16;   // 63,744
 constexpr int EPI_BYTES = 4 * 64 * 2 * 32 * 4;                     // the epilogue's transpose: 16 KiB per wave
 constexpr int MAIN_BYTES = STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES;
-constexpr int LDS_BYTES = MAIN_BYTES + 128 * 4;
+constexpr int STAT_BYTES = 4 * 64 * 4 * 4;                         // per wave [64 co][K, S, Q, n]
+constexpr int LDS_BYTES = MAIN_BYTES + 128 * 4 + STAT_BYTES;       // 70,144
 
 struct UpArgs {
   float* out;
@@ -64,6 +69,75 @@ struct UpArgs {
 
 struct Frags { f16x8 a[2][2]; f16x8 b[2][2]; };   // [piece][m] weights, [piece][r] input
 
+// Epilogue of one 32-channel half (m) of the wave's tile: both column parities interleaved through the wave's 16 KiB
+// LDS region as [co 32][r 2][64 output columns], then 16-byte stores / residual loads of contiguous output columns.
+//   W16 = false: (r, p) -> low-resolution row y0 + r,            output column 2*x0 + p        (p = 2*li + b < 64)
+//   W16 = true:            low-resolution row y0 + 2r + (p >> 5), output column 2*x0 + (p & 31)
+// Per-channel shifted statistics of the stored values go to stat[(32m + co)*4 .. +3] = (K, S, Q, n).
+template <bool W16>
+__device__ __forceinline__ void store_half(const f32x16 (&acc0)[2], const f32x16 (&acc1)[2], int m, float* tile,
+                                           const float* bs, float* stat, const ds_epi::Args& e) {
+  const int lane = threadIdx.x & 63;
+  const int li = lane & 31, lh = lane >> 5;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int co = (q & 3) + 8 * (q >> 2) + 4 * lh;                 // within the half
+    const float bv = bs[32 * m + co], sv = bs[64 + 32 * m + co];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      float v0 = acc0[r][q] * e.unscale, v1 = acc1[r][q] * e.unscale;
+      v0 = v0 + bv; v1 = v1 + bv;
+      v0 = v0 + sv; v1 = v1 + sv;
+      typedef float f32x2_t __attribute__((ext_vector_type(2)));
+      *reinterpret_cast<f32x2_t*>(&tile[((co * 2 + r) * 32 + li) * 2]) = f32x2_t{v0, v1};
+    }
+  }
+  // 16 lanes per (co, r) segment of 64 floats; lane -> (segment = 4*it + lane/16, vector = lane%16)
+  const int vq = lane & 15;
+  const int p4 = 4 * vq;
+  const int gx = 2 * e.x0 + (W16 ? (p4 & 31) : p4);
+  const int yq = W16 ? (p4 >> 5) : 0;
+  const size_t plane = (size_t)e.H * e.W;
+  const bool stats = e.tile_stats != nullptr;
+#pragma unroll
+  for (int it = 0; it < 16; ++it) {
+    const int seg = it * 4 + (lane >> 4);
+    const int co = seg >> 1, r = seg & 1;
+    const int gyl = e.y0 + (W16 ? 2 * r + yq : r);                  // low-resolution row
+    const int gy = 2 * gyl + e.pa;
+    const bool ok = e.co_base + 32 * m + co < e.Cout;
+    const size_t idx = ok ? ((size_t)e.b * e.Cout + e.co_base + 32 * m + co) * plane + (size_t)gy * e.W + gx : (size_t)0;
+    f32x4 v = *reinterpret_cast<const f32x4*>(&tile[seg * 64 + p4]);
+    if (e.res1) {
+      if (e.res1_up) {                                              // [B, Cout, H/2, W/2]: two low-resolution columns
+        const size_t lidx = ok ? (((size_t)e.b * e.Cout + e.co_base + 32 * m + co) * (e.H >> 1) + gyl) * (e.W >> 1) + (gx >> 1) : (size_t)0;
+        typedef float f32x2_t __attribute__((ext_vector_type(2)));
+        const f32x2_t lo = *reinterpret_cast<const f32x2_t*>(e.res1 + lidx);
+        v = v + f32x4{lo[0], lo[0], lo[1], lo[1]};
+      } else {
+        v = v + *reinterpret_cast<const f32x4*>(e.res1 + idx);
+      }
+    }
+    if (e.res2) v = v + *reinterpret_cast<const f32x4*>(e.res2 + idx);
+    if (ok) *reinterpret_cast<f32x4*>(e.out + idx) = v;
+    if (stats) {
+      // lanes 0-15 / 16-31 of a 32-lane half hold rows r = 0 / 1 of one channel; the shift K is the channel's first value
+      const float K = __shfl(ok ? v.x : 0.f, lane & 32, 64);
+      const f32x4 d = v - K;
+      float s1 = ok ? (d.x + d.y) + (d.z + d.w) : 0.f;
+      float s2 = ok ? (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w) : 0.f;
+      s1 = ds_epi::row16_sum(s1);
+      s2 = ds_epi::row16_sum(s2);
+      s1 += __shfl_xor(s1, 16, 64);
+      s2 += __shfl_xor(s2, 16, 64);
+      if ((lane & 31) == 0) {
+        f32x4 o = {K, s1, s2, ok ? 128.f : 0.f};                    // 2 rows x 64 columns per wave
+        *reinterpret_cast<f32x4*>(&stat[(32 * m + co) * 4]) = o;
+      }
+    }
+  }
+}
+
 template <bool W16, bool PRE, bool CIRC>
 __global__ __launch_bounds__(NT, 2) void k_convup(const UpArgs a) {
   constexpr int TH = Geo<W16>::TH, TW = Geo<W16>::TW, PW = Geo<W16>::PW, NPOS = Geo<W16>::NPOS;
@@ -73,6 +147,7 @@ __global__ __launch_bounds__(NT, 2) void k_convup(const UpArgs a) {
   u32x4* Xs = reinterpret_cast<u32x4*>(smem);                        // [buf][piece][h][pos]
   u32x4* Ws = Xs + 2 * XBUF_VEC;                                     // [slot][piece][t][h][co]
   float* BS = reinterpret_cast<float*>(smem + MAIN_BYTES);            // [2][64] bias, shift
+  float* ST = BS + 128;                                               // [4 waves][64 co][4]
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -81,9 +156,8 @@ __global__ __launch_bounds__(NT, 2) void k_convup(const UpArgs a) {
   const int wave_row = W16 ? 4 * wv : 2 * wv;
   constexpr int ROWS_PER_R = W16 ? 2 : 1;
 
-  // grid = (4 parities x channel tiles, pixel tiles, samples), renumbered so that each XCD owns a contiguous
-  // run (see ds_conv3h.hip): the 4 * Cout/64 workgroups that read one input patch share an L2, and so do the
-  // two column parities whose stores interleave in the same cache lines.
+  // grid = (2 row parities x channel tiles, pixel tiles, samples), renumbered so that each XCD owns a contiguous
+  // run (see ds_conv3h.hip): the 2 * Cout/64 workgroups that read one input patch share an L2.
   unsigned cp_u, tile_u, b_u;
   {
     const unsigned nx = gridDim.x, ny = gridDim.y;
@@ -97,18 +171,17 @@ __global__ __launch_bounds__(NT, 2) void k_convup(const UpArgs a) {
     tile_u = rest % ny;
     b_u = rest / ny;
   }
-  const int par = (int)(cp_u & 3u), cot = (int)(cp_u >> 2);
-  const int pa = par >> 1, pb = par & 1;
+  const int pa = (int)(cp_u & 1u), cot = (int)(cp_u >> 1);
   const int tile_id = (int)tile_u;
   const int b = (int)b_u;
   const int ty = a.tiles_x == 1 ? tile_id : (int)__umulhi((unsigned)tile_id, a.tiles_x_magic);
   const int tx = tile_id - ty * a.tiles_x;
   const int x0 = tx * TW, y0 = ty * TH;
   const int HW = a.Hl * a.Wl;
-  const int n_steps = a.n_chunks * 2;
+  const int n_steps = a.n_chunks * 4;
 
   // ---- staging plan (as ds_conv3h.hip): items 0 / 1 = position tid of channel half 0 / 1, item 2 = the
-  //      patch's tail with h = wave / 2.  Patch origin: (y0 - 1 + a, x0 - 1 + b). ----
+  //      patch's tail with h = wave / 2.  Patch origin: (y0 - 1 + a, x0 - 1). ----
   const int tail_h = wv >> 1;
   int xoff[XI], xlds[XI];
   unsigned xvalid = 0, xlive = 0;
@@ -119,7 +192,7 @@ __global__ __launch_bounds__(NT, 2) void k_convup(const UpArgs a) {
     const bool live = pos < NPOS;
     const int r = pos / PW;
     const int col = pos - r * PW;
-    int gy = y0 + r - 1 + pa, gx = x0 + col - 1 + pb;
+    int gy = y0 + r - 1 + pa, gx = x0 + col - 1;
     if (CIRC) {                                       // tiles divide the image: at most one pixel outside
       gy = gy < 0 ? gy + a.Hl : (gy >= a.Hl ? gy - a.Hl : gy);
       gx = gx < 0 ? gx + a.Wl : (gx >= a.Wl ? gx - a.Wl : gx);
@@ -131,7 +204,7 @@ __global__ __launch_bounds__(NT, 2) void k_convup(const UpArgs a) {
     if (live) xlive |= (1u << i);
   }
   const float* in_b = a.in + (size_t)b * a.Cin * HW;
-  const u32x4* wp = a.wp + (size_t)(cot * 4 + par) * n_steps * WSLAB_VEC;
+  const u32x4* wp = a.wp + (size_t)(cot * 2 + pa) * n_steps * WSLAB_VEC;
 
   float xr[XI][8];
   int xnch = KC;
@@ -197,15 +270,18 @@ __global__ __launch_bounds__(NT, 2) void k_convup(const UpArgs a) {
     }
   };
 
-  f32x16 acc[2][2];
+  f32x16 acc[2][2][2];                                             // [column parity b][m][r]
 #pragma unroll
-  for (int m = 0; m < 2; ++m)
+  for (int pb = 0; pb < 2; ++pb)
 #pragma unroll
-    for (int r = 0; r < 2; ++r)
+    for (int m = 0; m < 2; ++m)
 #pragma unroll
-      for (int q = 0; q < 16; ++q) acc[m][r][q] = 0.f;
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[pb][m][r][q] = 0.f;
 
-  auto frag_load = [&](Frags& f, int slot, int xbuf, int s, int t) __attribute__((always_inline)) {
+  // operands of (ring slot, X buffer, row tap s, column parity pb, column tap t): the patch column is x + pb + t
+  auto frag_load = [&](Frags& f, int slot, int xbuf, int s, int pb, int t) __attribute__((always_inline)) {
     const u32x4* wb = Ws + slot * WSLAB_VEC;
     const u32x4* xb = Xs + xbuf * XBUF_VEC;
 #pragma unroll
@@ -215,10 +291,10 @@ __global__ __launch_bounds__(NT, 2) void k_convup(const UpArgs a) {
         f.a[p][m] = *reinterpret_cast<const f16x8*>(&wb[((p * 2 + t) * 2 + lh) * COT + 32 * m + li]);
 #pragma unroll
       for (int r = 0; r < 2; ++r)
-        f.b[p][r] = *reinterpret_cast<const f16x8*>(&xb[(p * 2 + lh) * NPOS + (wave_row + ROWS_PER_R * r + s) * PW + lane_pos + t]);
+        f.b[p][r] = *reinterpret_cast<const f16x8*>(&xb[(p * 2 + lh) * NPOS + (wave_row + ROWS_PER_R * r + s) * PW + lane_pos + pb + t]);
     }
   };
-  auto frag_mma = [&](const Frags& f) __attribute__((always_inline)) {               // lo*hi, hi*lo, hi*hi
+  auto frag_mma = [&](const Frags& f, int pb) __attribute__((always_inline)) {       // lo*hi, hi*lo, hi*hi
     constexpr int PA[3] = {1, 0, 0};
     constexpr int PB[3] = {0, 1, 0};
 #pragma unroll
@@ -227,7 +303,7 @@ __global__ __launch_bounds__(NT, 2) void k_convup(const UpArgs a) {
       for (int m = 0; m < 2; ++m)
 #pragma unroll
         for (int r = 0; r < 2; ++r)
-          acc[m][r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[PA[t]][m], f.b[PB[t]][r], acc[m][r], 0, 0, 0);
+          acc[pb][m][r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[PA[t]][m], f.b[PB[t]][r], acc[pb][m][r], 0, 0, 0);
   };
   auto reads_between_mfmas = [&]() __attribute__((always_inline)) {
 #pragma unroll
@@ -238,50 +314,51 @@ __global__ __launch_bounds__(NT, 2) void k_convup(const UpArgs a) {
     __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
   };
 
-  // ---- prologue: patch 0 staged, patch 1 in flight, weight slabs 0 and 1 ----
+  // ---- prologue: patch 0, weight slabs 0 and 1 ----
   ds_epi::load_bias_shift(BS, a.bias, a.shift, a.shift_stride, b, cot * COT, a.Cout);
   x_fetch(0);
   w_fetch(0, 0);
-  w_fetch(1, 1);                                                 // n_steps >= 2 always
+  w_fetch(1, 1);                                                 // n_steps >= 4 always
   x_store(0);
-  if (a.n_chunks > 1) x_fetch(1);                                // stored at the end of step (0, s = 0)
   __syncthreads();
 
   Frags fA, fB;
-  frag_load(fA, 0, 0, 0, 0);
+  frag_load(fA, 0, 0, 0, 0, 0);
 
-  // One step = (chunk, s).  fA holds the operands of t = 0 on entry and, on exit, those of the next step's t = 0.
-  // slot = g % 3 for step g = 2*chunk + s.
-  auto step = [&](int chunk, int s, int slot) __attribute__((always_inline)) {
-    const int g = chunk * 2 + s;
+  // One step = (chunk, k) with k = 2*s + pb.  fA holds the operands of t = 0 on entry and, on exit, those of the
+  // next step's t = 0.  slot = g % 3 for step g = 4*chunk + k: compile-time at every call site (3-chunk unroll).
+  auto step = [&](int chunk, int k, int slot) __attribute__((always_inline)) {
+    const int g = chunk * 4 + k;
+    const int s = k >> 1, pb = k & 1;
     const int xbuf = chunk & 1;
     if (g + 2 < n_steps) w_fetch(g + 2, slot >= 1 ? slot - 1 : 2);      // (slot + 2) % 3
-    if (s == 1 && chunk + 2 < a.n_chunks) x_fetch(chunk + 2);
+    if (k == 0 && chunk + 1 < a.n_chunks) x_fetch(chunk + 1);
     __builtin_amdgcn_sched_barrier(0);
-    frag_load(fB, slot, xbuf, s, 1);
-    frag_mma(fA);
+    frag_load(fB, slot, xbuf, s, pb, 1);
+    frag_mma(fA, pb);
     reads_between_mfmas();
     __builtin_amdgcn_sched_barrier(0);
     if (g + 1 < n_steps) {
       const int nslot = slot == 2 ? 0 : slot + 1;
-      frag_load(fA, nslot, s == 1 ? xbuf ^ 1 : xbuf, s ^ 1, 0);
+      const int nk = k == 3 ? 0 : k + 1;
+      frag_load(fA, nslot, k == 3 ? xbuf ^ 1 : xbuf, nk >> 1, nk & 1, 0);
     }
-    frag_mma(fB);
+    frag_mma(fB, pb);
     if (g + 1 < n_steps) reads_between_mfmas();
     __builtin_amdgcn_sched_barrier(0);
-    if (s == 0 && chunk + 1 < a.n_chunks) x_store(xbuf ^ 1);            // published by this step's barrier
+    if (k == 2 && chunk + 1 < a.n_chunks) x_store(xbuf ^ 1);            // published by this step's barrier
     __syncthreads();
   };
 
-  // slot pattern repeats every three chunks: (0,1) (2,0) (1,2)
+  // slot pattern of a chunk's four steps repeats every three chunks: (0,1,2,0) (1,2,0,1) (2,0,1,2)
   int chunk = 0;
   for (; chunk + 2 < a.n_chunks; chunk += 3) {
-    step(chunk, 0, 0); step(chunk, 1, 1);
-    step(chunk + 1, 0, 2); step(chunk + 1, 1, 0);
-    step(chunk + 2, 0, 1); step(chunk + 2, 1, 2);
+    step(chunk, 0, 0); step(chunk, 1, 1); step(chunk, 2, 2); step(chunk, 3, 0);
+    step(chunk + 1, 0, 1); step(chunk + 1, 1, 2); step(chunk + 1, 2, 0); step(chunk + 1, 3, 1);
+    step(chunk + 2, 0, 2); step(chunk + 2, 1, 0); step(chunk + 2, 2, 1); step(chunk + 2, 3, 2);
   }
-  if (chunk < a.n_chunks) { step(chunk, 0, 0); step(chunk, 1, 1); ++chunk; }
-  if (chunk < a.n_chunks) { step(chunk, 0, 2); step(chunk, 1, 0); }
+  if (chunk < a.n_chunks) { step(chunk, 0, 0); step(chunk, 1, 1); step(chunk, 2, 2); step(chunk, 3, 0); ++chunk; }
+  if (chunk < a.n_chunks) { step(chunk, 0, 1); step(chunk, 1, 2); step(chunk, 2, 0); step(chunk, 3, 1); }
 
   {
     ds_epi::Args e;
@@ -289,19 +366,26 @@ __global__ __launch_bounds__(NT, 2) void k_convup(const UpArgs a) {
     e.unscale = a.unscale; e.shift_stride = a.shift_stride;
     e.b = b; e.co_base = cot * COT; e.y0 = y0 + wave_row; e.x0 = x0;
     e.Cout = a.Cout; e.H = 2 * a.Hl; e.W = 2 * a.Wl;
-    e.pa = pa; e.pb = pb;
-    e.tile_stats = a.tile_stats; e.tile = (ty * a.tiles_x + tx) * 4 + par; e.ntiles = a.tiles_x * a.tiles_y * 4;
+    e.pa = pa; e.pb = 0;
+    // statistics: this workgroup covers the two column-parity "tiles" of its row parity; all 512 pixels are
+    // accounted in the first entry, the second one is empty
+    e.tile_stats = a.tile_stats; e.tile = (ty * a.tiles_x + tx) * 4 + pa * 2; e.ntiles = a.tiles_x * a.tiles_y * 4;
     float* tile = reinterpret_cast<float*>(smem) + wv * (64 * 2 * 32);
-    ds_epi::store_tile<W16, true>(acc, tile, BS, e);
+    float* stat = ST + wv * 256;
+    store_half<W16>(acc[0][0], acc[1][0], 0, tile, BS, stat, e);
+    store_half<W16>(acc[0][1], acc[1][1], 1, tile, BS, stat, e);
     if (a.tile_stats) {
       __syncthreads();
-      ds_epi::store_tile_stats(reinterpret_cast<const float*>(smem), 64 * 2 * 32, e);
+      ds_epi::store_tile_stats(ST, 256, e);
+      if (tid < 64 && e.co_base + tid < e.Cout)
+        *reinterpret_cast<f32x4*>(a.tile_stats + (((size_t)b * a.Cout + e.co_base + tid) * e.ntiles + e.tile + 1) * 4) =
+            f32x4{0.f, 0.f, 0.f, 0.f};
     }
   }
 }
 
-// torch [Cout][Cin][3][3] fp32 -> [cot][parity 4][chunk][s 2][piece 2][t 2][h 2][co 64][ci 8] fp16 of the
-// collapsed 2x2 taps (times 2^wshift)
+// torch [Cout][Cin][3][3] fp32 -> [cot][row parity a][chunk][s 2][column parity b][piece 2][t 2][h 2][co 64][ci 8]
+// fp16 of the collapsed 2x2 taps (times 2^wshift)
 __global__ void k_pack_up(_Float16* packed, const float* __restrict__ w, int Cout, int Cin, int n_chunks, float scale,
                           size_t total) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -312,11 +396,11 @@ __global__ void k_pack_up(_Float16* packed, const float* __restrict__ w, int Cou
   const int h = t % 2; t /= 2;
   const int tt = t % 2; t /= 2;
   const int piece = t % 2; t /= 2;
+  const int pb = t % 2; t /= 2;
   const int s = t % 2; t /= 2;
   const int chunk = t % n_chunks; t /= n_chunks;
-  const int par = t % 4; t /= 4;
+  const int pa = t % 2; t /= 2;
   const int cot = (int)t;
-  const int pa = par >> 1, pb = par & 1;
   const int co = cot * COT + co64, ci = chunk * KC + 8 * h + c8;
   float v = 0.f;
   if (co < Cout && ci < Cin) {
@@ -346,7 +430,7 @@ int launch_up(const UpArgs& a, hipStream_t s) {
   const long long tiles = (long long)a.tiles_y * a.tiles_x;
   DS_REQUIRE(tiles > 0 && tiles < 65536 && a.B < 65536, DS_ERR_SHAPE,
              "ds_conv2d_h3_up: %lld pixel tiles x %d samples exceed the grid limits (65535 each)", tiles, a.B);
-  hipLaunchKernelGGL((k_convup<W16, PRE, CIRC>), dim3((unsigned)a.n_cot * 4u, (unsigned)tiles, (unsigned)a.B), dim3(NT),
+  hipLaunchKernelGGL((k_convup<W16, PRE, CIRC>), dim3((unsigned)a.n_cot * 2u, (unsigned)tiles, (unsigned)a.B), dim3(NT),
                      LDS_BYTES, s, a);
   DS_CHECK_LAUNCH("ds_conv2d_h3_up");
   return DS_OK;
