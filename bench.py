@@ -71,11 +71,12 @@ def parse():
 
 def build_module(args, dev):
     import diffsci_amd.models as M
-    from oracle import punetg_ref                       # synthetic weight generator only
-    cfg = punetg_ref.default_config(model_channels=args.channels)
-    sd = punetg_ref.random_state_dict(cfg, seed=0)
+    # random-init weights of the architecture: the network's own containers carry the reference's default
+    # initialisers (Kaiming-uniform convolutions / linears, unit norms, Fourier W ~ N(0, 30^2)); nothing from oracle/
+    torch.manual_seed(0)
     net = M.PUNetG(M.PUNetGConfig(model_channels=args.channels))
-    net.load_state_dict(sd)
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}      # CPU copy for the cpu_baseline leg
+    cfg = dict(model_channels=args.channels)
     net.conv_precision = args.precision
     net.fuse_norm = not args.no_fuse_norm
     net.direct_out = not args.no_direct_out
@@ -217,7 +218,7 @@ def cpu_baseline(sd, cfg, args):
     B, N = 8, 8                                   # 8-step Heun = 15 network evaluations (~10-20 s)
     g = torch.Generator().manual_seed(1)
     wn = torch.randn(B, 1, args.size, args.size, generator=g)
-    net = punetg_ref.make_net(sd, cfg)
+    net = punetg_ref.make_net(sd, punetg_ref.default_config(**cfg))
     with torch.inference_mode():
         K.propagate_white_noise(net, wn[:1], 2)    # warm-up (3 evaluations of one sample)
         t0 = time.time()
