@@ -3,7 +3,7 @@
 Same constructor, ``net(x, t, y=None)`` protocol and state_dict key names as the reference's
 ``ADM`` / ``ADMConfig`` (adm.py:8-216), for the default family: 2-D fields, default convolutions,
 GroupLN(1 group) + GroupRMS(1 group) norms, avg-pool down / nearest up inside the last block of a
-layer, decoder_type 1, single-head attention in the middle block.  The torch.nn layers are
+layer, decoder_type 1 or 2, single-head attention in the middle block.  The torch.nn layers are
 parameter containers only; every tensor operation is a launch into libdiffsci_hip.so:
 
   input/output layer, conv1 (+nearest-up load), conv2 (+residual)   ds_conv2d*
@@ -88,7 +88,7 @@ class ADMConfig(object):
             (self.num_groups == 1, "num_groups=1"),
             (self.kernel_size == 3, "kernel_size=3"),
             (self.transition_scale_factor == 2, "transition_scale_factor=2"),
-            (self.decoder_type == 1, "decoder_type=1"),
+            (self.decoder_type in (1, 2), "decoder_type 1 or 2"),
             (self.skip_integration_type in ("concat", "add"), "skip_integration_type 'concat' or 'add'"),
             (self.dropout == 0.0 and self.cond_dropout == 0.0, "dropout=0 (sampling path)"),
             (self.number_resnet_downward_block >= 1 and self.number_resnet_upward_block >= 1,
@@ -175,7 +175,10 @@ class ADM(torch.nn.Module):
         for i in range(len(mult) - 1):                                   # adm.py:731-762
             cin, cout = mc * rmult[i], mc * rmult[i + 1]
             cb = 2 * cin if config.skip_integration_type == "concat" else cin
-            dec.append(_Layer([_Block(cb, cb, ce, circular=circ, **nk) for _ in range(nb - 1)] +
+            # decoder_type 1 (ADMDecoderLayer1, adm.py:690-776): the skip joins once, in front of the layer;
+            # decoder_type 2 (ADMDecoderLayer2, :777-852): every block of the layer integrates the same skip again
+            cmid = cb if config.decoder_type == 1 else cin
+            dec.append(_Layer([_Block(cb, cmid, ce, circular=circ, **nk) for _ in range(nb - 1)] +
                               [_Block(cb, cout, ce, "up", circular=circ, **nk)]))
         self.decoder = _Layers(dec)
         self.input_layer = torch.nn.Conv2d(config.input_channels, mc, 3, padding="same")
@@ -414,26 +417,40 @@ class ADM(torch.nn.Module):
                 give(h, hs)
             h, hs = h2, hs2
         nl = len(self.decoder.layers)
-        for li, lay in enumerate(self.decoder.layers):                          # adm.py:764-774, 927-934
-            skip, sks = skips.pop()
+
+        def join(h, hs, skip, sks):                                              # adm.py:297-304
             if cfg.skip_integration_type == "concat":
                 hc = ops.concat2(h, skip, out=ws.take((B, h.shape[1] + skip.shape[1]) + tuple(h.shape[2:]), dev))
-                hcs = (hs, sks) if (hs is not None and sks is not None) else None   # statistics of a concat are additive
-            else:
-                hc = ops.add(h, skip, out=ws.take(h.shape, dev))
-                hcs = None
-            pending = [(h, hs)] + ([(skip, sks)] if skip is not h else [])         # statistics are read by block 0's table
-            for j, blk in enumerate(lay.input_blocks):
-                final = li == nl - 1 and j == len(lay.input_blocks) - 1           # feeds the output layer: no norm follows
-                h2, hs2 = self._block(blk, hc, film(), pk, ws, xs=hcs, want_stats=not final)
-                if j == 0:
+                return hc, ((hs, sks) if (hs is not None and sks is not None) else None)   # statistics of a concat are additive
+            return ops.add(h, skip, out=ws.take(h.shape, dev)), None
+
+        for li, lay in enumerate(self.decoder.layers):                          # adm.py:764-774, 927-934
+            skip, sks = skips.pop()
+            nblk = len(lay.input_blocks)
+            if cfg.decoder_type == 1:
+                hc, hcs = join(h, hs, skip, sks)
+                pending = [(h, hs)] + ([(skip, sks)] if skip is not h else [])     # statistics are read by block 0's table
+                for j, blk in enumerate(lay.input_blocks):
+                    final = li == nl - 1 and j == nblk - 1                        # feeds the output layer: no norm follows
+                    h2, hs2 = self._block(blk, hc, film(), pk, ws, xs=hcs, want_stats=not final)
+                    if j == 0:
+                        ws.give(hc)
+                        for t, ts in pending:
+                            give(t, ts)
+                    else:
+                        give(hc, hcs)
+                    hc, hcs = h2, hs2
+                h, hs = hc, hcs
+            else:                                                               # every block joins the skip (adm.py:848-851)
+                for j, blk in enumerate(lay.input_blocks):
+                    final = li == nl - 1 and j == nblk - 1
+                    hc, hcs = join(h, hs, skip, sks)
+                    h2, hs2 = self._block(blk, hc, film(), pk, ws, xs=hcs, want_stats=not final)
                     ws.give(hc)
-                    for t, ts in pending:
-                        give(t, ts)
-                else:
-                    give(hc, hcs)
-                hc, hcs = h2, hs2
-            h, hs = hc, hcs
+                    if h is not skip:
+                        give(h, hs)
+                    h, hs = h2, hs2
+                give(skip, sks)
         for s_, ss in skips:                                                     # the stem copy is never consumed
             if s_ is not h:
                 give(s_, ss)

@@ -9,7 +9,7 @@ Functional forward pass driven by a ``state_dict`` with the reference's key name
   diffsci/models/nets/adm.py:744-774,893-900   decoder type 1: cat/add the skip once per layer
   diffsci/models/nets/adm.py:1014-1053   middle block, ADMTimeEmbedding
 for the default family: 2-D, default convolutions, GroupLN + GroupRMS, avg-pool down / nearest up
-inside the last block of each layer, decoder_type 1, attention only in the middle block.
+inside the last block of each layer, decoder_type 1 or 2, attention only in the middle block.
 """
 import torch
 import torch.nn.functional as F
@@ -101,11 +101,18 @@ def adm_forward(sd, cfg, x, t, ye=None):
     for j in range(nmid):
         x = block(sd, f"middle_block.middle_blocks.{j}.", x, te, has_attn=flags[j],
                   attn_residual=cfg["attn_residual"], circular=circ, norms=norms)
+    def join(a, h):                                                  # adm.py:297-304
+        return torch.cat([a, h], dim=1) if cfg["skip_integration_type"] == "concat" else a + h
+
+    dtype2 = cfg.get("decoder_type", 1) == 2
     for i in range(nl):
         h = skips.pop()
-        x = torch.cat([x, h], dim=1) if cfg["skip_integration_type"] == "concat" else x + h
+        if not dtype2:                                               # ADMDecoderLayer1.forward, adm.py:764-774
+            x = join(x, h)
         nb = cfg["number_resnet_upward_block"]
         for j in range(nb):
+            if dtype2:                                               # ADMDecoderLayer2: every block (adm.py:848-851)
+                x = join(x, h)
             x = block(sd, f"decoder.layers.{i}.input_blocks.{j}.", x, te, sample="up" if j == nb - 1 else None, circular=circ, norms=norms)
     return F.conv2d(x, sd["output_layer.weight"], sd["output_layer.bias"], padding="same")
 

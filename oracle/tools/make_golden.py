@@ -567,7 +567,10 @@ def adm_norms():
     with affine_norm=False -- which the reference's ADM silently ignores (the flag is not forwarded to the blocks)."""
     for i, (tag, over) in enumerate((("rms_ln", dict(first_resblock_norm="GroupRMS", second_resblock_norm="GroupLN")),
                                      ("ln_ln_noaffine", dict(first_resblock_norm="GroupLN", second_resblock_norm="GroupLN",
-                                                             affine_norm=False)))):
+                                                             affine_norm=False)),
+                                     ("dec2", dict(decoder_type=2)))):
+        if os.environ.get("ADM_ONLY") and tag not in os.environ["ADM_ONLY"].split(","):
+            continue
         torch.manual_seed(100 + i)
         cfg = M.nets.ADMConfig(model_channels=8, time_embed_dim=8, output_embed_dim=16, **over)
         net = M.nets.ADM(cfg).eval()

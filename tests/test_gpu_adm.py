@@ -112,7 +112,8 @@ def test_adm_trajectories_vs_reference(M, dev, skip, use_graph):
 
 
 ADM_NORMS = {"rms_ln": dict(first_resblock_norm="GroupRMS", second_resblock_norm="GroupLN"),
-             "ln_ln_noaffine": dict(first_resblock_norm="GroupLN", second_resblock_norm="GroupLN", affine_norm=False)}
+             "ln_ln_noaffine": dict(first_resblock_norm="GroupLN", second_resblock_norm="GroupLN", affine_norm=False),
+             "dec2": dict(decoder_type=2)}                    # ADMDecoderLayer2: every decoder block joins the skip
 
 
 @pytest.mark.parametrize("fuse", [True, False])
@@ -171,7 +172,7 @@ def test_adm_against_oracle_on_fresh_inputs(M, dev):
 
 def test_adm_rejects_unsupported_configurations(M):
     with pytest.raises(NotImplementedError, match="decoder_type"):
-        M.ADM(M.ADMConfig(decoder_type=2))
+        M.ADM(M.ADMConfig(decoder_type=3))
     with pytest.raises(NotImplementedError, match="dimension"):
         M.ADM(M.ADMConfig(dimension=3))
 

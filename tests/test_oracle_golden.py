@@ -438,13 +438,14 @@ def test_latent_boundary_and_edm_batch_norm():
 
 @pytest.mark.parametrize("tag,over", [
     ("rms_ln", dict(first_resblock_norm="GroupRMS", second_resblock_norm="GroupLN")),
-    ("ln_ln_noaffine", dict(first_resblock_norm="GroupLN", second_resblock_norm="GroupLN", affine_norm=False))])
+    ("ln_ln_noaffine", dict(first_resblock_norm="GroupLN", second_resblock_norm="GroupLN", affine_norm=False)),
+    ("dec2", dict(decoder_type=2))])
 def test_adm_norm_choices(tag, over):
     """make_norm_layers (adm.py:385-406): either norm in either slot; ADM ignores affine_norm=False (keys stay)."""
     from oracle import adm_ref
     v, sd = load("adm8_" + tag)
     cfg = adm_ref.default_config(model_channels=8, time_embed_dim=8, output_embed_dim=16, **over)
-    norms = (over["first_resblock_norm"], over["second_resblock_norm"])
+    norms = (over.get("first_resblock_norm", "GroupLN"), over.get("second_resblock_norm", "GroupRMS"))
     with torch.inference_mode():
         te = adm_ref.time_embedding(sd, v["t"])
         b0 = adm_ref.block(sd, "encoder.layers.0.input_blocks.0.", v["stem"], te, norms=norms)

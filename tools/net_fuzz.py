@@ -64,7 +64,7 @@ def main():
                         number_resnet_upward_block=ri(1, 3), number_resnet_attn_block=ri(1, 2),
                         number_resnet_before_attn_block=ri(0, 1), number_resnet_after_attn_block=ri(0, 1),
                         skip_integration_type=pick(["concat", "add"]), attn_residual=bool(ri(0, 1)),
-                        convolution_type=pick(["default", "default", "circular"]),
+                        convolution_type=pick(["default", "default", "circular"]), decoder_type=pick([1, 1, 2]),
                         first_resblock_norm=pick(["GroupLN", "GroupLN", "GroupRMS"]),
                         second_resblock_norm=pick(["GroupRMS", "GroupRMS", "GroupLN"]))
             net = M.ADM(M.ADMConfig(**over))
@@ -90,7 +90,7 @@ def main():
             errs.append(max(rel(got, want), rel(got, want64)))
         e = max(errs)
         worst = max(worst, e)
-        tag = f"{family} exp={exp} B={B} cin={cin} {H}x{W} " + " ".join(f"{k}={v}" for k, v in over.items() if k.startswith("number") or k in ("model_channels", "skip_integration_type", "convolution_type", "first_resblock_norm", "second_resblock_norm", "affine_norm", "bias"))
+        tag = f"{family} exp={exp} B={B} cin={cin} {H}x{W} " + " ".join(f"{k}={v}" for k, v in over.items() if k.startswith("number") or k in ("model_channels", "skip_integration_type", "convolution_type", "first_resblock_norm", "second_resblock_norm", "affine_norm", "bias", "decoder_type"))
         if e > tol:
             print("FAIL", tag, errs, tol)
             sys.exit(1)
