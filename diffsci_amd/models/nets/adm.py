@@ -22,7 +22,7 @@ import yaml
 
 from ... import ops
 from ..._native import DS_LOAD_AVGPOOL2, DS_LOAD_PLAIN, DS_LOAD_UPSAMPLE2
-from .punetg import _AffineHolder, _Attn, _CircConv, _Fourier, _Workspace, make_conv
+from .punetg import _AffineHolder, _Attn, _CircConv, _Fourier, _Workspace, make_conv, require_eval
 
 _FIELDS = dict(
     input_channels=1, output_channels=1, dimension=2, model_channels=64, time_embed_dim=64,
@@ -90,7 +90,6 @@ class ADMConfig(object):
             (self.transition_scale_factor == 2, "transition_scale_factor=2"),
             (self.decoder_type in (1, 2), "decoder_type 1 or 2"),
             (self.skip_integration_type in ("concat", "add"), "skip_integration_type 'concat' or 'add'"),
-            (self.dropout == 0.0 and self.cond_dropout == 0.0, "dropout=0 (sampling path)"),
             (self.number_resnet_downward_block >= 1 and self.number_resnet_upward_block >= 1,
              "at least one block per layer"),
         ]
@@ -378,6 +377,7 @@ class ADM(torch.nn.Module):
 
     def forward_with_shifts(self, x, shifts, row=None, out=None):
         """UNet body given the per-block FiLM rows (see PUNetG.forward_with_shifts)."""
+        require_eval(self, self.config.dropout, self.config.cond_dropout)
         pk = self.packed_weights()
         ws = self._ws
         cfg = self.config

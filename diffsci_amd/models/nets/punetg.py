@@ -177,6 +177,27 @@ class _Fourier(torch.nn.Module):
         self.register_buffer("W", torch.randn(embed_dim // 2) * scale)
 
 
+class _ConditionDrop(torch.nn.Module):
+    """ConditionDrop parameters (commonlayers.py:1100-1127): identity outside training; the null embedding is only a
+    state_dict entry here."""
+
+    def __init__(self, p, hidden_dim, null_is_learnable=True):
+        super().__init__()
+        self.p = p
+        if null_is_learnable:
+            self.null_embedding = torch.nn.Parameter(torch.randn(1, hidden_dim))
+        else:
+            self.register_buffer("null_embedding", torch.zeros(1, hidden_dim))
+
+
+def require_eval(net, *rates):
+    """Dropout, condition dropout and ConditionDrop are the identity in eval mode -- the only mode the sampling path
+    implements.  A network left in training mode with a non-zero rate would silently differ from the reference."""
+    if net.training and any(r for r in rates if r):
+        raise NotImplementedError("dropout / cond_dropout / cond_drop > 0 in training mode are outside the HIP sampling "
+                                  "path: call .eval() (the reference samples under eval() too)")
+
+
 class _Workspace:
     """Shape-keyed pool of device buffers.  A forward pass takes and gives buffers in a fixed
     order, so after the first pass no allocation happens -- a requirement for hipGraph capture."""
@@ -217,6 +238,8 @@ class PUNetG(torch.nn.Module):
         mult = config.extended_channel_expansion
         self.time_projection = _Fourier(mc, config.time_projection_scale)
         self.conditional_embedding = conditional_embedding
+        self.cond_drop = (_ConditionDrop(config.cond_drop, mc, config.cond_drop_learnable)
+                          if config.cond_drop is not None and config.cond_drop > 0 else None)     # punetg.py:102-106
         self.circular = config.convolution_type == "circular"
         circ = config.convolution_type                     # conv kind: "default" | "circular" | "mp"
         self.mp = config.convolution_type == "mp"
@@ -429,6 +452,7 @@ class PUNetG(torch.nn.Module):
         """UNet body given the per-block time shifts.  shifts[k] is [M, C_k]; row selects one row
         shared by the whole batch (sampling: sigma is a per-step constant), row=None means one row
         per sample (M == B).  Every activation travels with the tile statistics its producer left."""
+        require_eval(self, self.config.dropout, self.config.cond_dropout, self.config.cond_drop)
         pk = self.packed_weights()
         ws = self._ws
         cfg = self.config

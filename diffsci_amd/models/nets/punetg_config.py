@@ -62,8 +62,6 @@ class PUNetGConfig(object):
             (self.transition_scale_factor == 2, "transition_scale_factor=2"),
             (not self.in_embedding, "in_embedding=False"),
             (self.attn_type in ("default", "cosine"), "attn_type 'default' or 'cosine'"),
-            (self.dropout == 0.0 and self.cond_dropout == 0.0, "dropout=0 (sampling path)"),
-            (not self.cond_drop, "cond_drop=0 (sampling path)"),
         ]
         bad = [msg for ok, msg in checks if not ok]
         return None if not bad else "diffsci_amd PUNetG supports: " + "; ".join(bad)

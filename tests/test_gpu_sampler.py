@@ -345,6 +345,26 @@ def test_get_score_and_denoiser_per_sample_sigma(M, net8, dev):
     assert rel_l2(module.get_score(x, sigma.to(dev)).cpu(), want_s) < REL
 
 
+def test_dropout_configurations_sample_in_eval_mode(M, net8, dev):
+    """dropout / cond_dropout / cond_drop > 0 (training-time regularisers of the reference, identity under eval())
+    are accepted so that such checkpoints load; training mode with a non-zero rate is refused."""
+    v, sd = load("punetg8_forward")
+    net = M.PUNetG(M.PUNetGConfig(model_channels=8, dropout=0.1, cond_dropout=0.2, cond_drop=0.3))
+    r = net.load_state_dict(sd, strict=False)
+    assert r.missing_keys == ["cond_drop.null_embedding"] and not r.unexpected_keys
+    net = net.to(dev).eval()
+    out = net(v["x"].to(dev), v["t"].to(dev)).cpu()
+    assert rel_l2(out, v["out_f32"]) < REL
+    net.train()
+    with pytest.raises(NotImplementedError, match="eval"):
+        net(v["x"].to(dev), v["t"].to(dev))
+    net8.train()                                             # all rates zero: training mode changes nothing
+    try:
+        assert rel_l2(net8(v["x"].to(dev), v["t"].to(dev)).cpu(), v["out_f32"]) < REL
+    finally:
+        net8.eval()
+
+
 def test_cpu_tensors_are_refused(M, net8):
     module = M.KarrasModule(net8, M.KarrasModuleConfig.from_edm())
     with pytest.raises(RuntimeError, match="no CPU path"):

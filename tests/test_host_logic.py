@@ -176,6 +176,10 @@ def test_punetg_config_roundtrip_and_unsupported_options():
         mine = net.state_dict()
         assert set(mine) == set(sd) and all(tuple(mine[k].shape) == tuple(sd[k].shape) for k in sd), tag
         net.load_state_dict(sd)
+    # checkpoints trained with dropout / condition dropping load too (both are the identity under eval())
+    dn = M.PUNetG(M.PUNetGConfig(model_channels=8, dropout=0.1, cond_dropout=0.2, cond_drop=0.3))
+    assert tuple(dn.state_dict()["cond_drop.null_embedding"].shape) == (1, 8)
+    assert "cond_drop.null_embedding" not in M.PUNetG(M.PUNetGConfig(model_channels=8)).state_dict()
     mp = M.PUNetG(M.PUNetGConfig(model_channels=8, convolution_type="mp"))
     assert "attn_block.0.mhattn.q_proj_matrix" in mp.state_dict() and float(mp.convin.weight.std()) > 0.5   # N(0,1) init
     circ = M.PUNetG(M.PUNetGConfig(model_channels=8, convolution_type="circular"))
