@@ -4,7 +4,9 @@ from .integrators import (Integrator, EulerIntegrator, HeunIntegrator,  # noqa: 
                           EulerMaruyamaIntegrator, KarrasIntegrator, name_to_integrator)
 from .preconditioners import (KarrasPreconditioner, EDMPreconditioner,  # noqa: F401
                               NullPreconditioner, SR3Preconditioner, VPPreconditioner, VEPreconditioner)
-from .noisesamplers import NoiseSampler, EDMNoiseSampler, VPNoiseSampler, VENoiseSampler  # noqa: F401
+from .noisesamplers import (NoiseSampler, EDMNoiseSampler, VPNoiseSampler, VENoiseSampler,  # noqa: F401
+                            UniformNoiseSampler)
+from .autoregressivesample import LatentSpaceAutoregressive  # noqa: F401
 from .schedulingfunctions import (SchedulingFunctions, EDMSchedulingFunctions,  # noqa: F401
                                   VPSchedulingFunctions, VESchedulingFunctions,
                                   name_to_scheduling_functions)

@@ -107,6 +107,28 @@ class KarrasModuleConfig(object):
     def export_description(self) -> dict[str, Any]:
         return dict(tag=self.tag, extra_args=self.extra_args)
 
+    @classmethod
+    def load_from_description_with_tag(cls, description: dict[str, Any]):
+        """karrasmodule.py:348-366: the inverse of export_description for the tagged constructors."""
+        tag = description["tag"]
+        extra_args = description["extra_args"]
+        if tag == "custom":
+            raise ValueError("Cannot load from a custom tag")
+        if tag == "edm":
+            return cls.from_edm(**extra_args)
+        if tag == "vp":
+            return cls.from_vp(**extra_args)
+        if tag == "ve":
+            return cls.from_ve(**extra_args)
+        if tag == "conditionalSR3":
+            raise NotImplementedError("conditionalSR3 is broken in the reference itself (it passes sigma_min / sigma_max to "
+                                      "EDMNoiseSampler, karrasmodule.py:310-313) and is not reproduced")
+        raise ValueError(f"Unknown tag: {tag}")
+
+    @property
+    def has_dynamic_loss_weight(self):
+        return self.dynamic_loss_weight is not None
+
 
 class _Plan:
     """A captured N-step run: static buffers + hipGraph."""
@@ -156,6 +178,23 @@ class KarrasModule(torch.nn.Module, LatentSpaceAutoregressive):
         self._plans = {}
         self._static_fields = {}
         return super()._apply(fn, *a, **k)
+
+    def export_description(self) -> dict[str, Any]:
+        """karrasmodule.py:462-474."""
+        return dict(config_description=self.config.export_description(), conditional=self.conditional,
+                    masked=self.masked, autoencoder=True if self.autoencoder else False,
+                    autoencoder_conditional=self.autoencoder_conditional, encode_y=self.encode_y)
+
+    def start_edm_batch_norm(self):
+        """karrasmodule.py:1236-1241 (already done by the constructor; kept for callers that re-initialise it)."""
+        self.edm_batch_norm = (edmbatchnorm.DimensionAgnosticBatchNorm(sigma=self.config.extra_args.get("sigma_data", 0.5))
+                               if self.config.has_edm_batch_norm else None)
+
+    def freeze_autoencoder(self):
+        """karrasmodule.py: the autoencoder takes no gradients (a no-op for sampling, kept for drop-in scripts)."""
+        if self.autoencoder is not None:
+            for p in self.autoencoder.parameters():
+                p.requires_grad = False
 
     # ---------------------------------------------------------------- denoiser / score (public API)
     def _coefs(self, sigma):
@@ -247,6 +286,34 @@ class KarrasModule(torch.nn.Module, LatentSpaceAutoregressive):
                                               move_to_cpu=move_to_cpu, latent_shape=is_latent_shape,
                                               squeeze_memory_efficiency=squeeze_memory_efficiency,
                                               return_in_latent_space=return_in_latent_space)
+
+    def sample_and_filter(self, nsamples: int, shape: list[int], filter_fn, y=None, guidance: float = 1.0,
+                          nsteps: int = 100, record_history: bool = False, maximum_batch_size: None | int = None,
+                          integrator=None, move_to_cpu: bool = False, return_only_positives: bool = False):
+        """karrasmodule.py:735-799: sample, then filter_fn(encode(samples)) -> {'samples', 'filter', 'hit_rate'}."""
+        if record_history:
+            raise ValueError("record_history is not supported for filtering at the moment")
+        if maximum_batch_size is not None:
+            samples, filters, num_positive = [], [], 0
+            for b in get_minibatch_sizes(nsamples, maximum_batch_size):
+                r = self.sample_and_filter(b, shape, filter_fn, y, guidance, nsteps, record_history,
+                                           maximum_batch_size=None, integrator=integrator,
+                                           return_only_positives=return_only_positives, move_to_cpu=move_to_cpu)
+                samples.append(r["samples"])
+                filters.append(r["filter"])
+                num_positive += r["filter"].sum().item()
+            return dict(samples=torch.cat(samples, dim=0), filter=torch.cat(filters, dim=0),
+                        hit_rate=num_positive / nsamples)
+        samples = self.sample(nsamples, shape, y=y, guidance=guidance, nsteps=nsteps, record_history=record_history,
+                              maximum_batch_size=maximum_batch_size, integrator=integrator, move_to_cpu=False)
+        with torch.inference_mode():
+            filt = filter_fn(self.encode(samples, y, record_history))
+        if return_only_positives:
+            samples = samples[filt]
+            filt = filt[filt]
+        if move_to_cpu:
+            samples = samples.detach().cpu()
+        return dict(samples=samples, filter=filt, hit_rate=filt.sum() / nsamples)
 
     def propagate_white_noise(self, x, y=None, guidance: float = 1.0, nsteps: int = 100,
                               record_history: bool = False, integrator=None, original_y=None,

@@ -58,3 +58,20 @@ class VENoiseSampler(NoiseSampler):
         unif = torch.rand(shape).to(self.sigma_min.device)
         logsigma_min, logsigma_max = torch.log(self.sigma_min), torch.log(self.sigma_max)
         return torch.exp(logsigma_min + unif * (logsigma_max - logsigma_min))
+
+
+class UniformNoiseSampler(NoiseSampler):
+    """noisesamplers.py:90-111: sigma ~ U(t, T); EDM loss weighting."""
+
+    def __init__(self, t: float = 0.0, T: float = 1.0, sigma_data: float = 0.5):
+        super().__init__()
+        self.register_buffer("t", torch.tensor(t))
+        self.register_buffer("T", torch.tensor(T))
+        self.register_buffer("sigma_data", torch.tensor(sigma_data))
+
+    def loss_weighting(self, sigma):
+        return (sigma ** 2 + self.sigma_data ** 2) / ((sigma * self.sigma_data) ** 2)
+
+    def sample(self, shape):
+        sigma = torch.rand(shape).to(self.t.device)
+        return self.t + sigma * (self.T - self.t)

@@ -245,6 +245,24 @@ def test_sample_minibatching_and_cpu_noise(M, net8, dev, grids):
     assert rel_l2(out, v["sample_seed5_n3_mb2_N4"]) < max(4 * ref_err, REL)
 
 
+def test_sample_and_filter(M, net8, dev):
+    """KarrasModule.sample_and_filter (karrasmodule.py:735-799): sample, filter_fn(encode(samples)), hit rate."""
+    module = M.KarrasModule(net8, M.KarrasModuleConfig.from_edm())
+    fn = lambda x: x.mean(dim=(1, 2, 3)) > 0                                      # noqa: E731
+    torch.manual_seed(4)
+    r = module.sample_and_filter(5, [1, 32, 32], fn, nsteps=4)
+    torch.manual_seed(4)
+    s = module.sample(5, [1, 32, 32], nsteps=4)
+    assert torch.equal(r["samples"], s) and torch.equal(r["filter"], fn(s))
+    assert float(r["hit_rate"]) == float(fn(s).sum()) / 5
+    torch.manual_seed(4)
+    r2 = module.sample_and_filter(5, [1, 32, 32], fn, nsteps=4, maximum_batch_size=2, return_only_positives=True,
+                                  move_to_cpu=True)
+    assert r2["samples"].device.type == "cpu" and r2["samples"].shape[0] == int(r2["filter"].sum()) and bool(r2["filter"].all())
+    with pytest.raises(ValueError, match="record_history"):
+        module.sample_and_filter(2, [1, 32, 32], fn, record_history=True)
+
+
 def test_classifier_free_guidance(M, dev, grids):
     v, _ = load("punetg8_cfg")
     _, sd = load("punetg8_forward")

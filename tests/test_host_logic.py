@@ -216,3 +216,27 @@ def test_global_noise_is_the_reference_draw():
     got = torch.cat([global_white_noise(6, [1, 4, 4], 123, rows=shard_rows(6, 4, r)) for r in range(4)])
     assert torch.equal(got, want)
     assert torch.equal(torch.random.get_rng_state(), state)      # global generator untouched
+
+
+def test_config_descriptions_round_trip():
+    """KarrasModuleConfig.export_description / load_from_description_with_tag (karrasmodule.py:343-366) and
+    KarrasModule.export_description (:462-474)."""
+    for ctor, kw in ((M.KarrasModuleConfig.from_edm, dict(sigma_data=0.7)), (M.KarrasModuleConfig.from_ve, dict(sigma_max=50.0)),
+                     (M.KarrasModuleConfig.from_vp, dict(beta_min=0.2))):
+        c = ctor(**kw)
+        d = c.export_description()
+        c2 = M.KarrasModuleConfig.load_from_description_with_tag(d)
+        assert c2.export_description() == d and type(c2.noisescheduler) is type(c.noisescheduler)
+    with pytest.raises(ValueError, match="custom"):
+        M.KarrasModuleConfig.load_from_description_with_tag(dict(tag="custom", extra_args={}))
+    with pytest.raises(ValueError, match="Unknown tag"):
+        M.KarrasModuleConfig.load_from_description_with_tag(dict(tag="nope", extra_args={}))
+    module = M.KarrasModule(M.MLPUncond(2, [20]), M.KarrasModuleConfig.from_edm(), conditional=True)
+    d = module.export_description()
+    assert d["conditional"] is True and d["autoencoder"] is False and d["config_description"]["tag"] == "edm"
+    assert not module.config.has_dynamic_loss_weight
+    from diffsci_amd.models.karras import UniformNoiseSampler, LatentSpaceAutoregressive
+    assert issubclass(M.KarrasModule, LatentSpaceAutoregressive)
+    torch.manual_seed(0)
+    s = UniformNoiseSampler(t=0.5, T=2.0).sample([1000])
+    assert float(s.min()) >= 0.5 and float(s.max()) <= 2.0
