@@ -348,6 +348,82 @@ class PUNetG(torch.nn.Module):
         for lv in self.upward_blocks:
             yield from lv
 
+    # ------------------------------------------------------------------ the reference's public stages
+    # PUNetG.encode / bottom_forward / decode and their helpers (punetg.py:336-387) for callers that drive the
+    # stages themselves (e.g. the encoder / decoder halves of punetg_encdec.py).  Eager launches of the same
+    # kernels as forward(); te is the [B, model_channels] embedding (time projection + condition); results are
+    # fresh tensors, never workspace buffers.
+    def _shift_of(self, blk, te):
+        pk = self.packed_weights() if self.mp else None
+        n = blk.timeblock.net
+        wgt = (lambda lin: pk[(id(lin), "eff")]) if pk is not None else (lambda lin: lin.weight)
+        h = ops.linear(te, wgt(n[0]), n[0].bias, act=1)
+        h = ops.linear(h, wgt(n[2]), n[2].bias, act=1)
+        return ops.linear(h, wgt(n[4]), n[4].bias, act=0)
+
+    def _run_blocks(self, x, te, resnet_block, attn_block=()):
+        """-> (tensor, stats, owned): owned tensors are workspace buffers the caller must clone and give back."""
+        pk, ws = self.packed_weights(), self._ws
+        h, hs, own = x, None, False
+        for i, blk in enumerate(resnet_block):
+            h2, hs2 = self._res(blk, h, self._shift_of(blk, te), pk, ws, xs=hs)
+            if own:
+                ws.give(h)
+                if hs is not None:
+                    ws.give(hs)
+            h, hs, own = h2, hs2, True
+            if i < len(attn_block):
+                hs2 = self._stats_buf(ws, h.shape[0], h.shape[1], h.shape[2], h.shape[3], h.device)
+                h2 = self._attention(attn_block[i], h, pk, ws, tile_stats=hs2)
+                ws.give(h)
+                if hs is not None:
+                    ws.give(hs)
+                h, hs = h2, hs2
+        return h, hs, own
+
+    def _release(self, h, hs, own):
+        out = h.clone() if own else h
+        if own:
+            self._ws.give(h)
+        if hs is not None:
+            self._ws.give(hs)
+        return out
+
+    def resnet_block_forward(self, x, te, resnet_block):
+        require_eval(self, self.config.dropout, self.config.cond_dropout, self.config.cond_drop)
+        ops.require_device(x, "x")
+        return self._release(*self._run_blocks(x.contiguous(), te, resnet_block))
+
+    def resnet_attn_block_forward(self, x, te, resnet_block, attn_block):
+        require_eval(self, self.config.dropout, self.config.cond_dropout, self.config.cond_drop)
+        ops.require_device(x, "x")
+        return self._release(*self._run_blocks(x.contiguous(), te, resnet_block, attn_block))
+
+    def encode(self, x, te):
+        """punetg.py:356-365 -> (x at the bottom resolution, [level outputs])."""
+        pk = self.packed_weights()
+        intermediate_outputs = []
+        for resnet_block, downsampler in zip(self.downward_blocks, self.downsamplers):
+            x = self.resnet_block_forward(x, te, resnet_block)
+            intermediate_outputs.append(x.clone())
+            x = self._conv(downsampler.conv, x, pk, load_mode=DS_LOAD_MAXPOOL2)
+        return x, intermediate_outputs
+
+    def decode(self, x, te, intermediate_outputs):
+        """punetg.py:367-376 (pops the skips, like the reference)."""
+        pk = self.packed_weights()
+        for resnet_block, upsampler in zip(self.upward_blocks, self.upsamplers):
+            x = self._conv(upsampler.conv, x.contiguous(), pk, load_mode=DS_LOAD_UPSAMPLE2, res1=intermediate_outputs.pop())
+            x = self.resnet_block_forward(x, te, resnet_block)
+        return x
+
+    def bottom_forward(self, x, te):
+        """punetg.py:378-387."""
+        x = self.resnet_block_forward(x, te, self.before_block)
+        xa = self.resnet_attn_block_forward(x, te, self.attn_resnet_block, self.attn_block)
+        x = ops.add(x, xa)
+        return self.resnet_block_forward(x, te, self.after_block)
+
     # ------------------------------------------------------------------ weights
     def _conv_modules(self):
         yield self.convin

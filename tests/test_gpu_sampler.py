@@ -245,6 +245,28 @@ def test_sample_minibatching_and_cpu_noise(M, net8, dev, grids):
     assert rel_l2(out, v["sample_seed5_n3_mb2_N4"]) < max(4 * ref_err, REL)
 
 
+def test_punetg_public_stages(M, net8, dev):
+    """PUNetG.encode / bottom_forward / decode / resnet_block_forward (punetg.py:336-387) compose to forward(), and the
+    first stage outputs match the reference's layer fixtures."""
+    v, _ = load("punetg8_forward")
+    x, t = v["x"].to(dev), v["t"].to(dev)
+    want = net8(x, t)
+    pk = net8.packed_weights()
+    te = net8.embed_time(t)
+    h = net8._conv(net8.convin, x, pk)
+    r = net8.resnet_block_forward(v["convin"].to(dev), te, [net8.downward_blocks[0][0]])
+    assert rel_l2(r.cpu(), v["resblock"]) < 2e-6
+    z, skips = net8.encode(h, te)
+    assert len(skips) == 2 and skips[0].shape == (2, 8, 32, 32) and z.shape == (2, 32, 8, 8)
+    z = net8.bottom_forward(z, te)
+    z = net8.decode(z, te, skips)
+    assert skips == []                                           # popped, like the reference
+    out = net8._out_conv(net8.convout, z, pk, None, net8.circular)
+    assert rel_l2(out.cpu(), want.cpu()) < 2e-6 and rel_l2(out.cpu(), v["out_f32"]) < REL
+    again = net8(x, t)                                           # the stages left the workspace consistent
+    assert torch.equal(again, want)
+
+
 def test_sample_and_filter(M, net8, dev):
     """KarrasModule.sample_and_filter (karrasmodule.py:735-799): sample, filter_fn(encode(samples)), hit rate."""
     module = M.KarrasModule(net8, M.KarrasModuleConfig.from_edm())
