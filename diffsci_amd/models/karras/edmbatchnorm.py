@@ -47,3 +47,33 @@ class DimensionAgnosticBatchNorm(torch.nn.Module):
 
     def unnormalize(self, x):
         return self.unnorm(x)
+
+
+class ConstantBatchNorm(torch.nn.Module):
+    """aux_scripts/batchnorm.py:172-187: x / sigma and back."""
+
+    def __init__(self, sigma: float = 1.0):
+        super().__init__()
+        self.sigma = sigma
+
+    def forward(self, x):
+        return ops.div_scalar(x.contiguous(), self.sigma)
+
+    def unnorm(self, x):
+        return ops.scale(x.contiguous(), self.sigma)
+
+    normalize = forward
+    unnormalize = unnorm
+
+
+class IdentityBatchNorm(torch.nn.Module):
+    """aux_scripts/batchnorm.py:190-204."""
+
+    def forward(self, x):
+        return x
+
+    def unnorm(self, x):
+        return x
+
+    normalize = forward
+    unnormalize = unnorm

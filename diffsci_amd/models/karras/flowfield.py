@@ -20,6 +20,7 @@ import torch
 from ... import ops
 from ..._native import DS_IN_FLOW, DS_IN_NETWORK
 from .engine import Loop, ModuleSource
+from . import edmbatchnorm
 from .karrasmodule import _condition_key, dict_map, dict_to, dict_unsqueeze
 from .steptable import EvalRow, StepRow, StepTable
 
@@ -153,17 +154,56 @@ class _Adapter:
 class SIModule(torch.nn.Module):
     def __init__(self, config: SIModuleConfig, model: torch.nn.Module, autoencoder: torch.nn.Module | None = None):
         super().__init__()
-        if autoencoder is not None:
-            raise NotImplementedError("latent autoencoders are outside the HIP sampling path")
-        if isinstance(config.initial_norm, bool) and config.initial_norm:
-            raise NotImplementedError("DimensionAgnosticBatchNorm (initial_norm=True) is outside the HIP sampling path")
         object.__setattr__(self, "config", config)
         self.model = model
-        self.autoencoder = None
-        self.norm_sigma = None if isinstance(config.initial_norm, bool) else float(config.initial_norm)
+        # latent models (flowfield.py:300-334): the autoencoder is a user module, run as given
+        self.autoencoder = autoencoder
+        if self.autoencoder:
+            self.freeze_autoencoder()
+        self.set_initial_norm()
         self.use_graph = True
         self._plans = {}
         self._stream = None
+
+    def freeze_autoencoder(self):
+        """flowfield.py:304-310."""
+        for param in self.autoencoder.parameters():
+            param.requires_grad = False
+
+    def set_initial_norm(self):
+        """flowfield.py:336-345: the data <-> network-space map undone after integration."""
+        n = self.config.initial_norm
+        if isinstance(n, bool):
+            self.initial_norm = (edmbatchnorm.DimensionAgnosticBatchNorm(self.config.num_channels) if n
+                                 else edmbatchnorm.IdentityBatchNorm())
+        elif isinstance(n, (float, int)):
+            self.initial_norm = edmbatchnorm.ConstantBatchNorm(n)
+        else:
+            raise ValueError(f"Invalid initial norm: {n}")
+
+    def encode(self, x, y=None):
+        """flowfield.py:312-325."""
+        if not self.autoencoder:
+            return x, y
+        c = self.config
+        if not c.autoencoder_is_conditional and not c.encode_condition:
+            x = self.autoencoder.encode(x)
+        elif c.autoencoder_is_conditional and not c.encode_condition:
+            x = self.autoencoder.encode(x, y)
+        elif not c.autoencoder_is_conditional and c.encode_condition:
+            raise ValueError("Cannot encode condition if autoencoder is not conditional")
+        else:
+            x, y = self.autoencoder.encode(x, y)
+        if isinstance(x, dict):
+            x = x['zsample']
+        return x, y
+
+    def decode(self, x, y=None):
+        """flowfield.py:327-334."""
+        if not self.autoencoder:
+            return x, y
+        x = self.autoencoder.decode(x, y) if self.config.autoencoder_is_conditional else self.autoencoder.decode(x)
+        return x, y
 
     @property
     def device(self):
@@ -243,11 +283,18 @@ class SIModule(torch.nn.Module):
             if y is not None:
                 warnings.warn("Moving y to device: {}".format(self.device))
                 y = dict_to(y, self.device)
+            if not is_latent_shape and self.autoencoder:
+                x, _ = self.encode(x, y)                 # only to learn the latent shape (flowfield.py:525-528)
+                x = torch.randn_like(x)
+            if y is not None:
                 y = dict_unsqueeze(y, 0)
             time_schedule = torch.linspace(1, 0, nsteps)
             sigma_init = self.config.sigma_fn(time_schedule[0])
-            return self._integrate(x, time_schedule, y, guidance, False, integrate_on_sigma, noise_injection,
-                                   scale=float(sigma_init))
+            x = self._integrate(x, time_schedule, y, guidance, False, integrate_on_sigma, noise_injection,
+                                scale=float(sigma_init))
+            if not return_latents:
+                x, _ = self.decode(x, y)
+            return x
 
     def integrate_flow_field(self, x, time_schedule, y=None, guidance: float = 1.0, return_history: bool = False,
                              integrate_on_sigma: bool = False, noise_injection: bool = False):
@@ -268,11 +315,9 @@ class SIModule(torch.nn.Module):
             loop.load(x, scale)
             loop.launch()
             out = loop.result()
-        if self.norm_sigma is not None:
-            out = ops.scale(out.contiguous(), self.norm_sigma)                    # initial_norm.unnorm
-        if return_history:
-            return [(table.t[i].to(x.device), out[i]) for i in range(out.shape[0])]
-        return out
+        if return_history:                                                        # initial_norm.unnorm, flowfield.py:742-747
+            return [(table.t[i].to(x.device), self.initial_norm.unnorm(out[i])) for i in range(out.shape[0])]
+        return self.initial_norm.unnorm(out)
 
     def _run_planned(self, table, src, x, y, guidance, return_history, integrate_on_sigma, scale):
         """Capture the whole run once per (shape, schedule, guidance, condition) and replay it."""
@@ -322,12 +367,43 @@ class SIModule(torch.nn.Module):
             x = ops.axpby(x, 1.0, torch.randn_like(x), float(torch.sqrt(omega * torch.abs(dt))), out=x)
             if return_history:
                 history.append((ts[i + 1], x))
-        if self.norm_sigma is not None:
-            if return_history:
-                history = [(t, ops.scale(h, self.norm_sigma)) for t, h in history]
-            else:
-                x = ops.scale(x, self.norm_sigma)
-        return history if return_history else x
+        if return_history:
+            return [(t, self.initial_norm.unnorm(h)) for t, h in history]
+        return self.initial_norm.unnorm(x)
+
+    def integration_step(self, x, t_curr, t_next, y=None, guidance: float = 1.0, method: str = 'euler',
+                         integrate_on_sigma: bool = False, noise_injection: bool = False):
+        """flowfield.py:749-795: one Euler / Heun / Euler-Maruyama step between two times (every sample of the
+        batch at the same time, as in the reference's own loop).  The loops above run whole schedules through the fused
+        stepper; this is the single-step entry point the reference exposes."""
+        ops.require_device(x, "x")
+        tc, tn = (torch.as_tensor(t, dtype=torch.float32).detach().cpu().reshape(-1) for t in (t_curr, t_next))
+        if bool((tc != tc[0]).any()) or bool((tn != tn[0]).any()):
+            raise NotImplementedError("integration_step: per-sample times (the sampler uses one time per step)")
+        tc, tn = tc[0], tn[0]
+        c = self.config
+        dt = float((c.sigma_fn(tn) - c.sigma_fn(tc)) if integrate_on_sigma else (tn - tc))
+        if method in ('euler', 'heun'):
+            assert not noise_injection, "Noise injection is not supported for Euler and Heun methods"
+        kw = dict(y=y, guidance=guidance, integrate_on_sigma=integrate_on_sigma)
+        x = x.contiguous()
+        if method == 'euler':
+            return ops.axpby(x, 1.0, self.get_flow_field(x, tc, **kw), dt)
+        if method == 'heun':
+            v1 = self.get_flow_field(x, tc, **kw)
+            v2 = self.get_flow_field(ops.axpby(x, 1.0, v1, dt), tn, **kw)
+            vs = ops.add(v1, v2)                                                  # x + dt*(v1 + v2)/2
+            return ops.axpby(x, 1.0, ops.div_scalar(ops.scale(vs, dt), 2.0), 1.0)
+        if method == 'euler_maruyama':
+            if not noise_injection:
+                raise ValueError("Noise injection is required for Euler-Maruyama method")
+            v = self.get_flow_field(x, tc, **kw)
+            score = self.get_score_field_from_flow_field(v, x, tc)
+            omega = c.sigma_fn(tc)
+            d = ops.axpby(v, 1.0, score, -float(0.5 * omega))
+            x = ops.axpby(x, 1.0, d, dt)
+            return ops.axpby(x, 1.0, torch.randn_like(x), float(torch.sqrt(omega * abs(dt))))
+        raise ValueError(f"Invalid integration method: {method}")
 
     def inpaint(self, *a, **k):
         raise NotImplementedError("SIModule.inpaint is outside the HIP path (use KarrasModule.inpaint)")

@@ -81,3 +81,13 @@ def sample(sch, kind, model, noise, nsteps, y=None, guidance=1.0, norm_sigma=Non
     ts = torch.linspace(1, 0, nsteps).to(noise)
     x = integrate(sch, kind, model, noise * sch["sigma"](ts[0]), ts, y, guidance)
     return x if norm_sigma is None else x * norm_sigma
+
+
+def integration_step(sch, kind, model, x, t_curr, t_next, method="euler", y=None, guidance=1.0):
+    """flowfield.py:749-781 (deterministic methods, integrate_on_sigma=False)."""
+    dt = _bcast(t_next - t_curr, x)
+    v1 = flow_field(sch, kind, model, x, t_curr, y, guidance)
+    if method == "euler":
+        return x + dt * v1
+    v2 = flow_field(sch, kind, model, x + dt * v1, t_next, y, guidance)
+    return x + dt * (v1 + v2) / 2

@@ -443,6 +443,33 @@ def si():
     npz("si8", **arrs)
 
 
+def si_latent():
+    """SIModule with a latent autoencoder and the batch-norm initial_norm (flowfield.py:300-345, 503-544, 742-747), plus
+    its single-step entry point integration_step (:749-795).  Network: the latent8 fixture's (4 -> 4 channels)."""
+    z = np.load(os.path.join(OUT, "latent8.npz"))
+    sd = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd/")}
+    net = M.nets.PUNetG(M.nets.PUNetGConfig(input_channels=4, output_channels=4, model_channels=8)).eval()
+    net.load_state_dict(sd)
+    torch.manual_seed(130)
+    noise = torch.randn(2, 4, 16, 16)
+    arrs = dict(noise=noise)
+    mod = M.SIModule(M.SIModuleConfig(scheduler="linear", initial_norm=True, num_channels=4), net,
+                     autoencoder=ToyAutoencoder()).eval()
+    mod.initial_norm.running_mean = torch.tensor([0.3, -0.2, 0.05, 1.1])
+    mod.initial_norm.running_var = torch.tensor([2.5, 0.4, 1.0, 0.09])
+    arrs["sd_keys"] = np.array(sorted(k for k in mod.state_dict() if not k.startswith("model.")))
+    ts = torch.linspace(1, 0, 5)
+    with torch.inference_mode():
+        arrs["sample_N5"] = mod.sample(2, [4, 16, 16], nsteps=5, orig_noise=noise, is_latent_shape=True)
+        arrs["latents_N5"] = mod.sample(2, [4, 16, 16], nsteps=5, orig_noise=noise, is_latent_shape=True, return_latents=True)
+        h = mod.integrate_flow_field(noise * mod.config.sigma_fn(ts[0]), ts, return_history=True)
+        arrs["hist_N5"] = torch.stack([x for _, x in h])
+        t0, t1 = torch.full((2,), 0.7), torch.full((2,), 0.45)
+        arrs["step_euler"] = mod.integration_step(noise, t0, t1, method="euler")
+        arrs["step_heun"] = mod.integration_step(noise, t0, t1, method="heun")
+    npz("si8_latent", **arrs)
+
+
 def porosity():
     """BASELINE config 5's shape of the path: 4-channel conditional PUNetG with the in-repo dict-style
     PorosityEmbedder (nets/embedder.py:198-229), classifier-free guidance, un-batched dict y."""
@@ -711,6 +738,6 @@ def latent():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["schedule", "toy", "punetg", "porosity", "inpaint", "vpve", "circular", "si", "punetgcond", "langevin", "adm", "variants", "latent", "adm_norms", "autoregressive"]
+    which = sys.argv[1:] or ["schedule", "toy", "punetg", "porosity", "inpaint", "vpve", "circular", "si", "punetgcond", "langevin", "adm", "variants", "latent", "adm_norms", "autoregressive", "si_latent"]
     for name in which:
         globals()[name]()

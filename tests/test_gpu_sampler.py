@@ -783,6 +783,41 @@ def ops_scale(x, s):
     return ops.scale(x.contiguous(), s)
 
 
+def test_si_latent_boundary_and_single_step(M, dev):
+    """SIModule(autoencoder=..., initial_norm=True): user autoencoder run as given, the batch-norm unnorm through
+    ds_batchnorm_eval, the schedule through the captured stepper; integration_step = one eager step."""
+    v, _ = load("si8_latent")
+    _, sd = load("latent8")
+    net = M.PUNetG(M.PUNetGConfig(input_channels=4, output_channels=4, model_channels=8))
+    net.load_state_dict(sd)
+    mod = M.SIModule(M.SIModuleConfig(scheduler="linear", initial_norm=True, num_channels=4), net,
+                     autoencoder=ToyAutoencoder())
+    assert sorted(k for k in mod.state_dict() if not k.startswith("model.")) == [
+        "initial_norm.running_mean", "initial_norm.running_var"]
+    mod = mod.to(dev).eval()
+    with torch.no_grad():
+        mod.initial_norm.running_mean.copy_(torch.tensor([0.3, -0.2, 0.05, 1.1]))
+        mod.initial_norm.running_var.copy_(torch.tensor([2.5, 0.4, 1.0, 0.09]))
+    noise = v["noise"].to(dev)
+    for _ in range(2):                                           # second pass: graph replay
+        out = mod.sample(2, [4, 16, 16], nsteps=5, orig_noise=noise, is_latent_shape=True).cpu()
+        assert out.shape == (2, 1, 32, 32) and rel_l2(out, v["sample_N5"]) < REL
+    lat = mod.sample(2, [4, 16, 16], nsteps=5, orig_noise=noise, is_latent_shape=True, return_latents=True).cpu()
+    assert rel_l2(lat, v["latents_N5"]) < REL
+    ts = torch.linspace(1, 0, 5)
+    h = mod.integrate_flow_field(noise * float(mod.config.sigma_fn(ts[0])), ts, return_history=True)
+    assert rel_l2(torch.stack([x for _, x in h]).cpu(), v["hist_N5"]) < REL
+    t0, t1 = torch.full((2,), 0.7), torch.full((2,), 0.45)
+    for m in ("euler", "heun"):
+        assert rel_l2(mod.integration_step(noise, t0, t1, method=m).cpu(), v["step_" + m]) < REL
+    em = mod.integration_step(noise, t0, t1, method="euler_maruyama", noise_injection=True)
+    assert em.shape == noise.shape and torch.isfinite(em).all()
+    with pytest.raises(ValueError, match="Noise injection is required"):
+        mod.integration_step(noise, t0, t1, method="euler_maruyama")
+    s = mod.sample(3, [1, 32, 32], nsteps=3)                      # data-space shape: encoded once for the latent shape
+    assert s.shape == (3, 1, 32, 32) and torch.isfinite(s).all()
+
+
 def test_reference_punetg_test_shape(M, dev):
     """The reference's own tests/test_punetg.py: PUNetG(model_channels=4) on [16, 1, 32, 32] (attention with
     E = 16: generic attention path; 4/8/16-channel convolutions: one ragged 16-channel chunk)."""

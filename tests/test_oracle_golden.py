@@ -351,6 +351,33 @@ def test_punetg_layer_variants(tag):
         assert_exact_or_rel(hist, v["hist_heun_N6_f32"], tag + " hist_heun_N6_f32", 2e-6)
 
 
+def test_si_latent_boundary_and_single_step():
+    """SIModule with an autoencoder and the batch-norm initial_norm (flowfield.py:300-345, 742-747), and its
+    single-step entry point integration_step (:749-781)."""
+    from oracle import si_ref as S
+    v, _ = load("si8_latent")
+    _, sd = load("latent8")
+    cfg = punetg_ref.default_config(model_channels=8, input_channels=4, output_channels=4)
+    base = punetg_ref.make_net(sd, cfg)
+    model = lambda x, t, y=None: base(x, t, y)                                  # noqa: E731
+    sch = S.scheduler("linear")
+    bn = dict(mean=torch.tensor([0.3, -0.2, 0.05, 1.1]), var=torch.tensor([2.5, 0.4, 1.0, 0.09]), sigma=1.0)
+    ae = ToyAutoencoder()
+    noise = v["noise"]
+    ts = torch.linspace(1, 0, 5)
+    with torch.inference_mode():
+        lat = K.batchnorm_eval(S.sample(sch, "identity", model, noise, 5), inverse=True, **bn)
+        assert_exact_or_rel(lat, v["latents_N5"], "latents", 2e-6)
+        assert_exact_or_rel(ae.decode(lat), v["sample_N5"], "decoded sample", 2e-6)
+        h = S.integrate(sch, "identity", model, noise * sch["sigma"](ts[0]), ts, return_history=True)
+        hu = torch.stack([K.batchnorm_eval(x, inverse=True, **bn) for x in h])
+        assert_exact_or_rel(hu, v["hist_N5"], "unnormalised history", 2e-6)
+        t0, t1 = torch.full((2,), 0.7), torch.full((2,), 0.45)
+        for m in ("euler", "heun"):
+            assert_exact_or_rel(S.integration_step(sch, "identity", model, noise, t0, t1, m), v["step_" + m], m + " step", 2e-6)
+    assert str(v["sd_keys"]) == "['initial_norm.running_mean' 'initial_norm.running_var']"
+
+
 class TinyCondNet(torch.nn.Module):
     """The stand-in network of the autoreg8 fixture's cond_time = 3 case (oracle/tools/make_golden.py)."""
 
