@@ -197,13 +197,36 @@ def hbm_class(module, args, dev):
                             "ms": round(ms, 4)}
     k = EvalCoef(c_out=0.4, c_skip=0.1, sigma_sq=2.0, neg_mult=-1.4, neg_lang=0.0, guidance=1.0,
                  one_minus_guidance=0.0, input_kind=0, stochastic=0)
+
+    def timed_in_graph(fn, launches=200, reps=5):
+        """The sampler replays its step kernels from a hipGraph; a 4 MiB step is a ~5 us kernel, shorter than one
+        eager launch through ctypes takes to issue.  Capture `launches` back-to-back launches and time the replay."""
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            fn(); side.synchronize()
+            with ops.Graph() as g:
+                for _ in range(launches):
+                    fn()
+            g.launch(); side.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(side)
+            for _ in range(reps):
+                g.launch()
+            e1.record(side); side.synchronize()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        return e0.elapsed_time(e1) / (reps * launches)
+
     for label, n in (("heun_step_cfg2_4MiB", B * S * S), ("heun_step_256MiB", B * C * S * S)):
         xs, f1, f2 = (torch.randn(n, device=dev) for _ in range(3))
         xo, xi = torch.empty(n, device=dev), torch.empty(n, device=dev)
-        ms = timed(lambda: ops.heun(xs, f1, k, f2, k, -0.5, x_out=xo, xin_out=xi, c_in_next=0.3))
+        step = lambda: ops.heun(xs, f1, k, f2, k, -0.5, x_out=xo, xin_out=xi, c_in_next=0.3)   # noqa: E731
+        ms_eager = timed(step)
+        ms = timed_in_graph(step) if n <= (1 << 22) else ms_eager
         gbs = n * 20 / (ms * 1e-3) / 1e9          # corrector: R x, F1, F2; W x', c_in*x'  = 20 B/elt
         out[label] = {"bytes_per_elt": 20, "GB/s": round(gbs, 1), "frac_hbm_peak": round(gbs / HBM_PEAK_GBS, 4),
-                      "ms": round(ms, 5)}
+                      "ms": round(ms, 5), "timed": "hipGraph replay of 200 launches" if ms is not ms_eager else "eager launches",
+                      "ms_eager_launch": round(ms_eager, 5)}
     return out
 
 
