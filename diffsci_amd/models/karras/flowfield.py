@@ -397,13 +397,92 @@ class SIModule(torch.nn.Module):
         if method == 'euler_maruyama':
             if not noise_injection:
                 raise ValueError("Noise injection is required for Euler-Maruyama method")
-            v = self.get_flow_field(x, tc, **kw)
-            score = self.get_score_field_from_flow_field(v, x, tc)
-            omega = c.sigma_fn(tc)
-            d = ops.axpby(v, 1.0, score, -float(0.5 * omega))
-            x = ops.axpby(x, 1.0, d, dt)
-            return ops.axpby(x, 1.0, torch.randn_like(x), float(torch.sqrt(omega * abs(dt))))
+            return self._em_step(x, tc, tn, y, guidance, integrate_on_sigma, torch.randn_like)
         raise ValueError(f"Invalid integration method: {method}")
 
-    def inpaint(self, *a, **k):
-        raise NotImplementedError("SIModule.inpaint is outside the HIP path (use KarrasModule.inpaint)")
+    def inpaint(self, x_orig, mask, nsamples: int = 1, y=None, guidance: float = 1.0, nsteps: int = 30,
+                integrate_on_sigma: bool = False, noise_injection: bool = False, orig_noise=None,
+                mask_falloff: int = 0, resample_steps: int = 0, jump_length: int = 1, mask_start_t: float = 1.0,
+                noise=None):
+        """flowfield.py:546-641: Euler-Maruyama steps; after each one the known region (mask = 1) is replaced by a
+        freshly noised copy of x_orig at the step's noise level, optionally with RePaint-style jumps back.
+        noise (extension, for reproducibility): an iterator of the standard-normal draws the loop consumes, in the
+        reference's order -- per inner iteration: the step's [B, *shape], the patch's [1, *shape], and for a jump the
+        re-noising [B, *shape] and its patch [1, *shape]."""
+        warnings.warn("We are assuming we are in latent space for inpainting")
+        draws = iter(noise) if noise is not None else None
+
+        def randn_like(t):
+            if draws is None:
+                return torch.randn_like(t)
+            e = next(draws).to(t)
+            if tuple(e.shape) != tuple(t.shape):
+                raise ValueError(f"injected noise has shape {tuple(e.shape)}, expected {tuple(t.shape)}")
+            return e.contiguous()
+
+        with torch.inference_mode():
+            if y is not None:
+                warnings.warn("Moving y to device: {}".format(self.device))
+                y = dict_to(y, self.device)
+            x_orig = x_orig.to(self.device)
+            mask = mask.to(self.device)
+            shape = x_orig.shape
+            soft_mask = (self._create_soft_mask(mask, mask_falloff) if mask_falloff > 0 else mask).to(torch.float32).contiguous()
+            x_orig = self.initial_norm(x_orig.unsqueeze(0).contiguous())
+            if orig_noise is None:
+                x = torch.randn(nsamples, *shape).to(self.device)
+            else:
+                assert orig_noise.shape[0] == nsamples, "Number of samples must match"
+                assert orig_noise.shape[1:] == shape, "Shape of noise must match"
+                x = orig_noise.to(self.device)
+            c = self.config
+            ts = torch.linspace(1, 0, nsteps)
+            x = ops.scale(x.contiguous(), float(c.sigma_fn(ts[0])))
+            B = x.shape[0]
+
+            def blend(x, t):                              # (1 - m)*x + m*(alpha(t)*x_orig + sigma(t)*eps)
+                patch = ops.axpby(x_orig, float(c.alpha_fn(t)), randn_like(x_orig), float(c.sigma_fn(t)))
+                return ops.mask_blend(x, patch.expand(B, *shape).contiguous(), soft_mask)
+
+            for i in range(nsteps - 1):
+                t_curr, t_next = ts[i], ts[i + 1]
+                for r in range(resample_steps + 1):
+                    x = self._em_step(x, t_curr, t_next, y, guidance, integrate_on_sigma, randn_like)
+                    if t_next.item() <= mask_start_t:
+                        x = blend(x, t_next)
+                        if r < resample_steps and i + jump_length < nsteps - 1:
+                            # jump back to the current level: re-noise the sample, re-impose the known region
+                            x = ops.axpby(x, float(c.alpha_fn(t_curr)), randn_like(x), float(c.sigma_fn(t_curr)))
+                            x = blend(x, t_curr)
+            return self.initial_norm.unnorm(x)
+
+    def _em_step(self, x, tc, tn, y, guidance, integrate_on_sigma, randn_like):
+        """The Euler-Maruyama branch of integration_step (flowfield.py:783-793) with an injectable noise source."""
+        c = self.config
+        dt = float((c.sigma_fn(tn) - c.sigma_fn(tc)) if integrate_on_sigma else (tn - tc))
+        v = self.get_flow_field(x, tc, y=y, guidance=guidance, integrate_on_sigma=integrate_on_sigma)
+        score = self.get_score_field_from_flow_field(v, x, tc)
+        omega = c.sigma_fn(tc)
+        d = ops.axpby(v, 1.0, score, -float(0.5 * omega))
+        x = ops.axpby(x, 1.0, d, dt)
+        return ops.axpby(x, 1.0, randn_like(x), float(torch.sqrt(omega * abs(dt))))
+
+    @staticmethod
+    def _create_soft_mask(mask, falloff: int):
+        """flowfield.py:643-702: box-filtered mask / (itself + box-filtered complement), cosine-smoothed.  One-off
+        preprocessing of the mask with torch ops (2-D and 3-D masks; others are returned unchanged)."""
+        if falloff <= 0:
+            return mask
+        import numpy as np
+        import torch.nn.functional as F
+        ndim = mask.dim() - 1
+        m = mask.unsqueeze(0).float()
+        pool = {2: F.avg_pool2d, 3: F.avg_pool3d}.get(ndim)
+        if pool is None:
+            return mask
+        k, p = 2 * falloff + 1, falloff
+        m_dilated = pool(m, kernel_size=k, stride=1, padding=p)
+        m_eroded = pool(1 - m, kernel_size=k, stride=1, padding=p)
+        soft = m_dilated / (m_dilated + m_eroded + 1e-8)
+        soft = (1 - torch.cos(soft * np.pi)) / 2
+        return soft.squeeze(0)

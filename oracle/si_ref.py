@@ -7,6 +7,7 @@ Restates, in the reference's operation order, diffsci/models/karras/flowfield.py
   :460-481  get_score_field
   :503-544  sample (linspace(1, 0, nsteps), x * sigma(t0))
   :704-795  integrate_flow_field / integration_step (Heun, last step Euler)
+  :546-702  inpaint (Euler-Maruyama + re-imposed known region + jumps) and the soft mask
 """
 import numpy as np
 import torch
@@ -91,3 +92,51 @@ def integration_step(sch, kind, model, x, t_curr, t_next, method="euler", y=None
         return x + dt * v1
     v2 = flow_field(sch, kind, model, x + dt * v1, t_next, y, guidance)
     return x + dt * (v1 + v2) / 2
+
+
+def score_from_flow(sch, v, x, t):
+    """flowfield.py:483-501."""
+    alpha, sigma = _bcast(sch["alpha"](t), x), _bcast(sch["sigma"](t), x)
+    alpha_dot, sigma_dot = _bcast(sch["alpha_dot"](t), x), _bcast(sch["sigma_dot"](t), x)
+    return (alpha * v - alpha_dot * x) / (sigma * (alpha_dot * sigma - alpha * sigma_dot))
+
+
+def soft_mask(mask, falloff):
+    """flowfield.py:643-702 (2-D)."""
+    import torch.nn.functional as F
+    m = mask.unsqueeze(0).float()
+    k, p = 2 * falloff + 1, falloff
+    dil = F.avg_pool2d(m, kernel_size=k, stride=1, padding=p)
+    ero = F.avg_pool2d(1 - m, kernel_size=k, stride=1, padding=p)
+    s = dil / (dil + ero + 1e-8)
+    return ((1 - torch.cos(s * np.pi)) / 2).squeeze(0)
+
+
+def inpaint(sch, kind, model, x_orig, mask, orig_noise, nsteps, draws, norm_sigma=None, mask_falloff=0,
+            resample_steps=0, jump_length=1, mask_start_t=1.0):
+    """flowfield.py:546-641 with the loop's randn_like draws supplied in order (`draws`)."""
+    it = iter(draws)
+    sm = soft_mask(mask, mask_falloff) if mask_falloff > 0 else mask
+    xo = x_orig.unsqueeze(0)
+    if norm_sigma is not None:
+        xo = xo / norm_sigma
+    ts = torch.linspace(1, 0, nsteps).to(orig_noise)
+    x = orig_noise * sch["sigma"](ts[0])
+    for i in range(nsteps - 1):
+        t_curr = ts[i] * torch.ones(x.shape[0]).to(x)
+        t_next = ts[i + 1] * torch.ones(x.shape[0]).to(x)
+        for r in range(resample_steps + 1):
+            dt = _bcast(t_next - t_curr, x)
+            v = flow_field(sch, kind, model, x, t_curr)
+            sc = score_from_flow(sch, v, x, t_curr)
+            omega = _bcast(sch["sigma"](t_curr), x)
+            x = x + dt * (v - 0.5 * omega * sc)
+            x = x + torch.sqrt(omega * torch.abs(dt)) * next(it)
+            if ts[i + 1].item() <= mask_start_t:
+                sigma, alpha = _bcast(sch["sigma"](t_next), xo), _bcast(sch["alpha"](t_next), xo)
+                x = (1 - sm) * x + sm * (alpha * xo + sigma * next(it))
+                if r < resample_steps and i + jump_length < nsteps - 1:
+                    sj, aj = _bcast(sch["sigma"](ts[i]), x), _bcast(sch["alpha"](ts[i]), x)
+                    x = aj * x + sj * next(it)
+                    x = (1 - sm) * x + sm * (aj * xo + sj * next(it))
+    return x if norm_sigma is None else x * norm_sigma

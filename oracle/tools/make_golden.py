@@ -470,6 +470,36 @@ def si_latent():
     npz("si8_latent", **arrs)
 
 
+def si_inpaint():
+    """SIModule.inpaint (flowfield.py:546-702): Euler-Maruyama steps with the known region re-imposed at every noise
+    level, RePaint-style jumps, soft mask.  Every randn_like draw is recorded in order.  Network: punetg8_forward's."""
+    z = np.load(os.path.join(OUT, "punetg8_forward.npz"))
+    sd = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd/")}
+    net = M.nets.PUNetG(M.nets.PUNetGConfig(model_channels=8)).eval()
+    net.load_state_dict(sd)
+    torch.manual_seed(140)
+    x_orig = torch.randn(1, 32, 32) * 0.5
+    mask = torch.zeros(1, 32, 32)
+    mask[:, 8:24, 4:20] = 1.0
+    noise0 = torch.randn(2, 1, 32, 32)
+    arrs = dict(x_orig=x_orig, mask=mask, orig_noise=noise0)
+    import warnings
+    for tag, cfgkw, kw in (("hard", dict(scheduler="linear"), dict(nsteps=5)),
+                           ("soft_jump", dict(scheduler="cosine", precondition_fn="edm", initial_norm=2.0),
+                            dict(nsteps=5, mask_falloff=2, resample_steps=1, mask_start_t=0.8))):
+        mod = M.SIModule(M.SIModuleConfig(**cfgkw), net).eval()
+        with RandnRecorder() as rec, warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            out = mod.inpaint(x_orig, mask, nsamples=2, orig_noise=noise0, **kw)
+        arrs[tag + "_out"] = out
+        arrs[tag + "_ndraws"] = np.array(len(rec.draws))
+        for i, d in enumerate(rec.draws):
+            arrs[f"{tag}_eps{i:02d}"] = d
+        if kw.get("mask_falloff"):
+            arrs[tag + "_soft_mask"] = mod._create_soft_mask(mask, kw["mask_falloff"])
+    npz("si8_inpaint", **arrs)
+
+
 def porosity():
     """BASELINE config 5's shape of the path: 4-channel conditional PUNetG with the in-repo dict-style
     PorosityEmbedder (nets/embedder.py:198-229), classifier-free guidance, un-batched dict y."""
@@ -738,6 +768,6 @@ def latent():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["schedule", "toy", "punetg", "porosity", "inpaint", "vpve", "circular", "si", "punetgcond", "langevin", "adm", "variants", "latent", "adm_norms", "autoregressive", "si_latent"]
+    which = sys.argv[1:] or ["schedule", "toy", "punetg", "porosity", "inpaint", "vpve", "circular", "si", "punetgcond", "langevin", "adm", "variants", "latent", "adm_norms", "autoregressive", "si_latent", "si_inpaint"]
     for name in which:
         globals()[name]()

@@ -774,8 +774,28 @@ def test_si_flow_matching_sampler(M, dev):
     assert out.shape == noise.shape and torch.isfinite(out).all()
     with pytest.raises(NotImplementedError):
         M.SIModuleConfig(autonomous_flow=True)
-    with pytest.raises(NotImplementedError):
-        mod.inpaint()
+
+
+def test_si_inpaint(M, net8, dev):
+    """SIModule.inpaint (flowfield.py:546-702) with the reference's recorded noise draws injected in order."""
+    import warnings
+    v, _ = load("si8_inpaint")
+    cases = (("hard", dict(scheduler="linear"), dict(nsteps=5)),
+             ("soft_jump", dict(scheduler="cosine", precondition_fn="edm", initial_norm=2.0),
+              dict(nsteps=5, mask_falloff=2, resample_steps=1, mask_start_t=0.8)))
+    for tag, cfgkw, kw in cases:
+        mod = M.SIModule(M.SIModuleConfig(**cfgkw), net8).to(dev).eval()
+        draws = [v[f"{tag}_eps{i:02d}"] for i in range(int(v[tag + "_ndraws"]))]
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            out = mod.inpaint(v["x_orig"], v["mask"], nsamples=2, orig_noise=v["orig_noise"], noise=draws, **kw).cpu()
+            assert rel_l2(out, v[tag + "_out"]) < REL
+            if kw.get("mask_falloff"):
+                assert rel_l2(mod._create_soft_mask(v["mask"].to(dev), 2).cpu(), v[tag + "_soft_mask"]) < 1e-6
+            free = mod.inpaint(v["x_orig"], v["mask"], nsamples=2, **kw)          # device RNG: runs, stays finite
+            assert free.shape == (2, 1, 32, 32) and torch.isfinite(free).all()
+            with pytest.raises(StopIteration):
+                mod.inpaint(v["x_orig"], v["mask"], nsamples=2, orig_noise=v["orig_noise"], noise=draws[:2], **kw)
 
 
 def ops_scale(x, s):

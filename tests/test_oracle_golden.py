@@ -378,6 +378,29 @@ def test_si_latent_boundary_and_single_step():
     assert str(v["sd_keys"]) == "['initial_norm.running_mean' 'initial_norm.running_var']"
 
 
+def _inpaint_draws(v, tag):
+    return [v[f"{tag}_eps{i:02d}"] for i in range(int(v[tag + "_ndraws"]))]
+
+
+SI_INPAINT = (("hard", "linear", "identity", None, dict(nsteps=5)),
+              ("soft_jump", "cosine", "edm", 2.0, dict(nsteps=5, mask_falloff=2, resample_steps=1, mask_start_t=0.8)))
+
+
+def test_si_inpaint():
+    """SIModule.inpaint (flowfield.py:546-702) with the reference's recorded noise draws."""
+    from oracle import si_ref as S
+    v, _ = load("si8_inpaint")
+    _, sd = load("punetg8_forward")
+    base = punetg_ref.make_net(sd, punetg_ref.default_config(model_channels=8))
+    model = lambda x, t, y=None: base(x, t, y)                                  # noqa: E731
+    with torch.inference_mode():
+        assert_exact_or_ulp(S.soft_mask(v["mask"], 2), v["soft_jump_soft_mask"], "soft mask")
+        for tag, sname, kind, ns, kw in SI_INPAINT:
+            out = S.inpaint(S.scheduler(sname), kind, model, v["x_orig"], v["mask"], v["orig_noise"],
+                            draws=_inpaint_draws(v, tag), norm_sigma=ns, **kw)
+            assert_exact_or_rel(out, v[tag + "_out"], "inpaint " + tag, 2e-6)
+
+
 class TinyCondNet(torch.nn.Module):
     """The stand-in network of the autoreg8 fixture's cond_time = 3 case (oracle/tools/make_golden.py)."""
 
