@@ -61,6 +61,7 @@ _PROTOS = {
     "ds_gnorm1_table": (c_int, [_P, _P, c_int, c_int, _P, c_int, c_int, _P, _P, _P, _P, c_int, c_int, c_longlong,
                                 c_float, c_int, _P]),
     "ds_conv2d_direct": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "ds_conv3d_direct": (c_int, [_P, _P, _P, _P, _P, c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "ds_conv1x1_h3_packed_bytes": (c_size_t, [c_int, c_int]),
     "ds_conv1x1_h3_pack_weights": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     "ds_conv1x1_h3": (c_int, [_P, _P, _P, c_int, _P, _P, c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P]),

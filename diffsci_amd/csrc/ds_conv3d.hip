@@ -1,0 +1,188 @@
+// 3x3x3 'same' convolution for volumes [B, C, D, H, W] (PUNetG with dimension = 3: torch.nn.Conv3d / CircularConv3d /
+// MagnitudePreservingConv3d, commonlayers.py:25-160,973-1040, normedlayers.py:58-92), exact fp32 FMA chains on the
+// vector ALUs.  First, correctness-first version of the 3-D path: the 2-D networks' convolutions run on the matrix
+// cores (ds_conv3h.hip); volumes get there next.  Same fusions as the 2-D kernels so that the 3-D network never
+// materialises a pooled / upsampled tensor: MaxPool3d(2) or nearest x2 upsampling in the loader, zero or periodic
+// padding, bias / time shift / up to two residuals in the epilogue.
+//
+// Workgroup = 256 threads = a 4 x 8 x 8 (z, y, x) block of output voxels x 16 output channels.  Input channels are
+// walked four at a time: their 6 x 10 x 10 halo patches and the 4 x 27 x 16 weights are staged in LDS; every
+// thread then reads its 27 taps once per channel and reuses each across the 16 output channels (weights come
+// as 16-byte broadcast reads).
+#include "ds_common.h"
+
+namespace {
+
+constexpr int NT = 256;
+constexpr int TZ = 4, TY = 8, TX = 8;
+constexpr int PZ = TZ + 2, PY = TY + 2, PX = TX + 2;
+constexpr int PVOL = PZ * PY * PX;                  // 600 floats per channel
+constexpr int CO = 16, CC = 4;
+
+struct C3Args {
+  float* out;
+  const float* in;
+  const float* w;        // torch layout [Cout][Cin][3][3][3]
+  const float* bias;
+  const float* shift;
+  const float* res1;
+  const float* res2;
+  int shift_stride;
+  int B, Cin, Cout, D, H, W;      // output volume
+  int Di, Hi, Wi;                 // input volume (2x for MAXPOOL2, /2 for UPSAMPLE2)
+  int tiles_y, tiles_x;
+};
+
+__device__ __forceinline__ int wrap(int g, int n) {
+  g = g < 0 ? g + n : g;
+  return g >= n ? g - n : g;
+}
+
+template <int MODE, bool CIRC>
+__global__ __launch_bounds__(NT) void k_conv3d(const C3Args a) {
+  __shared__ __attribute__((aligned(16))) float patch[CC][PVOL];
+  __shared__ __attribute__((aligned(16))) float wts[CC][27][CO];
+  const int t = threadIdx.x;
+  const int tx = t & 7, ty = (t >> 3) & 7, tz = t >> 6;
+  int tile = blockIdx.x;
+  const int bx = tile % a.tiles_x; tile /= a.tiles_x;
+  const int by = tile % a.tiles_y;
+  const int bz = tile / a.tiles_y;
+  const int x0 = bx * TX, y0 = by * TY, z0 = bz * TZ;
+  const int co0 = blockIdx.y * CO;
+  const int b = blockIdx.z;
+  const size_t in_plane = (size_t)a.Di * a.Hi * a.Wi;
+  const float* in_b = a.in + (size_t)b * a.Cin * in_plane;
+
+  float acc[CO];
+#pragma unroll
+  for (int k = 0; k < CO; ++k) acc[k] = 0.f;
+
+  for (int c0 = 0; c0 < a.Cin; c0 += CC) {
+    // ---- stage the halo patches of up to CC input channels ----
+    for (int i = t; i < CC * PVOL; i += NT) {
+      const int c = i / PVOL;
+      int r = i - c * PVOL;
+      const int pz = r / (PY * PX); r -= pz * (PY * PX);
+      const int py = r / PX;
+      const int px = r - py * PX;
+      int gz = z0 + pz - 1, gy = y0 + py - 1, gx = x0 + px - 1;
+      float v = 0.f;
+      if (c0 + c < a.Cin) {
+        if (CIRC) {
+          // a ragged tile may reach more than one voxel past the volume: those positions only feed outputs that are
+          // never stored; clamp after the single wrap
+          gz = wrap(gz, a.D); gy = wrap(gy, a.H); gx = wrap(gx, a.W);
+          gz = gz >= a.D ? a.D - 1 : gz; gy = gy >= a.H ? a.H - 1 : gy; gx = gx >= a.W ? a.W - 1 : gx;
+        }
+        if (gz >= 0 && gz < a.D && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
+          const float* p = in_b + (size_t)(c0 + c) * in_plane;
+          if (MODE == DS_LOAD_PLAIN) {
+            v = p[((size_t)gz * a.Hi + gy) * a.Wi + gx];
+          } else if (MODE == DS_LOAD_UPSAMPLE2) {
+            v = p[((size_t)(gz >> 1) * a.Hi + (gy >> 1)) * a.Wi + (gx >> 1)];
+          } else {                                            // MaxPool3d(2): 2 x 2 x 2 window
+            const float* q = p + ((size_t)(2 * gz) * a.Hi + 2 * gy) * a.Wi + 2 * gx;
+            const size_t sz = (size_t)a.Hi * a.Wi;
+            float m0 = fmaxf(fmaxf(q[0], q[1]), fmaxf(q[a.Wi], q[a.Wi + 1]));
+            float m1 = fmaxf(fmaxf(q[sz], q[sz + 1]), fmaxf(q[sz + a.Wi], q[sz + a.Wi + 1]));
+            v = fmaxf(m0, m1);
+          }
+        }
+      }
+      patch[c][(pz * PY + py) * PX + px] = v;
+    }
+    // ---- stage the weights [c][tap][co] ----
+    for (int i = t; i < CC * 27 * CO; i += NT) {
+      const int co = i / (CC * 27);
+      const int r = i - co * (CC * 27);
+      const int c = r / 27, tap = r - c * 27;
+      float v = 0.f;
+      if (co0 + co < a.Cout && c0 + c < a.Cin) v = a.w[((size_t)(co0 + co) * a.Cin + c0 + c) * 27 + tap];
+      wts[c][tap][co] = v;
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int c = 0; c < CC; ++c) {
+#pragma unroll
+      for (int dz = 0; dz < 3; ++dz)
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+          for (int dx = 0; dx < 3; ++dx) {
+            const float v = patch[c][((tz + dz) * PY + ty + dy) * PX + tx + dx];
+            const float4* wv = reinterpret_cast<const float4*>(&wts[c][(dz * 3 + dy) * 3 + dx][0]);
+#pragma unroll
+            for (int q = 0; q < CO / 4; ++q) {
+              const float4 w4 = wv[q];
+              acc[4 * q + 0] = __builtin_fmaf(v, w4.x, acc[4 * q + 0]);
+              acc[4 * q + 1] = __builtin_fmaf(v, w4.y, acc[4 * q + 1]);
+              acc[4 * q + 2] = __builtin_fmaf(v, w4.z, acc[4 * q + 2]);
+              acc[4 * q + 3] = __builtin_fmaf(v, w4.w, acc[4 * q + 3]);
+            }
+          }
+    }
+    __syncthreads();
+  }
+
+  const int gz = z0 + tz, gy = y0 + ty, gx = x0 + tx;
+  if (gz >= a.D || gy >= a.H || gx >= a.W) return;
+  const size_t plane = (size_t)a.D * a.H * a.W;
+  const size_t vox = ((size_t)gz * a.H + gy) * a.W + gx;
+#pragma unroll
+  for (int k = 0; k < CO; ++k) {
+    const int co = co0 + k;
+    if (co >= a.Cout) break;
+    const size_t idx = ((size_t)b * a.Cout + co) * plane + vox;
+    float v = acc[k];
+    v = v + (a.bias ? a.bias[co] : 0.f);
+    v = v + (a.shift ? a.shift[(size_t)b * a.shift_stride + co] : 0.f);
+    if (a.res1) v = v + a.res1[idx];
+    if (a.res2) v = v + a.res2[idx];
+    a.out[idx] = v;
+  }
+}
+
+template <int MODE>
+int launch3d(const C3Args& a, bool circ, hipStream_t s) {
+  const long long tiles = (long long)((a.D + TZ - 1) / TZ) * a.tiles_y * a.tiles_x;
+  const int cots = (a.Cout + CO - 1) / CO;
+  DS_REQUIRE(tiles < (1ll << 31) && cots < 65536 && a.B < 65536, DS_ERR_SHAPE, "ds_conv3d_direct: grid too large");
+  dim3 g((unsigned)tiles, (unsigned)cots, (unsigned)a.B);
+  if (circ) hipLaunchKernelGGL((k_conv3d<MODE, true>), g, dim3(NT), 0, s, a);
+  else hipLaunchKernelGGL((k_conv3d<MODE, false>), g, dim3(NT), 0, s, a);
+  DS_CHECK_LAUNCH("ds_conv3d_direct");
+  return DS_OK;
+}
+
+}  // namespace
+
+extern "C" int ds_conv3d_direct(float* out, const float* in, const float* w, const float* bias, const float* shift,
+                                int shift_stride, const float* res1, const float* res2, int B, int Cin, int Cout, int D,
+                                int H, int W, int load_mode, void* stream) {
+  DS_REQUIRE(out && in && w, DS_ERR_NULL, "ds_conv3d_direct: NULL pointer");
+  DS_REQUIRE(B >= 0 && Cin > 0 && Cout > 0 && D > 0 && H > 0 && W > 0, DS_ERR_SHAPE,
+             "ds_conv3d_direct: bad shape B=%d Cin=%d Cout=%d D=%d H=%d W=%d", B, Cin, Cout, D, H, W);
+  const bool circ = (load_mode & DS_PAD_CIRCULAR) != 0;
+  load_mode &= ~DS_PAD_CIRCULAR;
+  DS_REQUIRE(load_mode == DS_LOAD_PLAIN || load_mode == DS_LOAD_MAXPOOL2 || load_mode == DS_LOAD_UPSAMPLE2,
+             DS_ERR_UNSUPPORTED, "ds_conv3d_direct: load_mode %d", load_mode);
+  DS_REQUIRE(load_mode != DS_LOAD_UPSAMPLE2 || (D % 2 == 0 && H % 2 == 0 && W % 2 == 0), DS_ERR_SHAPE,
+             "ds_conv3d_direct: UPSAMPLE2 needs an even output volume (got %d x %d x %d)", D, H, W);
+  DS_REQUIRE(shift == nullptr || shift_stride == 0 || shift_stride >= Cout, DS_ERR_SHAPE,
+             "ds_conv3d_direct: shift_stride %d < Cout %d", shift_stride, Cout);
+  if (B == 0) return DS_OK;
+  C3Args a;
+  a.out = out; a.in = in; a.w = w; a.bias = bias; a.shift = shift; a.res1 = res1; a.res2 = res2;
+  a.shift_stride = shift_stride;
+  a.B = B; a.Cin = Cin; a.Cout = Cout; a.D = D; a.H = H; a.W = W;
+  const int f2 = load_mode == DS_LOAD_MAXPOOL2 ? 2 : 1;
+  a.Di = load_mode == DS_LOAD_UPSAMPLE2 ? D / 2 : D * f2;
+  a.Hi = load_mode == DS_LOAD_UPSAMPLE2 ? H / 2 : H * f2;
+  a.Wi = load_mode == DS_LOAD_UPSAMPLE2 ? W / 2 : W * f2;
+  a.tiles_y = (H + TY - 1) / TY; a.tiles_x = (W + TX - 1) / TX;
+  hipStream_t s = ds::as_stream(stream);
+  if (load_mode == DS_LOAD_PLAIN) return launch3d<DS_LOAD_PLAIN>(a, circ, s);
+  if (load_mode == DS_LOAD_MAXPOOL2) return launch3d<DS_LOAD_MAXPOOL2>(a, circ, s);
+  return launch3d<DS_LOAD_UPSAMPLE2>(a, circ, s);
+}

@@ -58,9 +58,9 @@ class _MPConv(torch.nn.Module):
     """MagnitudePreservingConv2d parameters (normedlayers.py:26-44): N(0,1) weight, zero bias."""
     mp = True
 
-    def __init__(self, cin, cout, k, bias=True):
+    def __init__(self, cin, cout, k, bias=True, dim=2):
         super().__init__()
-        self.weight = torch.nn.Parameter(torch.randn(cout, cin, k, k))
+        self.weight = torch.nn.Parameter(torch.randn(cout, cin, *([k] * dim)))
         self.bias = torch.nn.Parameter(torch.zeros(cout)) if bias else None
         self.in_channels, self.out_channels = cin, cout
 
@@ -121,11 +121,11 @@ class _TimeBlock(torch.nn.Module):
 
 
 class _CircConv(torch.nn.Module):
-    """CircularConv2d parameters (commonlayers.py:918-971): the weights live one level down, in .conv."""
+    """CircularConv2d / CircularConv3d parameters (commonlayers.py:918-1040): the weights live one level down, in .conv."""
 
-    def __init__(self, cin, cout, k, bias=True):
+    def __init__(self, cin, cout, k, bias=True, dim=2):
         super().__init__()
-        self.conv = torch.nn.Conv2d(cin, cout, k, bias=bias)
+        self.conv = (torch.nn.Conv3d if dim == 3 else torch.nn.Conv2d)(cin, cout, k, bias=bias)
         self.in_channels, self.out_channels = cin, cout
 
     @property
@@ -137,31 +137,31 @@ class _CircConv(torch.nn.Module):
         return self.conv.bias
 
 
-def make_conv(cin, cout, k, kind="default", bias=True):
-    """choose_conv_cls (punetg.py:217-236): kind = convolution_type ("default" | "circular" | "mp")."""
+def make_conv(cin, cout, k, kind="default", bias=True, dim=2):
+    """choose_conv_cls (punetg.py:217-236): kind = convolution_type ("default" | "circular" | "mp"), dim 2 or 3."""
     if kind is True or kind == "circular":
-        return _CircConv(cin, cout, k, bias)
+        return _CircConv(cin, cout, k, bias, dim)
     if kind == "mp":
-        return _MPConv(cin, cout, k, bias)
-    return torch.nn.Conv2d(cin, cout, k, padding="same", bias=bias)
+        return _MPConv(cin, cout, k, bias, dim)
+    return (torch.nn.Conv3d if dim == 3 else torch.nn.Conv2d)(cin, cout, k, padding="same", bias=bias)
 
 
 class _ResBlock(torch.nn.Module):
     """ResnetBlockC parameters (commonlayers.py:766-807)."""
 
-    def __init__(self, C, embed, conv_kind="default", bias=True, norms=("GroupLN", "GroupRMS"), affine=True):
+    def __init__(self, C, embed, conv_kind="default", bias=True, norms=("GroupLN", "GroupRMS"), affine=True, dim=2):
         super().__init__()
         self.gnorm1 = make_norm(norms[0], C, affine)
         self.gnorm2 = make_norm(norms[1], C, affine)
-        self.conv1 = make_conv(C, C, 3, conv_kind, bias)
-        self.conv2 = make_conv(C, C, 3, conv_kind, bias)
+        self.conv1 = make_conv(C, C, 3, conv_kind, bias, dim)
+        self.conv2 = make_conv(C, C, 3, conv_kind, bias, dim)
         self.timeblock = _TimeBlock(embed, C, mp=conv_kind == "mp")
 
 
 class _Sampler(torch.nn.Module):
-    def __init__(self, cin, cout, conv_kind="default", bias=True):
+    def __init__(self, cin, cout, conv_kind="default", bias=True, dim=2):
         super().__init__()
-        self.conv = make_conv(cin, cout, 3, conv_kind, bias)
+        self.conv = make_conv(cin, cout, 3, conv_kind, bias, dim)
 
 
 class _Attn(torch.nn.Module):
@@ -249,21 +249,22 @@ class PUNetG(torch.nn.Module):
         norms = (config.first_resblock_norm, config.second_resblock_norm)
         self.norm_kinds = tuple(NORM_KINDS.get(n, 2) for n in norms)
         # bias=False: no convolution biases; a constant-one input channel is appended instead (punetg.py:190-191,390-394)
-        self.convin = make_conv(config.input_channels + (0 if hb else 1), mc, 3, circ, hb)
-        self.convout = make_conv(mc, config.output_channels, 3, circ, hb)
+        dim = self.dim = config.dimension
+        self.convin = make_conv(config.input_channels + (0 if hb else 1), mc, 3, circ, hb, dim)
+        self.convout = make_conv(mc, config.output_channels, 3, circ, hb, dim)
 
         def blocks(m, n):
-            return torch.nn.ModuleList([_ResBlock(m * mc, mc, circ, hb, norms, bool(config.affine_norm)) for _ in range(n)])
+            return torch.nn.ModuleList([_ResBlock(m * mc, mc, circ, hb, norms, bool(config.affine_norm), dim) for _ in range(n)])
 
         self.downward_blocks = torch.nn.ModuleList(
             [blocks(mult[i], config.number_resnet_downward_block) for i in range(len(mult) - 1)])
         self.downsamplers = torch.nn.ModuleList(
-            [_Sampler(mult[i] * mc, mult[i + 1] * mc, circ, hb) for i in range(len(mult) - 1)])
+            [_Sampler(mult[i] * mc, mult[i + 1] * mc, circ, hb, dim) for i in range(len(mult) - 1)])
         rmult = list(reversed(mult))
         self.upward_blocks = torch.nn.ModuleList(
             [blocks(rmult[i + 1], config.number_resnet_upward_block) for i in range(len(mult) - 1)])
         self.upsamplers = torch.nn.ModuleList(
-            [_Sampler(rmult[i] * mc, rmult[i + 1] * mc, circ, hb) for i in range(len(mult) - 1)])
+            [_Sampler(rmult[i] * mc, rmult[i + 1] * mc, circ, hb, dim) for i in range(len(mult) - 1)])
         self.before_block = blocks(mult[-1], config.number_resnet_before_attn_block)
         self.after_block = blocks(mult[-1], config.number_resnet_after_attn_block)
         self.attn_resnet_block = blocks(mult[-1], config.number_resnet_attn_block)
@@ -363,6 +364,8 @@ class PUNetG(torch.nn.Module):
 
     def _run_blocks(self, x, te, resnet_block, attn_block=()):
         """-> (tensor, stats, owned): owned tensors are workspace buffers the caller must clone and give back."""
+        if self.dim != 2:
+            raise NotImplementedError("the public stage methods are implemented for 2-D networks")
         pk, ws = self.packed_weights(), self._ws
         h, hs, own = x, None, False
         for i, blk in enumerate(resnet_block):
@@ -460,7 +463,8 @@ class PUNetG(torch.nn.Module):
                 if getattr(m, "mp", False):
                     w = mp_weight(w)
                     pk[(id(m), "eff")] = w                         # the direct output-layer kernel takes the raw layout
-                pk[id(m)] = ops.pack_conv(w, self.conv_precision, upsampled=id(m) in ups)
+                if self.dim == 2:                                  # volumes: ds_conv3d_direct reads the torch layout
+                    pk[id(m)] = ops.pack_conv(w, self.conv_precision, upsampled=id(m) in ups)
             prec = "fp16x3" if self.conv_precision == "fp16x3" else "fp32"
             for a in self.attn_block:
                 E = a.mhattn.embed_dim
@@ -529,6 +533,8 @@ class PUNetG(torch.nn.Module):
         shared by the whole batch (sampling: sigma is a per-step constant), row=None means one row
         per sample (M == B).  Every activation travels with the tile statistics its producer left."""
         require_eval(self, self.config.dropout, self.config.cond_dropout, self.config.cond_drop)
+        if self.dim == 3:
+            return self._forward3d(x, shifts, row=row, out=out)
         pk = self.packed_weights()
         ws = self._ws
         cfg = self.config
@@ -620,6 +626,74 @@ class PUNetG(torch.nn.Module):
         y = self._out_conv(self.convout, h, pk, out, self.circular)
         give(h, hs)
         return y
+
+    # ------------------------------------------------------------------ volumes (dimension = 3)
+    def _forward3d(self, x, shifts, row=None, out=None):
+        """The same network on [B, C, D, H, W] volumes (punetg.py:217-236,389-416 with Conv3d / MaxPool3d /
+        Upsample / ThreeDimensionalAttention): exact-fp32 ds_conv3d_direct convolutions with the pooling / upsampling /
+        skip / residual / time-shift fusions of the 2-D path, standalone per-(sample, channel) norms over D*H*W,
+        attention over the flattened voxels.  Eager launches (the captured-loop planner handles 4-D fields)."""
+        if x.dim() != 5:
+            raise ValueError("a dimension=3 network takes [B, C, D, H, W] volumes")
+        pk = self.packed_weights()
+        cfg = self.config
+        B, dev = x.shape[0], x.device
+        it = iter(range(len(shifts)))
+        k1, k2 = self.norm_kinds
+
+        def sh():
+            s = shifts[next(it)]
+            if row is not None:
+                return s[row:row + 1]
+            if s.shape[0] not in (1, B):
+                raise ValueError("time embedding batch does not match x")
+            return s
+
+        def conv(m, h, **kw):
+            return ops.conv3d(h, pk.get((id(m), "eff"), m.weight), bias=m.bias, circular=self.circular, **kw)
+
+        def res(blk, h, res2=None):                                               # ResnetBlockC.forward
+            w1, b1 = getattr(blk.gnorm1, "weight", None), getattr(blk.gnorm1, "bias", None)
+            w2, b2 = getattr(blk.gnorm2, "weight", None), getattr(blk.gnorm2, "bias", None)
+            a = ops.inorm_silu(h, w1, b1, kind=k1, eps=1e-5)
+            y = conv(blk.conv1, a, shift=sh())
+            ops.inorm_silu(y, w2, b2, kind=k2, eps=1e-5, out=a)
+            return conv(blk.conv2, a, res1=h, res2=res2, out=y)
+
+        def attn(att, h, res2=None):                                              # ThreeDimensionalAttention
+            Bq, E, D, H, W = h.shape
+            r2 = None if res2 is None else res2.reshape(Bq, E, D * H, W)
+            y = self._attention(att, h.reshape(Bq, E, D * H, W), pk, self._ws, res2=r2)
+            out3 = y.reshape(Bq, E, D, H, W).clone()
+            self._ws.give(y)
+            return out3
+
+        if not cfg.bias:                                                          # punetg.py:390-394
+            x = torch.cat([x, torch.ones_like(x[:, :1])], dim=1)
+        h = conv(self.convin, x.contiguous())
+        skips = []
+        for lv, blocks in enumerate(self.downward_blocks):
+            for blk in blocks:
+                h = res(blk, h)
+            skips.append(h)
+            h = conv(self.downsamplers[lv].conv, h, load_mode=DS_LOAD_MAXPOOL2)
+        for blk in self.before_block:
+            h = res(blk, h)
+        xa = h
+        nattn = len(self.attn_resnet_block)
+        for i, blk in enumerate(self.attn_resnet_block):
+            last = i == nattn - 1
+            xa = res(blk, xa, res2=h if (last and i >= len(self.attn_block)) else None)
+            if i < len(self.attn_block):
+                xa = attn(self.attn_block[i], xa, res2=h if last else None)
+        h = xa if nattn else ops.add(h, h)
+        for blk in self.after_block:
+            h = res(blk, h)
+        for lv, blocks in enumerate(self.upward_blocks):
+            h = conv(self.upsamplers[lv].conv, h, load_mode=DS_LOAD_UPSAMPLE2, res1=skips.pop())
+            for blk in blocks:
+                h = res(blk, h)
+        return conv(self.convout, h, out=out)
 
     def _attention(self, att, x, pk, ws, res2=None, tile_stats=None):
         """TwoDimensionalAttention.forward (attention.py:67-72,82-90), channel-major throughout."""

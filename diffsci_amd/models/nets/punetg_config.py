@@ -55,7 +55,7 @@ class PUNetGConfig(object):
     def unsupported_reason(self):
         """None if the HIP path implements this configuration, else why not."""
         checks = [
-            (self.dimension == 2, "only 2-D fields (dimension=2)"),
+            (self.dimension in (2, 3), "2-D fields or 3-D volumes (dimension 2 or 3)"),
             (self.convolution_type in ("default", "circular", "mp"), "convolution_type 'default', 'circular' or 'mp'"),
             (self.kernel_size == 3 and self.in_out_kernel_size == 3 and self.transition_kernel_size == 3,
              "3x3 kernels"),

@@ -171,6 +171,42 @@ def inorm_silu(x, w, b, kind, eps=1e-5, out=None):
     return out
 
 
+def conv3d(x, w, bias=None, shift=None, res1=None, res2=None, load_mode=N.DS_LOAD_PLAIN, circular=False, out=None):
+    """3x3x3 'same' convolution of a volume [B, Cin, Di, Hi, Wi] with raw torch weights [Cout, Cin, 3, 3, 3], exact
+    fp32; MaxPool3d(2) / nearest x2 upsampling fused in the loader; shift [1 or B, Cout]."""
+    require_device(x, "x")
+    B, Cin, Di, Hi, Wi = x.shape
+    Cout = w.shape[0]
+    if tuple(w.shape) != (Cout, Cin, 3, 3, 3):
+        raise ValueError(f"conv3d: weight must be [Cout, {Cin}, 3, 3, 3]; got {tuple(w.shape)}")
+    if load_mode == N.DS_LOAD_MAXPOOL2:
+        if Di % 2 or Hi % 2 or Wi % 2:
+            raise ValueError("pooling load needs an even input volume")
+        D, H, W = Di // 2, Hi // 2, Wi // 2
+    elif load_mode == N.DS_LOAD_UPSAMPLE2:
+        D, H, W = 2 * Di, 2 * Hi, 2 * Wi
+    else:
+        D, H, W = Di, Hi, Wi
+    if out is None:
+        out = torch.empty((B, Cout, D, H, W), dtype=torch.float32, device=x.device)
+    elif tuple(out.shape) != (B, Cout, D, H, W):
+        raise ValueError(f"out has shape {tuple(out.shape)}, expected {(B, Cout, D, H, W)}")
+    stride = 0
+    if shift is not None:
+        if shift.dim() != 2 or shift.shape[1] != Cout or shift.shape[0] not in (1, B):
+            raise ValueError(f"shift must be [1 or B, Cout]; got {tuple(shift.shape)}")
+        stride = 0 if shift.shape[0] == 1 else Cout
+    for r in (res1, res2):
+        if r is not None and tuple(r.shape) != (B, Cout, D, H, W):
+            raise ValueError("residual shape mismatch")
+    if bias is not None and bias.numel() != Cout:
+        raise ValueError("bias must have Cout entries")
+    N.check(N.lib().ds_conv3d_direct(_p(out), _p(x.contiguous()), _p(w.contiguous()), _p(bias), _p(shift), stride, _p(res1),
+                                     _p(res2), B, Cin, Cout, D, H, W,
+                                     load_mode | (N.DS_PAD_CIRCULAR if circular else 0), _stream()), "ds_conv3d_direct")
+    return out
+
+
 def gnorm1_stats(x, kind, eps=1e-5, stats=None, workspace=None):
     """Per-sample (mean, rstd) [kind 0] or (0, rms denominator) [kind 1] over (C, H, W)."""
     B, C = x.shape[0], x.shape[1]

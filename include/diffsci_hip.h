@@ -226,6 +226,15 @@ int ds_gnorm1_table(float* table, const float* stats_a, int Ca, int ntiles_a, co
 int ds_conv2d_direct(float* out, const float* in, const float* w, const float* bias, int B, int Cin, int Cout,
                      int H, int W, int circular, void* stream);
 
+/* 3x3x3 'same' convolution of volumes [B,Cin,D,H,W] -> [B,Cout,D,H,W] (PUNetG dimension = 3: Conv3d, CircularConv3d,
+ * MagnitudePreservingConv3d -- commonlayers.py:25-160,973-1040; normedlayers.py:58-92), exact fp32, torch weight
+ * layout [Cout,Cin,3,3,3].  load_mode: DS_LOAD_PLAIN, DS_LOAD_MAXPOOL2 (in is [B,Cin,2D,2H,2W]: DownSampler's
+ * MaxPool3d(2) in the loader) or DS_LOAD_UPSAMPLE2 (in is [B,Cin,D/2,H/2,W/2]: UpSampler's nearest x2), optionally
+ * OR-ed with DS_PAD_CIRCULAR.  out = (((conv + bias[co]) + shift[b,co]) + res1) + res2. */
+int ds_conv3d_direct(float* out, const float* in, const float* w, const float* bias, const float* shift,
+                     int shift_stride, const float* res1, const float* res2, int B, int Cin, int Cout, int D, int H,
+                     int W, int load_mode, void* stream);
+
 /* 1x1 convolution in the fp16x3 scheme of ds_conv2d_h3 (same epilogue terms, same domain
  * |in| < 65504).  ADM's residual projection convresidual(resample(x)) (adm.py:345-349) with the
  * resampling folded into the load: load_mode PLAIN, UPSAMPLE2 (nearest x2, in is [B,Cin,H/2,W/2])

@@ -68,16 +68,22 @@ def conv3x3(sd, name, x, circular=False):
     """torch.nn.Conv2d(padding='same'), or CircularConv2d (commonlayers.py:918-971: F.pad circular in W,
     then in H, then an unpadded convolution; parameters one level down, in `<name>.conv`), or -- circular ==
     "mp" -- MagnitudePreservingConv2d (normedlayers.py:26-55)."""
+    conv = F.conv3d if x.dim() == 5 else F.conv2d            # dimension = 3: Conv3d / CircularConv3d (:973-1034)
     if circular == "mp":
-        return F.conv2d(x, mp_effective(sd[name + ".weight"]), sd.get(name + ".bias"), padding="same")
+        return conv(x, mp_effective(sd[name + ".weight"]), sd.get(name + ".bias"), padding="same")
     if circular:
-        x = F.pad(x, (1, 1, 0, 0), mode="circular")
-        x = F.pad(x, (0, 0, 1, 1), mode="circular")
-        return F.conv2d(x, sd[name + ".conv.weight"], sd.get(name + ".conv.bias"))
-    return F.conv2d(x, sd[name + ".weight"], sd.get(name + ".bias"), padding="same")      # bias=False: no bias keys
+        if x.dim() == 5:                                     # W, then H, then D
+            x = F.pad(x, (1, 1, 0, 0, 0, 0), mode="circular")
+            x = F.pad(x, (0, 0, 1, 1, 0, 0), mode="circular")
+            x = F.pad(x, (0, 0, 0, 0, 1, 1), mode="circular")
+        else:
+            x = F.pad(x, (1, 1, 0, 0), mode="circular")
+            x = F.pad(x, (0, 0, 1, 1), mode="circular")
+        return conv(x, sd[name + ".conv.weight"], sd.get(name + ".conv.bias"))
+    return conv(x, sd[name + ".weight"], sd.get(name + ".bias"), padding="same")      # bias=False: no bias keys
 
 
-def time_shift(sd, prefix, te, mp=False):
+def time_shift(sd, prefix, te, mp=False, ndim=2):
     """ResnetTimeBlock: Linear-SiLU-Linear-SiLU-Linear, commonlayers.py:512-522,546-549 (magnitude-preserving
     linears when mp)."""
     def w(i):
@@ -88,7 +94,7 @@ def time_shift(sd, prefix, te, mp=False):
     h = F.linear(h, w(2), sd[prefix + "net.2.bias"])
     h = F.silu(h)
     h = F.linear(h, w(4), sd[prefix + "net.4.bias"])
-    return h.view(*h.shape, 1, 1)
+    return h.view(*h.shape, *([1] * ndim))
 
 
 def block_norm(kind, sd, prefix, x):
@@ -115,7 +121,7 @@ def resnet_block(sd, prefix, x, te, circular=False, norms=("GroupLN", "GroupRMS"
     """ResnetBlockC.forward, commonlayers.py:824-833."""
     h = block_norm(norms[0], sd, prefix + "gnorm1.", x)
     y = conv3x3(sd, prefix + "conv1", F.silu(h), circular)
-    y = y + time_shift(sd, prefix + "timeblock.", te, mp=circular == "mp")
+    y = y + time_shift(sd, prefix + "timeblock.", te, mp=circular == "mp", ndim=x.dim() - 2)   # [B, C, 1, 1(, 1)]
     h = block_norm(norms[1], sd, prefix + "gnorm2.", y)
     y = conv3x3(sd, prefix + "conv2", F.silu(h), circular)
     return y + x
@@ -125,6 +131,10 @@ def mp_attention_2d(sd, prefix, x, attn_residual=False, magnitude_preserving=Tru
     """TwoDimensionalAttention around the in-house MultiHeadAttention(1 head, dk = dv = C), attention.py:29-52,
     156-247: 'dot' (250-296) or 'cosine' (300-372) logits; weights renormalised only when magnitude preserving,
     always divided by sqrt(fan_in)."""
+    if x.dim() == 5:
+        Bv, Cv, Dv, Hv, Wv = x.shape
+        return mp_attention_2d(sd, prefix, x.reshape(Bv, Cv, Dv * Hv, Wv), attn_residual, magnitude_preserving,
+                               cosine).reshape(x.shape)
     B, C, Hh, Ww = x.shape
     xr = x.permute(0, 2, 3, 1).reshape(B, Hh * Ww, C)
     ws = []
@@ -155,6 +165,9 @@ def mp_attention_2d(sd, prefix, x, attn_residual=False, magnitude_preserving=Tru
 
 def attention_2d(sd, prefix, x, attn_residual=False):
     """TwoDimensionalAttention (attention.py:67-90) around nn.MultiheadAttention(E, 1 head)."""
+    if x.dim() == 5:                                     # ThreeDimensionalAttention (attention.py:93-102): flatten the voxels
+        Bv, Cv, Dv, Hv, Wv = x.shape
+        return attention_2d(sd, prefix, x.reshape(Bv, Cv, Dv * Hv, Wv), attn_residual).reshape(x.shape)
     B, C, Hh, Ww = x.shape
     xr = x.permute(0, 2, 3, 1).reshape(B, Hh * Ww, C)   # 'b c w h -> b (w h) c'
     out, _ = F.multi_head_attention_forward(
@@ -188,7 +201,7 @@ def punetg_forward(sd, cfg, x, t, ye=None):
         for r in range(cfg["number_resnet_downward_block"]):
             x = resnet_block(sd, f"downward_blocks.{lv}.{r}.", x, te, circ, norms)
         skips.append(x)
-        x = conv3x3(sd, f"downsamplers.{lv}.conv", F.max_pool2d(x, 2), circ)
+        x = conv3x3(sd, f"downsamplers.{lv}.conv", (F.max_pool3d if x.dim() == 5 else F.max_pool2d)(x, 2), circ)
     for r in range(cfg["number_resnet_before_attn_block"]):         # bottom, punetg.py:378-387
         x = resnet_block(sd, f"before_block.{r}.", x, te, circ, norms)
     xa = x

@@ -707,6 +707,41 @@ class TinyCondNet(torch.nn.Module):
         return self.gain * x + (f * wts).sum(dim=1) + 0.1 * t.view(-1, 1, 1, 1)
 
 
+def volumes():
+    """PUNetG with dimension = 3 (Conv3d / MaxPool3d / Upsample / ThreeDimensionalAttention), default
+    and circular convolutions, 16^3 volumes."""
+    for i, (tag, over) in enumerate((("3d", {}), ("3d_circular", dict(convolution_type="circular")))):
+        torch.manual_seed(150 + i)
+        cfg = M.nets.PUNetGConfig(model_channels=8, dimension=3, **over)
+        net = M.nets.PUNetG(cfg).eval()
+        with torch.no_grad():
+            for k, v in net.state_dict().items():
+                if "gnorm" in k or k.endswith("in_proj_bias") or k.endswith("out_proj.bias"):
+                    v.add_(0.25 * torch.randn_like(v))
+        sd = net.state_dict()
+        torch.manual_seed(160 + i)
+        x = torch.randn(2, 1, 16, 16, 16)
+        t = torch.tensor([0.3, -1.1])
+        arrs = dict(sd_arrays(sd), x=x, t=t)
+        with torch.inference_mode():
+            arrs["out_f32"] = net(x, t)
+            h = net.convin(x)
+            arrs["convin"] = h
+            arrs["down0"] = net.downsamplers[0](h)
+            arrs["up1"] = net.upsamplers[1](arrs["down0"])
+            arrs["resblock"] = net.downward_blocks[0][0](h, net.time_projection(t))
+        net64 = M.nets.PUNetG(cfg).double().eval()
+        net64.load_state_dict({k: v.double() for k, v in sd.items()})
+        with torch.inference_mode():
+            arrs["out_f64"] = net64(x.double(), t.double())
+        if tag == "3d":
+            module = M.KarrasModule(net, M.KarrasModuleConfig.from_edm()).eval()
+            wn = torch.randn(2, 1, 16, 16, 16)
+            arrs["white_noise"] = wn
+            arrs["hist_heun_N4_f32"] = module.propagate_white_noise(wn, nsteps=4, record_history=True)
+        npz(f"punetg8_{tag}", **arrs)
+
+
 class ToyAutoencoder(torch.nn.Module):
     """Parameter-free stand-in for a latent autoencoder (ours, not the reference's): 2x2 pixel-unshuffle with a gain.
     tests/test_gpu_sampler.py defines the same three lines."""
@@ -768,6 +803,6 @@ def latent():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["schedule", "toy", "punetg", "porosity", "inpaint", "vpve", "circular", "si", "punetgcond", "langevin", "adm", "variants", "latent", "adm_norms", "autoregressive", "si_latent", "si_inpaint"]
+    which = sys.argv[1:] or ["schedule", "toy", "punetg", "porosity", "inpaint", "vpve", "circular", "si", "punetgcond", "langevin", "adm", "variants", "latent", "adm_norms", "autoregressive", "si_latent", "si_inpaint", "volumes"]
     for name in which:
         globals()[name]()

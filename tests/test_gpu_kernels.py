@@ -603,3 +603,40 @@ def test_graph_capture_refuses_allocations(dev):
             with ops.Graph():
                 ops.scale(x, 3.0)                    # allocates its result inside the capture
     torch.cuda.current_stream(dev).wait_stream(side)
+
+
+@pytest.mark.parametrize("case", [
+    # B, Cin, Cout, D, H, W, mode (0 plain, 1 maxpool, 2 upsample), circular
+    (2, 3, 5, 4, 8, 8, 0, False),
+    (1, 9, 20, 5, 7, 9, 0, True),            # ragged tiles and channel tiles, periodic padding
+    (2, 6, 16, 4, 6, 10, 1, False),          # MaxPool3d(2) in the loader
+    (1, 5, 17, 6, 8, 4, 2, False),           # nearest x2 upsampling in the loader
+    (1, 4, 8, 2, 4, 6, 1, True),
+    (1, 4, 8, 4, 4, 8, 2, True),
+])
+def test_conv3d_direct(dev, case):
+    """ds_conv3d_direct against torch's fp64 conv3d with the same pooling / upsampling / padding and epilogue terms."""
+    ops = _ops()
+    B, Cin, Cout, D, H, W, mode, circ = case
+    g = torch.Generator().manual_seed(sum(int(v) * (i + 2) for i, v in enumerate(case)))
+    shp = {0: (D, H, W), 1: (2 * D, 2 * H, 2 * W), 2: (D // 2, H // 2, W // 2)}[mode]
+    x = torch.randn(B, Cin, *shp, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, 3, generator=g) / math.sqrt(Cin * 27)
+    bias, shift = torch.randn(Cout, generator=g), torch.randn(B, Cout, generator=g)
+    r1, r2 = torch.randn(B, Cout, D, H, W, generator=g), torch.randn(B, Cout, D, H, W, generator=g)
+    src = x.double()
+    if mode == 1:
+        src = F.max_pool3d(src, 2)
+    elif mode == 2:
+        src = F.interpolate(src, scale_factor=2.0, mode="nearest")
+    if circ:
+        src = F.pad(src, (1, 1, 1, 1, 1, 1), mode="circular")
+        want = F.conv3d(src, w.double(), bias.double())
+    else:
+        want = F.conv3d(src, w.double(), bias.double(), padding=1)
+    want = want + shift.double()[:, :, None, None, None] + r1.double() + r2.double()
+    got = ops.conv3d(x.to(dev), w.to(dev), bias=bias.to(dev), shift=shift.to(dev), res1=r1.to(dev), res2=r2.to(dev),
+                     load_mode=mode, circular=circ).cpu()
+    assert got.shape == want.shape and rel_l2(got, want) < 3e-7
+    with pytest.raises(ValueError, match="weight must be"):
+        ops.conv3d(x.to(dev), w.to(dev)[:, :, :, :, :2])

@@ -700,6 +700,35 @@ def test_latent_boundary_and_edm_batch_norm(M, dev, grids):
     assert rel_l2(plain.propagate_white_noise(wn, nsteps=4).cpu(), v["plain_sample_N4"]) < REL
 
 
+@pytest.mark.parametrize("tag", ["3d", "3d_circular"])
+def test_punetg_volumes(M, dev, grids, tag):
+    """PUNetG(dimension=3) on [B, C, D, H, W] volumes against the reference (first,
+    correctness-first 3-D path: exact-fp32 direct convolutions, eager launches)."""
+    v, sd = load("punetg8_" + tag)
+    circ = tag.endswith("circular")
+    net = M.PUNetG(M.PUNetGConfig(model_channels=8, dimension=3, convolution_type="circular" if circ else "default"))
+    r = net.load_state_dict(sd, strict=True)
+    assert not r.missing_keys and not r.unexpected_keys
+    net = net.to(dev).eval()
+    from diffsci_amd import ops
+    h = ops.conv3d(v["x"].to(dev), net.convin.weight, bias=net.convin.bias, circular=circ)
+    assert rel_l2(h.cpu(), v["convin"]) < 1e-6
+    d = ops.conv3d(v["convin"].to(dev), net.downsamplers[0].conv.weight, bias=net.downsamplers[0].conv.bias, load_mode=1, circular=circ)
+    assert rel_l2(d.cpu(), v["down0"]) < 1e-6
+    u = ops.conv3d(v["down0"].to(dev), net.upsamplers[1].conv.weight, bias=net.upsamplers[1].conv.bias, load_mode=2, circular=circ)
+    assert rel_l2(u.cpu(), v["up1"]) < 1e-6
+    out = net(v["x"].to(dev), v["t"].to(dev)).cpu()
+    assert out.shape == (2, 1, 16, 16, 16) and rel_l2(out, v["out_f32"]) < REL
+    assert rel_l2(out, v["out_f64"]) < max(4 * rel_l2(v["out_f32"], v["out_f64"]), 2e-6)
+    if not circ:
+        module = M.KarrasModule(net, M.KarrasModuleConfig.from_edm())
+        _pin_grid(module, grids)
+        hist = module.propagate_white_noise(v["white_noise"].to(dev), nsteps=4, record_history=True).cpu()
+        assert rel_l2(hist, v["hist_heun_N4_f32"]) < REL
+        with pytest.raises(ValueError, match="volumes"):
+            net(v["x"][:, :, 0].to(dev), v["t"].to(dev))
+
+
 @pytest.mark.parametrize("shape", [(2, 1, 20, 28), (1, 1, 36, 40), (3, 1, 64, 16)])
 def test_odd_field_sizes_against_oracle(M, dev, shape):
     """Ragged tiles everywhere: widths that are not multiples of 32, 16 or 4 (element-wise epilogue and

@@ -185,7 +185,9 @@ def test_punetg_config_roundtrip_and_unsupported_options():
     circ = M.PUNetG(M.PUNetGConfig(model_channels=8, convolution_type="circular"))
     assert "convin.conv.weight" in circ.state_dict() and "downsamplers.0.conv.conv.bias" in circ.state_dict()
     with pytest.raises(NotImplementedError, match="dimension"):
-        M.PUNetG(M.PUNetGConfig(dimension=3))
+        M.PUNetG(M.PUNetGConfig(dimension=1))
+    vol = M.PUNetG(M.PUNetGConfig(model_channels=8, dimension=3))
+    assert tuple(vol.convin.weight.shape) == (8, 1, 3, 3, 3) and len(vol.state_dict()) == 213
     with pytest.raises(TypeError):
         M.PUNetGConfig(not_an_option=1)
 

@@ -503,6 +503,30 @@ def test_adm_norm_choices(tag, over):
         assert_exact_or_rel(adm_ref.adm_forward(sd, cfg, v["x"], v["t"]), v["out_f32"], tag + " out", 2e-6)
 
 
+@pytest.mark.parametrize("tag", ["3d", "3d_circular"])
+def test_punetg_volumes(tag):
+    """PUNetG(dimension=3) -- Conv3d / CircularConv3d, MaxPool3d, nearest upsampling, attention over
+    the flattened voxels."""
+    import torch.nn.functional as F
+    v, sd = load("punetg8_" + tag)
+    circ = tag.endswith("circular")
+    cfg = punetg_ref.default_config(model_channels=8, convolution_type="circular" if circ else "default")
+    with torch.inference_mode():
+        h = punetg_ref.conv3x3(sd, "convin", v["x"], circ)
+        assert_exact_or_ulp(h, v["convin"], "Conv3d convin")
+        d = punetg_ref.conv3x3(sd, "downsamplers.0.conv", F.max_pool3d(h, 2), circ)
+        assert_exact_or_ulp(d, v["down0"], "3-D DownSampler")
+        u = punetg_ref.conv3x3(sd, "upsamplers.1.conv", F.interpolate(d, scale_factor=2.0, mode="nearest"), circ)
+        assert_exact_or_ulp(u, v["up1"], "3-D UpSampler")
+        te = punetg_ref.fourier_features(v["t"], sd["time_projection.W"])
+        r = punetg_ref.resnet_block(sd, "downward_blocks.0.0.", v["convin"], te, circ)
+        assert_exact_or_rel(r, v["resblock"], "3-D resblock", 1e-6)
+        assert_exact_or_rel(punetg_ref.punetg_forward(sd, cfg, v["x"], v["t"]), v["out_f32"], "3-D forward", 2e-6)
+        if not circ:
+            hist = K.propagate_white_noise(punetg_ref.make_net(sd, cfg), v["white_noise"], 4, record_history=True)
+            assert_exact_or_rel(hist, v["hist_heun_N4_f32"], "3-D trajectory", 2e-6)
+
+
 def test_adm_circular_convolutions():
     from oracle import adm_ref
     v, sd = load("adm8_circular")
