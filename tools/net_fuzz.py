@@ -31,6 +31,7 @@ def main():
     for it in range(a.n):
         torch.manual_seed(1000 + it)
         family = "punetg" if it % 2 == 0 else "adm"
+        vol = family == "punetg" and it % 6 == 4                   # every third PUNetG case is a 3-D volume
         exp = pick([[2], [2, 4], [1, 2], [2, 2, 2]])
         lev = len(exp)
         B, cin = ri(1, 3), ri(1, 3)
@@ -39,6 +40,10 @@ def main():
         if B * (H // unit) * (W // unit) < 2:
             B = 2                                   # torch's group_norm (hence the reference) refuses a single value per channel
         x = torch.randn(B, cin, H, W)
+        if vol:
+            D = unit * ri(1, 2)
+            H, W = min(H, 2 * unit), min(W, 3 * unit)
+            x = torch.randn(B, cin, D, H, W)
         t = torch.rand(B) * 3 - 1.5
         if family == "punetg":
             over = dict(model_channels=pick([4, 8, 16]), channel_expansion=exp, input_channels=cin, output_channels=ri(1, 5),
@@ -49,7 +54,8 @@ def main():
             over.update(convolution_type=pick(["default", "default", "circular", "mp"]),
                         first_resblock_norm=pick(["GroupLN", "GroupLN", "GroupRMS", "none"]),
                         second_resblock_norm=pick(["GroupRMS", "GroupRMS", "GroupLN", "none"]),
-                        affine_norm=bool(ri(0, 3)), bias=bool(ri(0, 3)))
+                        affine_norm=bool(ri(0, 3)), bias=bool(ri(0, 3)), attn_type=pick(["default", "default", "cosine"]),
+                        dimension=3 if vol else 2)
             cfg = punetg_ref.default_config(**over)
             net = M.PUNetG(M.PUNetGConfig(**over))
             with torch.no_grad():
@@ -92,7 +98,7 @@ def main():
             errs.append(max(rel(got, want), rel(got, want64)))
         e = max(errs)
         worst = max(worst, e)
-        tag = f"{family} exp={exp} B={B} cin={cin} {H}x{W} " + " ".join(f"{k}={v}" for k, v in over.items() if k.startswith("number") or k in ("model_channels", "skip_integration_type", "convolution_type", "first_resblock_norm", "second_resblock_norm", "affine_norm", "bias", "decoder_type"))
+        tag = f"{family}{'3d' if vol else ''} exp={exp} B={B} cin={cin} {'x'.join(map(str, x.shape[2:]))} " + " ".join(f"{k}={v}" for k, v in over.items() if k.startswith("number") or k in ("model_channels", "skip_integration_type", "convolution_type", "first_resblock_norm", "second_resblock_norm", "affine_norm", "bias", "decoder_type", "attn_type"))
         if e > tol:
             print("FAIL", tag, errs, tol)
             sys.exit(1)
