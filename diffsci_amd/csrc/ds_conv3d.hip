@@ -186,3 +186,85 @@ extern "C" int ds_conv3d_direct(float* out, const float* in, const float* w, con
   if (load_mode == DS_LOAD_MAXPOOL2) return launch3d<DS_LOAD_MAXPOOL2>(a, circ, s);
   return launch3d<DS_LOAD_UPSAMPLE2>(a, circ, s);
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Volumes on the matrix cores: a 3x3x3 convolution is three 3x3 convolutions over (H, W), one per depth tap,
+//     out[b, :, z] = sum_kz conv2d(in[b, :, z + kz - 1], w[:, :, kz]),
+// so the 2-D fp16x3 kernels (ds_conv3h.hip / ds_convup.hip) can do the work if a depth slice looks like a 2-D sample.
+// The two kernels below move a volume between the network's layout [B, C, D, H, W] and a slice-major, depth-padded
+// one  S[b][zp][c][y][x], zp = z + 1 in [0, D + 2):  the flat slice index b*(D+2) + zp then IS the 2-D batch index, a
+// depth tap is a pointer offset of one slice, and the pad slices (zero, or the wrapped neighbours for periodic
+// padding) make the taps that leave the volume read the right thing without any per-sample logic in the hot kernel.
+// Outputs computed AT pad slices are garbage by construction and never read back.
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+
+// depth_mode 0: copy; 1: max over the depth pairs (2z, 2z+1) -- the depth half of MaxPool3d(2), the (H, W) half is the
+// 2-D kernel's MAXPOOL2 loader; 2: nearest x2 in depth (z >> 1) -- likewise for the upsampling
+__global__ __launch_bounds__(256) void k_to_slices(float* S, const float* __restrict__ x, int C, int D, int Din, size_t HW,
+                                                  int depth_mode, int circular) {
+  const int zp = blockIdx.y % (D + 2);
+  const int b = blockIdx.y / (D + 2);
+  const int c = blockIdx.z;
+  float* dst = S + (((size_t)b * (D + 2) + zp) * C + c) * HW;
+  int z = zp - 1;
+  bool zero = false;
+  if (z < 0) { zero = !circular; z = D - 1; }
+  if (z >= D) { zero = !circular; z = 0; }
+  const float* src = x + ((size_t)b * C + c) * Din * HW;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < HW; i += (size_t)gridDim.x * 256) {
+    float v = 0.f;
+    if (!zero) {
+      if (depth_mode == 0) v = src[(size_t)z * HW + i];
+      else if (depth_mode == 1) v = fmaxf(src[(size_t)(2 * z) * HW + i], src[(size_t)(2 * z + 1) * HW + i]);
+      else v = src[(size_t)(z >> 1) * HW + i];
+    }
+    dst[i] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_from_slices(float* y, const float* __restrict__ S, const float* __restrict__ r1,
+                                                    const float* __restrict__ r2, int C, int D, size_t HW) {
+  const int z = blockIdx.y % D;
+  const int b = blockIdx.y / D;
+  const int c = blockIdx.z;
+  const float* src = S + (((size_t)b * (D + 2) + z + 1) * C + c) * HW;
+  const size_t o = (((size_t)b * C + c) * D + z) * HW;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < HW; i += (size_t)gridDim.x * 256) {
+    float v = src[i];
+    if (r1) v = v + r1[o + i];
+    if (r2) v = v + r2[o + i];
+    y[o + i] = v;
+  }
+}
+
+}  // namespace
+
+extern "C" int ds_volume_to_slices(float* slices, const float* x, int B, int C, int D, size_t HW, int depth_mode,
+                                   int circular, void* stream) {
+  DS_REQUIRE(slices && x, DS_ERR_NULL, "ds_volume_to_slices: NULL pointer");
+  DS_REQUIRE(B >= 0 && C > 0 && D > 0 && HW > 0 && depth_mode >= 0 && depth_mode <= 2, DS_ERR_SHAPE,
+             "ds_volume_to_slices: bad arguments B=%d C=%d D=%d mode=%d", B, C, D, depth_mode);
+  DS_REQUIRE(depth_mode != 2 || D % 2 == 0, DS_ERR_SHAPE, "ds_volume_to_slices: upsampling needs an even output depth");
+  DS_REQUIRE((long long)B * (D + 2) < 65536 && C < 65536, DS_ERR_SHAPE, "ds_volume_to_slices: B*(D+2) and C must stay below 65536");
+  if (B == 0) return DS_OK;
+  const int Din = depth_mode == 1 ? 2 * D : (depth_mode == 2 ? D / 2 : D);
+  const size_t gx = (HW + 1023) / 1024;
+  hipLaunchKernelGGL(k_to_slices, dim3((unsigned)(gx > 64 ? 64 : gx), (unsigned)(B * (D + 2)), (unsigned)C), dim3(256), 0,
+                     ds::as_stream(stream), slices, x, C, D, Din, HW, depth_mode, circular);
+  DS_CHECK_LAUNCH("ds_volume_to_slices");
+  return DS_OK;
+}
+
+extern "C" int ds_slices_to_volume(float* y, const float* slices, const float* res1, const float* res2, int B, int C, int D,
+                                   size_t HW, void* stream) {
+  DS_REQUIRE(y && slices, DS_ERR_NULL, "ds_slices_to_volume: NULL pointer");
+  DS_REQUIRE(B >= 0 && C > 0 && D > 0 && HW > 0, DS_ERR_SHAPE, "ds_slices_to_volume: bad shape");
+  DS_REQUIRE((long long)B * D < 65536 && C < 65536, DS_ERR_SHAPE, "ds_slices_to_volume: B*D and C must stay below 65536");
+  if (B == 0) return DS_OK;
+  const size_t gx = (HW + 1023) / 1024;
+  hipLaunchKernelGGL(k_from_slices, dim3((unsigned)(gx > 64 ? 64 : gx), (unsigned)(B * D), (unsigned)C), dim3(256), 0,
+                     ds::as_stream(stream), y, slices, res1, res2, C, D, HW);
+  DS_CHECK_LAUNCH("ds_slices_to_volume");
+  return DS_OK;
+}

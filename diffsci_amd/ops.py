@@ -207,6 +207,54 @@ def conv3d(x, w, bias=None, shift=None, res1=None, res2=None, load_mode=N.DS_LOA
     return out
 
 
+def pack_conv3d(w, upsampled=False):
+    """A 3x3x3 weight [Cout, Cin, 3, 3, 3] as three fp16x3-packed 3x3 weights, one per depth tap (see conv3d_mfma)."""
+    if w.dim() != 5 or tuple(w.shape[2:]) != (3, 3, 3):
+        raise ValueError("pack_conv3d: weight must be [Cout, Cin, 3, 3, 3]")
+    return [pack_conv(w[:, :, kz].contiguous(), "fp16x3", upsampled=upsampled) for kz in range(3)]
+
+
+def conv3d_mfma(x, packs, bias=None, shift=None, res1=None, res2=None, load_mode=N.DS_LOAD_PLAIN, circular=False, out=None):
+    """3x3x3 'same' convolution of a volume on the matrix cores: three 2-D fp16x3 convolutions (one per depth tap) over
+    a slice-major, depth-padded copy of the volume (ds_volume_to_slices / ds_slices_to_volume).  Same arguments and
+    fusions as conv3d; packs = pack_conv3d(weight)."""
+    require_device(x, "x")
+    B, Cin, Din, Hi, Wi = x.shape
+    Cout = packs[0].Cout
+    if load_mode == N.DS_LOAD_MAXPOOL2:
+        if Din % 2 or Hi % 2 or Wi % 2:
+            raise ValueError("pooling load needs an even input volume")
+        D, H, W, depth_mode = Din // 2, Hi // 2, Wi // 2, 1
+    elif load_mode == N.DS_LOAD_UPSAMPLE2:
+        D, H, W, depth_mode = 2 * Din, 2 * Hi, 2 * Wi, 2
+    else:
+        D, H, W, depth_mode = Din, Hi, Wi, 0
+    if out is None:
+        out = torch.empty((B, Cout, D, H, W), dtype=torch.float32, device=x.device)
+    elif tuple(out.shape) != (B, Cout, D, H, W):
+        raise ValueError(f"out has shape {tuple(out.shape)}, expected {(B, Cout, D, H, W)}")
+    for r in (res1, res2):
+        if r is not None and tuple(r.shape) != (B, Cout, D, H, W):
+            raise ValueError("residual shape mismatch")
+    ns = B * (D + 2)
+    s_in = torch.empty((ns, Cin, Hi, Wi), dtype=torch.float32, device=x.device)
+    N.check(N.lib().ds_volume_to_slices(_p(s_in), _p(x.contiguous()), B, Cin, D, Hi * Wi, depth_mode, 1 if circular else 0,
+                                        _stream()), "ds_volume_to_slices")
+    s_out = torch.empty((ns, Cout, H, W), dtype=torch.float32, device=x.device)
+    acc = s_out[1:ns - 1]                                   # every slice but the outermost two pads: the 2-D "batch"
+    rows = None
+    if shift is not None:
+        if shift.dim() != 2 or shift.shape[1] != Cout or shift.shape[0] not in (1, B):
+            raise ValueError(f"shift must be [1 or B, Cout]; got {tuple(shift.shape)}")
+        rows = shift if shift.shape[0] == 1 else shift.repeat_interleave(D + 2, dim=0)[1:ns - 1].contiguous()
+    for n, dz in enumerate((0, -1, 1)):                     # centre tap first: it initialises the accumulator
+        conv(s_in[1 + dz:ns - 1 + dz], packs[dz + 1], bias=bias if n == 0 else None, shift=rows if n == 0 else None,
+             res1=None if n == 0 else acc, load_mode=load_mode, circular=circular, out=acc)
+    N.check(N.lib().ds_slices_to_volume(_p(out), _p(s_out), _p(res1), _p(res2), B, Cout, D, H * W, _stream()),
+            "ds_slices_to_volume")
+    return out
+
+
 def gnorm1_stats(x, kind, eps=1e-5, stats=None, workspace=None):
     """Per-sample (mean, rstd) [kind 0] or (0, rms denominator) [kind 1] over (C, H, W)."""
     B, C = x.shape[0], x.shape[1]

@@ -235,6 +235,20 @@ int ds_conv3d_direct(float* out, const float* in, const float* w, const float* b
                      int shift_stride, const float* res1, const float* res2, int B, int Cin, int Cout, int D, int H,
                      int W, int load_mode, void* stream);
 
+/* Volumes on the matrix cores: out[b,:,z] = sum_kz conv2d(in[b,:,z+kz-1], w[:,:,kz]) -- three launches of the 2-D
+ * fp16x3 kernels per 3x3x3 convolution -- on a slice-major, depth-padded copy S[b][zp][c][y][x] (zp = z + 1 of D + 2
+ * slices; pads zero, or the wrapped neighbours when circular), in which a depth slice is a 2-D sample and a depth tap a
+ * pointer offset of one slice (C*HW floats).
+ *   ds_volume_to_slices: x [B,C,Din,HW] -> S [B,D+2,C,HW]; depth_mode 0 copy (Din = D), 1 max of depth pairs (Din = 2D:
+ *     the depth half of MaxPool3d(2); the 2-D loader's MAXPOOL2 does H, W), 2 nearest x2 in depth (Din = D/2).
+ *   ds_slices_to_volume: y [B,C,D,HW] = S interior (+ res1 + res2, volume layout).
+ * The caller runs ds_conv2d_h3 on batch B*(D+2) - 2, in = S_in + (1 + dz)*Cin*HW_in, out = S_out + Cout*HW,
+ * accumulating the second and third tap through res1 = out. */
+int ds_volume_to_slices(float* slices, const float* x, int B, int C, int D, size_t HW, int depth_mode, int circular,
+                        void* stream);
+int ds_slices_to_volume(float* y, const float* slices, const float* res1, const float* res2, int B, int C, int D,
+                        size_t HW, void* stream);
+
 /* 1x1 convolution in the fp16x3 scheme of ds_conv2d_h3 (same epilogue terms, same domain
  * |in| < 65504).  ADM's residual projection convresidual(resample(x)) (adm.py:345-349) with the
  * resampling folded into the load: load_mode PLAIN, UPSAMPLE2 (nearest x2, in is [B,Cin,H/2,W/2])

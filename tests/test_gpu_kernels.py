@@ -640,3 +640,42 @@ def test_conv3d_direct(dev, case):
     assert got.shape == want.shape and rel_l2(got, want) < 3e-7
     with pytest.raises(ValueError, match="weight must be"):
         ops.conv3d(x.to(dev), w.to(dev)[:, :, :, :, :2])
+
+
+@pytest.mark.parametrize("case", [
+    (2, 16, 24, 4, 8, 32, 0, False),
+    (1, 9, 70, 5, 12, 20, 0, True),
+    (2, 16, 32, 3, 8, 16, 1, False),         # MaxPool3d(2): depth pairs in the slice copy, (H, W) in the 2-D loader
+    (1, 24, 17, 6, 16, 32, 2, False),        # nearest x2: depth in the slice copy, (H, W) by the parity kernel
+    (1, 8, 8, 4, 8, 12, 2, True),
+    (2, 8, 8, 2, 4, 6, 1, True),
+])
+def test_conv3d_on_the_matrix_cores(dev, case):
+    """ops.conv3d_mfma (three 2-D fp16x3 launches over a slice-major, depth-padded copy of the volume) against torch's
+    fp64 conv3d and against the direct fp32 kernel."""
+    ops = _ops()
+    B, Cin, Cout, D, H, W, mode, circ = case
+    g = torch.Generator().manual_seed(sum(int(v) * (i + 5) for i, v in enumerate(case)))
+    shp = {0: (D, H, W), 1: (2 * D, 2 * H, 2 * W), 2: (D // 2, H // 2, W // 2)}[mode]
+    x = torch.randn(B, Cin, *shp, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, 3, generator=g) / math.sqrt(Cin * 27)
+    bias, shift = torch.randn(Cout, generator=g), torch.randn(B, Cout, generator=g)
+    r1, r2 = torch.randn(B, Cout, D, H, W, generator=g), torch.randn(B, Cout, D, H, W, generator=g)
+    src = x.double()
+    if mode == 1:
+        src = F.max_pool3d(src, 2)
+    elif mode == 2:
+        src = F.interpolate(src, scale_factor=2.0, mode="nearest")
+    if circ:
+        want = F.conv3d(F.pad(src, (1, 1, 1, 1, 1, 1), mode="circular"), w.double(), bias.double())
+    else:
+        want = F.conv3d(src, w.double(), bias.double(), padding=1)
+    want = want + shift.double()[:, :, None, None, None] + r1.double() + r2.double()
+    kw = dict(bias=bias.to(dev), shift=shift.to(dev), res1=r1.to(dev), res2=r2.to(dev), load_mode=mode, circular=circ)
+    got = ops.conv3d_mfma(x.to(dev), ops.pack_conv3d(w.to(dev), upsampled=mode == 2), **kw).cpu()
+    assert got.shape == want.shape and rel_l2(got, want) < 5e-7
+    direct = ops.conv3d(x.to(dev), w.to(dev), **kw).cpu()
+    assert rel_l2(got, direct.double()) < 5e-7
+    one = ops.conv3d_mfma(x.to(dev), ops.pack_conv3d(w.to(dev)), bias=bias.to(dev), shift=shift[:1].to(dev), load_mode=mode,
+                          circular=circ).cpu()                      # one shift row shared by the batch
+    assert rel_l2(one, want - r1.double() - r2.double() + (shift[:1] - shift).double()[:, :, None, None, None]) < 5e-7

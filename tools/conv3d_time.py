@@ -23,4 +23,16 @@ for (B, Cin, Cout, S, mode) in [(8, 64, 64, 32, 0), (8, 128, 128, 16, 0), (8, 64
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 10
     fl = 2.0 * B * Cout * Cin * 27 * S ** 3
-    print(f"B={B} {Cin}->{Cout} @{S}^3 mode={mode}: {ms:.3f} ms  {fl / ms / 1e9:.2f} TFLOP/s")
+    line = f"B={B} {Cin}->{Cout} @{S}^3 mode={mode}: direct {ms:.3f} ms = {fl / ms / 1e9:.1f} TFLOP/s"
+    if Cout > 4:
+        packs = ops.pack_conv3d(w, upsampled=mode == 2)
+        ops.conv3d_mfma(x, packs, load_mode=mode, out=out)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(10):
+            ops.conv3d_mfma(x, packs, load_mode=mode, out=out)
+        e1.record()
+        torch.cuda.synchronize()
+        ms2 = e0.elapsed_time(e1) / 10
+        line += f";  matrix cores (3 x 2-D fp16x3 + slice copies) {ms2:.3f} ms = {fl / ms2 / 1e9:.1f} TFLOP/s-equivalent"
+    print(line)
