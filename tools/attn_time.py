@@ -4,7 +4,7 @@ sys.path.insert(0, os.getcwd())
 import torch
 from diffsci_amd import ops
 dev = torch.device("cuda:0")
-for (B, E, L) in [(64, 256, 1024), (16, 256, 4096)]:
+for (B, E, L) in [(64, 256, 1024), (16, 256, 4096), (64, 128, 1024), (64, 64, 1024)]:
     qkv = torch.randn(B, 3 * E, L, device=dev)
     out = torch.empty(B, E, L, device=dev)
     f = lambda: ops.attention(qkv, E, out=out, precision="fp16x3")
