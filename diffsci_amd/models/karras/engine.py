@@ -52,7 +52,8 @@ class ModuleSource:
         self.like = like
         self.conditional = bool(module.conditional) and self.guidance != 0.0
         self.cfg = self.conditional and self.guidance != 1.0
-        self.planned = bool(getattr(self.model, "forward_with_shifts", None)) and like.dim() == 4
+        self.planned = bool(getattr(self.model, "forward_with_shifts", None)) and (
+            like.dim() == 4 or (like.dim() == 5 and getattr(self.model, "dim", 2) == 3))
         self._out = {}
 
     def prepare(self, table: StepTable):

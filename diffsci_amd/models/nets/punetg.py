@@ -637,10 +637,12 @@ class PUNetG(torch.nn.Module):
         matrix-core kernels per 3x3x3 convolution over a slice-major copy of the volume (ops.conv3d_mfma); otherwise, and
         for the <= 4-channel output layer, the exact-fp32 direct kernel (ops.conv3d) -- both with the pooling /
         upsampling / skip / residual / time-shift fusions of the 2-D path.  Standalone per-(sample, channel) norms over
-        D*H*W, attention over the flattened voxels.  Eager launches (the captured-loop planner handles 4-D fields)."""
+        D*H*W, attention over the flattened voxels.  All buffers come from the workspace: the sampler's planner captures
+        this path as a hipGraph too."""
         if x.dim() != 5:
             raise ValueError("a dimension=3 network takes [B, C, D, H, W] volumes")
         pk = self.packed_weights()
+        ws = self._ws
         cfg = self.config
         B, dev = x.shape[0], x.device
         it = iter(range(len(shifts)))
@@ -654,56 +656,95 @@ class PUNetG(torch.nn.Module):
                 raise ValueError("time embedding batch does not match x")
             return s
 
-        def conv(m, h, **kw):
+        def conv(m, h, load_mode=0, dst=None, fresh=False, **kw):
+            """Every buffer comes from the workspace (a captured loop must not allocate); fresh: the caller's result."""
+            f = {0: (1, 1), DS_LOAD_MAXPOOL2: (1, 2), DS_LOAD_UPSAMPLE2: (2, 1)}[load_mode]
+            shape = (h.shape[0], m.out_channels) + tuple(v * f[0] // f[1] for v in h.shape[2:])
+            if dst is None and not fresh:
+                dst = ws.take(shape, dev)
             packs = pk.get((id(m), "3d"))
             # fp16x3 (default): three 2-D MFMA launches per convolution -- 0.30 vs 1.33 ms at 64 -> 64 channels, 8 x 32^3;
             # the thin input / output layers stay on the direct kernel (0.08 vs 0.14 ms for 1 -> 64)
             if packs is not None and m.out_channels > 4 and m.in_channels > 4:
-                return ops.conv3d_mfma(h, packs, bias=m.bias, circular=self.circular, **kw)
-            return ops.conv3d(h, pk.get((id(m), "eff"), m.weight), bias=m.bias, circular=self.circular, **kw)
+                return ops.conv3d_mfma(h, packs, bias=m.bias, circular=self.circular, load_mode=load_mode, out=dst, ws=ws, **kw)
+            return ops.conv3d(h, pk.get((id(m), "eff"), m.weight), bias=m.bias, circular=self.circular, load_mode=load_mode,
+                              out=dst, **kw)
 
-        def res(blk, h, res2=None):                                               # ResnetBlockC.forward
+        def res(blk, h, res2=None):                                               # ResnetBlockC.forward; h untouched
             w1, b1 = getattr(blk.gnorm1, "weight", None), getattr(blk.gnorm1, "bias", None)
             w2, b2 = getattr(blk.gnorm2, "weight", None), getattr(blk.gnorm2, "bias", None)
-            a = ops.inorm_silu(h, w1, b1, kind=k1, eps=1e-5)
+            a = ops.inorm_silu(h, w1, b1, kind=k1, eps=1e-5, out=ws.take(h.shape, dev))
             y = conv(blk.conv1, a, shift=sh())
             ops.inorm_silu(y, w2, b2, kind=k2, eps=1e-5, out=a)
-            return conv(blk.conv2, a, res1=h, res2=res2, out=y)
+            conv(blk.conv2, a, res1=h, res2=res2, dst=y)
+            ws.give(a)
+            return y
 
         def attn(att, h, res2=None):                                              # ThreeDimensionalAttention
             Bq, E, D, H, W = h.shape
-            r2 = None if res2 is None else res2.reshape(Bq, E, D * H, W)
-            y = self._attention(att, h.reshape(Bq, E, D * H, W), pk, self._ws, res2=r2)
-            out3 = y.reshape(Bq, E, D, H, W).clone()
-            self._ws.give(y)
-            return out3
+            r2 = None if res2 is None else res2.view(Bq, E, D * H, W)
+            y = self._attention(att, h.view(Bq, E, D * H, W), pk, ws, res2=r2)
+            o = ws.take(h.shape, dev)
+            o.copy_(y.view(h.shape))
+            ws.give(y)
+            return o
 
+        x = x.contiguous()
+        xe = None
         if not cfg.bias:                                                          # punetg.py:390-394
-            x = torch.cat([x, torch.ones_like(x[:, :1])], dim=1)
-        h = conv(self.convin, x.contiguous())
+            ones = ws.take((B, 1) + tuple(x.shape[2:]), dev)
+            ones.fill_(1.0)
+            xe = ops.concat2(x, ones, out=ws.take((B, x.shape[1] + 1) + tuple(x.shape[2:]), dev))
+            ws.give(ones)
+            x = xe
+        h = conv(self.convin, x)
+        if xe is not None:
+            ws.give(xe)
         skips = []
         for lv, blocks in enumerate(self.downward_blocks):
             for blk in blocks:
-                h = res(blk, h)
+                h2 = res(blk, h)
+                ws.give(h)
+                h = h2
             skips.append(h)
             h = conv(self.downsamplers[lv].conv, h, load_mode=DS_LOAD_MAXPOOL2)
         for blk in self.before_block:
-            h = res(blk, h)
+            h2 = res(blk, h)
+            ws.give(h)
+            h = h2
         xa = h
         nattn = len(self.attn_resnet_block)
         for i, blk in enumerate(self.attn_resnet_block):
             last = i == nattn - 1
-            xa = res(blk, xa, res2=h if (last and i >= len(self.attn_block)) else None)
+            xa2 = res(blk, xa, res2=h if (last and i >= len(self.attn_block)) else None)
+            if xa is not h:
+                ws.give(xa)
+            xa = xa2
             if i < len(self.attn_block):
-                xa = attn(self.attn_block[i], xa, res2=h if last else None)
-        h = xa if nattn else ops.add(h, h)
+                xa2 = attn(self.attn_block[i], xa, res2=h if last else None)
+                ws.give(xa)
+                xa = xa2
+        if nattn == 0:
+            xa = ops.add(h, h, out=ws.take(h.shape, dev))
+        ws.give(h)
+        h = xa
         for blk in self.after_block:
-            h = res(blk, h)
+            h2 = res(blk, h)
+            ws.give(h)
+            h = h2
         for lv, blocks in enumerate(self.upward_blocks):
-            h = conv(self.upsamplers[lv].conv, h, load_mode=DS_LOAD_UPSAMPLE2, res1=skips.pop())
+            skip = skips.pop()
+            h2 = conv(self.upsamplers[lv].conv, h, load_mode=DS_LOAD_UPSAMPLE2, res1=skip)
+            ws.give(h)
+            ws.give(skip)
+            h = h2
             for blk in blocks:
-                h = res(blk, h)
-        return conv(self.convout, h, out=out)
+                h2 = res(blk, h)
+                ws.give(h)
+                h = h2
+        y = conv(self.convout, h, dst=out, fresh=out is None)
+        ws.give(h)
+        return y
 
     def _attention(self, att, x, pk, ws, res2=None, tile_stats=None):
         """TwoDimensionalAttention.forward (attention.py:67-72,82-90), channel-major throughout."""

@@ -214,10 +214,12 @@ def pack_conv3d(w, upsampled=False):
     return [pack_conv(w[:, :, kz].contiguous(), "fp16x3", upsampled=upsampled) for kz in range(3)]
 
 
-def conv3d_mfma(x, packs, bias=None, shift=None, res1=None, res2=None, load_mode=N.DS_LOAD_PLAIN, circular=False, out=None):
+def conv3d_mfma(x, packs, bias=None, shift=None, res1=None, res2=None, load_mode=N.DS_LOAD_PLAIN, circular=False, out=None,
+                ws=None):
     """3x3x3 'same' convolution of a volume on the matrix cores: three 2-D fp16x3 convolutions (one per depth tap) over
     a slice-major, depth-padded copy of the volume (ds_volume_to_slices / ds_slices_to_volume).  Same arguments and
-    fusions as conv3d; packs = pack_conv3d(weight)."""
+    fusions as conv3d; packs = pack_conv3d(weight).  ws: an optional buffer pool (take(shape, device) / give(tensor)) for
+    the two slice copies, so that a captured loop allocates nothing."""
     require_device(x, "x")
     B, Cin, Din, Hi, Wi = x.shape
     Cout = packs[0].Cout
@@ -237,10 +239,13 @@ def conv3d_mfma(x, packs, bias=None, shift=None, res1=None, res2=None, load_mode
         if r is not None and tuple(r.shape) != (B, Cout, D, H, W):
             raise ValueError("residual shape mismatch")
     ns = B * (D + 2)
-    s_in = torch.empty((ns, Cin, Hi, Wi), dtype=torch.float32, device=x.device)
+
+    def take(shape):
+        return torch.empty(shape, dtype=torch.float32, device=x.device) if ws is None else ws.take(shape, x.device)
+    s_in = take((ns, Cin, Hi, Wi))
     N.check(N.lib().ds_volume_to_slices(_p(s_in), _p(x.contiguous()), B, Cin, D, Hi * Wi, depth_mode, 1 if circular else 0,
                                         _stream()), "ds_volume_to_slices")
-    s_out = torch.empty((ns, Cout, H, W), dtype=torch.float32, device=x.device)
+    s_out = take((ns, Cout, H, W))
     acc = s_out[1:ns - 1]                                   # every slice but the outermost two pads: the 2-D "batch"
     rows = None
     if shift is not None:
@@ -252,6 +257,9 @@ def conv3d_mfma(x, packs, bias=None, shift=None, res1=None, res2=None, load_mode
              res1=None if n == 0 else acc, load_mode=load_mode, circular=circular, out=acc)
     N.check(N.lib().ds_slices_to_volume(_p(out), _p(s_out), _p(res1), _p(res2), B, Cout, D, H * W, _stream()),
             "ds_slices_to_volume")
+    if ws is not None:
+        ws.give(s_in)
+        ws.give(s_out)
     return out
 
 

@@ -723,8 +723,11 @@ def test_punetg_volumes(M, dev, grids, tag):
     if not circ:
         module = M.KarrasModule(net, M.KarrasModuleConfig.from_edm())
         _pin_grid(module, grids)
-        hist = module.propagate_white_noise(v["white_noise"].to(dev), nsteps=4, record_history=True).cpu()
-        assert rel_l2(hist, v["hist_heun_N4_f32"]) < REL
+        for use_graph in (False, True, True):                   # eager stepper, graph capture, graph replay
+            module.use_graph = use_graph
+            hist = module.propagate_white_noise(v["white_noise"].to(dev), nsteps=4, record_history=True).cpu()
+            assert rel_l2(hist, v["hist_heun_N4_f32"]) < REL
+        assert len(module._plans) == 1
         with pytest.raises(ValueError, match="volumes"):
             net(v["x"][:, :, 0].to(dev), v["t"].to(dev))
 
