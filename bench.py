@@ -90,7 +90,7 @@ def build_module(args, dev):
 
 def dominant_kernel_roofline(module, args, dev, reps=40):
     """Average launch duration of the dominant kernel (k_conv3h<PLAIN, *>: the 3x3 convolutions of
-    the residual blocks, convin and convout) over one network evaluation's worth of its launches,
+    the residual blocks and convin; convout too when it is not on the direct kernel) over one network evaluation's worth of its launches,
     timed with events on the launch stream, against its algorithmic FLOPs.  The launches carry what
     they carry in the network: conv1 = fused norm+SiLU loader + time shift + tile statistics,
     conv2 = fused norm+SiLU loader + residual + tile statistics (the fused parts only with
@@ -99,7 +99,9 @@ def dominant_kernel_roofline(module, args, dev, reps=40):
     net = module.model
     pk = net.packed_weights()
     B, S = args.batch, args.size
-    mods = [net.convin] + [c for blk in net._resblocks() for c in (blk.conv1, blk.conv2)] + [net.convout]
+    mods = [net.convin] + [c for blk in net._resblocks() for c in (blk.conv1, blk.conv2)]
+    if not (net.convout.out_channels <= 4 and getattr(net, "direct_out", True)):
+        mods.append(net.convout)              # otherwise the output layer runs on ds_conv2d_direct, not on this kernel
     # spatial size of every launch, in forward order
     mult = net.config.extended_channel_expansion
     def side(c):
