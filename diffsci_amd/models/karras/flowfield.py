@@ -78,20 +78,39 @@ class SIScheduler(object):
 
 
 class Preconditioner(object):
-    """flowfield.py:114-169.  Only the named parameterisations ('identity', 'edm', None) of a
-    time-dependent network are on the HIP path."""
+    """flowfield.py:114-169.  The named parameterisations ('identity', 'edm', None) of a time-dependent network run
+    on the fused stepper through eval_row; autonomous flows (model(x, y=y), no time input) and user precondition
+    callables cannot be tabulated -- they are evaluated step by step (`generic`), the callable as given, the
+    arithmetic around the network on the HIP elementwise kernels."""
 
     def __init__(self, scheduler: SIScheduler, precondition_fn='identity', is_autonomous: bool = False, **kwargs):
-        if is_autonomous:
-            raise NotImplementedError("autonomous flows (model(x, y=y) without time) are not on the HIP path")
-        if precondition_fn is not None and not isinstance(precondition_fn, str):
-            raise NotImplementedError("user precondition callables are not on the HIP path; use 'identity' or 'edm'")
-        if precondition_fn not in (None, 'identity', 'edm'):
+        if isinstance(precondition_fn, str) and precondition_fn not in ('identity', 'edm'):
             raise ValueError(f"Invalid condition function: {precondition_fn}")
         self.scheduler = scheduler
         self.precondition_fn = precondition_fn
         self.is_autonomous = is_autonomous
         self.kwargs = kwargs
+
+    @property
+    def generic(self):
+        return self.is_autonomous or callable(self.precondition_fn)
+
+    def __call__(self, model, x, t=None, y=None):
+        """get_flow_field of the reference for the generic cases; t: [B] device tensor (one value)."""
+        fn = self.precondition_fn
+        if callable(fn):
+            return fn(model, x, y=y) if self.is_autonomous else fn(model, x, t, y=y)
+        if fn in (None, 'identity'):                                   # autonomous identity
+            return model(x, y=y)
+        # autonomous 'edm' (flowfield.py:163-164): cskip*x + cout*model(x / cin, y=y) -- as written there, without
+        # the sigma'/sigma factor of the time-dependent branch
+        sigma_data = self.kwargs.get("sigma_data", 0.5)
+        sigma = self.scheduler.sigma_fn(t.reshape(-1)[0].cpu())
+        cin = 1 / torch.sqrt(sigma_data ** 2 + sigma ** 2)
+        cout = sigma * sigma_data / torch.sqrt(sigma_data ** 2 + sigma ** 2)
+        cskip = sigma_data ** 2 / (sigma_data ** 2 + sigma ** 2)
+        f = model(ops.div_scalar(x.contiguous(), float(cin)), y=y)
+        return ops.axpby(x.contiguous(), float(cskip), f.contiguous(), float(cout))
 
     @property
     def kind(self):
@@ -224,8 +243,19 @@ class SIModule(torch.nn.Module):
         return tt.reshape(-1)[0].reshape(())
 
     def get_flow_field(self, x_noised, t, guidance: float = 1.0, y=None, integrate_on_sigma: bool = False):
-        """flowfield.py:441-458 for a batch at one time t."""
+        """flowfield.py:441-458.  t: a scalar or [B]; samples at different times are evaluated group by group."""
         ops.require_device(x_noised, "x_noised")
+        tt = torch.as_tensor(t, dtype=torch.float32).detach().cpu().reshape(-1)
+        if tt.numel() > 1 and bool((tt != tt[0]).any()):
+            if tt.numel() != x_noised.shape[0]:
+                raise ValueError("t must be a scalar or have one entry per sample")
+            out = torch.empty_like(x_noised)
+            for u in torch.unique(tt):
+                idx = torch.nonzero(tt == u).reshape(-1).to(x_noised.device)
+                out[idx] = self.get_flow_field(x_noised[idx].contiguous(), u, guidance, y, integrate_on_sigma)
+            return out
+        if self.config.preconditioner.generic:
+            return self._generic_flow(x_noised.contiguous(), tt[0], guidance, y, integrate_on_sigma)
         row = self.config.preconditioner.eval_row(self._eval_scalars(t), integrate_on_sigma)
         src = self._source(y, guidance, x_noised)
         table = StepTable(kind="euler", t=torch.zeros(2), rows=[StepRow(row, None, 0.0)])
@@ -234,8 +264,28 @@ class SIModule(torch.nn.Module):
         f, fu = src.evaluate(x_noised, xin, row, 0, 0)
         return ops.drift(x_noised.contiguous(), f, row.coef(src.input_kind, src.guidance), fu=fu)
 
+    def _generic_flow(self, x, t, guidance, y, integrate_on_sigma):
+        """Autonomous flows / user precondition callables: the preconditioner is called as the reference calls it;
+        guidance blend and the optional 1/sigma' on the HIP elementwise kernels (flowfield.py:449-457)."""
+        pre = self.config.preconditioner
+        tb = torch.full((x.shape[0],), float(t), device=x.device)
+        v = pre(self.model, x, tb, y=y)
+        if not (guidance == 1.0 or y is None):
+            vu = pre(self.model, x, tb, y=None)
+            v = ops.axpby(v.contiguous(), float(guidance), vu.contiguous(), float(1 - guidance))
+        if integrate_on_sigma:
+            v = ops.div_scalar(v.contiguous(), float(self.config.sigma_fn_dot(t)))
+        return v
+
     def get_score_field_from_flow_field(self, flow_field, x_noised, t):
         """flowfield.py:483-501: (alpha v - alpha' x) / (sigma (alpha' sigma - alpha sigma'))."""
+        tv = torch.as_tensor(t, dtype=torch.float32).detach().cpu().reshape(-1)
+        if tv.numel() > 1 and bool((tv != tv[0]).any()):                 # per-sample times: group by group
+            out = torch.empty_like(flow_field)
+            for u in torch.unique(tv):
+                idx = torch.nonzero(tv == u).reshape(-1).to(flow_field.device)
+                out[idx] = self.get_score_field_from_flow_field(flow_field[idx].contiguous(), x_noised[idx].contiguous(), u)
+            return out
         tt = self._eval_scalars(t)
         c = self.config
         alpha, sigma, alpha_dot, sigma_dot = c.alpha_fn(tt), c.sigma_fn(tt), c.alpha_fn_dot(tt), c.sigma_fn_dot(tt)
@@ -306,6 +356,8 @@ class SIModule(torch.nn.Module):
         ops.require_device(x, "x")
         if noise_injection:
             return self._integrate_em(x, time_schedule, y, guidance, return_history, integrate_on_sigma, scale)
+        if self.config.preconditioner.generic:
+            return self._integrate_generic(x, time_schedule, y, guidance, return_history, integrate_on_sigma, scale)
         table = self._table(time_schedule, integrate_on_sigma)
         src = self._source(y, guidance, x)
         if src.planned and self.use_graph:
@@ -349,6 +401,22 @@ class SIModule(torch.nn.Module):
             out = plan[0].result().clone()
         caller.wait_stream(self._stream)
         return out
+
+    def _integrate_generic(self, x, time_schedule, y, guidance, return_history, integrate_on_sigma, scale):
+        """integrate_flow_field for preconditioners that cannot be tabulated: Heun steps, the last one Euler
+        (flowfield.py:719-747), each through integration_step."""
+        ts = torch.as_tensor(time_schedule, dtype=torch.float32).detach().cpu()
+        x = ops.scale(x.contiguous(), scale) if scale is not None else x.contiguous()
+        history = [(ts[0], x)] if return_history else None
+        n = ts.numel()
+        for i in range(n - 1):
+            x = self.integration_step(x, ts[i], ts[i + 1], y, guidance, method='euler' if i == n - 2 else 'heun',
+                                      integrate_on_sigma=integrate_on_sigma)
+            if return_history:
+                history.append((ts[i + 1], x))
+        if return_history:
+            return [(t, self.initial_norm.unnorm(h)) for t, h in history]
+        return self.initial_norm.unnorm(x)
 
     def _integrate_em(self, x, time_schedule, y, guidance, return_history, integrate_on_sigma, scale):
         """Euler-Maruyama with noise injection (flowfield.py:783-793), one HIP pass per operation group."""

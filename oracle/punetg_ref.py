@@ -193,7 +193,10 @@ def punetg_forward(sd, cfg, x, t, ye=None):
         xe_shape[1] = 1
         x = torch.cat([x, torch.ones(xe_shape).to(x)], dim=1)
     x = conv3x3(sd, "convin", x, circ)
-    te = fourier_features(t, sd["time_projection.W"])
+    if t is None:                                                    # punetg.py:396-399: no time input
+        te = torch.zeros(x.shape[0], cfg["model_channels"]).to(x)
+    else:
+        te = fourier_features(t, sd["time_projection.W"])
     if ye is not None:
         te = te + ye
     skips = []

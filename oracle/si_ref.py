@@ -34,6 +34,16 @@ def scheduler(name, expoent=7.0, sigma_min=0.02, sigma_max=80.0):
 
 
 def precondition(sch, kind, model, x, t, y=None, sigma_data=0.5):
+    if callable(kind):                                   # user precondition callable (flowfield.py:140-144)
+        return kind(model, x, t, y=y)
+    if kind == "auto_identity":                          # autonomous flows: the network sees no time (:147-150, 162-164)
+        return model(x, y=y)
+    if kind == "auto_edm":
+        sigma = _bcast(sch["sigma"](t), x)
+        cin = 1 / torch.sqrt(sigma_data ** 2 + sigma ** 2)
+        cout = sigma * sigma_data / torch.sqrt(sigma_data ** 2 + sigma ** 2)
+        cskip = sigma_data ** 2 / (sigma_data ** 2 + sigma ** 2)
+        return cskip * x + cout * model(x / cin, y=y)
     if kind == "identity":
         return model(x, t, y=y)
     sigma = _bcast(sch["sigma"](t), x)

@@ -500,6 +500,40 @@ def si_inpaint():
     npz("si8_inpaint", **arrs)
 
 
+def si_custom_precondition(model, x, t, y=None):
+    """A user precondition callable (ours; tests define the same function)."""
+    return 0.5 * model(x, t, y=y) - 0.1 * x
+
+
+def si_generic():
+    """SIModule with preconditioners that cannot be tabulated: autonomous flows (model(x, y=y), flowfield.py:147-165) and a
+    user callable; per-sample times in get_flow_field / get_score_field.  Network: punetg8_forward's."""
+    z = np.load(os.path.join(OUT, "punetg8_forward.npz"))
+    sd = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd/")}
+    net = M.nets.PUNetG(M.nets.PUNetGConfig(model_channels=8)).eval()
+    net.load_state_dict(sd)
+    torch.manual_seed(170)
+    noise = torch.randn(2, 1, 32, 32)
+    arrs = dict(noise=noise)
+    ts = torch.linspace(1, 0, 5)
+    cases = (("auto_identity", dict(scheduler="linear", autonomous_flow=True)),
+             ("auto_edm", dict(scheduler="cosine", autonomous_flow=True, precondition_fn="edm")),
+             ("callable", dict(scheduler="linear", precondition_fn=si_custom_precondition)))
+    for tag, kw in cases:
+        mod = M.SIModule(M.SIModuleConfig(**kw), net).eval()
+        with torch.inference_mode():
+            arrs[tag + "_sample_N5"] = mod.sample(2, [1, 32, 32], nsteps=5, orig_noise=noise)
+            h = mod.integrate_flow_field(noise * mod.config.sigma_fn(ts[0]), ts, return_history=True)
+            arrs[tag + "_hist_N5"] = torch.stack([x for _, x in h])
+    mod = M.SIModule(M.SIModuleConfig(scheduler="cosine", precondition_fn="edm"), net).eval()
+    tt = torch.tensor([0.4, 0.7])
+    with torch.inference_mode():
+        arrs["persample_t"] = tt
+        arrs["persample_flow"] = mod.get_flow_field(noise, tt)
+        arrs["persample_score"] = mod.get_score_field(noise, tt)
+    npz("si8_generic", **arrs)
+
+
 def porosity():
     """BASELINE config 5's shape of the path: 4-channel conditional PUNetG with the in-repo dict-style
     PorosityEmbedder (nets/embedder.py:198-229), classifier-free guidance, un-batched dict y."""
@@ -803,6 +837,6 @@ def latent():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["schedule", "toy", "punetg", "porosity", "inpaint", "vpve", "circular", "si", "punetgcond", "langevin", "adm", "variants", "latent", "adm_norms", "autoregressive", "si_latent", "si_inpaint", "volumes"]
+    which = sys.argv[1:] or ["schedule", "toy", "punetg", "porosity", "inpaint", "vpve", "circular", "si", "punetgcond", "langevin", "adm", "variants", "latent", "adm_norms", "autoregressive", "si_latent", "si_inpaint", "volumes", "si_generic"]
     for name in which:
         globals()[name]()

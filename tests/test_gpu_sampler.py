@@ -804,8 +804,33 @@ def test_si_flow_matching_sampler(M, dev):
     # the stochastic variant runs end to end; unsupported corners say so
     out = mod.sample(2, [1, 32, 32], nsteps=6, orig_noise=noise, noise_injection=True)
     assert out.shape == noise.shape and torch.isfinite(out).all()
-    with pytest.raises(NotImplementedError):
-        M.SIModuleConfig(autonomous_flow=True)
+
+
+def si_custom_precondition(model, x, t, y=None):
+    """The user precondition callable of the si8_generic fixture (oracle/tools/make_golden.py)."""
+    return 0.5 * model(x, t, y=y) - 0.1 * x
+
+
+def test_si_generic_preconditioners_and_per_sample_times(M, net8, dev):
+    """Autonomous flows and a user precondition callable (flowfield.py:127-165) -- evaluated step by step, the
+    arithmetic around the network on the HIP elementwise kernels -- and per-sample times in the field getters."""
+    v, _ = load("si8_generic")
+    noise = v["noise"].to(dev)
+    ts = torch.linspace(1, 0, 5)
+    for tag, kw in (("auto_identity", dict(scheduler="linear", autonomous_flow=True)),
+                    ("auto_edm", dict(scheduler="cosine", autonomous_flow=True, precondition_fn="edm")),
+                    ("callable", dict(scheduler="linear", precondition_fn=si_custom_precondition))):
+        mod = M.SIModule(M.SIModuleConfig(**kw), net8).to(dev).eval()
+        out = mod.sample(2, [1, 32, 32], nsteps=5, orig_noise=noise).cpu()
+        assert rel_l2(out, v[tag + "_sample_N5"]) < REL
+        h = mod.integrate_flow_field(noise * float(mod.config.sigma_fn(ts[0])), ts, return_history=True)
+        assert rel_l2(torch.stack([x for _, x in h]).cpu(), v[tag + "_hist_N5"]) < REL
+    mod = M.SIModule(M.SIModuleConfig(scheduler="cosine", precondition_fn="edm"), net8).to(dev).eval()
+    tt = v["persample_t"]
+    assert rel_l2(mod.get_flow_field(noise, tt).cpu(), v["persample_flow"]) < REL
+    assert rel_l2(mod.get_score_field(noise, tt).cpu(), v["persample_score"]) < REL
+    with pytest.raises(ValueError, match="Invalid condition function"):
+        M.SIModuleConfig(precondition_fn="nope")
 
 
 def test_si_inpaint(M, net8, dev):

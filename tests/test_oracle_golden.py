@@ -378,6 +378,34 @@ def test_si_latent_boundary_and_single_step():
     assert str(v["sd_keys"]) == "['initial_norm.running_mean' 'initial_norm.running_var']"
 
 
+def si_custom_precondition(model, x, t, y=None):
+    """The user precondition callable of the si8_generic fixture (oracle/tools/make_golden.py)."""
+    return 0.5 * model(x, t, y=y) - 0.1 * x
+
+
+def test_si_generic_preconditioners_and_per_sample_times():
+    """Autonomous flows, a user precondition callable (flowfield.py:127-165), per-sample times in the field getters."""
+    from oracle import si_ref as S
+    v, _ = load("si8_generic")
+    _, sd = load("punetg8_forward")
+    cfg = punetg_ref.default_config(model_channels=8)
+
+    def model(x, t=None, y=None):                                   # PUNetG.forward: t = None -> zero time embedding
+        return punetg_ref.punetg_forward(sd, cfg, x, t)
+    noise = v["noise"]
+    ts = torch.linspace(1, 0, 5)
+    with torch.inference_mode():
+        for tag, sname, kind in (("auto_identity", "linear", "auto_identity"), ("auto_edm", "cosine", "auto_edm"),
+                                 ("callable", "linear", si_custom_precondition)):
+            sch = S.scheduler(sname)
+            assert_exact_or_rel(S.sample(sch, kind, model, noise, 5), v[tag + "_sample_N5"], tag, 2e-6)
+            h = S.integrate(sch, kind, model, noise * sch["sigma"](ts[0]), ts, return_history=True)
+            assert_exact_or_rel(h, v[tag + "_hist_N5"], tag + " history", 2e-6)
+        sch = S.scheduler("cosine")
+        assert_exact_or_rel(S.flow_field(sch, "edm", model, noise, v["persample_t"]), v["persample_flow"], "per-sample flow", 2e-6)
+        assert_exact_or_rel(S.score_field(sch, "edm", model, noise, v["persample_t"]), v["persample_score"], "per-sample score", 2e-6)
+
+
 def _inpaint_draws(v, tag):
     return [v[f"{tag}_eps{i:02d}"] for i in range(int(v[tag + "_ndraws"]))]
 
