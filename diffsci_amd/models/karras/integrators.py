@@ -84,10 +84,12 @@ class KarrasIntegrator(Integrator):
         t_noise = scheduler_fns.inverse_noise_fn(sigma_noise)
         scale = scheduler_fns.scaling_fn(t)
         scale_noise = scheduler_fns.scaling_fn(t_noise)
-        if float(scale_noise / scale) != 1.0:
-            raise NotImplementedError("churn with a non-constant scaling function")
         std = scale_noise * torch.sqrt(sigma_noise ** 2 - sigma ** 2)
-        x_noise = ops.churn(x, torch.randn_like(x), float(std * self.s_noise), xhat_out=torch.empty_like(x))
+        ratio = float(scale_noise / scale)
+        if ratio == 1.0:                                   # EDM / VE: x + (std*S_noise)*eps in one pass
+            x_noise = ops.churn(x, torch.randn_like(x), float(std * self.s_noise), xhat_out=torch.empty_like(x))
+        else:                                              # VP: (s(t^)/s(t))*x + (std*S_noise)*eps, integrators.py:103-104
+            x_noise = ops.axpby(x.contiguous(), ratio, torch.randn_like(x), float(std * self.s_noise))
         d1 = rhs(x_noise, t_noise)
         dt_noise = (t + dt) - t_noise
         k = _drift_coef()

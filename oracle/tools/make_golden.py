@@ -348,6 +348,22 @@ def vpve():
     npz("vpve8", **arrs)
 
 
+def vp_karras():
+    """The sigma-churn integrator on a NON-constant scaling (VP): x_hat = (s(t_hat)/s(t))*x + std*S_noise*eps
+    (integrators.py:94-113), toy Gaussian score, recorded draws."""
+    import diffsci.data
+    torch.manual_seed(45)
+    gs = diffsci.data.ZeroMeanGaussianDataset(num_samples=8, shape=[2], scale=0.7)
+    sch = M.KarrasModuleConfig.from_vp(M=2).noisescheduler
+    x = torch.randn(8, 2)
+    arrs = dict(x=x, steps_6=sch.create_steps(7))
+    sch.set_temporary_integrator("karras")
+    with RandnRecorder() as rec:
+        arrs["hist_N6"] = sch.propagate_backward(x * sch.maximum_scale, gs.gradlogprob, 6, record_history=True)
+    arrs["eps"] = torch.stack(rec.draws)
+    npz("vp_karras", **arrs)
+
+
 def circular():
     """PUNetG with convolution_type='circular' (periodic padding in every 3x3 convolution)."""
     torch.manual_seed(50)
@@ -837,6 +853,6 @@ def latent():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["schedule", "toy", "punetg", "porosity", "inpaint", "vpve", "circular", "si", "punetgcond", "langevin", "adm", "variants", "latent", "adm_norms", "autoregressive", "si_latent", "si_inpaint", "volumes", "si_generic"]
+    which = sys.argv[1:] or ["schedule", "toy", "punetg", "porosity", "inpaint", "vpve", "circular", "si", "punetgcond", "langevin", "adm", "variants", "latent", "adm_norms", "autoregressive", "si_latent", "si_inpaint", "volumes", "si_generic", "vp_karras"]
     for name in which:
         globals()[name]()

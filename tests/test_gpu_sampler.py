@@ -565,6 +565,20 @@ def test_vp_ve_parameterisations(M, net8, dev, tag):
         assert not torch.isfinite(bad).all()
 
 
+def test_vp_sigma_churn(M, dev, monkeypatch):
+    """KarrasIntegrator on the VP parameterisation (non-constant scaling: the churn rescales x by s(t_hat)/s(t),
+    integrators.py:103), with the reference's recorded draws replayed through torch.randn_like."""
+    v, _ = load("vp_karras")
+    sch = M.KarrasModuleConfig.from_vp(M=2).noisescheduler
+    sch.create_steps = lambda n: v["steps_6"].clone()
+    draws = iter(v["eps"])
+    monkeypatch.setattr(torch, "randn_like", lambda t, *a, **k: next(draws).to(t))
+    sch.set_temporary_integrator("karras")
+    h = sch.propagate_backward((v["x"] * sch.maximum_scale).to(dev), K.gaussian_target_score(0.7), 6, record_history=True).cpu()
+    sch.unset_temporary_integrator()
+    torch.testing.assert_close(h, v["hist_N6"], rtol=1e-5, atol=1e-5 * sch.maximum_scale)
+
+
 def test_punetg_circular_convolutions(M, dev, grids):
     """PUNetGConfig(convolution_type='circular') against the reference."""
     v, sd = load("punetg8_circular")

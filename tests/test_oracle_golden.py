@@ -299,6 +299,17 @@ def test_vp_ve_parameterisations(tag):
             assert_exact_or_rel(h, v["ve_punetg_karras_N4"], "VE PUNetG sigma-churn", 2e-6)
 
 
+def test_vp_sigma_churn():
+    """The Karras integrator on the VP parameterisation: the churn rescales x by s(t_hat)/s(t) (integrators.py:103)."""
+    from oracle import vpve_ref as V
+    v, _ = load("vp_karras")
+    fns = V.VP()
+    assert_exact_or_ulp(V.vp_steps(7), v["steps_6"], "vp grid")
+    scale = float(fns.scaling_fn(v["steps_6"][0]) * fns.noise_fn(v["steps_6"][0]))
+    h = V.propagate(fns, v["steps_6"], v["x"] * scale, K.gaussian_target_score(0.7), "karras", record_history=True, eps=v["eps"])
+    assert_exact_or_rel(h, v["hist_N6"], "VP sigma-churn", 2e-6)
+
+
 def test_punetg_circular_convolutions():
     """convolution_type='circular' -- periodic padding, parameters under `.conv`."""
     v, sd = load("punetg8_circular")
