@@ -3,7 +3,8 @@
 batch 64 per GPU (BASELINE.json configs[1]); synthetic random-init weights and Gaussian noise.
 
     python bench.py --gpus 1 --steps 3 --warmup 1
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus N ...            # self-launching: starts N ranks through torch.distributed.run
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   # or under a launcher
 
 One "step" = one full sampling run (50 Heun steps = 99 network evaluations) of one batch per
 rank, replayed from the captured hipGraph, followed (N>1) by the RCCL all-gather of the samples.
@@ -57,6 +58,7 @@ def parse():
     ap.add_argument("--channels", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-other-precisions", action="store_true", help="skip the bf16x6 / exact-fp32 legs of the line")
     ap.add_argument("--fuse-max-cot", type=int, default=None, help="fuse norms only in layers with Cout/64 <= this")
     ap.add_argument("--no-up-parity", action="store_true", help="UpSampler convolutions through the generic gather loader")
     ap.add_argument("--no-direct-out", action="store_true", help="output layer on the MFMA kernel (Cout padded to 64)")
@@ -202,7 +204,8 @@ def hbm_class(module, args, dev):
 
     def timed_in_graph(fn, launches=200, reps=5):
         """The sampler replays its step kernels from a hipGraph; a 4 MiB step is a ~5 us kernel, shorter than one
-        eager launch through ctypes takes to issue.  Capture `launches` back-to-back launches and time the replay."""
+        eager launch through ctypes takes to issue.  Capture `launches` back-to-back calls of fn and time the replay;
+        returns ms per call of fn."""
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
@@ -219,16 +222,77 @@ def hbm_class(module, args, dev):
         torch.cuda.current_stream(dev).wait_stream(side)
         return e0.elapsed_time(e1) / (reps * launches)
 
-    for label, n in (("heun_step_cfg2_4MiB", B * S * S), ("heun_step_256MiB", B * C * S * S)):
+    # The fused Karras-Heun step = Euler predictor (R x, R F1, W c_in*x_e: 12 B/elt) + Heun corrector (R x, R F1, R F2,
+    # W x', W c_in*x': 20 B/elt) = 32 algorithmic bytes per element per step.  Timed as the sampler runs
+    # it: replayed from a hipGraph, back to back.  At config 2 the tensors are 4 MiB each: the whole working set
+    # (24 MiB) sits in L2 / Infinity Cache, so that figure is a CACHE rate (the kernel pair is launch-latency bound:
+    # ~1.5 us of dependent-launch boundary per kernel) and is labelled so; the HBM figure is the 256 MiB case, whose
+    # working set (1.5 GiB) cannot be cache resident.
+    for label, n, resident in (("heun_step_cfg2_4MiB", B * S * S, True), ("heun_step_256MiB", B * C * S * S, False)):
         xs, f1, f2 = (torch.randn(n, device=dev) for _ in range(3))
         xo, xi = torch.empty(n, device=dev), torch.empty(n, device=dev)
-        step = lambda: ops.heun(xs, f1, k, f2, k, -0.5, x_out=xo, xin_out=xi, c_in_next=0.3)   # noqa: E731
-        ms_eager = timed(step)
-        ms = timed_in_graph(step) if n <= (1 << 22) else ms_eager
-        gbs = n * 20 / (ms * 1e-3) / 1e9          # corrector: R x, F1, F2; W x', c_in*x'  = 20 B/elt
-        out[label] = {"bytes_per_elt": 20, "GB/s": round(gbs, 1), "frac_hbm_peak": round(gbs / HBM_PEAK_GBS, 4),
-                      "ms": round(ms, 5), "timed": "hipGraph replay of 200 launches" if ms is not ms_eager else "eager launches",
-                      "ms_eager_launch": round(ms_eager, 5)}
+
+        def step():
+            ops.euler(xs, f1, k, -0.5, x_out=None, xin_out=xi, c_in_next=0.3)              # predictor: only c_in*x_e is stored
+            ops.heun(xs, f1, k, f2, k, -0.5, x_out=xo, xin_out=xi, c_in_next=0.3)          # corrector
+
+        def corrector():
+            ops.heun(xs, f1, k, f2, k, -0.5, x_out=xo, xin_out=xi, c_in_next=0.3)
+        launches = 100 if resident else 10
+        ms = timed_in_graph(step, launches=launches) * 1.0          # per (predictor + corrector) pair
+        ms_c = timed_in_graph(corrector, launches=launches)
+        gbs = n * 32 / (ms * 1e-3) / 1e9
+        out[label] = {"bytes_per_elt": 32, "GB/s": round(gbs, 1), "frac_hbm_peak": round(gbs / HBM_PEAK_GBS, 4),
+                      "ms": round(ms, 5), "cache_resident": resident,
+                      "timed": f"hipGraph replay of {launches} (Euler predictor + Heun corrector) pairs",
+                      "corrector_only": {"bytes_per_elt": 20, "ms": round(ms_c, 5),
+                                         "GB/s": round(n * 20 / (ms_c * 1e-3) / 1e9, 1)}}
+        del xs, f1, f2, xo, xi
+    # ADM's per-sample GroupNorm(1, C) pair at config 3's level-0 size ([32, 128, 256, 256] = 1 GiB): statistics pass
+    # (4 B/elt) + apply pass (8 B/elt) = 12 B/elt
+    try:
+        xa = torch.randn(32, 128, 256, 256, device=dev)
+        ya = torch.empty_like(xa)
+        wa = torch.ones(128, device=dev)
+        stats = torch.empty(32, 2, device=dev)
+        wsb = torch.empty(N_gnorm_ws(32) // 4, device=dev)
+        ms_s = timed(lambda: ops.gnorm1_stats(xa, 0, stats=stats, workspace=wsb), reps=10)
+        ms_a = timed(lambda: ops.gnorm1_apply(xa, stats, wa, wa, 0, out=ya), reps=10)
+        ne = xa.numel()
+        out["adm_group1_norm_cfg3_1GiB"] = {
+            "stats": {"bytes_per_elt": 4, "ms": round(ms_s, 4), "GB/s": round(ne * 4 / (ms_s * 1e-3) / 1e9, 1)},
+            "apply": {"bytes_per_elt": 8, "ms": round(ms_a, 4), "GB/s": round(ne * 8 / (ms_a * 1e-3) / 1e9, 1)},
+            "bytes_per_elt": 12, "GB/s": round(ne * 12 / ((ms_s + ms_a) * 1e-3) / 1e9, 1),
+            "frac_hbm_peak": round(ne * 12 / ((ms_s + ms_a) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "cache_resident": False}
+        del xa, ya
+    except Exception as e:                                   # reporting only: never fail the bench line on it
+        out["adm_group1_norm_cfg3_1GiB"] = {"error": str(e)[:200]}
+    return out
+
+
+def N_gnorm_ws(B):
+    from diffsci_amd import _native as N
+    return N.lib().ds_gnorm1_workspace_bytes(B)
+
+
+def other_precisions(args, dev, wn):
+    """The same workload on the two other convolution arithmetics (one timed batch each): the exact 3-way bf16 split
+    (6 MFMA products, no range limit -- what the range guard falls back to) and the exact-fp32 MFMA."""
+    import copy
+    out = {}
+    for prec in ("bf16x6", "fp32"):
+        a = copy.copy(args)
+        a.precision = prec
+        module, _, _ = build_module(a, dev)
+        module.propagate_white_noise(wn, nsteps=a.nsteps)            # eager pass + capture + first replay
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        module.propagate_white_noise(wn, nsteps=a.nsteps)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out[prec] = {"samples/s": round(wn.shape[0] / dt, 3), "ms_per_step": round(dt * 1e3, 1)}
+        del module
+        torch.cuda.empty_cache()
     return out
 
 
@@ -257,14 +321,40 @@ def cpu_baseline(sd, cfg, args):
                       f"scaled by {full}/{evals} evaluations to the {args.nsteps}-step workload"}
 
 
+def launcher_command(argv, n, port):
+    """The command `python bench.py --gpus N` runs for itself when no launcher started it: one rank per GPU through
+    torch.distributed.run on this node (the reference's multi-GPU sampler spawns its own workers too,
+    stochasticity_paper/scripts/test-diffusion-cifar10karras-colormap-parallel.py:191-291)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(args):
+    """Parent of a multi-rank run started without a launcher.  Runs BEFORE anything touches the GPU in this process
+    (a process that has initialised HIP must not be replaced or forked into ranks); relays the children's output
+    (rank 0 prints the JSON line) and exits with their status."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, host_cores() // max(1, args.gpus))))
+    cmd = launcher_command(sys.argv[1:], args.gpus, port)
+    print(f"[bench] starting {args.gpus} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} rank(s)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -320,6 +410,7 @@ def main():
             "config": {"workload": f"PUNetG {args.channels}-base-ch, 1x{args.size}x{args.size} fields, batch {B} per GPU, "
                                    f"{args.nsteps}-step Heun deterministic sampler ({2*args.nsteps-1} network evaluations)",
                        "global_batch": B * world, "parallelism": f"dp{world} (batch shards, all-gather of samples)",
+                       "rccl_world_size": dist.get_world_size() if dist is not None else 1,
                        "hipgraph": not args.no_graph},
         }
         print(f"[bench] {value:.3f} samples/s, {dt / args.steps * 1e3:.1f} ms per {B}-sample batch", file=sys.stderr, flush=True)
@@ -327,6 +418,9 @@ def main():
         print(f"[bench] roofline {line['roofline']}", file=sys.stderr, flush=True)
         line["roofline_hbm_class"] = hbm_class(module, args, dev)
         print(f"[bench] hbm class {line['roofline_hbm_class']}", file=sys.stderr, flush=True)
+        if world == 1 and not args.no_other_precisions and args.precision == "fp16x3":
+            line["other_precisions"] = other_precisions(args, dev, noise[0])
+            print(f"[bench] other precisions {line['other_precisions']}", file=sys.stderr, flush=True)
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(sd, cfg, args)
         print(json.dumps(line), flush=True)

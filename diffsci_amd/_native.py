@@ -5,11 +5,12 @@ point of diffsci_amd raises.  Build it with ``python build.py`` (hipcc, gfx950).
 """
 import ctypes
 import os
-from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_longlong, c_size_t, c_void_p
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_longlong, c_size_t, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DIFFSCI_HIP_LIB") or os.path.join(_HERE, "_lib", "libdiffsci_hip.so")
 
+ABI_VERSION = 2
 DS_IN_NETWORK, DS_IN_SCORE, DS_IN_DRIFT, DS_IN_FLOW = 0, 1, 2, 3
 DS_LOAD_PLAIN, DS_LOAD_MAXPOOL2, DS_LOAD_UPSAMPLE2, DS_LOAD_AVGPOOL2 = 0, 1, 2, 3
 DS_PAD_CIRCULAR = 16
@@ -35,11 +36,12 @@ _PROTOS = {
     "ds_karras_scale": (c_int, [_P, _P, c_float, c_size_t, _P]),
     "ds_karras_drift": (c_int, [_P, _P, _P, _P, POINTER(EvalCoef), c_size_t, _P]),
     "ds_karras_score": (c_int, [_P, _P, _P, _P, POINTER(EvalCoef), c_size_t, _P]),
+    "ds_philox_normal": (c_int, [_P, _P, c_uint64, c_size_t, _P]),
     "ds_karras_euler": (c_int, [_P, _P, _P, _P, _P, POINTER(EvalCoef), c_float, c_float,
-                                _P, c_float, c_float, c_size_t, _P]),
+                                _P, _P, c_uint64, c_float, c_float, c_size_t, _P]),
     "ds_karras_heun": (c_int, [_P, _P, _P, _P, _P, POINTER(EvalCoef), _P, _P, POINTER(EvalCoef),
                                c_float, c_float, c_size_t, _P]),
-    "ds_karras_churn": (c_int, [_P, _P, _P, _P, c_float, c_float, c_size_t, _P]),
+    "ds_karras_churn": (c_int, [_P, _P, _P, _P, _P, c_uint64, c_float, c_float, c_size_t, _P]),
     "ds_karras_denoiser": (c_int, [_P, _P, _P, _P, c_float, c_float, _P, _P, c_int, c_size_t, _P]),
     "ds_inorm_silu": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_float, c_int, _P]),
     "ds_conv2d_packed_floats": (c_size_t, [c_int, c_int, c_int]),
@@ -117,8 +119,8 @@ def lib():
             raise NativeLibraryError(f"{LIB_PATH} does not export {name}; rebuild with build.py") from e
         fn.restype = res
         fn.argtypes = args
-    if L.ds_version() != 1:
-        raise NativeLibraryError(f"ABI version {L.ds_version()} != 1; rebuild with build.py")
+    if L.ds_version() != ABI_VERSION:
+        raise NativeLibraryError(f"ABI version {L.ds_version()} != {ABI_VERSION}; rebuild with build.py")
     _lib = L
     return L
 

@@ -22,7 +22,7 @@ struct ds_graph {
 
 extern "C" {
 
-int ds_version(void) { return 1; }
+int ds_version(void) { return 2; }
 
 const char* ds_last_error(void) { return ds::get_error(); }
 

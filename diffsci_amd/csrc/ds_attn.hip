@@ -149,12 +149,9 @@ template <int ET, int ETO = ET>
 int launch_attn(float* out, const float* qkv, int B, int L, float scale, hipStream_t s) {
   constexpr int E = 32 * ET;
   const size_t lds = (size_t)(E * KB + 32 * ETO * VSTR) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set && lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn<ET, ETO>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return ds::hip_fail(e, "hipFuncSetAttribute(attn)");
-    attr_set = true;
+  if (lds > 48 * 1024) {
+    const int rc = ds::ensure_dynamic_lds<&k_attn<ET, ETO>>((int)lds, "hipFuncSetAttribute(attn)");
+    if (rc != DS_OK) return rc;
   }
   dim3 g((L + 127) / 128, B, ET / ETO);
   hipLaunchKernelGGL((k_attn<ET, ETO>), g, dim3(NT), lds, s, out, qkv, L, scale);

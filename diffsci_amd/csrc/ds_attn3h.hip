@@ -302,16 +302,12 @@ template <int ET>
 int launch_attn3h(float* out, const float* qkv, int B, int L, float scale, hipStream_t s) {
   constexpr int E = 32 * ET;
   const size_t lds = (size_t)2 * (2 * (E / 8) * KB + 2 * 4 * E) * 16;    // K and V, double-buffered
-  static bool attr_set = false;
-  if (!attr_set && lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn3h<ET>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return ds::hip_fail(e, "hipFuncSetAttribute(attn3h)");
-    attr_set = true;
+  if (lds > 48 * 1024) {
+    const int rc = ds::ensure_dynamic_lds<&k_attn3h<ET>>((int)lds, "hipFuncSetAttribute(attn3h)");
+    if (rc != DS_OK) return rc;
   }
   dim3 g((L + 127) / 128, B);
-  static float thr = -1.f;
-  if (thr < 0.f) { const char* e = getenv("DS_ATTN_T"); thr = e ? (float)atof(e) : RESCALE_T; }
+  static const float thr = [] { const char* e = getenv("DS_ATTN_T"); return e ? (float)atof(e) : RESCALE_T; }();   // diagnostic knob
   hipLaunchKernelGGL((k_attn3h<ET>), g, dim3(NT), lds, s, out, qkv, L, scale, thr);
   DS_CHECK_LAUNCH("ds_attention_h3");
   return DS_OK;

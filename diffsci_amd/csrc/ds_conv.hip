@@ -302,12 +302,9 @@ template <int KS, int MODE>
 int launch_conv(const ConvArgs& a, hipStream_t s) {
   using G = Geo<KS>;
   const size_t lds = 2 * G::STAGE_FLOATS * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv<KS, MODE>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return ds::hip_fail(e, "hipFuncSetAttribute(conv)");
-    attr_set = true;
+  {
+    const int rc = ds::ensure_dynamic_lds<&k_conv<KS, MODE>>((int)lds, "hipFuncSetAttribute(conv)");
+    if (rc != DS_OK) return rc;
   }
   const long long blocks = (long long)a.B * a.tiles_y * a.tiles_x * a.n_cot;
   DS_REQUIRE(blocks > 0 && blocks < (1ll << 31), DS_ERR_SHAPE, "ds_conv2d: grid of %lld workgroups is out of range", blocks);

@@ -257,12 +257,9 @@ __global__ void k_pack1h(_Float16* packed, const float* __restrict__ w, int Cout
 
 template <int MODE, bool W16>
 int launch_conv1h(const Conv1hArgs& a, hipStream_t s) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv1h<MODE, W16>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    if (e != hipSuccess) return ds::hip_fail(e, "hipFuncSetAttribute(conv1h)");
-    attr_set = true;
+  {
+    const int rc = ds::ensure_dynamic_lds<&k_conv1h<MODE, W16>>((int)(LDS_BYTES), "hipFuncSetAttribute(conv1h)");
+    if (rc != DS_OK) return rc;
   }
   hipLaunchKernelGGL((k_conv1h<MODE, W16>), dim3(a.n_blocks), dim3(NT), LDS_BYTES, s, a);
   DS_CHECK_LAUNCH("ds_conv1x1_h3");

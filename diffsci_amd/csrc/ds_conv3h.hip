@@ -398,12 +398,9 @@ __global__ void k_pack3h(_Float16* packed, const float* __restrict__ w, int Cout
 
 template <int MODE, bool W16, bool PRE, bool CIRC>
 int launch_conv3h_c(const Conv3hArgs& a, hipStream_t s) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3h<MODE, W16, PRE, CIRC>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    if (e != hipSuccess) return ds::hip_fail(e, "hipFuncSetAttribute(conv3h)");
-    attr_set = true;
+  {
+    const int rc = ds::ensure_dynamic_lds<&k_conv3h<MODE, W16, PRE, CIRC>>((int)(LDS_BYTES), "hipFuncSetAttribute(conv3h)");
+    if (rc != DS_OK) return rc;
   }
   const long long tiles = (long long)a.tiles_y * a.tiles_x;
   DS_REQUIRE(tiles > 0 && tiles < 65536 && a.B < 65536, DS_ERR_SHAPE,

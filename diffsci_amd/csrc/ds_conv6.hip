@@ -331,12 +331,9 @@ __global__ void k_pack6(unsigned short* packed, const float* __restrict__ w, int
 
 template <int MODE>
 int launch_conv6(const Conv6Args& a, hipStream_t s) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv6<MODE>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    if (e != hipSuccess) return ds::hip_fail(e, "hipFuncSetAttribute(conv6)");
-    attr_set = true;
+  {
+    const int rc = ds::ensure_dynamic_lds<&k_conv6<MODE>>((int)(LDS_BYTES), "hipFuncSetAttribute(conv6)");
+    if (rc != DS_OK) return rc;
   }
   const long long blocks = (long long)a.B * a.tiles_y * a.tiles_x * a.n_cot;
   DS_REQUIRE(blocks > 0 && blocks < (1ll << 31), DS_ERR_SHAPE, "ds_conv2d_x6: grid of %lld workgroups is out of range", blocks);

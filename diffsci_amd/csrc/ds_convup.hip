@@ -420,12 +420,9 @@ __global__ void k_pack_up(_Float16* packed, const float* __restrict__ w, int Cou
 
 template <bool W16, bool PRE, bool CIRC>
 int launch_up(const UpArgs& a, hipStream_t s) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_convup<W16, PRE, CIRC>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    if (e != hipSuccess) return ds::hip_fail(e, "hipFuncSetAttribute(convup)");
-    attr_set = true;
+  {
+    const int rc = ds::ensure_dynamic_lds<&k_convup<W16, PRE, CIRC>>((int)(LDS_BYTES), "hipFuncSetAttribute(convup)");
+    if (rc != DS_OK) return rc;
   }
   const long long tiles = (long long)a.tiles_y * a.tiles_x;
   DS_REQUIRE(tiles > 0 && tiles < 65536 && a.B < 65536, DS_ERR_SHAPE,

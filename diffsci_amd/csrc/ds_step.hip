@@ -42,6 +42,61 @@ inline int grid_for(size_t n4) {
   return (int)g;
 }
 
+// ---- counter-based noise: Philox4x32-10 + Box-Muller (the in-kernel eps of SURVEY 8a6 / 8b) ----------------
+// eps for element e of step j comes from counter  state[1] + offset_j + e/4  under key state[0]; its four 32-bit
+// outputs give the four normals of elements 4*(e/4) .. 4*(e/4)+3.  Nothing depends on the launch geometry, so
+// a replay with the same (seed, offset) reproduces the draw bit for bit and the launch is graph-capturable:
+// (seed, base offset) live in device memory, the per-step offset is a by-value argument.
+// oracle/philox_ref.py restates this stream in numpy.
+__device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
+    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
+    c = make_uint4(hi1 ^ c.y ^ k.x, lo1, hi0 ^ c.w ^ k.y, lo0);
+    k.x += 0x9E3779B9u;
+    k.y += 0xBB67AE85u;
+  }
+  return c;
+}
+
+__device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float& z0, float& z1) {
+  const float u1 = (float)a * 2.3283064365386963e-10f + 1.1641532182693481e-10f;   // (0, 1]
+  const float u2 = (float)b * 2.3283064365386963e-10f;                               // [0, 1]
+  const float rad = sqrtf(-2.0f * logf(u1));
+  float sn, cs;
+  sincospif(2.0f * u2, &sn, &cs);
+  z0 = rad * cs;
+  z1 = rad * sn;
+}
+
+__device__ __forceinline__ float4 philox_normal4(const unsigned long long* __restrict__ state, unsigned long long offset,
+                                                 size_t i4) {
+  const unsigned long long seed = state[0], ctr = state[1] + offset + (unsigned long long)i4;
+  const uint4 r = philox4x32_10(make_uint4((uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u),
+                                make_uint2((uint32_t)seed, (uint32_t)(seed >> 32)));
+  float4 z;
+  box_muller(r.x, r.y, z.x, z.y);
+  box_muller(r.z, r.w, z.z, z.w);
+  return z;
+}
+
+__device__ __forceinline__ float philox_normal1(const unsigned long long* __restrict__ state, unsigned long long offset,
+                                                size_t e) {
+  const float4 z = philox_normal4(state, offset, e >> 2);
+  const int j = (int)(e & 3);
+  return j == 0 ? z.x : j == 1 ? z.y : j == 2 ? z.z : z.w;
+}
+
+__global__ __launch_bounds__(kThreads) void k_philox_normal(float* __restrict__ out, const unsigned long long* state,
+                                                            unsigned long long offset, size_t n4, size_t n) {
+  size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x;
+  size_t stride = (size_t)gridDim.x * kThreads;
+  for (; i < n4; i += stride) reinterpret_cast<float4*>(out)[i] = philox_normal4(state, offset, i);
+  for (size_t t = n4 * 4 + (size_t)blockIdx.x * kThreads + threadIdx.x; t < n; t += stride)
+    out[t] = philox_normal1(state, offset, t);
+}
+
 __global__ __launch_bounds__(kThreads) void k_scale(float* __restrict__ out, const float* __restrict__ x, float s,
                                                     size_t n4, size_t n) {
   size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x;
@@ -51,9 +106,8 @@ __global__ __launch_bounds__(kThreads) void k_scale(float* __restrict__ out, con
     v.x = s * v.x; v.y = s * v.y; v.z = s * v.z; v.w = s * v.w;
     reinterpret_cast<float4*>(out)[i] = v;
   }
-  // tail (n not a multiple of 4)
-  size_t t = n4 * 4 + (size_t)blockIdx.x * kThreads + threadIdx.x;
-  if (t < n) out[t] = s * x[t];
+  // tail (n not a multiple of 4), or everything when a pointer is not 16-byte aligned (n4 = 0)
+  for (size_t t = n4 * 4 + (size_t)blockIdx.x * kThreads + threadIdx.x; t < n; t += stride) out[t] = s * x[t];
 }
 
 template <bool HAS_U, bool HAS_EPS>
@@ -66,11 +120,13 @@ __device__ __forceinline__ void euler_one(float x, float f, float fu, float e, c
   xi = c_in_next * r;
 }
 
-template <bool HAS_U, bool HAS_EPS>
+template <bool HAS_U, int NOISE>        // NOISE: 0 none, 1 injected eps, 2 in-kernel Philox
 __global__ __launch_bounds__(kThreads) void k_euler(float* x_out, float* xin_out, const float* x,
                                                     const float* __restrict__ f, const float* __restrict__ fu,
-                                                    const float* __restrict__ eps, ds_eval_coef k, float dt,
+                                                    const float* __restrict__ eps, const unsigned long long* rng,
+                                                    unsigned long long rng_offset, ds_eval_coef k, float dt,
                                                     float c_in_next, float noise_coef, float sq, size_t n4, size_t n) {
+  constexpr bool HAS_EPS = NOISE != 0;
   size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x;
   size_t stride = (size_t)gridDim.x * kThreads;
   for (; i < n4; i += stride) {
@@ -78,7 +134,8 @@ __global__ __launch_bounds__(kThreads) void k_euler(float* x_out, float* xin_out
     float4 vf = reinterpret_cast<const float4*>(f)[i];
     float4 vu = make_float4(0, 0, 0, 0), ve = make_float4(0, 0, 0, 0);
     if (HAS_U) vu = reinterpret_cast<const float4*>(fu)[i];
-    if (HAS_EPS) ve = reinterpret_cast<const float4*>(eps)[i];
+    if (NOISE == 1) ve = reinterpret_cast<const float4*>(eps)[i];
+    if (NOISE == 2) ve = philox_normal4(rng, rng_offset, i);
     float4 o, q;
     euler_one<HAS_U, HAS_EPS>(vx.x, vf.x, vu.x, ve.x, k, dt, noise_coef, sq, c_in_next, o.x, q.x);
     euler_one<HAS_U, HAS_EPS>(vx.y, vf.y, vu.y, ve.y, k, dt, noise_coef, sq, c_in_next, o.y, q.y);
@@ -87,11 +144,10 @@ __global__ __launch_bounds__(kThreads) void k_euler(float* x_out, float* xin_out
     if (x_out) reinterpret_cast<float4*>(x_out)[i] = o;
     if (xin_out) reinterpret_cast<float4*>(xin_out)[i] = q;
   }
-  size_t t = n4 * 4 + (size_t)blockIdx.x * kThreads + threadIdx.x;
-  if (t < n) {
+  for (size_t t = n4 * 4 + (size_t)blockIdx.x * kThreads + threadIdx.x; t < n; t += stride) {
     float o, q;
-    euler_one<HAS_U, HAS_EPS>(x[t], f[t], HAS_U ? fu[t] : 0.f, HAS_EPS ? eps[t] : 0.f, k, dt, noise_coef, sq,
-                              c_in_next, o, q);
+    const float e = NOISE == 1 ? eps[t] : NOISE == 2 ? philox_normal1(rng, rng_offset, t) : 0.f;
+    euler_one<HAS_U, HAS_EPS>(x[t], f[t], HAS_U ? fu[t] : 0.f, e, k, dt, noise_coef, sq, c_in_next, o, q);
     if (x_out) x_out[t] = o;
     if (xin_out) xin_out[t] = q;
   }
@@ -133,8 +189,7 @@ __global__ __launch_bounds__(kThreads) void k_heun(float* x_out, float* xin_out,
     reinterpret_cast<float4*>(x_out)[i] = o;
     if (xin_out) reinterpret_cast<float4*>(xin_out)[i] = q;
   }
-  size_t t = n4 * 4 + (size_t)blockIdx.x * kThreads + threadIdx.x;
-  if (t < n) {
+  for (size_t t = n4 * 4 + (size_t)blockIdx.x * kThreads + threadIdx.x; t < n; t += stride) {
     float o, q;
     heun_one<HAS_U>(x[t], f1[t], HAS_U ? f1u[t] : 0.f, f2[t], HAS_U ? f2u[t] : 0.f, k1, k2, dt, c_in_next, o, q);
     x_out[t] = o;
@@ -154,23 +209,24 @@ __global__ __launch_bounds__(kThreads) void k_drift(float* out, const float* x, 
   }
 }
 
+template <bool PHILOX>
 __global__ __launch_bounds__(kThreads) void k_churn(float* xhat, float* xin_out, const float* x,
-                                                    const float* __restrict__ eps, float coef, float c_in, size_t n4,
+                                                    const float* __restrict__ eps, const unsigned long long* rng,
+                                                    unsigned long long rng_offset, float coef, float c_in, size_t n4,
                                                     size_t n) {
   size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x;
   size_t stride = (size_t)gridDim.x * kThreads;
   for (; i < n4; i += stride) {
     float4 vx = reinterpret_cast<const float4*>(x)[i];
-    float4 ve = reinterpret_cast<const float4*>(eps)[i];
+    float4 ve = PHILOX ? philox_normal4(rng, rng_offset, i) : reinterpret_cast<const float4*>(eps)[i];
     float4 o, q;
     o.x = vx.x + coef * ve.x; o.y = vx.y + coef * ve.y; o.z = vx.z + coef * ve.z; o.w = vx.w + coef * ve.w;
     q.x = c_in * o.x; q.y = c_in * o.y; q.z = c_in * o.z; q.w = c_in * o.w;
     reinterpret_cast<float4*>(xhat)[i] = o;
     if (xin_out) reinterpret_cast<float4*>(xin_out)[i] = q;
   }
-  size_t t = n4 * 4 + (size_t)blockIdx.x * kThreads + threadIdx.x;
-  if (t < n) {
-    float o = x[t] + coef * eps[t];
+  for (size_t t = n4 * 4 + (size_t)blockIdx.x * kThreads + threadIdx.x; t < n; t += stride) {
+    float o = x[t] + coef * (PHILOX ? philox_normal1(rng, rng_offset, t) : eps[t]);
     xhat[t] = o;
     if (xin_out) xin_out[t] = c_in * o;
   }
@@ -276,48 +332,64 @@ __global__ __launch_bounds__(kThreads) void k_add(float* out, const float* __res
     va.x += vb.x; va.y += vb.y; va.z += vb.z; va.w += vb.w;
     reinterpret_cast<float4*>(out)[i] = va;
   }
-  size_t t = n4 * 4 + (size_t)blockIdx.x * kThreads + threadIdx.x;
-  if (t < n) out[t] = a[t] + b[t];
+  for (size_t t = n4 * 4 + (size_t)blockIdx.x * kThreads + threadIdx.x; t < n; t += stride) out[t] = a[t] + b[t];
 }
 
 inline bool blends(int input_kind) { return input_kind == DS_IN_NETWORK || input_kind == DS_IN_FLOW; }
-inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// float4 iterations of a launch: n/4 when every (non-NULL) pointer is 16-byte aligned, else 0 -- the kernels'
+// scalar grid-stride tail then covers everything (odd-sized states: history[i] / eps[i] slices of [B,2] toys with
+// odd B, per-sample views x[b] of 3x3 fields, ...; the reference accepts any shape).
+inline size_t vec4_count(size_t n, std::initializer_list<const void*> ptrs) {
+  for (const void* p : ptrs)
+    if (p && (reinterpret_cast<uintptr_t>(p) & 15u)) return 0;
+  return n / 4;
+}
+inline int grid_elems(size_t n4, size_t n) { return grid_for(n4 ? n4 : (n + 3) / 4); }
 
 }  // namespace
-
-#define DS_ALIGN_OK(p) ((p) == nullptr || aligned16(p))
 
 extern "C" {
 
 int ds_karras_scale(float* out, const float* x, float s, size_t n, void* stream) {
   DS_REQUIRE(out && x, DS_ERR_NULL, "ds_karras_scale: NULL pointer");
-  DS_REQUIRE(aligned16(out) && aligned16(x), DS_ERR_SHAPE, "ds_karras_scale: pointers must be 16-byte aligned");
   if (n == 0) return DS_OK;
-  size_t n4 = n / 4;
-  hipLaunchKernelGGL(k_scale, dim3(grid_for(n4 ? n4 : 1)), dim3(kThreads), 0, ds::as_stream(stream), out, x, s, n4, n);
+  const size_t n4 = vec4_count(n, {out, x});
+  hipLaunchKernelGGL(k_scale, dim3(grid_elems(n4, n)), dim3(kThreads), 0, ds::as_stream(stream), out, x, s, n4, n);
   DS_CHECK_LAUNCH("ds_karras_scale");
   return DS_OK;
 }
 
+int ds_philox_normal(float* out, const uint64_t* philox_state, uint64_t philox_offset, size_t n, void* stream) {
+  DS_REQUIRE(out && philox_state, DS_ERR_NULL, "ds_philox_normal: NULL pointer");
+  DS_REQUIRE((reinterpret_cast<uintptr_t>(philox_state) & 7u) == 0, DS_ERR_SHAPE, "ds_philox_normal: state must be 8-byte aligned");
+  if (n == 0) return DS_OK;
+  const size_t n4 = vec4_count(n, {out});
+  hipLaunchKernelGGL(k_philox_normal, dim3(grid_elems(n4, n)), dim3(kThreads), 0, ds::as_stream(stream), out,
+                     reinterpret_cast<const unsigned long long*>(philox_state), (unsigned long long)philox_offset, n4, n);
+  DS_CHECK_LAUNCH("ds_philox_normal");
+  return DS_OK;
+}
+
 int ds_karras_euler(float* x_out, float* xin_out, const float* x, const float* f, const float* fu,
-                    const ds_eval_coef* k, float dt, float c_in_next, const float* eps, float noise_coef,
-                    float sqrt_abs_dt, size_t n, void* stream) {
+                    const ds_eval_coef* k, float dt, float c_in_next, const float* eps, const uint64_t* philox_state,
+                    uint64_t philox_offset, float noise_coef, float sqrt_abs_dt, size_t n, void* stream) {
   DS_REQUIRE(x && f && k, DS_ERR_NULL, "ds_karras_euler: NULL pointer");
   DS_REQUIRE(x_out || xin_out, DS_ERR_NULL, "ds_karras_euler: no output requested");
-  DS_REQUIRE(DS_ALIGN_OK(x_out) && DS_ALIGN_OK(xin_out) && aligned16(x) && aligned16(f) && DS_ALIGN_OK(fu) &&
-                 DS_ALIGN_OK(eps),
-             DS_ERR_SHAPE, "ds_karras_euler: pointers must be 16-byte aligned");
+  DS_REQUIRE(!(eps && philox_state), DS_ERR_SHAPE, "ds_karras_euler: give injected eps or a Philox state, not both");
+  DS_REQUIRE((reinterpret_cast<uintptr_t>(philox_state) & 7u) == 0, DS_ERR_SHAPE, "ds_karras_euler: state must be 8-byte aligned");
   DS_REQUIRE(!(!blends(k->input_kind) && fu), DS_ERR_SHAPE, "ds_karras_euler: guidance blend needs network outputs or flow fields");
   if (n == 0) return DS_OK;
-  size_t n4 = n / 4;
-  dim3 g(grid_for(n4 ? n4 : 1)), b(kThreads);
+  const size_t n4 = vec4_count(n, {x_out, xin_out, x, f, fu, eps});
+  dim3 g(grid_elems(n4, n)), b(kThreads);
   hipStream_t s = ds::as_stream(stream);
+  const unsigned long long* rng = reinterpret_cast<const unsigned long long*>(philox_state);
+  const unsigned long long off = (unsigned long long)philox_offset;
 #define L(U, E) \
-  hipLaunchKernelGGL((k_euler<U, E>), g, b, 0, s, x_out, xin_out, x, f, fu, eps, *k, dt, c_in_next, noise_coef, sqrt_abs_dt, n4, n)
-  if (fu && eps) L(true, true);
-  else if (fu) L(true, false);
-  else if (eps) L(false, true);
-  else L(false, false);
+  hipLaunchKernelGGL((k_euler<U, E>), g, b, 0, s, x_out, xin_out, x, f, fu, eps, rng, off, *k, dt, c_in_next, noise_coef, sqrt_abs_dt, n4, n)
+  const int noise = eps ? 1 : (rng ? 2 : 0);
+  if (fu) { if (noise == 1) L(true, 1); else if (noise == 2) L(true, 2); else L(true, 0); }
+  else    { if (noise == 1) L(false, 1); else if (noise == 2) L(false, 2); else L(false, 0); }
 #undef L
   DS_CHECK_LAUNCH("ds_karras_euler");
   return DS_OK;
@@ -329,14 +401,11 @@ int ds_karras_heun(float* x_out, float* xin_out, const float* x, const float* f1
   DS_REQUIRE(x_out && x && f1 && f2 && k1 && k2, DS_ERR_NULL, "ds_karras_heun: NULL pointer");
   DS_REQUIRE((f1u == nullptr) == (f2u == nullptr), DS_ERR_SHAPE,
              "ds_karras_heun: f1u and f2u must both be given or both be NULL");
-  DS_REQUIRE(aligned16(x_out) && DS_ALIGN_OK(xin_out) && aligned16(x) && aligned16(f1) && aligned16(f2) &&
-                 DS_ALIGN_OK(f1u) && DS_ALIGN_OK(f2u),
-             DS_ERR_SHAPE, "ds_karras_heun: pointers must be 16-byte aligned");
   DS_REQUIRE(!((!blends(k1->input_kind) || !blends(k2->input_kind)) && f1u), DS_ERR_SHAPE,
              "ds_karras_heun: guidance blend needs network outputs or flow fields");
   if (n == 0) return DS_OK;
-  size_t n4 = n / 4;
-  dim3 g(grid_for(n4 ? n4 : 1)), b(kThreads);
+  const size_t n4 = vec4_count(n, {x_out, xin_out, x, f1, f2, f1u, f2u});
+  dim3 g(grid_elems(n4, n)), b(kThreads);
   hipStream_t s = ds::as_stream(stream);
   if (f1u)
     hipLaunchKernelGGL((k_heun<true>), g, b, 0, s, x_out, xin_out, x, f1, f1u, f2, f2u, *k1, *k2, dt, c_in_next, n4, n);
@@ -376,15 +445,22 @@ int ds_karras_score(float* s_out, const float* x, const float* f, const float* f
   return launch_drift(s_out, x, f, fu, k, n, stream, true, "ds_karras_score");
 }
 
-int ds_karras_churn(float* xhat_out, float* xin_out, const float* x, const float* eps, float coef, float c_in,
-                    size_t n, void* stream) {
-  DS_REQUIRE(xhat_out && x && eps, DS_ERR_NULL, "ds_karras_churn: NULL pointer");
-  DS_REQUIRE(aligned16(xhat_out) && DS_ALIGN_OK(xin_out) && aligned16(x) && aligned16(eps), DS_ERR_SHAPE,
-             "ds_karras_churn: pointers must be 16-byte aligned");
+int ds_karras_churn(float* xhat_out, float* xin_out, const float* x, const float* eps, const uint64_t* philox_state,
+                    uint64_t philox_offset, float coef, float c_in, size_t n, void* stream) {
+  DS_REQUIRE(xhat_out && x, DS_ERR_NULL, "ds_karras_churn: NULL pointer");
+  DS_REQUIRE((eps != nullptr) != (philox_state != nullptr), DS_ERR_NULL,
+             "ds_karras_churn: exactly one of eps (injected noise) and philox_state (in-kernel noise) must be given");
+  DS_REQUIRE((reinterpret_cast<uintptr_t>(philox_state) & 7u) == 0, DS_ERR_SHAPE, "ds_karras_churn: state must be 8-byte aligned");
   if (n == 0) return DS_OK;
-  size_t n4 = n / 4;
-  hipLaunchKernelGGL(k_churn, dim3(grid_for(n4 ? n4 : 1)), dim3(kThreads), 0, ds::as_stream(stream), xhat_out,
-                     xin_out, x, eps, coef, c_in, n4, n);
+  const size_t n4 = vec4_count(n, {xhat_out, xin_out, x, eps});
+  dim3 g(grid_elems(n4, n)), b(kThreads);
+  hipStream_t s = ds::as_stream(stream);
+  if (eps)
+    hipLaunchKernelGGL((k_churn<false>), g, b, 0, s, xhat_out, xin_out, x, eps, nullptr, 0ull, coef, c_in, n4, n);
+  else
+    hipLaunchKernelGGL((k_churn<true>), g, b, 0, s, xhat_out, xin_out, x, eps,
+                       reinterpret_cast<const unsigned long long*>(philox_state), (unsigned long long)philox_offset, coef,
+                       c_in, n4, n);
   DS_CHECK_LAUNCH("ds_karras_churn");
   return DS_OK;
 }
@@ -458,10 +534,9 @@ int ds_lerp_stack(float* out, const float* x1, const float* x2, int n, size_t nu
 
 int ds_add(float* out, const float* a, const float* b, size_t n, void* stream) {
   DS_REQUIRE(out && a && b, DS_ERR_NULL, "ds_add: NULL pointer");
-  DS_REQUIRE(aligned16(out) && aligned16(a) && aligned16(b), DS_ERR_SHAPE, "ds_add: pointers must be 16-byte aligned");
   if (n == 0) return DS_OK;
-  size_t n4 = n / 4;
-  hipLaunchKernelGGL(k_add, dim3(grid_for(n4 ? n4 : 1)), dim3(kThreads), 0, ds::as_stream(stream), out, a, b, n4, n);
+  const size_t n4 = vec4_count(n, {out, a, b});
+  hipLaunchKernelGGL(k_add, dim3(grid_elems(n4, n)), dim3(kThreads), 0, ds::as_stream(stream), out, a, b, n4, n);
   DS_CHECK_LAUNCH("ds_add");
   return DS_OK;
 }

@@ -38,6 +38,20 @@ class ScoreFnSource:
         return s.contiguous(), None
 
 
+def condition_signature(y):
+    """Structure of a condition (keys, shapes, dtypes) -- what a captured plan depends on.  The VALUES never enter a
+    plan key: everything derived from them lives in plan-owned buffers that `ModuleSource.refresh` rewrites before
+    every replay (an address- or checksum-based key cannot tell two one-hot labels, or a new tensor that reuses a
+    freed block, apart)."""
+    if y is None:
+        return None
+    if isinstance(y, dict):
+        return tuple((k, condition_signature(v)) for k, v in sorted(y.items()))
+    if torch.is_tensor(y):
+        return (tuple(y.shape), str(y.dtype), str(y.device))
+    return repr(type(y))
+
+
 class ModuleSource:
     """model(c_in*x, c_noise[, y]) of KarrasModule.get_denoiser (karrasmodule.py:702-716)."""
     input_kind = DS_IN_NETWORK
@@ -55,6 +69,19 @@ class ModuleSource:
         self.planned = bool(getattr(self.model, "forward_with_shifts", None)) and (
             like.dim() == 4 or (like.dim() == 5 and getattr(self.model, "dim", 2) == 3))
         self._out = {}
+        self.shifts_c = self.shifts_u = None
+
+    def _tables(self, ye):
+        """Time-conditioning rows of every evaluation: [n_evals, C] per block, or [n_evals, B, C] when the embedded
+        condition differs per sample (punetg.py:400-410 adds ye to the time embedding row by row)."""
+        m, cn, n = self.model, self._cn, self._cn.numel()
+        if ye is not None and ye.shape[0] != 1:
+            if ye.shape[0] != self.batch:
+                raise ValueError(f"conditional embedding batch {ye.shape[0]} does not match the {self.batch} samples")
+            B = self.batch
+            te = m.embed_time(cn.repeat_interleave(B), ye.repeat(n, 1))          # row e*B + b = (eval e, sample b)
+            return [s.view(n, B, s.shape[1]) for s in m.time_shifts(te)]
+        return m.time_shifts(m.embed_time(cn, ye))
 
     def prepare(self, table: StepTable):
         evals = table.evals
@@ -64,16 +91,28 @@ class ModuleSource:
             # sigma is shared by the batch, so the whole time-conditioning path (Fourier features,
             # conditional embedding, 14 time MLPs) is evaluated once for all evaluations of the run.
             m = self.model
-            cn = cn.to(dev)
+            self._cn = cn.to(dev)
             ye = m.embed_condition(self.y) if self.conditional else None
-            if ye is not None and ye.shape[0] != 1:
-                raise NotImplementedError("per-sample conditions in the planned sampler (y is un-batched in sample())")
-            self.shifts_c = m.time_shifts(m.embed_time(cn, ye))
-            self.shifts_u = m.time_shifts(m.embed_time(cn, None)) if (self.cfg or not self.conditional) else None
+            self.shifts_c = self._tables(ye)
+            self.shifts_u = self._tables(None) if (self.cfg or not self.conditional) else None
             if not self.conditional:
                 self.shifts_c = self.shifts_u
         else:
             self.cnoise = cn[:, None].expand(len(evals), self.batch).contiguous().to(dev)
+
+    def refresh(self, y):
+        """A new condition of the same structure for an existing (possibly captured) run: recompute what depends on
+        y INTO the buffers the launch sequence already reads.  The unconditional tables depend only on the step
+        table and the weights, both part of the plan key."""
+        self.y = y
+        if not (self.planned and self.conditional):
+            return
+        ye = self.model.embed_condition(y)           # PUNetGCond also refreshes its channel-field buffer here
+        new = self._tables(ye)
+        if len(new) != len(self.shifts_c) or any(a.shape != b.shape for a, b in zip(new, self.shifts_c)):
+            raise RuntimeError("the condition changed shape under a captured plan (plan key out of date)")
+        for dst, src in zip(self.shifts_c, new):
+            dst.copy_(src)
 
     def _buf(self, slot, name):
         key = (slot, name)
@@ -98,15 +137,30 @@ class ModuleSource:
         return f.contiguous(), (None if fu is None else fu.contiguous())
 
 
+def device_generator_state(device, counters):
+    """(seed, offset) for one stochastic run from torch's CUDA generator of `device` -- so torch.manual_seed(s)
+    makes the in-kernel noise reproducible, and consecutive runs draw disjoint counter ranges -- advancing the
+    generator by what the run consumes (torch keeps its Philox offset a multiple of 4)."""
+    gen = torch.cuda.default_generators[device.index if device.index is not None else torch.cuda.current_device()]
+    seed, offset = int(gen.initial_seed()), int(gen.get_offset())
+    gen.set_offset(offset + (int(counters) + 3) // 4 * 4)
+    return seed, offset
+
+
 class Loop:
     """Buffers + launch sequence of one tabulated run.  Construction allocates everything and lets
     the source precompute its per-evaluation tables; ``launch`` only enqueues kernels (plus
     whatever the source's evaluation does), so for a planned ModuleSource it can be captured into
     a hipGraph and replayed.
 
-    Usage: loop.load(x0[, scale]); loop.launch(); loop.result()."""
+    Noise of the stochastic integrators (reference: one torch.randn_like(x) per step, integrators.py:66-69,103-104):
+      injected_noise=True   eps [nsteps, *shape] supplied by the caller (parity runs replay the reference's draws);
+      injected_noise=False  generated inside the churn / Euler-Maruyama kernels by Philox from a 16-byte device
+                            state (seed, base offset) that set_noise() rewrites -- no eps buffer, graph-capturable.
 
-    def __init__(self, table: StepTable, source, like, record_history=False):
+    Usage: loop.load(x0[, scale]); loop.set_noise(eps); loop.launch(); loop.result()."""
+
+    def __init__(self, table: StepTable, source, like, record_history=False, injected_noise=False):
         ops.require_device(like, "x")
         self.table, self.source, self.record_history = table, source, record_history
         n = len(table.rows)
@@ -121,7 +175,13 @@ class Loop:
         self.xin = new() if source.wants_xin else None
         self.tmp = new() if (not source.wants_xin or table.kind == "karras") else None
         self.tmp2 = new() if (not source.wants_xin and table.kind == "karras") else None
-        self.eps = (torch.empty((n,) + shape, dtype=torch.float32, device=dev) if table.needs_noise else None)
+        self.eps = self.rng = None
+        self.counters_per_step = ops.philox_counters(like.numel())
+        if table.needs_noise:
+            if injected_noise:
+                self.eps = torch.empty((n,) + shape, dtype=torch.float32, device=dev)
+            else:
+                self.rng = torch.zeros(2, dtype=torch.int64, device=dev)
         source.prepare(table)
 
     def load(self, x0, scale=None):
@@ -135,17 +195,33 @@ class Loop:
         else:
             ops.scale(x0, scale, out=self.x)
 
-    def set_noise(self, eps=None):
-        """eps [nsteps, *shape]: injected noise; None draws it on the device generator, one tensor
-        per step in step order (the reference calls randn_like once per step)."""
-        if self.eps is None:
+    def set_noise(self, eps=None, seed_offset=None):
+        """Injected mode: eps [>= nsteps, *shape] is copied in.  Generator mode: (seed, offset) -- given, or taken from
+        (and advancing) torch's CUDA generator -- is written to the device state the kernels read."""
+        if not self.table.needs_noise:
             return
-        if eps is None:
-            self.eps.normal_()
-        else:
-            if eps.shape[0] < self.eps.shape[0] or tuple(eps.shape[1:]) != tuple(self.eps.shape[1:]):
+        n = len(self.table.rows)
+        if self.eps is not None:
+            if eps is None:
+                raise ValueError("this loop was built for injected noise: pass eps [nsteps, *x.shape]")
+            if eps.shape[0] < n or tuple(eps.shape[1:]) != tuple(self.eps.shape[1:]):
                 raise ValueError("eps must be [nsteps, *x.shape]")
-            self.eps.copy_(eps[:self.eps.shape[0]])
+            self.eps.copy_(eps[:n])
+            return
+        if eps is not None:
+            raise ValueError("this loop generates its noise in the kernels: build it with injected_noise=True to pass eps")
+        if seed_offset is None:
+            seed_offset = device_generator_state(self.x.device, n * self.counters_per_step)
+        seed, offset = seed_offset
+        self.seed_offset = (int(seed), int(offset))
+        as_i64 = lambda v: v - (1 << 64) if v >= (1 << 63) else v      # noqa: E731  (uint64 bit pattern in an int64 tensor)
+        self.rng.copy_(torch.tensor([as_i64(int(seed) & (2**64 - 1)), as_i64(int(offset) & (2**64 - 1))], dtype=torch.int64))
+
+    def step_noise(self, i):
+        """The eps of step i as a tensor (generator mode regenerates it from the counters: tests / diagnostics)."""
+        if self.eps is not None:
+            return self.eps[i]
+        return ops.philox_normal(self.rng, i * self.counters_per_step, self.x.shape)
 
     def launch(self):
         table, source = self.table, self.source
@@ -153,6 +229,7 @@ class Loop:
         kind, g = source.input_kind, source.guidance
         xin, tmp, eps = self.xin, self.tmp, self.eps
         karras = table.kind == "karras"
+        em = table.kind == "euler-maruyama"
         cur = self.x
         e = 0
         if source.wants_xin and n > 0 and not karras:
@@ -164,15 +241,17 @@ class Loop:
             c_in_next = nxt_row.first.c_in if chain else 1.0
             xin_next = xin if chain else None
             base = cur
+            eps_i = eps[i] if eps is not None else None
+            philox_i = (self.rng, i * self.counters_per_step) if (self.rng is not None) else None
             if karras:
                 base = tmp                                           # x_hat, integrators.py:104-105
-                ops.churn(cur, eps[i], row.churn_coef, xhat_out=base, xin_out=xin, c_in=row.first.c_in)
+                ops.churn(cur, eps_i, row.churn_coef, xhat_out=base, xin_out=xin, c_in=row.first.c_in, philox=philox_i)
             k1 = row.first.coef(kind, g)
             f1, f1u = source.evaluate(base, xin, row.first, e, 0)
             e += 1
             if row.second is None:
                 ops.euler(base, f1, k1, row.dt, fu=f1u, x_out=nxt, xin_out=xin_next, c_in_next=c_in_next,
-                          eps=eps[i] if table.kind == "euler-maruyama" else None,
+                          eps=eps_i if em else None, philox=philox_i if em else None,
                           noise_coef=row.noise_coef, sqrt_abs_dt=row.sqrt_abs_dt)
             else:
                 k2 = row.second.coef(kind, g)
@@ -191,9 +270,61 @@ class Loop:
         return self.history if self.record_history else self._final
 
 
+class PlanCache:
+    """Captured runs (static buffers + hipGraph), keyed by everything a capture bakes in; shared by KarrasModule and
+    SIModule.  hipGraph capture needs a non-default stream: planned runs live on a side stream that is ordered after
+    the caller's stream on entry and before it on exit."""
+
+    def __init__(self, capacity=4):
+        self.capacity = capacity
+        self.plans = {}
+        self.stream = None
+
+    def clear(self):
+        self.plans = {}
+
+    def run(self, key, make_loop, x, y=None, scale=None, eps=None):
+        if self.stream is None or self.stream.device != x.device:
+            self.stream = torch.cuda.Stream(device=x.device)
+        caller = torch.cuda.current_stream(x.device)
+        self.stream.wait_stream(caller)
+        with torch.cuda.stream(self.stream):
+            plan = self.plans.get(key)
+            if plan is None:
+                loop = make_loop()
+                loop.load(x, scale)
+                loop.set_noise(eps)
+                loop.launch()                  # eager pass: allocates the workspace, validates shapes
+                self.stream.synchronize()
+                with ops.Graph() as g:
+                    loop.launch()
+                plan = (loop, g)
+                if len(self.plans) >= self.capacity:
+                    self.plans.pop(next(iter(self.plans)))
+                self.plans[key] = plan
+                if loop.table.needs_noise and loop.rng is not None:
+                    loop.set_noise(None, seed_offset=loop.seed_offset)    # the replay below repeats the eager pass's draw
+                    replay_same_noise = True
+                else:
+                    replay_same_noise = False
+            else:
+                replay_same_noise = False
+                refresh = getattr(plan[0].source, "refresh", None)
+                if refresh is not None:
+                    refresh(y)
+            loop, g = plan
+            loop.load(x, scale)
+            if not replay_same_noise:
+                loop.set_noise(eps)
+            g.launch()
+            out = loop.result().clone()
+        caller.wait_stream(self.stream)
+        return out
+
+
 def run_table(table: StepTable, source, x, record_history=False, eps=None):
     """One eager pass: returns the final state (a new tensor) or the history [len(rows)+1, *x.shape]."""
-    loop = Loop(table, source, x, record_history)
+    loop = Loop(table, source, x, record_history, injected_noise=eps is not None)
     loop.load(x)
     loop.set_noise(eps)
     loop.launch()

@@ -18,10 +18,11 @@ import numpy as np
 import torch
 
 from ... import ops
+from ..nets import precision
 from ..._native import DS_IN_FLOW, DS_IN_NETWORK
-from .engine import Loop, ModuleSource
+from .engine import Loop, ModuleSource, PlanCache, condition_signature
 from . import edmbatchnorm
-from .karrasmodule import _condition_key, dict_map, dict_to, dict_unsqueeze
+from .karrasmodule import dict_to, dict_unsqueeze
 from .steptable import EvalRow, StepRow, StepTable
 
 
@@ -181,8 +182,7 @@ class SIModule(torch.nn.Module):
             self.freeze_autoencoder()
         self.set_initial_norm()
         self.use_graph = True
-        self._plans = {}
-        self._stream = None
+        self._plans = PlanCache()
 
     def freeze_autoencoder(self):
         """flowfield.py:304-310."""
@@ -242,6 +242,7 @@ class SIModule(torch.nn.Module):
             raise NotImplementedError("per-sample times in get_flow_field (the sampler uses one time per step)")
         return tt.reshape(-1)[0].reshape(())
 
+    @ops.device_guard
     def get_flow_field(self, x_noised, t, guidance: float = 1.0, y=None, integrate_on_sigma: bool = False):
         """flowfield.py:441-458.  t: a scalar or [B]; samples at different times are evaluated group by group."""
         ops.require_device(x_noised, "x_noised")
@@ -277,6 +278,7 @@ class SIModule(torch.nn.Module):
             v = ops.div_scalar(v.contiguous(), float(self.config.sigma_fn_dot(t)))
         return v
 
+    @ops.device_guard
     def get_score_field_from_flow_field(self, flow_field, x_noised, t):
         """flowfield.py:483-501: (alpha v - alpha' x) / (sigma (alpha' sigma - alpha sigma'))."""
         tv = torch.as_tensor(t, dtype=torch.float32).detach().cpu().reshape(-1)
@@ -352,6 +354,7 @@ class SIModule(torch.nn.Module):
         with torch.inference_mode():
             return self._integrate(x, time_schedule, y, guidance, return_history, integrate_on_sigma, noise_injection)
 
+    @ops.device_guard
     def _integrate(self, x, time_schedule, y, guidance, return_history, integrate_on_sigma, noise_injection, scale=None):
         ops.require_device(x, "x")
         if noise_injection:
@@ -359,48 +362,32 @@ class SIModule(torch.nn.Module):
         if self.config.preconditioner.generic:
             return self._integrate_generic(x, time_schedule, y, guidance, return_history, integrate_on_sigma, scale)
         table = self._table(time_schedule, integrate_on_sigma)
-        src = self._source(y, guidance, x)
-        if src.planned and self.use_graph:
-            out = self._run_planned(table, src, x, y, guidance, return_history, integrate_on_sigma, scale)
-        else:
+
+        def run():
+            src = self._source(y, guidance, x)
+            if src.planned and self.use_graph:
+                return self._run_planned(table, src, x, y, guidance, return_history, integrate_on_sigma, scale)
             loop = Loop(table, src, x, return_history)
             loop.load(x, scale)
             loop.launch()
-            out = loop.result()
+            return loop.result()
+
+        out = run()
+        if precision.needs_escalation(self.model, out, x):      # an activation left the fp16x3 range: nets/precision.py
+            precision.escalate(self.model)
+            out = run()
         if return_history:                                                        # initial_norm.unnorm, flowfield.py:742-747
             return [(table.t[i].to(x.device), self.initial_norm.unnorm(out[i])) for i in range(out.shape[0])]
         return self.initial_norm.unnorm(out)
 
     def _run_planned(self, table, src, x, y, guidance, return_history, integrate_on_sigma, scale):
-        """Capture the whole run once per (shape, schedule, guidance, condition) and replay it."""
-        ykey = None if y is None else repr(dict_map(_condition_key, y))
-        key = (tuple(x.shape), tuple(float(v) for v in table.t), float(guidance), ykey, bool(return_history),
+        """Capture the whole run once per (shape, schedule, guidance, condition structure) and replay it; what depends
+        on the condition's values is refreshed in plan-owned buffers before every replay (engine.PlanCache)."""
+        key = (tuple(x.shape), tuple(float(v) for v in table.t), float(guidance), condition_signature(y), bool(return_history),
                bool(integrate_on_sigma), getattr(self.model, "conv_precision", None), getattr(self.model, "fuse_norm", None),
                getattr(self.model, "fuse_max_cot", None))
         key = key + (str(x.device), tuple((p.data_ptr(), p._version) for p in self.model.parameters()))
-        # hipGraph capture needs a non-default stream (see KarrasModule._run_planned)
-        if self._stream is None or self._stream.device != x.device:
-            self._stream = torch.cuda.Stream(device=x.device)
-        caller = torch.cuda.current_stream(x.device)
-        self._stream.wait_stream(caller)
-        with torch.cuda.stream(self._stream):
-            plan = self._plans.get(key)
-            if plan is None:
-                loop = Loop(table, src, x, return_history)
-                loop.load(x, scale)
-                loop.launch()                  # eager pass: allocates the workspace, validates shapes
-                self._stream.synchronize()
-                with ops.Graph() as g:
-                    loop.launch()
-                plan = (loop, g)
-                if len(self._plans) >= 4:
-                    self._plans.pop(next(iter(self._plans)))
-                self._plans[key] = plan
-            plan[0].load(x, scale)
-            plan[1].launch()
-            out = plan[0].result().clone()
-        caller.wait_stream(self._stream)
-        return out
+        return self._plans.run(key, lambda: Loop(table, src, x, return_history), x, y=y, scale=scale)
 
     def _integrate_generic(self, x, time_schedule, y, guidance, return_history, integrate_on_sigma, scale):
         """integrate_flow_field for preconditioners that cannot be tabulated: Heun steps, the last one Euler
@@ -439,6 +426,7 @@ class SIModule(torch.nn.Module):
             return [(t, self.initial_norm.unnorm(h)) for t, h in history]
         return self.initial_norm.unnorm(x)
 
+    @ops.device_guard
     def integration_step(self, x, t_curr, t_next, y=None, guidance: float = 1.0, method: str = 'euler',
                          integrate_on_sigma: bool = False, noise_injection: bool = False):
         """flowfield.py:749-795: one Euler / Heun / Euler-Maruyama step between two times (every sample of the

@@ -16,10 +16,11 @@ from typing import Any
 import torch
 
 from ... import ops
+from ..nets import precision
 from ..._native import DS_IN_NETWORK
 from . import edmbatchnorm, noisesamplers, preconditioners, schedulers
 from .autoregressivesample import LatentSpaceAutoregressive
-from .engine import Loop, ModuleSource
+from .engine import Loop, ModuleSource, PlanCache, condition_signature
 from .steptable import build_step_table
 
 
@@ -35,18 +36,6 @@ def dict_map(func, d):
 def dict_unsqueeze(d, dim):
     """diffsci/torchutils.py:75-77."""
     return dict_map(lambda x: torch.unsqueeze(x, dim), d)
-
-
-def _condition_key(t):
-    """Identity of a condition tensor for the plan cache: small tensors by value, fields by storage (the
-    captured graph reads them in place, so a different tensor means a different plan)."""
-    if t.numel() <= 64:
-        return (tuple(t.shape), t.flatten().tolist())
-    if getattr(t, "_ds_static", False):                  # a plan-owned copy of a channel field: refreshed before replay
-        return (tuple(t.shape), t.data_ptr(), "static")
-    if t.is_inference():                                 # no version counter: a checksum stands in for it
-        return (tuple(t.shape), t.data_ptr(), float(t.double().sum()), float(t.double().abs().sum()))
-    return (tuple(t.shape), t.data_ptr(), t._version)
 
 
 def dict_to(d, device):
@@ -130,13 +119,6 @@ class KarrasModuleConfig(object):
         return self.dynamic_loss_weight is not None
 
 
-class _Plan:
-    """A captured N-step run: static buffers + hipGraph."""
-
-    def __init__(self, loop, graph):
-        self.loop, self.graph = loop, graph
-
-
 class KarrasModule(torch.nn.Module, LatentSpaceAutoregressive):
     def __init__(self, model: torch.nn.Module, config: KarrasModuleConfig, conditional: bool = False,
                  masked: bool = False, autoencoder: None | torch.nn.Module = None,
@@ -158,9 +140,7 @@ class KarrasModule(torch.nn.Module, LatentSpaceAutoregressive):
         self.edm_batch_norm = (edmbatchnorm.DimensionAgnosticBatchNorm(sigma=config.extra_args.get("sigma_data", 0.5))
                                if config.has_edm_batch_norm else None)
         self.use_graph = True          # capture the loop as a hipGraph for HIP-native networks
-        self._plans = {}
-        self._static_fields = {}
-        self._stream = None
+        self._plans = PlanCache()
 
     # ---------------------------------------------------------------- bookkeeping
     @property
@@ -175,8 +155,7 @@ class KarrasModule(torch.nn.Module, LatentSpaceAutoregressive):
         return self.autoencoder is not None
 
     def _apply(self, fn, *a, **k):
-        self._plans = {}
-        self._static_fields = {}
+        self._plans.clear()
         return super()._apply(fn, *a, **k)
 
     def export_description(self) -> dict[str, Any]:
@@ -227,12 +206,14 @@ class KarrasModule(torch.nn.Module, LatentSpaceAutoregressive):
             f = self.model(xin, cn)
         return x, f.contiguous(), (None if fu is None else fu.contiguous()), c_skip, c_out, cn
 
+    @ops.device_guard
     def get_denoiser(self, x, sigma, y=None, guidance: float = 1.0):
         """karrasmodule.py:673-719.  sigma: [B] (values may differ per sample)."""
         x, f, fu, c_skip, c_out, cn = self._run_model(x, sigma, y, guidance)
         D = ops.denoiser(x, f, c_out.to(x.device), c_skip.to(x.device), fu=fu, guidance=guidance)
         return D, cn
 
+    @ops.device_guard
     def get_score(self, x, sigma, y=None, guidance: float = 1.0):
         """(D - x)/sigma^2, karrasmodule.py:721-733 -- fused with the denoiser in one pass."""
         from ..._native import EvalCoef
@@ -344,6 +325,7 @@ class KarrasModule(torch.nn.Module, LatentSpaceAutoregressive):
         return self._propagate(x, y, guidance, nsteps, record_history, integrator, eps, None,
                                initial_step, final_step)
 
+    @ops.device_guard                              # launches go to x's GPU whatever the caller's current device is
     def _propagate(self, x, y, guidance, nsteps, record_history, integrator, eps, scale, i0, i1):
         ops.require_device(x, "x")
         sch = self.config.noisescheduler
@@ -363,77 +345,32 @@ class KarrasModule(torch.nn.Module, LatentSpaceAutoregressive):
         finally:
             if integrator is not None:
                 sch.unset_temporary_integrator()
-        if self.use_graph and y is not None:
-            y = self._static_channel_fields(y)
-        src = ModuleSource(self, y, guidance, x.shape[0], x)
-        if src.planned and self.use_graph:
-            return self._run_planned(table, src, x, y, guidance, nsteps, record_history, integ, eps, scale,
-                                     i0, i1)
-        loop = Loop(table, src, x, record_history)
-        loop.load(x, scale)
-        loop.set_noise(eps)
-        loop.launch()
-        return loop.result()
+        injected = eps is not None
 
-    def _static_channel_fields(self, y):
-        """Channel-concatenated condition fields (PUNetGCond.channel_conditional_items) are read in place by the
-        captured graph.  Callers such as autoregressive_sample pass a NEW field tensor on every call; keying the plan
-        on its storage would re-capture the whole loop each time.  The module therefore keeps one buffer per (item,
-        shape), copies the caller's values into it, and hands that buffer to the plan."""
-        items = getattr(self.model, "channel_conditional_items", None)
-        if not items or not isinstance(y, dict):
-            return y
-        y = dict(y)
-        for item in items:
-            t = y.get(item)
-            if not torch.is_tensor(t) or t.numel() <= 64 or not t.is_cuda:
-                continue
-            key = (item, tuple(t.shape), str(t.device))
-            buf = self._static_fields.get(key)
-            if buf is None:
-                if len(self._static_fields) >= 8:
-                    self._static_fields.pop(next(iter(self._static_fields)))
-                buf = torch.empty(t.shape, dtype=torch.float32, device=t.device)
-                buf._ds_static = True
-                self._static_fields[key] = buf
-            buf.copy_(t)                                   # on the caller's stream; the plan's stream waits on it
-            y[item] = buf
-        return y
+        def run():
+            src = ModuleSource(self, y, guidance, x.shape[0], x)
 
-    def _run_planned(self, table, src, x, y, guidance, nsteps, record_history, integ, eps, scale, i0, i1):
-        sch = self.config.noisescheduler
-        ykey = None if y is None else repr(dict_map(_condition_key, y))
-        key = (tuple(x.shape), str(x.device), nsteps, i0, i1, record_history, table.kind,
-               (integ.s_schurn, integ.s_tmin, integ.s_tmax, integ.s_noise) if table.kind == "karras" else None,
-               float(guidance), ykey, float(sch.langevin_const), repr(sch.langevin_interval),
-               tuple(float(v) for v in table.t.tolist()),
-               tuple((p.data_ptr(), p._version) for p in self.model.parameters()),
-               tuple(getattr(self.model, a, None) for a in ("conv_precision", "fuse_norm", "fuse_max_cot", "direct_out", "upsample_parity")))
-        # hipGraph capture needs a non-default stream: planned runs live on a side stream that is
-        # ordered after the caller's stream on entry and before it on exit.
-        if self._stream is None or self._stream.device != x.device:
-            self._stream = torch.cuda.Stream(device=x.device)
-        caller = torch.cuda.current_stream(x.device)
-        self._stream.wait_stream(caller)
-        with torch.cuda.stream(self._stream):
-            plan = self._plans.get(key)
-            if plan is None:
-                loop = Loop(table, src, x, record_history)
-                loop.load(x, scale)
-                loop.set_noise(eps)
-                loop.launch()                  # eager pass: allocates the workspace, validates shapes
-                self._stream.synchronize()
-                with ops.Graph() as g:
-                    loop.launch()
-                plan = _Plan(loop, g)
-                if len(self._plans) >= 4:
-                    self._plans.pop(next(iter(self._plans)))
-                self._plans[key] = plan
-            plan.loop.load(x, scale)
-            plan.loop.set_noise(eps)
-            plan.graph.launch()
-            out = plan.loop.result().clone()
-        caller.wait_stream(self._stream)
+            def make_loop():
+                return Loop(table, src, x, record_history, injected_noise=injected)
+
+            if src.planned and self.use_graph:
+                key = (tuple(x.shape), str(x.device), nsteps, i0, i1, record_history, table.kind, injected,
+                       (integ.s_schurn, integ.s_tmin, integ.s_tmax, integ.s_noise) if table.kind == "karras" else None,
+                       float(guidance), condition_signature(y), float(sch.langevin_const), repr(sch.langevin_interval),
+                       tuple(float(v) for v in table.t.tolist()),
+                       tuple((p.data_ptr(), p._version) for p in self.model.parameters()),
+                       tuple(getattr(self.model, a, None) for a in ("conv_precision", "fuse_norm", "fuse_max_cot", "direct_out", "upsample_parity")))
+                return self._plans.run(key, make_loop, x, y=y, scale=scale, eps=eps)
+            loop = make_loop()
+            loop.load(x, scale)
+            loop.set_noise(eps)
+            loop.launch()
+            return loop.result()
+
+        out = run()
+        if precision.needs_escalation(self.model, out, x):      # an activation left the fp16x3 range: see nets/precision.py
+            precision.escalate(self.model)
+            out = run()
         return out
 
     # ---------------------------------------------------------------- encode / decode (non-latent)

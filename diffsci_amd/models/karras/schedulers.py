@@ -40,6 +40,7 @@ class Scheduler(torch.nn.Module):
         self.langevin_interval = None
 
     # -------------------------------------------------------------- N-step loop
+    @ops.device_guard
     def propagate(self, x, score_fn, nsteps: int = 100, record_history: bool = False,
                   backward: bool = True, stochastic: bool = False, eps=None):
         """schedulers.py:48-89.  ``eps`` (extension): [nsteps, *x.shape] injected noise for the
@@ -58,6 +59,7 @@ class Scheduler(torch.nn.Module):
         return self._propagate_custom(x, score_fn, integrator, nsteps, record_history, backward,
                                       0, None)
 
+    @ops.device_guard
     def propagate_partial(self, x, score_fn, nsteps: int = 100, initial_step: int = 0,
                           final_step: int = 100, record_history: bool = False,
                           backward: bool = True, stochastic: bool = False, eps=None):
@@ -74,6 +76,7 @@ class Scheduler(torch.nn.Module):
                                       initial_step, final_step)
 
     # -------------------------------------------------------------- inpainting loops
+    @ops.device_guard
     def inpaint(self, x, y, mask, score_fn, nsteps: int = 100, record_history: bool = False):
         """schedulers.py:91-121: one integrator step, then re-impose the known region from the
         noised original ``y`` ([nsteps+1, B, *shape], most noised last); mask [*shape], 1 = known."""
@@ -90,6 +93,7 @@ class Scheduler(torch.nn.Module):
                 history[i + 1] = x
         return history if record_history else x
 
+    @ops.device_guard
     def repaint(self, x, y, mask, score_fn, nsteps: int = 100, rsteps: int = 10, nresamples: int = 10,
                 record_history: bool = False, noise=None):
         """schedulers.py:123-164 (RePaint resampling).  ``noise`` (extension): an iterable of tensors
@@ -178,6 +182,7 @@ class Scheduler(torch.nn.Module):
         """schedulers.py:242-245."""
         return torch.sqrt(2 * self.langevin_factor(t))
 
+    @ops.device_guard
     def rhs(self, x, ti, score_fn, backward: bool = True, stochastic: bool = False):
         """Drift of the backward ODE/SDE at time ti (schedulers.py:247-274): one score_fn call,
         one HIP pass.  ti: python float or 0-dim tensor (host)."""
@@ -209,6 +214,7 @@ class Scheduler(torch.nn.Module):
     def create_steps(self, n: int):
         raise NotImplementedError
 
+    @ops.device_guard
     def apply_noise(self, x, nsteps: int = 100, step: int = 0):
         """x_noised = s*x + s*sigma*noise (schedulers.py:327-340); EDM: s = 1."""
         if step > nsteps:
@@ -222,6 +228,7 @@ class Scheduler(torch.nn.Module):
             return ops.axpby(x.contiguous(), float(scale), noise, float(scale * sigma))
         return ops.churn(x.contiguous(), noise, float(scale * sigma), xhat_out=torch.empty_like(x))
 
+    @ops.device_guard
     def renoise(self, x, t: float, t_noise: float, noise=None):
         """schedulers.py:166-176.  noise (extension): the draw to use instead of randn_like(x)."""
         t = torch.as_tensor(t, dtype=torch.float32)

@@ -22,6 +22,7 @@ import yaml
 
 from ... import ops
 from ..._native import DS_LOAD_AVGPOOL2, DS_LOAD_PLAIN, DS_LOAD_UPSAMPLE2
+from . import precision
 from .punetg import _AffineHolder, _Attn, _CircConv, _Fourier, _Workspace, make_conv, require_eval
 
 _FIELDS = dict(
@@ -183,6 +184,7 @@ class ADM(torch.nn.Module):
         self.input_layer = torch.nn.Conv2d(config.input_channels, mc, 3, padding="same")
         self.output_layer = torch.nn.Conv2d(mc, config.output_channels, 3, padding="same")
         self.conv_precision = "fp16x3"       # see PUNetG.conv_precision
+        self.auto_precision = True           # see PUNetG.auto_precision
         # see PUNetG.fuse_norm / fuse_max_cot.  Measured on MI355X at config 3: folding the norms of the layers with
         # up to 256 channels (1 GiB .. 134 MB tensors: the standalone pass is HBM-bound) gives 8.28 samples/s against
         # 8.05 with standalone kernels everywhere and 8.22 with a 128-channel limit; folding every layer is slower
@@ -203,11 +205,17 @@ class ADM(torch.nn.Module):
     def set_conditional_embedding(self, conditional_embedding: torch.nn.Module | None = None):
         self.conditional_embedding = conditional_embedding
 
+    @ops.device_guard
     def forward(self, x, t, y=None):
         """adm.py:199-216."""
         ops.require_device(x, "x")
         te = self.embed_time(t.reshape(-1).to(x), self.embed_condition(y))
-        return self.forward_with_shifts(x.contiguous(), self.time_shifts(te), row=None)
+        shifts = self.time_shifts(te)
+        out = self.forward_with_shifts(x.contiguous(), shifts, row=None)
+        if precision.needs_escalation(self, out, x, te):
+            precision.escalate(self)
+            out = self.forward_with_shifts(x.contiguous(), shifts, row=None)
+        return out
 
     # ------------------------------------------------------------------ conditioning
     def embed_condition(self, y):
@@ -387,6 +395,8 @@ class ADM(torch.nn.Module):
         def film():
             s = shifts[next(it)]
             if row is not None:
+                if s.dim() == 3:                       # [n_evals, B, 2C]: per-sample conditions in the planned sampler
+                    return s[row]
                 return s[row:row + 1]
             if s.shape[0] not in (1, B):
                 raise ValueError("time embedding batch does not match x")

@@ -20,6 +20,7 @@ class MLPUncond(torch.nn.Module):
         layers.append(torch.nn.Linear(in_dim, dim))
         self.net = torch.nn.Sequential(*layers)
 
+    @ops.device_guard
     def forward(self, x, t):
         ops.require_device(x, "x")
         h = torch.cat([x, t.to(x)[..., None]], dim=-1).contiguous()       # mlp.py:55-57 (pure data movement)

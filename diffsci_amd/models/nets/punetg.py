@@ -20,6 +20,7 @@ import torch
 
 from ... import ops
 from ..._native import DS_LOAD_MAXPOOL2, DS_LOAD_UPSAMPLE2
+from . import precision
 from .punetg_config import PUNetGConfig
 
 
@@ -275,6 +276,9 @@ class PUNetG(torch.nn.Module):
         #   "bf16x6": exact 3-way bf16 split, 6 MFMA products (no range limit, half the speed)
         #   "fp32"  : exact-fp32 MFMA (1/16 of the 16-bit rate)
         self.conv_precision = "fp16x3"
+        # fp16x3 only: a non-finite output from finite inputs means an activation left fp16's range; switch to the
+        # range-free "bf16x6" once and recompute (nets/precision.py) instead of handing the user NaNs
+        self.auto_precision = True
         # With the fp16x3 kernels the two norms of a residual block are folded into the convolutions
         # around them (statistics from the producer's epilogue, normalise + SiLU in the consumer's
         # loader): the normalised tensors never touch HBM.  False: standalone ds_inorm_silu kernels.
@@ -298,6 +302,7 @@ class PUNetG(torch.nn.Module):
     def set_conditional_embedding(self, conditional_embedding: torch.nn.Module | None = None):
         self.conditional_embedding = conditional_embedding
 
+    @ops.device_guard
     def forward(self, x, t=None, y=None):
         """punetg.py:389-416.  x [B, Cin, H, W]; t [B] noise conditioning; y optional condition."""
         ops.require_device(x, "x")
@@ -307,7 +312,11 @@ class PUNetG(torch.nn.Module):
         else:
             te = self.embed_time(t.reshape(-1).to(x), self.embed_condition(y))
         shifts = self.time_shifts(te)
-        return self.forward_with_shifts(x.contiguous(), shifts, row=None)
+        out = self.forward_with_shifts(x.contiguous(), shifts, row=None)
+        if precision.needs_escalation(self, out, x, te):
+            precision.escalate(self)
+            out = self.forward_with_shifts(x.contiguous(), shifts, row=None)
+        return out
 
     # ------------------------------------------------------------------ conditioning
     def embed_condition(self, y):
@@ -392,11 +401,13 @@ class PUNetG(torch.nn.Module):
             self._ws.give(hs)
         return out
 
+    @ops.device_guard
     def resnet_block_forward(self, x, te, resnet_block):
         require_eval(self, self.config.dropout, self.config.cond_dropout, self.config.cond_drop)
         ops.require_device(x, "x")
         return self._release(*self._run_blocks(x.contiguous(), te, resnet_block))
 
+    @ops.device_guard
     def resnet_attn_block_forward(self, x, te, resnet_block, attn_block):
         require_eval(self, self.config.dropout, self.config.cond_dropout, self.config.cond_drop)
         ops.require_device(x, "x")
@@ -548,6 +559,10 @@ class PUNetG(torch.nn.Module):
         def sh():
             s = shifts[next(it)]
             if row is not None:
+                if s.dim() == 3:                       # [n_evals, B, C]: per-sample conditions in the planned sampler
+                    if s.shape[1] != B:
+                        raise ValueError("time embedding batch does not match x")
+                    return s[row]
                 return s[row:row + 1]
             if s.shape[0] not in (1, B):
                 raise ValueError("time embedding batch does not match x")
@@ -651,6 +666,10 @@ class PUNetG(torch.nn.Module):
         def sh():
             s = shifts[next(it)]
             if row is not None:
+                if s.dim() == 3:                       # [n_evals, B, C]: per-sample conditions in the planned sampler
+                    if s.shape[1] != B:
+                        raise ValueError("time embedding batch does not match x")
+                    return s[row]
                 return s[row:row + 1]
             if s.shape[0] not in (1, B):
                 raise ValueError("time embedding batch does not match x")
@@ -780,6 +799,7 @@ class PUNetGCond(PUNetG):
         super().__init__(config, conditional_embedding, extra_residual=extra_residual)
         self.channel_conditional_items = channel_conditional_items
         self._ycat = None
+        self._ycat_static = {}       # (shape, device) -> buffer holding the concatenated channel fields
 
     def export_description(self) -> dict[str, Any]:
         args = super().export_description()
@@ -791,9 +811,25 @@ class PUNetGCond(PUNetG):
             raise TypeError("PUNetGCond needs the condition dictionary y on every call (punetg.py:721-723)")
         fields = [y[item] for item in self.channel_conditional_items]
         rest = {k: v for k, v in y.items() if k not in self.channel_conditional_items}
-        ycat = fields[0] if len(fields) == 1 else torch.cat(fields, dim=1)
-        ops.require_device(ycat, "channel condition")
-        return (rest if len(rest) else None), ycat.to(torch.float32).contiguous()
+        for f in fields:
+            ops.require_device(f, "channel condition")
+            if f.dim() < 3 or tuple(f.shape[2:]) != tuple(fields[0].shape[2:]) or f.shape[0] != fields[0].shape[0]:
+                raise ValueError("channel condition fields must be [B or 1, C_i, *spatial] with equal batch and spatial sizes")
+        # torch.cat([y[item] ...], dim=1) of punetg.py:724-727 INTO a buffer the network owns: a captured sampling
+        # loop reads the fields at this address on every replay, so the caller's tensors (new ones on every call of
+        # autoregressive_sample; temporaries of torch.cat) must never be what the graph points at.  One buffer per
+        # (shape, device); every call -- eager or as the refresh before a replay -- rewrites it.
+        shape = (fields[0].shape[0], sum(f.shape[1] for f in fields)) + tuple(fields[0].shape[2:])
+        key = (shape, str(fields[0].device))
+        buf = self._ycat_static.get(key)
+        if buf is None:                  # never evicted: captured plans keep reading the buffer of their shape
+            buf = torch.empty(shape, dtype=torch.float32, device=fields[0].device)
+            self._ycat_static[key] = buf
+        c0 = 0
+        for f in fields:
+            buf[:, c0:c0 + f.shape[1]].copy_(f)
+            c0 += f.shape[1]
+        return (rest if len(rest) else None), buf
 
     def _with_condition(self, x, ycat, ws):
         B = x.shape[0]
@@ -811,11 +847,17 @@ class PUNetGCond(PUNetG):
             ws.give(yexp)
         return out
 
+    @ops.device_guard
     def forward(self, x, t, y=None):
         ops.require_device(x, "x")
         rest, self._ycat = self._split_condition(y)
         te = self.embed_time(t.reshape(-1).to(x), PUNetG.embed_condition(self, rest))
-        return self.forward_with_shifts(x.contiguous(), self.time_shifts(te), row=None)
+        shifts = self.time_shifts(te)
+        out = self.forward_with_shifts(x.contiguous(), shifts, row=None)
+        if precision.needs_escalation(self, out, x, te, self._ycat):
+            precision.escalate(self)
+            out = self.forward_with_shifts(x.contiguous(), shifts, row=None)
+        return out
 
     def embed_condition(self, y):
         """Planned sampler entry: remember the channel fields, embed what is left of y."""

@@ -17,6 +17,35 @@ def require_device(t, what="tensor"):
             "libdiffsci_hip.so (there is no CPU path; move the module and inputs to 'cuda').")
     if t.dtype != torch.float32:
         raise TypeError(f"{what} has dtype {t.dtype}; the HIP path is fp32 only")
+    if t.device.index != torch.cuda.current_device():
+        # the C ABI launches on the stream it is handed and never switches devices: a launch on cuda:0's stream
+        # with cuda:1 pointers would fault (or silently compute on the wrong GPU's copy of a kernel attribute)
+        raise RuntimeError(f"{what} lives on {t.device} but the current device is cuda:{torch.cuda.current_device()}: "
+                           "wrap the call in `with torch.cuda.device(tensor.device):` (KarrasModule / SIModule / the "
+                           "networks do this for their own entry points)")
+
+
+def on_device_of(t):
+    """Context manager: make t's GPU the current device (and its current stream the launch stream)."""
+    return torch.cuda.device(t.device)
+
+
+def device_guard(fn):
+    """Decorator for the public entry points of the modules: run with the GPU of the first CUDA tensor argument as
+    the current device, so a module on cuda:1 works while the caller's current device is cuda:0 (the C ABI launches
+    on the stream it is handed and never switches devices; every op checks its tensors against the current device)."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(*args, **kwargs):
+        for a in list(args) + list(kwargs.values()):
+            if isinstance(a, torch.Tensor) and a.is_cuda:
+                if a.device.index != torch.cuda.current_device():
+                    with torch.cuda.device(a.device):
+                        return fn(*args, **kwargs)
+                break
+        return fn(*args, **kwargs)
+    return wrapped
 
 
 def _p(t, what="tensor"):
@@ -122,11 +151,40 @@ def score(x, f, k, fu=None, out=None):
     return out
 
 
+def _philox(philox):
+    """(state tensor int64[2] on the device, offset) -> (pointer, offset) or (None, 0)."""
+    if philox is None:
+        return None, 0
+    state, offset = philox
+    if not (isinstance(state, torch.Tensor) and state.is_cuda and state.dtype == torch.int64 and state.numel() == 2
+            and state.is_contiguous()):
+        raise TypeError("philox state must be a contiguous int64[2] device tensor (seed, base offset)")
+    if state.device.index != torch.cuda.current_device():
+        raise RuntimeError("philox state lives on another device than the current one")
+    return state.data_ptr(), int(offset)
+
+
+def philox_counters(n):
+    """Philox counters one noise tensor of n elements consumes (4 normals per counter)."""
+    return (int(n) + 3) // 4
+
+
+def philox_normal(state, offset, shape, out=None):
+    """The standard-normal stream the stepper kernels generate in place for (state, offset): element e <- counter
+    state[1] + offset + e/4, output e%4."""
+    if out is None:
+        out = torch.empty(tuple(shape), dtype=torch.float32, device=state.device)
+    ps, po = _philox((state, offset))
+    N.check(N.lib().ds_philox_normal(_p(out, "out"), ps, po, out.numel(), _stream()), "ds_philox_normal")
+    return out
+
+
 def euler(x, f, k, dt, fu=None, x_out=None, xin_out=None, c_in_next=1.0, eps=None, noise_coef=0.0,
-          sqrt_abs_dt=0.0):
+          sqrt_abs_dt=0.0, philox=None):
     n = _same_numel(x, f, fu, x_out, xin_out, eps)
+    ps, po = _philox(philox)
     N.check(N.lib().ds_karras_euler(_p(x_out), _p(xin_out), _p(x), _p(f), _p(fu), ctypes.byref(k),
-                                    float(dt), float(c_in_next), _p(eps), float(noise_coef),
+                                    float(dt), float(c_in_next), _p(eps), ps, po, float(noise_coef),
                                     float(sqrt_abs_dt), n, _stream()), "ds_karras_euler")
     return x_out
 
@@ -139,9 +197,12 @@ def heun(x, f1, k1, f2, k2, dt, f1u=None, f2u=None, x_out=None, xin_out=None, c_
     return x_out
 
 
-def churn(x, eps, coef, xhat_out, xin_out=None, c_in=1.0):
+def churn(x, eps, coef, xhat_out, xin_out=None, c_in=1.0, philox=None):
+    """x_hat = x + coef*eps, with eps injected (a tensor) or, eps=None, generated in the kernel from
+    philox = (state, offset)."""
     n = _same_numel(x, eps, xhat_out, xin_out)
-    N.check(N.lib().ds_karras_churn(_p(xhat_out), _p(xin_out), _p(x), _p(eps), float(coef), float(c_in), n,
+    ps, po = _philox(philox)
+    N.check(N.lib().ds_karras_churn(_p(xhat_out), _p(xin_out), _p(x), _p(eps), ps, po, float(coef), float(c_in), n,
                                     _stream()), "ds_karras_churn")
     return xhat_out
 

@@ -17,13 +17,35 @@ def shard_rows(total, world, rank):
     return start, start + base + (1 if rank < extra else 0)
 
 
+_CHUNK_FLOATS = 1 << 24        # 64 MiB of throw-away noise at a time while skipping other ranks' rows
+
+
 def global_white_noise(total, shape, seed, rows=None):
     """Rows [rows[0], rows[1]) of torch.randn(total, *shape) under manual_seed(seed) (CPU
-    generator), without disturbing the global generator."""
+    generator), without disturbing the global generator.
+
+    A rank needs only its own rows.  torch's CPU normal fill consumes one uniform per element, in order, and turns
+    them into normals in aligned blocks of 16, so when a row holds a multiple of 16 floats the rows before `lo` can
+    be drawn (and dropped) chunk by chunk and the rows after `hi` not at all -- same values as the full draw
+    (tests/test_host_logic.py::test_global_noise_rows_without_the_full_tensor), without materialising G x shape
+    floats on every rank (config 5: 134 MB per rank per run)."""
     g = torch.Generator()
     g.manual_seed(seed)
-    full = torch.randn(total, *shape, generator=g)
-    return full if rows is None else full[rows[0]:rows[1]].contiguous()
+    if rows is None:
+        return torch.randn(total, *shape, generator=g)
+    lo, hi = rows
+    per_row = 1
+    for d in shape:
+        per_row *= int(d)
+    if per_row % 16 or per_row == 0 or total * per_row < 16:
+        return torch.randn(total, *shape, generator=g)[lo:hi].contiguous()
+    chunk_rows = max(1, _CHUNK_FLOATS // per_row)
+    r = 0
+    while r < lo:                                             # advance the generator past the rows of lower ranks
+        n = min(chunk_rows, lo - r)
+        torch.randn(n, per_row, generator=g)
+        r += n
+    return torch.randn(hi - lo, *shape, generator=g)
 
 
 def sample_sharded(module, nsamples, shape, nsteps=100, seed=0, y=None, guidance=1.0, integrator=None,
@@ -39,16 +61,16 @@ def sample_sharded(module, nsamples, shape, nsteps=100, seed=0, y=None, guidance
         local = white_noise[lo:hi]
     local = local.to(module.device)
     out = module.propagate_white_noise(local, y=y, guidance=guidance, nsteps=nsteps, integrator=integrator)
-    if world == 1 or not gather:
+    if not gather or not dist.is_initialized():
         return out
     return gather_samples(out, nsamples)
 
 
 def gather_samples(out, nsamples=None):
     """All-gather the per-rank sample shards (RCCL over xGMI; backend "nccl" is RCCL on ROCm)."""
-    world = dist.get_world_size() if dist.is_initialized() else 1
-    if world == 1:
+    if not dist.is_initialized():
         return out
+    world = dist.get_world_size()          # a one-rank group still goes through the collective (RCCL on the GPU)
     if nsamples is None:
         nsamples = out.shape[0] * world
     if nsamples % world == 0:

@@ -19,7 +19,10 @@
  *     launch may be captured into a hipGraph (ds_graph_*);
  *   - launches are asynchronous on the given stream; distinct streams may be driven from
  *     distinct host threads;
- *   - argument shapes are validated on the host before any launch (DS_ERR_SHAPE).
+ *   - argument shapes are validated on the host before any launch (DS_ERR_SHAPE);
+ *   - the elementwise stepper entry points take any element count and any 4-byte-aligned
+ *     pointers (16-byte-aligned operands run the float4 path, others a scalar path with
+ *     identical arithmetic): the reference accepts any tensor shape.
  */
 #ifndef DIFFSCI_HIP_H
 #define DIFFSCI_HIP_H
@@ -40,7 +43,7 @@ typedef enum ds_status {
 } ds_status;
 
 /* Library / device introspection. */
-int ds_version(void);                       /* ABI version, currently 1 */
+int ds_version(void);                       /* ABI version, currently 2 */
 const char* ds_last_error(void);            /* thread-local, never NULL */
 int ds_device_info(int* cu_count, int* lds_bytes_per_cu, char* arch_name, int arch_name_len);
 
@@ -79,19 +82,30 @@ int ds_karras_drift(float* d_out, const float* x, const float* f, const float* f
 int ds_karras_score(float* s_out, const float* x, const float* f, const float* fu,
                     const ds_eval_coef* k, size_t n, void* stream);
 
+/* Standard-normal noise generated inside the kernels that consume it (SURVEY 8a6 option (i); the reference
+ * draws torch.randn_like(x) per step: integrators.py:66-69,103-104).  Philox4x32-10, key = state[0] (seed),
+ * counter = state[1] + philox_offset + e/4 for element e, whose four 32-bit outputs give, by Box-Muller, the
+ * normals of elements 4*(e/4) .. 4*(e/4)+3.  `philox_state` is a DEVICE pointer to two uint64 {seed, base
+ * offset}: a captured graph bakes the per-step `philox_offset` and re-reads the state on every replay, so the
+ * host re-seeds a replay by rewriting 16 bytes.  The draw does not depend on launch geometry or alignment:
+ * the same (seed, offsets) reproduce it bit for bit.  ds_philox_normal writes the stream out (tests, and
+ * callers that want the eps a run used). */
+int ds_philox_normal(float* out, const uint64_t* philox_state, uint64_t philox_offset, size_t n, void* stream);
+
 /* Euler move from one evaluation:  d = drift(x, f);  x_out = x + dt*d  [+ (noise_coef*eps)*sqrt_abs_dt]
  * and, when xin_out != NULL, xin_out = c_in_next * x_out (the next evaluation's network input).
  *   drift: D = c_out*F + c_skip*x; score = (D - x)/sigma_sq; d = neg_mult*score [+ neg_lang*score]
  *   F = f, or (1-g)*fu + g*f when fu != NULL.
  * Replaces EulerIntegrator.step (integrators.py:29-35), the predictor half of
- * HeunIntegrator.step (integrators.py:44-47), EulerMaruyamaIntegrator.step (integrators.py:66-69,
- * eps != NULL) together with Scheduler.rhs (schedulers.py:247-274) and
+ * HeunIntegrator.step (integrators.py:44-47), EulerMaruyamaIntegrator.step (integrators.py:66-69:
+ * eps != NULL injects the noise, philox_state != NULL generates it in the kernel, both NULL: none)
+ * together with Scheduler.rhs (schedulers.py:247-274) and
  * KarrasModule.get_denoiser/get_score (karrasmodule.py:690-733).
  * x_out may be NULL (only xin_out wanted) ; x_out may alias x. */
 int ds_karras_euler(float* x_out, float* xin_out, const float* x, const float* f, const float* fu,
                     const ds_eval_coef* k, float dt, float c_in_next,
-                    const float* eps, float noise_coef, float sqrt_abs_dt,
-                    size_t n, void* stream);
+                    const float* eps, const uint64_t* philox_state, uint64_t philox_offset,
+                    float noise_coef, float sqrt_abs_dt, size_t n, void* stream);
 
 /* Heun corrector:  x_out = x + (0.5*(d1 + d2))*dt, with d1 recomputed from (x, f1) and d2 from
  * (x_e = x + dt*d1, f2) -- x_e is recomputed, never read.  integrators.py:44-53.
@@ -104,8 +118,10 @@ int ds_karras_heun(float* x_out, float* xin_out, const float* x,
 
 /* Noise injection x_hat = x + coef*eps; xin_out (optional) = c_in * x_hat.
  * KarrasIntegrator.step sigma-churn (integrators.py:98-105, coef = std*s_noise, scale ratio = 1)
- * and Scheduler.renoise (schedulers.py:166-176). */
+ * and Scheduler.renoise (schedulers.py:166-176).  Exactly one of eps (injected, [n]) and philox_state
+ * (generated in the kernel: 12 B per element instead of 16, no eps buffer) is given. */
 int ds_karras_churn(float* xhat_out, float* xin_out, const float* x, const float* eps,
+                    const uint64_t* philox_state, uint64_t philox_offset,
                     float coef, float c_in, size_t n, void* stream);
 
 /* Denoiser with per-sample coefficients (sigma differs across the batch):

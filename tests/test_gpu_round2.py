@@ -1,0 +1,318 @@
+"""Round-2 behaviours on a real MI355X: in-kernel Philox noise, condition refresh under a captured plan, several
+channel-condition items, per-sample conditions, odd-sized states (unaligned slices), a 1-rank RCCL group."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import karras_ref as K  # noqa: E402
+from oracle import mlp_ref, philox_ref, punetg_ref  # noqa: E402
+from tests.golden_util import load, rel_l2  # noqa: E402
+
+REL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def M():
+    import diffsci_amd.models as M
+    return M
+
+
+@pytest.fixture(scope="module")
+def grids():
+    v, _ = load("schedule")
+    return v
+
+
+def _pin_grid(module, grids):
+    sch = getattr(getattr(module, "config", None), "noisescheduler", module)
+    orig = sch.create_steps
+    sch.create_steps = lambda n: grids[f"steps_{n - 1}"].clone() if f"steps_{n - 1}" in grids else orig(n)
+    return sch
+
+
+def _state(dev, seed, base):
+    i64 = lambda v: v - (1 << 64) if v >= (1 << 63) else v        # noqa: E731
+    return torch.tensor([i64(seed), i64(base)], dtype=torch.int64, device=dev)
+
+
+# ----------------------------------------------------------------------------------------- Philox
+@pytest.mark.parametrize("seed,base,off,n", [(0, 0, 0, 1), (1234, 0, 0, 4099), (2**63 + 17, 2**40 + 3, 5, 1027),
+                                             (42, 2**32 - 2, 0, 64)])
+def test_philox_stream_matches_oracle(dev, seed, base, off, n):
+    """ds_philox_normal against the numpy restatement (oracle/philox_ref.py, pinned by the Random123 known answers
+    in test_oracle_golden.py): same counters, same key, same uniform -> normal map; the transcendental functions
+    differ in the last ulp, hence a tolerance of a few fp32 ulp.  The stream does not depend on pointer alignment."""
+    from diffsci_amd import ops
+    st = _state(dev, seed, base)
+    got = ops.philox_normal(st, off, (n,)).cpu().double().numpy()
+    want = philox_ref.normal(seed, base + off, n)
+    assert np.abs(got - want).max() <= 4e-6 * (1.0 + np.abs(want).max())
+    buf = torch.empty(n + 1, device=dev)
+    shifted = ops.philox_normal(st, off, (n,), out=buf[1:]).cpu()       # 4-byte aligned only: the scalar path
+    assert torch.equal(shifted, torch.from_numpy(got).float())
+
+
+def test_philox_moments_and_distribution(dev):
+    from scipy import stats
+    from diffsci_amd import ops
+    n = 1 << 22
+    z = ops.philox_normal(_state(dev, 7, 0), 0, (n,)).cpu().double().numpy()
+    assert abs(z.mean()) < 4 / np.sqrt(n) and abs(z.std() - 1) < 4 / np.sqrt(2 * n)
+    assert abs(stats.skew(z)) < 0.01 and abs(stats.kurtosis(z)) < 0.02
+    assert stats.kstest(z[:1 << 18], "norm").pvalue > 1e-3
+    assert abs(np.corrcoef(z[:-1], z[1:])[0, 1]) < 4 / np.sqrt(n)      # Box-Muller pairs are uncorrelated
+    z2 = ops.philox_normal(_state(dev, 8, 0), 0, (n,)).cpu().double().numpy()
+    assert abs(np.corrcoef(z, z2)[0, 1]) < 4 / np.sqrt(n)               # another key: another stream
+
+
+@pytest.mark.parametrize("n", [3, 4096, 2 * 33 * 35])
+def test_churn_and_euler_maruyama_generate_their_noise(dev, n):
+    """eps = NULL + a Philox state: the injection kernels compute x + coef*eps with eps from the stream above,
+    bit for bit what they compute from an injected copy of that stream."""
+    from diffsci_amd import ops
+    from diffsci_amd._native import EvalCoef
+    g = torch.Generator().manual_seed(n)
+    x, f = torch.randn(n, generator=g).to(dev) * 40, torch.randn(n, generator=g).to(dev)
+    st = _state(dev, 99, 1000)
+    eps = ops.philox_normal(st, 12, (n,))
+    a = ops.churn(x, eps, 3.25, xhat_out=torch.empty_like(x), xin_out=torch.empty_like(x), c_in=0.125)
+    xin = torch.empty_like(x)
+    b = ops.churn(x, None, 3.25, xhat_out=torch.empty_like(x), xin_out=xin, c_in=0.125, philox=(st, 12))
+    assert torch.equal(a, b) and torch.equal(xin, 0.125 * b) and torch.equal(b.cpu(), x.cpu() + 3.25 * eps.cpu())
+    k = EvalCoef(c_out=0.4, c_skip=0.1, sigma_sq=2.0, neg_mult=-1.4, neg_lang=-0.7, guidance=1.0, one_minus_guidance=0.0,
+                 input_kind=0, stochastic=1)
+    a = ops.euler(x, f, k, -0.5, x_out=torch.empty_like(x), eps=eps, noise_coef=1.3, sqrt_abs_dt=0.9)
+    b = ops.euler(x, f, k, -0.5, x_out=torch.empty_like(x), philox=(st, 12), noise_coef=1.3, sqrt_abs_dt=0.9)
+    assert torch.equal(a, b)
+    with pytest.raises(RuntimeError, match="exactly one of eps"):
+        ops.churn(x, None, 1.0, xhat_out=torch.empty_like(x))
+
+
+@pytest.fixture(scope="module")
+def net8(M, dev):
+    _, sd = load("punetg8_forward")
+    net = M.PUNetG(M.PUNetGConfig(model_channels=8))
+    net.load_state_dict(sd)
+    return net.to(dev).eval()
+
+
+@pytest.mark.parametrize("integrator", ["karras", "euler-maruyama"])
+def test_stochastic_samplers_in_generator_mode(M, net8, dev, grids, integrator):
+    """Without injected eps the noise is drawn inside the kernels from torch's CUDA generator state: the same seed
+    reproduces the run bit for bit (eager and hipGraph alike), the next run continues the stream, and the trajectory
+    equals the CPU oracle's when the oracle is fed the eps the kernels generated."""
+    from diffsci_amd import ops
+    v, sd = load("punetg8_forward")
+    module = M.KarrasModule(net8, M.KarrasModuleConfig.from_edm())
+    _pin_grid(module, grids)
+    if integrator == "euler-maruyama":
+        module.config.noisescheduler.langevin_const = 0.3
+    wn = load("punetg8_traj")[0]["white_noise"].to(dev)
+    gen = torch.cuda.default_generators[0]
+    outs = {}
+    for use_graph in (False, True):
+        module.use_graph = use_graph
+        torch.manual_seed(5)
+        seed, off = gen.initial_seed(), gen.get_offset()
+        a = module.propagate_white_noise(wn, nsteps=6, record_history=True, integrator=integrator)
+        used = gen.get_offset() - off
+        assert used == (6 * ops.philox_counters(wn.numel()) + 3) // 4 * 4
+        b = module.propagate_white_noise(wn, nsteps=6, record_history=True, integrator=integrator)     # stream continues
+        assert not torch.equal(a, b)
+        torch.manual_seed(5)
+        c = module.propagate_white_noise(wn, nsteps=6, record_history=True, integrator=integrator)
+        assert torch.equal(a, c)
+        outs[use_graph] = a
+    assert torch.equal(outs[False], outs[True])
+    st = _state(dev, seed, off)
+    per = ops.philox_counters(wn.numel())
+    eps = torch.stack([ops.philox_normal(st, i * per, wn.shape) for i in range(6)]).cpu()
+    ref = punetg_ref.make_net(sd, punetg_ref.default_config(model_channels=8))
+    kw = dict(langevin_const=0.3) if integrator == "euler-maruyama" else {}
+    want = K.propagate_white_noise(ref, wn.cpu(), 6, integrator=integrator, record_history=True, eps=eps,
+                                   sigma_grid=grids["steps_6"], **kw)
+    assert rel_l2(outs[True].cpu(), want) < REL
+    with pytest.raises(ValueError, match="injected"):        # a generator-mode plan and an injected run are different plans
+        from diffsci_amd.models.karras.engine import Loop, ModuleSource
+        from diffsci_amd.models.karras.steptable import build_step_table
+        sch = module.config.noisescheduler
+        sch.set_temporary_integrator(integrator)
+        table = build_step_table(sch, sch.integrator, 6, preconditioner=module.config.preconditioner)
+        sch.unset_temporary_integrator()
+        Loop(table, ModuleSource(module, None, 1.0, wn.shape[0], wn), wn).set_noise(eps.to(dev))
+    module.config.noisescheduler.langevin_const = 1.0
+
+
+# ----------------------------------------------------------------------------------------- odd sizes
+@pytest.mark.parametrize("B", [1, 3, 5])
+def test_odd_sized_states_with_history_and_noise(M, dev, grids, B):
+    """History / eps slices of a [B, 2] state with odd B start at addresses that are not multiples of 16 bytes; the
+    reference accepts any shape (record_history and the stochastic integrators raised DS_ERR_SHAPE)."""
+    v, sd = load("mlp_cfg1")
+    model = M.MLPUncond(2, [20])
+    model.load_state_dict(sd)
+    module = M.KarrasModule(model, M.KarrasModuleConfig.from_edm()).to(dev)
+    _pin_grid(module, grids)
+    ref = mlp_ref.make_net(sd)
+    wn = v["white_noise"][:B].contiguous()
+    for integ in ("heun", "euler"):
+        h = module.propagate_white_noise(wn.to(dev), nsteps=18, record_history=True, integrator=integ).cpu()
+        want = K.propagate_white_noise(ref, wn, 18, integrator=integ, record_history=True, sigma_grid=grids["steps_18"])
+        assert rel_l2(h, want) < REL
+    eps = v["eps_karras_N18"][:, :B].contiguous()
+    h = module.propagate_white_noise(wn.to(dev), nsteps=18, record_history=True, integrator="karras", eps=eps.to(dev)).cpu()
+    want = K.propagate_white_noise(ref, wn, 18, integrator="karras", record_history=True, eps=eps, sigma_grid=grids["steps_18"])
+    assert rel_l2(h, want) < REL
+    h = module.propagate_white_noise(wn.to(dev), nsteps=18, record_history=True, integrator="karras").cpu()   # generator mode
+    assert torch.isfinite(h).all() and h.shape == want.shape
+    # per-sample sigma: x[b] / out[b] views of a 3-float sample
+    x = torch.randn(B, 3, generator=torch.Generator().manual_seed(B)).to(dev)
+
+    class Net(torch.nn.Module):
+        def forward(self, xx, t):
+            return 0.5 * xx + t[:, None]
+    mod = M.KarrasModule(Net(), M.KarrasModuleConfig.from_edm())
+    sig = torch.linspace(0.5, 3.0, B)
+    s = mod.get_score(x, sig).cpu()
+    want = K.score(lambda xx, t: 0.5 * xx + t[:, None], x.cpu(), sig)
+    torch.testing.assert_close(s, want, rtol=2e-6, atol=1e-6)
+
+
+# ----------------------------------------------------------------------------------------- conditions under a captured plan
+class _WideLabelEmbedding(torch.nn.Module):
+    """A user conditional embedding over an 80-entry one-hot label (more than 64 elements: the plan cache of round 1
+    keyed such tensors by address + checksum, which cannot tell two one-hot labels apart)."""
+
+    def __init__(self, n, c):
+        super().__init__()
+        self.lin = torch.nn.Linear(n, c)
+
+    def forward(self, y):
+        return self.lin(y.reshape(1, -1))
+
+
+def test_plan_replays_follow_the_condition_values(M, dev, grids):
+    _, sd = load("punetg8_forward")
+    torch.manual_seed(3)
+    net = M.PUNetG(M.PUNetGConfig(model_channels=8), conditional_embedding=_WideLabelEmbedding(80, 8))
+    net.load_state_dict(sd, strict=False)
+    module = M.KarrasModule(net, M.KarrasModuleConfig.from_edm(), conditional=True).to(dev).eval()
+    _pin_grid(module, grids)
+    wn = load("punetg8_traj")[0]["white_noise"].to(dev)
+
+    def onehot(i):                                    # a FRESH tensor per call, as a user would make it
+        y = torch.zeros(80)
+        y[i] = 1.0
+        return y.to(dev)
+
+    want = {}
+    module.use_graph = False
+    for i in (3, 7):
+        want[i] = module.propagate_white_noise(wn, y=onehot(i), guidance=2.0, nsteps=4)
+    assert rel_l2(want[3], want[7]) > 1e-3
+    module.use_graph = True
+    for i in (3, 7, 3, 7):                            # first call captures; the others replay with refreshed tables
+        y = onehot(i)
+        got = module.propagate_white_noise(wn, y=y, guidance=2.0, nsteps=4)
+        del y
+        torch.empty(80, device=dev)                   # give the allocator a chance to recycle the label's block
+        assert torch.equal(got, want[i]), i
+    assert len(module._plans.plans) == 1
+
+
+def test_several_channel_condition_items(M, dev, grids):
+    """PUNetGCond with two channel_conditional_items (punetg.py:719-733): the fields are concatenated into a buffer
+    the network owns, so replays of a captured plan see the values of the current call."""
+    v, sd = load("punetg8_cond")
+    net = M.nets.PUNetGCond(M.PUNetGConfig(model_channels=8, input_channels=3, output_channels=1),
+                            channel_conditional_items=["a", "b"])
+    net.load_state_dict(sd, strict=True)
+    net = net.to(dev).eval()
+    module = M.KarrasModule(net, M.KarrasModuleConfig.from_edm(), conditional=True)
+    _pin_grid(module, grids)
+    wn = v["white_noise"].to(dev)
+    field = v["field"][0].to(dev)                                         # [2, H, W]: one channel per item
+    assert field.shape[0] == 2
+
+    def y_of(f):
+        return {"a": f[0:1].clone(), "b": f[1:2].clone()}
+
+    for use_graph in (False, True, True):
+        module.use_graph = use_graph
+        h = module.propagate_white_noise(wn, y=y_of(field), nsteps=4, record_history=True).cpu()
+        assert rel_l2(h, v["hist_heun_N4_f32"]) < REL                     # cat([a, b]) is the fixture's field
+    f2 = torch.stack([field[1] * 0.5, field[0] + 0.25])
+    module.use_graph = False
+    want = module.propagate_white_noise(wn, y=y_of(f2), nsteps=4)
+    module.use_graph = True
+    got = module.propagate_white_noise(wn, y=y_of(f2), nsteps=4)           # replay of the plan captured above
+    assert torch.equal(got, want) and rel_l2(got.cpu(), v["hist_heun_N4_f32"][-1]) > 1e-3
+    again = module.propagate_white_noise(wn, y=y_of(field), nsteps=4).cpu()
+    assert rel_l2(again, v["hist_heun_N4_f32"][-1]) < REL
+    out = net(v["x"].to(dev), v["t"].to(dev), {"a": v["field"][:, 0:1].to(dev), "b": v["field"][:, 1:2].to(dev)}).cpu()
+    assert rel_l2(out, v["out_f32"]) < REL
+
+
+class _TableEmbedding(torch.nn.Module):
+    """conditional_embedding returning one row per sample ([B, C]) for integer labels [.., B]."""
+
+    def __init__(self, n, c):
+        super().__init__()
+        self.table = torch.nn.Parameter(torch.randn(n, c))
+
+    def forward(self, y):
+        return self.table[y.reshape(-1).long()]
+
+
+def test_per_sample_conditions_in_the_captured_sampler(M, dev, grids):
+    """y with one condition per sample (the embedding returns [B, C]): the planned sampler tabulates the time shifts
+    per (evaluation, sample).  Row b of the batched run equals a run of sample b alone with its own condition."""
+    _, sd = load("punetg8_forward")
+    torch.manual_seed(4)
+    net = M.PUNetG(M.PUNetGConfig(model_channels=8), conditional_embedding=_TableEmbedding(10, 8))
+    net.load_state_dict(sd, strict=False)
+    module = M.KarrasModule(net, M.KarrasModuleConfig.from_edm(), conditional=True).to(dev).eval()
+    _pin_grid(module, grids)
+    wn = load("punetg8_traj")[0]["white_noise"].to(dev)
+    B = wn.shape[0]
+    labels = torch.arange(B, device=dev) * 3 % 10
+    res = {}
+    for use_graph in (False, True, True):
+        module.use_graph = use_graph
+        res[use_graph] = module.propagate_white_noise(wn, y=labels.float(), guidance=1.5, nsteps=4)
+    assert torch.equal(res[False], res[True])
+    for b in range(B):
+        one = module.propagate_white_noise(wn[b:b + 1], y=labels[b:b + 1].float(), guidance=1.5, nsteps=4)
+        assert rel_l2(res[True][b:b + 1], one) < 2e-6
+    other = module.propagate_white_noise(wn, y=((labels + 1) % 10).float(), guidance=1.5, nsteps=4)   # replay, new values
+    assert rel_l2(other, res[True]) > 1e-3
+
+
+# ----------------------------------------------------------------------------------------- RCCL, one rank
+def test_sample_sharded_on_a_one_rank_rccl_group(M, net8, dev, grids):
+    """parallel.sample_sharded through a real `nccl` (= RCCL) process group of world size 1: the all-gather path,
+    device placement and noise definition of the multi-GPU sampler with the real network."""
+    import os
+    import torch.distributed as dist
+    from diffsci_amd import parallel
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29531")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        module = M.KarrasModule(net8, M.KarrasModuleConfig.from_edm())
+        _pin_grid(module, grids)
+        got = parallel.sample_sharded(module, 5, [1, 32, 32], nsteps=4, seed=11)
+        torch.manual_seed(11)
+        wn = torch.randn(5, 1, 32, 32)
+        want = module.propagate_white_noise(wn.to(dev), nsteps=4)
+        assert got.shape == (5, 1, 32, 32) and torch.equal(got, want)
+    finally:
+        dist.destroy_process_group()

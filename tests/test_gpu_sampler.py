@@ -535,13 +535,15 @@ def test_vp_ve_parameterisations(M, net8, dev, tag):
     net = net8
     if tag == "ve":
         # VE feeds the network un-normalised inputs (c_in = 1) and this random-init network drives the
-        # trajectory to 1e6..1e8: outside the fp16x3 kernels' documented domain (|activation| < 65504,
-        # beyond which they return inf/nan, never a wrong finite value) -- use the range-free bf16x6 mode
+        # trajectory to 1e6..1e8: outside the fp16x3 kernels' domain (|activation| < 65504, beyond which they
+        # return inf/nan, never a wrong finite value).  The reference's fp32 convolutions take that range, so the
+        # DEFAULT configuration must too: the range guard (nets/precision.py) notices the overflow, switches this
+        # network to the range-free bf16x6 arithmetic and recomputes.  A private copy: the switch is sticky.
         _, sd = load("punetg8_forward")
         net = M.PUNetG(M.PUNetGConfig(model_channels=8))
         net.load_state_dict(sd)
-        net.conv_precision = "bf16x6"
         net = net.to(dev)
+        assert net.conv_precision == "fp16x3" and net.auto_precision
     module = M.KarrasModule(net, cfg)
     s = module.get_score(v[f"{tag}_xs"].to(dev), torch.tensor([0.3, 5.0], device=dev)).cpu()
     assert rel_l2(s, v[f"{tag}_score"]) < REL
@@ -550,7 +552,12 @@ def test_vp_ve_parameterisations(M, net8, dev, tag):
     # differs from its fp64 run by 5e-5 there; the bound is the usual one: 4x the reference's own error.
     ref_err = rel_l2(v[f"{tag}_punetg_heun_N6"], v[f"{tag}_punetg_heun_N6_f64"])
     tol = max(REL, 4 * ref_err)
-    h = module.propagate_white_noise(wn, nsteps=6, record_history=True).cpu()
+    if tag == "ve":
+        with pytest.warns(RuntimeWarning, match="exceeded the fp16x3 convolution range"):
+            h = module.propagate_white_noise(wn, nsteps=6, record_history=True).cpu()
+        assert net.conv_precision == "bf16x6"
+    else:
+        h = module.propagate_white_noise(wn, nsteps=6, record_history=True).cpu()
     assert rel_l2(h[:2], v[f"{tag}_punetg_heun_N6"][:2]) < REL                     # the first step is well conditioned
     assert rel_l2(h, v[f"{tag}_punetg_heun_N6"]) < tol
     assert rel_l2(h, v[f"{tag}_punetg_heun_N6_f64"]) < tol
@@ -560,9 +567,27 @@ def test_vp_ve_parameterisations(M, net8, dev, tag):
         h = module.propagate_white_noise(wn, nsteps=4, record_history=True, integrator="karras",
                                          eps=v["ve_punetg_karras_eps"].to(dev)).cpu()
         assert rel_l2(h, v["ve_punetg_karras_N4"]) < tol
-        # and the default fp16x3 mode reports the overflow instead of returning finite garbage
-        bad = M.KarrasModule(net8, cfg).propagate_white_noise(wn, nsteps=6).cpu()
-        assert not torch.isfinite(bad).all()
+        # with the guard off the fp16x3 kernels report the overflow as inf/nan (never finite garbage) ...
+        raw = M.PUNetG(M.PUNetGConfig(model_channels=8))
+        raw.load_state_dict(sd)
+        raw.auto_precision = False
+        bad = M.KarrasModule(raw.to(dev), cfg).propagate_white_noise(wn, nsteps=6).cpu()
+        assert not torch.isfinite(bad).all() and raw.conv_precision == "fp16x3"
+        # ... the eager network call is guarded too, and non-finite INPUTS are the caller's: no switch
+        big = M.PUNetG(M.PUNetGConfig(model_channels=8))
+        big.load_state_dict(sd)
+        big = big.to(dev)
+        xb = torch.full((1, 1, 32, 32), 3.0e5, device=dev)
+        with pytest.warns(RuntimeWarning, match="fp16x3 convolution range"):
+            ob = big(xb, torch.tensor([0.1], device=dev))
+        assert torch.isfinite(ob).all() and big.conv_precision == "bf16x6"
+        want = punetg_ref.make_net(sd, punetg_ref.default_config(model_channels=8))(xb.cpu(), torch.tensor([0.1]))
+        assert rel_l2(ob.cpu(), want) < REL
+        nan_in = M.PUNetG(M.PUNetGConfig(model_channels=8))
+        nan_in.load_state_dict(sd)
+        nan_in = nan_in.to(dev)
+        xn = torch.full((1, 1, 32, 32), float("nan"), device=dev)
+        assert not torch.isfinite(nan_in(xn, torch.tensor([0.1], device=dev))).any() and nan_in.conv_precision == "fp16x3"
 
 
 def test_vp_sigma_churn(M, dev, monkeypatch):

@@ -242,3 +242,47 @@ def test_config_descriptions_round_trip():
     torch.manual_seed(0)
     s = UniformNoiseSampler(t=0.5, T=2.0).sample([1000])
     assert float(s.min()) >= 0.5 and float(s.max()) <= 2.0
+
+
+def test_global_noise_rows_without_the_full_tensor():
+    """A rank draws only its rows (chunked skip of the lower ranks' rows): identical to slicing the full draw."""
+    import diffsci_amd.parallel as P
+    old = P._CHUNK_FLOATS
+    P._CHUNK_FLOATS = 1 << 10
+    try:
+        for total, shape in ((8, [1, 4, 4]), (5, [1, 4, 4]), (7, [3, 8, 8]), (4, [1, 3, 3]), (6, [2, 16, 16]), (1, [1, 4, 4])):
+            torch.manual_seed(7)
+            ref = torch.randn(total, *shape)
+            for world in (1, 2, 3, 4):
+                for rank in range(world):
+                    lo, hi = P.shard_rows(total, world, rank)
+                    assert torch.equal(P.global_white_noise(total, shape, 7, rows=(lo, hi)), ref[lo:hi])
+    finally:
+        P._CHUNK_FLOATS = old
+
+
+def test_plan_keys_depend_on_condition_structure_not_values():
+    """one-hot labels 3 and 7 (sum = |sum| = 1) and a fresh tensor in a recycled block must not be
+    told apart -- or confused -- by a plan key: the key is structural, the values are refreshed before every replay."""
+    from diffsci_amd.models.karras.engine import condition_signature
+    a, b = torch.zeros(80), torch.zeros(80)
+    a[3], b[7] = 1.0, 1.0
+    assert condition_signature(a) == condition_signature(b)
+    assert condition_signature({"y": a, "z": torch.zeros(2, 3)}) == condition_signature({"z": torch.ones(2, 3), "y": b})
+    assert condition_signature(a) != condition_signature(torch.zeros(81))
+    assert condition_signature({"y": a}) != condition_signature({"w": a})
+    assert condition_signature(None) is None
+
+
+def test_bench_self_launch_command():
+    """`python bench.py --gpus N` with no launcher around it starts N ranks through torch.distributed.run on
+    127.0.0.1 and hands its own arguments on."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(__file__)), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    cmd = bench.launcher_command(["--gpus", "4", "--steps", "2"], 4, 29555)
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29555"
+    assert cmd[-4:] == ["--gpus", "4", "--steps", "2"] and cmd[-5].endswith("bench.py")

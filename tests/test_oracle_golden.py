@@ -641,3 +641,20 @@ def test_euler_maruyama_langevin_interval():
                              eps=v["eps"], langevin_const=float(v["langevin_const"]),
                              langevin_interval=tuple(float(t) for t in v["langevin_interval"]))
     assert_exact_or_ulp(h, v["hist"], "EM with a Langevin interval")
+
+
+def test_philox_known_answers():
+    """The in-kernel noise generator is Philox4x32-10: its oracle (oracle/philox_ref.py) reproduces the published
+    Random123 known-answer vectors (kat_vectors: zero, all-ones and the pi-digits inputs)."""
+    import numpy as np
+    from oracle import philox_ref as P
+
+    def kat(c, k):
+        return [int(v) for v in P.philox4x32_10(np.array([c], dtype=np.uint64), np.array([k], dtype=np.uint64))[0]]
+    assert kat([0, 0, 0, 0], [0, 0]) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    assert kat([0xffffffff] * 4, [0xffffffff] * 2) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    assert kat([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0]) == \
+        [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+    z = P.normal(1234, 0, 1 << 18)
+    assert abs(z.mean()) < 0.01 and abs(z.std() - 1) < 0.01 and np.isfinite(z).all()
+    assert np.array_equal(P.normal(1234, 16, 64), P.normal(1234, 0, 128)[64:])          # offset = counter shift
