@@ -75,6 +75,7 @@ _PROTOS = {
     "ds_token_l2_normalize": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_float, c_float, _P]),
     "ds_linear": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "ds_fourier_features": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P]),
+    "ds_fourier_channels": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_size_t, _P]),
     "ds_gnorm1_workspace_bytes": (c_size_t, [c_int]),
     "ds_gnorm1_stats": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_float, c_int, _P]),
     "ds_gnorm1_apply": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),

@@ -31,8 +31,10 @@
 #ifdef DS_STAMP
 unsigned long long* g_stamps = nullptr;
 #define STAMP(slot) do { if (threadIdx.x == 0) a.stamps[((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define STAMP_CLK(slot) do { if (threadIdx.x == 0) a.stamps[((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define STAMP(slot) do {} while (0)
+#define STAMP_CLK(slot) do {} while (0)
 #endif
 
 namespace {
@@ -299,6 +301,7 @@ __global__ __launch_bounds__(NT, 2) void k_conv3h(const Conv3hArgs a) {
   x_store(0);
   __syncthreads();
   STAMP(2);
+  STAMP_CLK(6);
 
   Frags fA, fB;
   frag_load(fA, 0, 0, 0, 0);
@@ -351,6 +354,7 @@ __global__ __launch_bounds__(NT, 2) void k_conv3h(const Conv3hArgs a) {
   }
 
   STAMP(3);
+  STAMP_CLK(7);
   // ---- epilogue (ds_conv_epilogue.h): LDS transpose -> 16-byte stores.  The staging buffers are
   //      dead after the last step's barrier; each wave takes a private 16 KiB of them. ----
   {

@@ -52,9 +52,43 @@ __global__ void k_fourier(float* out, const float* __restrict__ t, const float* 
   out[(size_t)m * 2 * half + half + j] = c;
 }
 
+// ConvolutionalFourierProjection (commonlayers.py:229-255): xc[b,d,p] = sum_c x[b,c,p] * (2*pi*W[c,d]); out = cat[sin(xc), cos(xc)]
+// along channels.  One thread per (b, d, p), p fastest: coalesced reads of the C input planes and of both output planes.
+__global__ __launch_bounds__(256) void k_fourier_channels(float* __restrict__ out, const float* __restrict__ x,
+                                                          const float* __restrict__ W, int C, int D, size_t HW, size_t total) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < total; i += stride) {
+    const size_t p = i % HW;
+    const size_t bd = i / HW;
+    const int d = (int)(bd % D);
+    const size_t b = bd / D;
+    const float* xb = x + b * C * HW + p;
+    float acc = 0.f;
+    for (int c = 0; c < C; ++c) acc = acc + xb[(size_t)c * HW] * (W[(size_t)c * D + d] * 6.283185307179586f);
+    float sn, cs;
+    sincosf(acc, &sn, &cs);
+    float* ob = out + b * 2 * D * HW + p;
+    ob[(size_t)d * HW] = sn;
+    ob[(size_t)(D + d) * HW] = cs;
+  }
+}
+
 }  // namespace
 
 extern "C" {
+
+int ds_fourier_channels(float* out, const float* x, const float* W, int B, int C, int D, size_t HW, void* stream) {
+  DS_REQUIRE(out && x && W, DS_ERR_NULL, "ds_fourier_channels: NULL pointer");
+  DS_REQUIRE(B >= 0 && C > 0 && D > 0 && HW > 0, DS_ERR_SHAPE, "ds_fourier_channels: bad shape B=%d C=%d D=%d", B, C, D);
+  const size_t total = (size_t)B * D * HW;
+  if (total == 0) return DS_OK;
+  size_t g = (total + 255) / 256;
+  if (g > 8192) g = 8192;
+  hipLaunchKernelGGL(k_fourier_channels, dim3((unsigned)g), dim3(256), 0, ds::as_stream(stream), out, x, W, C, D, HW, total);
+  DS_CHECK_LAUNCH("ds_fourier_channels");
+  return DS_OK;
+}
 
 int ds_linear(float* y, const float* x, const float* w, const float* b, int M, int K, int N, int act, void* stream) {
   DS_REQUIRE(y && x && w, DS_ERR_NULL, "ds_linear: NULL pointer");

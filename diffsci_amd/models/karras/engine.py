@@ -66,7 +66,7 @@ class ModuleSource:
         self.like = like
         self.conditional = bool(module.conditional) and self.guidance != 0.0
         self.cfg = self.conditional and self.guidance != 1.0
-        self.planned = bool(getattr(self.model, "forward_with_shifts", None)) and (
+        self.planned = bool(getattr(self.model, "forward_with_shifts", None)) and getattr(self.model, "capturable", True) and (
             like.dim() == 4 or (like.dim() == 5 and getattr(self.model, "dim", 2) == 3))
         self._out = {}
         self.shifts_c = self.shifts_u = None
@@ -107,12 +107,13 @@ class ModuleSource:
         self.y = y
         if not (self.planned and self.conditional):
             return
-        ye = self.model.embed_condition(y)           # PUNetGCond also refreshes its channel-field buffer here
-        new = self._tables(ye)
-        if len(new) != len(self.shifts_c) or any(a.shape != b.shape for a, b in zip(new, self.shifts_c)):
-            raise RuntimeError("the condition changed shape under a captured plan (plan key out of date)")
-        for dst, src in zip(self.shifts_c, new):
-            dst.copy_(src)
+        with torch.inference_mode():                 # the tables may have been created under inference_mode
+            ye = self.model.embed_condition(y)       # PUNetGCond also refreshes its channel-field buffer here
+            new = self._tables(ye)
+            if len(new) != len(self.shifts_c) or any(a.shape != b.shape for a, b in zip(new, self.shifts_c)):
+                raise RuntimeError("the condition changed shape under a captured plan (plan key out of date)")
+            for dst, src in zip(self.shifts_c, new):
+                dst.copy_(src)
 
     def _buf(self, slot, name):
         key = (slot, name)

@@ -326,6 +326,7 @@ class KarrasModule(torch.nn.Module, LatentSpaceAutoregressive):
                                initial_step, final_step)
 
     @ops.device_guard                              # launches go to x's GPU whatever the caller's current device is
+    @torch.inference_mode()                        # sampling never differentiates; plan buffers live in one mode
     def _propagate(self, x, y, guidance, nsteps, record_history, integrator, eps, scale, i0, i1):
         ops.require_device(x, "x")
         sch = self.config.noisescheduler

@@ -178,6 +178,15 @@ class _Fourier(torch.nn.Module):
         self.register_buffer("W", torch.randn(embed_dim // 2) * scale)
 
 
+class _FourierInput(torch.nn.Module):
+    """ConvolutionalFourierProjection buffers (commonlayers.py:229-244), bias=False: W [input_dim, embed_dim/2]."""
+
+    def __init__(self, input_dim, embed_dim, scale):
+        super().__init__()
+        self.register_buffer("W", torch.randn(input_dim, embed_dim // 2) * scale)
+        self.in_channels, self.out_channels = input_dim, embed_dim
+
+
 class _ConditionDrop(torch.nn.Module):
     """ConditionDrop parameters (commonlayers.py:1100-1127): identity outside training; the null embedding is only a
     state_dict entry here."""
@@ -232,8 +241,11 @@ class PUNetG(torch.nn.Module):
         why = config.unsupported_reason()
         if why:
             raise NotImplementedError(why)
-        if extra_residual is not None:
-            raise NotImplementedError("extra_residual is not implemented on the HIP path")
+        # extra_residual (punetg.py:83-92,249-261; commonlayers.py:831-833): ONE user module shared by every residual
+        # block, y = (conv2(...) + x) + extra_residual(x).  It is ordinary torch code run as given (it may allocate), so a
+        # network that carries one is evaluated launch by launch instead of from a captured graph.
+        self.extra_residual = extra_residual
+        self.capturable = extra_residual is None
         self.config = config
         mc = config.model_channels
         mult = config.extended_channel_expansion
@@ -251,11 +263,18 @@ class PUNetG(torch.nn.Module):
         self.norm_kinds = tuple(NORM_KINDS.get(n, 2) for n in norms)
         # bias=False: no convolution biases; a constant-one input channel is appended instead (punetg.py:190-191,390-394)
         dim = self.dim = config.dimension
-        self.convin = make_conv(config.input_channels + (0 if hb else 1), mc, 3, circ, hb, dim)
+        if config.in_embedding:                           # fixed Fourier input embedding instead of a convolution, punetg.py:194-202
+            self.convin = _FourierInput(config.input_channels + (0 if hb else 1), mc, config.input_projection_scale)
+        else:
+            self.convin = make_conv(config.input_channels + (0 if hb else 1), mc, 3, circ, hb, dim)
         self.convout = make_conv(mc, config.output_channels, 3, circ, hb, dim)
 
         def blocks(m, n):
-            return torch.nn.ModuleList([_ResBlock(m * mc, mc, circ, hb, norms, bool(config.affine_norm), dim) for _ in range(n)])
+            bl = [_ResBlock(m * mc, mc, circ, hb, norms, bool(config.affine_norm), dim) for _ in range(n)]
+            if extra_residual is not None:
+                for b in bl:
+                    b.extra_residual = extra_residual          # the reference registers the shared module in every block
+            return torch.nn.ModuleList(bl)
 
         self.downward_blocks = torch.nn.ModuleList(
             [blocks(mult[i], config.number_resnet_downward_block) for i in range(len(mult) - 1)])
@@ -440,7 +459,8 @@ class PUNetG(torch.nn.Module):
 
     # ------------------------------------------------------------------ weights
     def _conv_modules(self):
-        yield self.convin
+        if not isinstance(self.convin, _FourierInput):
+            yield self.convin
         yield self.convout
         for blk in self._resblocks():
             yield blk.conv1
@@ -519,6 +539,20 @@ class PUNetG(torch.nn.Module):
         x untouched.  xs = tile statistics of x (from the convolution that produced it) or None."""
         B, C, H, W = x.shape
         dev = x.device
+        if self.extra_residual is not None:
+            er = self.extra_residual(x)
+            ops.require_device(er, "extra_residual output")
+            if tuple(er.shape) != tuple(x.shape):
+                raise ValueError("extra_residual must preserve the shape of its input")
+            saved, self.extra_residual = self.extra_residual, None
+            try:
+                y, _ = self._res(blk, x, shift, pk, ws, res2=None, xs=xs, want_stats=False)
+            finally:
+                self.extra_residual = saved
+            ops.add(y, er.contiguous(), out=y)                      # (conv2 + x) + extra_residual(x)
+            if res2 is not None:
+                ops.add(y, res2, out=y)                             # x + xa of bottom_forward, after the block as in the reference
+            return y, None                                          # no tile statistics of the sum: the consumer normalises standalone
         k1, k2 = self.norm_kinds                           # 0 GroupLN, 1 GroupRMS, 2 none, 3 GroupPix (not a table)
         w1, b1 = getattr(blk.gnorm1, "weight", None), getattr(blk.gnorm1, "bias", None)
         w2, b2 = getattr(blk.gnorm2, "weight", None), getattr(blk.gnorm2, "bias", None)
@@ -581,8 +615,12 @@ class PUNetG(torch.nn.Module):
             xe = ops.concat2(x, ones, out=ws.take((B, x.shape[1] + 1, H, W), dev))
             ws.give(ones)
             x = xe
-        hs = self._stats_buf(ws, B, cfg.model_channels, H, W, dev)
-        h = self._conv(self.convin, x, pk, tile_stats=hs, out=ws.take((B, cfg.model_channels, H, W), dev))
+        if isinstance(self.convin, _FourierInput):
+            hs = None                                                            # no producer statistics: standalone first norm
+            h = ops.fourier_channels(x, self.convin.W, out=ws.take((B, cfg.model_channels, H, W), dev))
+        else:
+            hs = self._stats_buf(ws, B, cfg.model_channels, H, W, dev)
+            h = self._conv(self.convin, x, pk, tile_stats=hs, out=ws.take((B, cfg.model_channels, H, W), dev))
         if xe is not None:
             ws.give(xe)
         skips = []
@@ -695,7 +733,13 @@ class PUNetG(torch.nn.Module):
             a = ops.inorm_silu(h, w1, b1, kind=k1, eps=1e-5, out=ws.take(h.shape, dev))
             y = conv(blk.conv1, a, shift=sh())
             ops.inorm_silu(y, w2, b2, kind=k2, eps=1e-5, out=a)
-            conv(blk.conv2, a, res1=h, res2=res2, dst=y)
+            if self.extra_residual is None:
+                conv(blk.conv2, a, res1=h, res2=res2, dst=y)
+            else:
+                conv(blk.conv2, a, res1=h, dst=y)
+                ops.add(y, self.extra_residual(h).contiguous(), out=y)
+                if res2 is not None:
+                    ops.add(y, res2, out=y)
             ws.give(a)
             return y
 
@@ -716,7 +760,10 @@ class PUNetG(torch.nn.Module):
             xe = ops.concat2(x, ones, out=ws.take((B, x.shape[1] + 1) + tuple(x.shape[2:]), dev))
             ws.give(ones)
             x = xe
-        h = conv(self.convin, x)
+        if isinstance(self.convin, _FourierInput):
+            h = ops.fourier_channels(x, self.convin.W, out=ws.take((B, cfg.model_channels) + tuple(x.shape[2:]), dev))
+        else:
+            h = conv(self.convin, x)
         if xe is not None:
             ws.give(xe)
         skips = []
@@ -821,14 +868,15 @@ class PUNetGCond(PUNetG):
         # (shape, device); every call -- eager or as the refresh before a replay -- rewrites it.
         shape = (fields[0].shape[0], sum(f.shape[1] for f in fields)) + tuple(fields[0].shape[2:])
         key = (shape, str(fields[0].device))
-        buf = self._ycat_static.get(key)
-        if buf is None:                  # never evicted: captured plans keep reading the buffer of their shape
-            buf = torch.empty(shape, dtype=torch.float32, device=fields[0].device)
-            self._ycat_static[key] = buf
-        c0 = 0
-        for f in fields:
-            buf[:, c0:c0 + f.shape[1]].copy_(f)
-            c0 += f.shape[1]
+        with torch.inference_mode():     # the sampler runs under inference_mode; an eager forward() may not: one mode for the buffer
+            buf = self._ycat_static.get(key)
+            if buf is None:              # never evicted: captured plans keep reading the buffer of their shape
+                buf = torch.empty(shape, dtype=torch.float32, device=fields[0].device)
+                self._ycat_static[key] = buf
+            c0 = 0
+            for f in fields:
+                buf[:, c0:c0 + f.shape[1]].copy_(f)
+                c0 += f.shape[1]
         return (rest if len(rest) else None), buf
 
     def _with_condition(self, x, ycat, ws):

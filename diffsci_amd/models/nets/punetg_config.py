@@ -60,7 +60,9 @@ class PUNetGConfig(object):
             (self.kernel_size == 3 and self.in_out_kernel_size == 3 and self.transition_kernel_size == 3,
              "3x3 kernels"),
             (self.transition_scale_factor == 2, "transition_scale_factor=2"),
-            (not self.in_embedding, "in_embedding=False"),
+            (not self.in_embedding or not self.bias,
+             "in_embedding only with bias=False (the reference's ConvolutionalFourierProjection raises with bias=True, "
+             "commonlayers.py:251-253)"),
             (self.attn_type in ("default", "cosine"), "attn_type 'default' or 'cosine'"),
         ]
         bad = [msg for ok, msg in checks if not ok]

@@ -639,6 +639,20 @@ def fourier_features(t, W, add=None, out=None):
     return out
 
 
+def fourier_channels(x, W, out=None):
+    """ConvolutionalFourierProjection: x [B, C, *spatial], W [C, D] -> [B, 2D, *spatial] = cat[sin, cos](x . 2*pi*W)."""
+    require_device(x, "x")
+    B, C = x.shape[0], x.shape[1]
+    if W.dim() != 2 or W.shape[0] != C:
+        raise ValueError(f"fourier_channels: W must be [{C}, D]; got {tuple(W.shape)}")
+    D = W.shape[1]
+    HW = x.numel() // max(B * C, 1)
+    if out is None:
+        out = torch.empty((B, 2 * D) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
+    N.check(N.lib().ds_fourier_channels(_p(out, "out"), _p(x, "x"), _p(W, "W"), B, C, D, HW, _stream()), "ds_fourier_channels")
+    return out
+
+
 class Graph:
     """A captured launch sequence (hipGraph) on torch's current stream."""
 

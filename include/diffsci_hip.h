@@ -306,6 +306,12 @@ int ds_linear(float* y, const float* x, const float* w, const float* b, int M, i
 int ds_fourier_features(float* out, const float* t, const float* W, const float* add, int add_rows,
                         int M, int half, void* stream);
 
+/* ConvolutionalFourierProjection.forward (commonlayers.py:246-255; PUNetG's convin when in_embedding=True, punetg.py:194-202):
+ * out[b, d, p] = sin(sum_c x[b,c,p] * (2*pi*W[c,d])), out[b, D+d, p] = cos(same); x [B,C,HW], W [C,D], out [B,2D,HW].
+ * (The reference layer only runs with bias=False -- its bias branch adds an int to a list -- in which case PUNetG
+ * appends a constant-one input channel whose W row acts as the phase.) */
+int ds_fourier_channels(float* out, const float* x, const float* W, int B, int C, int D, size_t HW, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * ADM score-network layers (adm.py) not shared with PUNetG.
  * ---------------------------------------------------------------------------------- */

@@ -117,14 +117,25 @@ def block_norm(kind, sd, prefix, x):
     return x                                                 # torch.nn.Identity
 
 
-def resnet_block(sd, prefix, x, te, circular=False, norms=("GroupLN", "GroupRMS")):
-    """ResnetBlockC.forward, commonlayers.py:824-833."""
+def resnet_block(sd, prefix, x, te, circular=False, norms=("GroupLN", "GroupRMS"), extra_residual=None):
+    """ResnetBlockC.forward, commonlayers.py:824-833; extra_residual: the user module of punetg.py:83-92 (a callable
+    here), added after the residual connection."""
     h = block_norm(norms[0], sd, prefix + "gnorm1.", x)
     y = conv3x3(sd, prefix + "conv1", F.silu(h), circular)
     y = y + time_shift(sd, prefix + "timeblock.", te, mp=circular == "mp", ndim=x.dim() - 2)   # [B, C, 1, 1(, 1)]
     h = block_norm(norms[1], sd, prefix + "gnorm2.", y)
     y = conv3x3(sd, prefix + "conv2", F.silu(h), circular)
-    return y + x
+    y = y + x
+    if extra_residual is not None:
+        y = y + extra_residual(x)
+    return y
+
+
+def fourier_input(sd, x):
+    """ConvolutionalFourierProjection.forward with bias=False (commonlayers.py:246-255): PUNetG's convin when
+    in_embedding=True (punetg.py:194-202)."""
+    xc = torch.einsum('bc...,cd->bd...', x, 2 * math.pi * sd["convin.W"])
+    return torch.cat([torch.sin(xc), torch.cos(xc)], dim=1)
 
 
 def mp_attention_2d(sd, prefix, x, attn_residual=False, magnitude_preserving=True, cosine=False):
@@ -192,7 +203,8 @@ def punetg_forward(sd, cfg, x, t, ye=None):
         xe_shape = list(x.shape)
         xe_shape[1] = 1
         x = torch.cat([x, torch.ones(xe_shape).to(x)], dim=1)
-    x = conv3x3(sd, "convin", x, circ)
+    er = cfg.get("extra_residual")                                   # a callable (test configurations only)
+    x = fourier_input(sd, x) if cfg.get("in_embedding", False) else conv3x3(sd, "convin", x, circ)
     if t is None:                                                    # punetg.py:396-399: no time input
         te = torch.zeros(x.shape[0], cfg["model_channels"]).to(x)
     else:
@@ -202,15 +214,15 @@ def punetg_forward(sd, cfg, x, t, ye=None):
     skips = []
     for lv in range(nlev):                                           # encode, punetg.py:356-365
         for r in range(cfg["number_resnet_downward_block"]):
-            x = resnet_block(sd, f"downward_blocks.{lv}.{r}.", x, te, circ, norms)
+            x = resnet_block(sd, f"downward_blocks.{lv}.{r}.", x, te, circ, norms, er)
         skips.append(x)
         x = conv3x3(sd, f"downsamplers.{lv}.conv", (F.max_pool3d if x.dim() == 5 else F.max_pool2d)(x, 2), circ)
     for r in range(cfg["number_resnet_before_attn_block"]):         # bottom, punetg.py:378-387
-        x = resnet_block(sd, f"before_block.{r}.", x, te, circ, norms)
+        x = resnet_block(sd, f"before_block.{r}.", x, te, circ, norms, er)
     xa = x
     nattn = cfg["number_resnet_attn_block"]
     for r in range(nattn):                                           # punetg.py:344-354
-        xa = resnet_block(sd, f"attn_resnet_block.{r}.", xa, te, circ, norms)
+        xa = resnet_block(sd, f"attn_resnet_block.{r}.", xa, te, circ, norms, er)
         if r < nattn - 1:
             cosine = cfg.get("attn_type", "default") == "cosine"
             if ctype == "mp" or cosine:
@@ -219,13 +231,13 @@ def punetg_forward(sd, cfg, x, t, ye=None):
                 xa = attention_2d(sd, f"attn_block.{r}.", xa, cfg["attn_residual"])
     x = x + xa
     for r in range(cfg["number_resnet_after_attn_block"]):
-        x = resnet_block(sd, f"after_block.{r}.", x, te, circ, norms)
+        x = resnet_block(sd, f"after_block.{r}.", x, te, circ, norms, er)
     for lv in range(nlev):                                           # decode, punetg.py:367-376
         x = F.interpolate(x, scale_factor=2.0, mode="nearest")
         x = conv3x3(sd, f"upsamplers.{lv}.conv", x, circ)
         x = x + skips.pop()
         for r in range(cfg["number_resnet_upward_block"]):
-            x = resnet_block(sd, f"upward_blocks.{lv}.{r}.", x, te, circ, norms)
+            x = resnet_block(sd, f"upward_blocks.{lv}.{r}.", x, te, circ, norms, er)
     return conv3x3(sd, "convout", x, circ)
 
 

@@ -628,6 +628,10 @@ def variants():
         "pix_ln": dict(first_resblock_norm="GroupPix", second_resblock_norm="GroupLN"),
         "none_rms_noaffine": dict(first_resblock_norm="none", second_resblock_norm="GroupRMS", affine_norm=False),
         "cosine": dict(attn_type="cosine"),
+        # round 2: the fixed Fourier input embedding (only runnable with bias=False in the reference) and a shared
+        # parameter-free extra_residual module
+        "fourier_in": dict(in_embedding=True, bias=False),
+        "extra_res": dict(),
     }
     only = os.environ.get("VARIANTS_ONLY")
     for i, (tag, over) in enumerate(cases.items()):
@@ -635,9 +639,10 @@ def variants():
             continue
         torch.manual_seed(70 + i)
         cfg = M.nets.PUNetGConfig(model_channels=8, **over)
+        extra = dict(extra_residual=torch.nn.AvgPool2d(3, stride=1, padding=1)) if tag == "extra_res" else {}
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
-            net = M.nets.PUNetG(cfg).eval()
+            net = M.nets.PUNetG(cfg, **extra).eval()
         with torch.no_grad():
             for k, v in net.state_dict().items():
                 if "gnorm" in k or k.endswith(".bias"):
@@ -658,7 +663,7 @@ def variants():
             arrs["attn_out"] = net.attn_block[0](hb)
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
-            net64 = M.nets.PUNetG(cfg).double().eval()
+            net64 = M.nets.PUNetG(cfg, **extra).double().eval()
         net64.load_state_dict({k: v.double() for k, v in sd.items()})
         with torch.inference_mode():
             arrs["out_f64"] = net64(x.double(), t.double())

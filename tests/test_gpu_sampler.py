@@ -636,19 +636,30 @@ def test_punetg_circular_convolutions(M, dev, grids):
     ("pix_ln", dict(first_resblock_norm="GroupPix", second_resblock_norm="GroupLN")),
     ("none_rms_noaffine", dict(first_resblock_norm="none", second_resblock_norm="GroupRMS", affine_norm=False)),
     ("cosine", dict(attn_type="cosine")),
+    ("fourier_in", dict(in_embedding=True, bias=False)),
+    ("extra_res", dict()),
 ])
 def test_punetg_layer_variants(M, dev, grids, tag, over, fuse):
     """magnitude-preserving convolutions / linears / attention (weights folded when packed)
     and the GroupPix / none / non-affine norm choices, against the reference's outputs; reference checkpoints
     load by key name."""
     v, sd = load("punetg8_" + tag)
-    net = M.PUNetG(M.PUNetGConfig(model_channels=8, **over))
+    extra = dict(extra_residual=torch.nn.AvgPool2d(3, stride=1, padding=1)) if tag == "extra_res" else {}
+    net = M.PUNetG(M.PUNetGConfig(model_channels=8, **over), **extra)
     r = net.load_state_dict(sd, strict=True)
     assert not r.missing_keys and not r.unexpected_keys
     net = net.to(dev)
     net.fuse_norm = fuse
     pk = net.packed_weights()
-    h = net._conv(net.convin, v["x"].to(dev), pk)
+    if tag == "fourier_in":      # ConvolutionalFourierProjection on [x, 1]: sin / cos of arguments up to ~2 pi * 4 sigma(W)
+        from diffsci_amd import ops
+        # the fixture's layer output is net.convin(x) on the bare 1-channel x, which einsum broadcasts over both rows of W
+        xin = torch.cat([v["x"], v["x"]], dim=1).to(dev)
+        h = ops.fourier_channels(xin, net.convin.W)
+        with pytest.raises(NotImplementedError, match="in_embedding only with bias=False"):
+            M.PUNetG(M.PUNetGConfig(model_channels=8, in_embedding=True))
+    else:
+        h = net._conv(net.convin, v["x"].to(dev), pk)
     assert rel_l2(h.cpu(), v["convin"]) < 2e-6
     ws = net._ws
     y = net._attention(net.attn_block[0], v["attn_in"].to(dev), pk, ws)
@@ -666,6 +677,8 @@ def test_punetg_layer_variants(M, dev, grids, tag, over, fuse):
     module = M.KarrasModule(net, M.KarrasModuleConfig.from_edm())
     _pin_grid(module, grids)
     hist = module.propagate_white_noise(v["white_noise"].to(dev), nsteps=6, record_history=True).cpu()
+    if tag == "extra_res":       # a user torch module inside every block: evaluated launch by launch, never captured
+        assert not net.capturable and len(module._plans.plans) == 0
     if ref_err < REL:
         assert rel_l2(hist, v["hist_heun_N6_f32"]) < REL
     else:
@@ -766,7 +779,7 @@ def test_punetg_volumes(M, dev, grids, tag):
             module.use_graph = use_graph
             hist = module.propagate_white_noise(v["white_noise"].to(dev), nsteps=4, record_history=True).cpu()
             assert rel_l2(hist, v["hist_heun_N4_f32"]) < REL
-        assert len(module._plans) == 1
+        assert len(module._plans.plans) == 1
         with pytest.raises(ValueError, match="volumes"):
             net(v["x"][:, :, 0].to(dev), v["t"].to(dev))
 

@@ -332,7 +332,10 @@ VARIANTS = {
     "pix_ln": dict(first_resblock_norm="GroupPix", second_resblock_norm="GroupLN"),
     "none_rms_noaffine": dict(first_resblock_norm="none", second_resblock_norm="GroupRMS", affine_norm=False),
     "cosine": dict(attn_type="cosine"),
+    "fourier_in": dict(in_embedding=True, bias=False),      # ConvolutionalFourierProjection as convin (punetg.py:194-202)
+    "extra_res": dict(),                                    # extra_residual = AvgPool2d(3, 1, 1) shared by every block
 }
+EXTRA_RES = torch.nn.AvgPool2d(3, stride=1, padding=1)
 
 
 @pytest.mark.parametrize("tag", sorted(VARIANTS))
@@ -342,15 +345,22 @@ def test_punetg_layer_variants(tag):
     v, sd = load("punetg8_" + tag)
     over = VARIANTS[tag]
     cfg = punetg_ref.default_config(model_channels=8, **over)
+    er = EXTRA_RES if tag == "extra_res" else None
+    cfg["extra_residual"] = er
     kind = "mp" if tag == "mp" else False
     norms = (over.get("first_resblock_norm", "GroupLN"), over.get("second_resblock_norm", "GroupRMS"))
     if not over.get("affine_norm", True):
         assert not any("gnorm" in k for k in sd)
     with torch.inference_mode():
-        h = punetg_ref.conv3x3(sd, "convin", v["x"], kind)
+        if tag == "fourier_in":
+            assert "convin.W" in sd and "convin.weight" not in sd
+            # the fixture's layer output is net.convin(x) on the bare 1-channel x: einsum broadcasts it over both rows of W
+            h = punetg_ref.fourier_input(sd, v["x"])
+        else:
+            h = punetg_ref.conv3x3(sd, "convin", v["x"], kind)
         assert_exact_or_ulp(h, v["convin"], tag + " convin")
         te = punetg_ref.fourier_features(v["t"], sd["time_projection.W"])
-        r = punetg_ref.resnet_block(sd, "downward_blocks.0.0.", v["convin"], te, kind, norms)
+        r = punetg_ref.resnet_block(sd, "downward_blocks.0.0.", v["convin"], te, kind, norms, er)
         assert_exact_or_rel(r, v["resblock"], tag + " resblock", 1e-6)
         if tag in ("mp", "cosine"):
             a = punetg_ref.mp_attention_2d(sd, "attn_block.0.", v["attn_in"], False, tag == "mp", tag == "cosine")

@@ -33,6 +33,6 @@ for it in range(60):
     torch.cuda.synchronize()
     peak.append(torch.cuda.memory_allocated() / 2 ** 20)
     if it % 10 == 9:
-        print(f"it {it}: {peak[-1]:.1f} MiB allocated, {len(module._plans)} plans", flush=True)
+        print(f"it {it}: {peak[-1]:.1f} MiB allocated, {len(module._plans.plans)} plans", flush=True)
 assert max(peak[40:]) <= max(peak[:40]) * 1.05 + 1, (max(peak[:40]), max(peak[40:]))
 print("soak ok: memory plateaued at", round(max(peak), 1), "MiB")
