@@ -30,11 +30,16 @@
 
 #ifdef DS_STAMP
 unsigned long long* g_stamps = nullptr;
-#define STAMP(slot) do { if (threadIdx.x == 0) a.stamps[((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#define STAMP_CLK(slot) do { if (threadIdx.x == 0) a.stamps[((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define STAMP_SLOTS 16
+#define STAMP_AT(slot) a.stamps[((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * STAMP_SLOTS + (slot)]
+#define STAMP(slot) do { if (threadIdx.x == 0) STAMP_AT(slot) = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define STAMP_CLK(slot) do { if (threadIdx.x == 0) STAMP_AT(slot) = __builtin_amdgcn_s_memtime(); } while (0)
+// where the workgroup runs: HW_REG_HW_ID (id 4) and HW_REG_XCC_ID (id 20), whole 32-bit registers
+#define STAMP_PLACE() do { if (threadIdx.x == 0) { STAMP_AT(8) = __builtin_amdgcn_s_getreg((31 << 11) | 4); STAMP_AT(9) = __builtin_amdgcn_s_getreg((31 << 11) | 20); } } while (0)
 #else
 #define STAMP(slot) do {} while (0)
 #define STAMP_CLK(slot) do {} while (0)
+#define STAMP_PLACE() do {} while (0)
 #endif
 
 namespace {
@@ -55,12 +60,11 @@ template <bool W16> struct Geo {
   static constexpr int TH = W16 ? 16 : 8, TW = W16 ? 16 : 32;
   static constexpr int PH = TH + 2, PW = TW + 2, NPOS = PH * PW;     // 340 / 324
   static constexpr int XITEMS = 2 * NPOS;                            // (h, position) staging items
-  static constexpr int XI = (XITEMS + NT - 1) / NT;                  // 3 per thread
   static constexpr int XBUF_VEC = 2 * 2 * NPOS;                      // 16-byte vectors per X buffer
 };
 constexpr int XBUF_VEC = Geo<false>::XBUF_VEC;              // LDS is sized for the larger geometry: 1360
 constexpr int WSLAB_VEC = 2 * 3 * 2 * COT;                  // 16-byte vectors per (chunk, ky) slab: 768
-constexpr int WDMA = WSLAB_VEC / 64 / 4;                    // LDS-DMA wave-instructions per wave: 3
+constexpr int WPIECES = WSLAB_VEC / 64;                     // LDS-DMA wave-instructions per slab: 12
 constexpr int STAGE_BYTES = (2 * XBUF_VEC + 3 * WSLAB_VEC) * 16;   // 80,384
 constexpr int LDS_BYTES = STAGE_BYTES + 128 * 4;              // + bias / shift of the channel tile = 80,896
 
@@ -81,17 +85,27 @@ struct Conv3hArgs {
   int B, Cin, Cout, H, W, Hin, Win;
   int tiles_x, tiles_y, n_cot, n_chunks;
   unsigned tiles_x_magic;   // floor(2^32 / tiles_x) + 1
+  unsigned stagger_lo, stagger_hi, stagger_ticks;   // workgroups with dispatch index in [lo, hi) start `ticks` x 10 ns late (see launch)
 #ifdef DS_STAMP
   unsigned long long* stamps;   // diagnostic build only (tools/conv3h_stamp.hip)
 #endif
 };
 
-struct Frags { f16x8 a[2][2]; f16x8 b[2][2]; };   // [piece][m] weights, [piece][r] input
+template <int MT> struct Frags { f16x8 a[2][MT]; f16x8 b[2][2]; };   // [piece][m] weights, [piece][r] input
 
-template <int MODE, bool W16, bool PRE, bool CIRC>
-__global__ __launch_bounds__(NT, 2) void k_conv3h(const Conv3hArgs a) {
+// NW = 4: four waves, each owning the whole 64-channel tile for two of the eight pixel rows (2 x 2 accumulators),
+//         two workgroups per CU (2 waves per SIMD);
+// NW = 8: eight waves = the same four row pairs x two 32-channel halves (1 x 2 accumulators per wave, 6 MFMAs per
+//         operand block instead of 12), two workgroups per CU = 4 waves per SIMD.  A single wave per SIMD cannot keep
+//         the matrix pipe busy through its own loader / staging / barrier gaps (stamped: 43 % while its partner
+//         workgroup is in its prologue or epilogue, 91 % when both are in the main loop); with four waves per SIMD
+//         one of them almost always has MFMAs ready.  Costs: 1.5x the LDS operand reads per MFMA.
+template <int MODE, bool W16, bool PRE, bool CIRC, int NW>
+__global__ __launch_bounds__(64 * NW, NW / 2) void k_conv3h(const Conv3hArgs a) {
   constexpr int TH = Geo<W16>::TH, TW = Geo<W16>::TW, PW = Geo<W16>::PW, NPOS = Geo<W16>::NPOS;
-  constexpr int XI = Geo<W16>::XI;
+  constexpr int NTH = 64 * NW;                                       // threads
+  constexpr int MT = 8 / NW;                                         // 32-channel tiles per wave: 2 or 1
+  constexpr int XI = (Geo<W16>::XITEMS + NTH - 1) / NTH;             // staging items per thread: 3 or 2
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   u32x4* Xs = reinterpret_cast<u32x4*>(smem);                        // [buf][piece][h][pos]
   u32x4* Ws = Xs + 2 * XBUF_VEC;                                     // [slot][piece][kx][h][co]
@@ -99,10 +113,12 @@ __global__ __launch_bounds__(NT, 2) void k_conv3h(const Conv3hArgs a) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int rw = wv & 3;                               // row group of the wave
+  const int mh = NW == 8 ? (wv >> 2) : 0;              // its 32-channel half (NW = 8)
   const int li = lane & 31, lh = lane >> 5;
   // position of (wave, r, lane) inside the halo patch, before the (ky, kx) tap offset
   const int lane_pos = W16 ? (li >> 4) * PW + (li & 15) : li;
-  const int wave_row = W16 ? 4 * wv : 2 * wv;
+  const int wave_row = W16 ? 4 * rw : 2 * rw;
   constexpr int ROWS_PER_R = W16 ? 2 : 1;
 
   // grid = (channel tiles, pixel tiles, samples): no runtime integer division in the prologue except one
@@ -124,6 +140,15 @@ __global__ __launch_bounds__(NT, 2) void k_conv3h(const Conv3hArgs a) {
     tile_u = rest % ny;
     b_u = rest / ny;
   }
+  STAMP_PLACE();
+  if (a.stagger_ticks) {
+    // Phase offset between the two workgroups that share a CU (see launch_conv3h_c): speed only, never correctness.
+    const unsigned id = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    if (id >= a.stagger_lo && id < a.stagger_hi) {
+      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+      while (__builtin_amdgcn_s_memrealtime() - t0 < a.stagger_ticks) __builtin_amdgcn_s_sleep(8);
+    }
+  }
   const int cot = (int)cot_u;
   const int tile_id = (int)tile_u;
   const int b = (int)b_u;
@@ -137,14 +162,17 @@ __global__ __launch_bounds__(NT, 2) void k_conv3h(const Conv3hArgs a) {
   // ---- input staging plan: item i of a thread -> (h = channel half, position of the halo patch);
   //      items 0 / 1: position tid of h = 0 / 1; item 2: the patch's tail (positions 256..NPOS-1),
   //      h = wave / 2, so h is wave-uniform for every item.  Addresses are always in bounds. ----
-  static_assert(XI == 3 && NPOS > NT && NPOS - NT <= NT / 2, "staging plan assumes 256 < NPOS <= 384");
-  const int tail_h = wv >> 1;                          // wave-uniform
+  //      NW = 8 (512 threads): item i = position tid of h = i; threads past NPOS idle.
+  static_assert((NW == 4 && XI == 3 && NPOS > NT && NPOS - NT <= NT / 2) || (NW == 8 && XI == 2 && NPOS <= NTH),
+                "staging plan assumes 256 < NPOS <= 384");
+  const int tail_h = (wv >> 1) & 1;                    // wave-uniform
+  auto item_h = [&](int i) __attribute__((always_inline)) { return NW == 8 ? i : (i == 0 ? 0 : (i == 1 ? 1 : tail_h)); };
   int xoff[XI], xlds[XI];
   unsigned xvalid = 0, xlive = 0;
 #pragma unroll
   for (int i = 0; i < XI; ++i) {
-    const int h = i == 0 ? 0 : (i == 1 ? 1 : tail_h);
-    const int pos = i < 2 ? tid : NT + (tid & (NT / 2 - 1));
+    const int h = item_h(i);
+    const int pos = (NW == 8 || i < 2) ? tid : NT + (tid & (NT / 2 - 1));
     const bool live = pos < NPOS;                      // the item exists
     const int r = pos / PW;
     const int col = pos - r * PW;
@@ -181,7 +209,7 @@ __global__ __launch_bounds__(NT, 2) void k_conv3h(const Conv3hArgs a) {
     xnch = a.Cin - cbase < KC ? a.Cin - cbase : KC;   // uniform; < KC only for a ragged last chunk
 #pragma unroll
     for (int i = 0; i < XI; ++i) {
-      const int h = i == 0 ? 0 : (i == 1 ? 1 : tail_h);
+      const int h = item_h(i);
       const float* p0 = src + xoff[i];
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
@@ -207,7 +235,7 @@ __global__ __launch_bounds__(NT, 2) void k_conv3h(const Conv3hArgs a) {
     // is what lets the compiler use s_load (vector loads + vmcnt(0) per channel pair otherwise)
     typedef const __attribute__((address_space(4))) f32x4* cptr;
     cptr pp = (cptr)(reinterpret_cast<const f32x4*>(pre_b) + xchunk * KC);
-    const int h = i == 0 ? 0 : (i == 1 ? 1 : tail_h);
+    const int h = item_h(i);
     // the table is padded to whole 16-channel chunks (zeros), so the 8 rows of this item are one contiguous
     // 128-byte scalar load: one s_load + one wait per item instead of one dependent round trip per channel pair
     f32x4 p[8];
@@ -218,11 +246,14 @@ __global__ __launch_bounds__(NT, 2) void k_conv3h(const Conv3hArgs a) {
   };
   auto x_store = [&](int buf) __attribute__((always_inline)) {                       // [normalise + SiLU,] split to fp16 pieces, write the LDS image
     u32x4* xb = Xs + buf * XBUF_VEC;
-    if (PRE) { x_activate(0); x_activate(1); x_activate(2); }
+    if (PRE) {
+#pragma unroll
+      for (int i = 0; i < XI; ++i) x_activate(i);
+    }
 #pragma unroll
     for (int i = 0; i < XI; ++i) {
-      if (i < 2 || ((xlive >> i) & 1u)) {
-        const int h = i == 0 ? 0 : (i == 1 ? 1 : tail_h);
+      if ((NW == 4 && i < 2) || ((xlive >> i) & 1u)) {
+        const int h = item_h(i);
         const bool item_ok = (xvalid >> i) & 1u;
         u32x4 qh, ql;
 #pragma unroll
@@ -242,54 +273,58 @@ __global__ __launch_bounds__(NT, 2) void k_conv3h(const Conv3hArgs a) {
     const u32x4* src = wp + (size_t)step * WSLAB_VEC;
     u32x4* dst = Ws + slot * WSLAB_VEC;
 #pragma unroll
-    for (int i = 0; i < WDMA; ++i) {
-      const int k = wv + 4 * i;                       // wave-uniform
-      __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void*)(src + 64 * k + lane),
-          (__attribute__((address_space(3))) void*)(dst + 64 * k), 16, 0, 0);
+    for (int i = 0; i < (WPIECES + NW - 1) / NW; ++i) {
+      const int k = wv + NW * i;                      // wave-uniform
+      if (k < WPIECES)
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(src + 64 * k + lane),
+            (__attribute__((address_space(3))) void*)(dst + 64 * k), 16, 0, 0);
     }
   };
 
-  f32x16 acc[2][2];
+  f32x16 acc[MT][2];
 #pragma unroll
-  for (int m = 0; m < 2; ++m)
+  for (int m = 0; m < MT; ++m)
 #pragma unroll
     for (int r = 0; r < 2; ++r)
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[m][r][q] = 0.f;
 
+  using FragsT = Frags<MT>;
   // operand fetch for (weight slot, X buffer, ky, kx)
-  auto frag_load = [&](Frags& f, int slot, int xbuf, int ky, int kx) __attribute__((always_inline)) {
+  auto frag_load = [&](FragsT& f, int slot, int xbuf, int ky, int kx) __attribute__((always_inline)) {
     const u32x4* wb = Ws + slot * WSLAB_VEC;
     const u32x4* xb = Xs + xbuf * XBUF_VEC;
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
 #pragma unroll
-      for (int m = 0; m < 2; ++m)
-        f.a[p][m] = *reinterpret_cast<const f16x8*>(&wb[((p * 3 + kx) * 2 + lh) * COT + 32 * m + li]);
+      for (int m = 0; m < MT; ++m)
+        f.a[p][m] = *reinterpret_cast<const f16x8*>(&wb[((p * 3 + kx) * 2 + lh) * COT + 32 * (m + mh) + li]);
 #pragma unroll
       for (int r = 0; r < 2; ++r)
         f.b[p][r] = *reinterpret_cast<const f16x8*>(&xb[(p * 2 + lh) * NPOS + (wave_row + ROWS_PER_R * r + ky) * PW + lane_pos + kx]);
     }
   };
-  auto frag_mma = [&](const Frags& f) __attribute__((always_inline)) {               // lo*hi, hi*lo, hi*hi
+  auto frag_mma = [&](const FragsT& f) __attribute__((always_inline)) {              // lo*hi, hi*lo, hi*hi
     constexpr int PA[3] = {1, 0, 0};
     constexpr int PB[3] = {0, 1, 0};
 #pragma unroll
     for (int t = 0; t < 3; ++t)
 #pragma unroll
-      for (int m = 0; m < 2; ++m)
+      for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int r = 0; r < 2; ++r)
           acc[m][r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[PA[t]][m], f.b[PB[t]][r], acc[m][r], 0, 0, 0);
   };
-  auto reads_between_mfmas = [&]() __attribute__((always_inline)) {                  // 8 ds_read_b128 slotted behind the first 8 MFMAs
+  auto reads_between_mfmas = [&]() __attribute__((always_inline)) {                  // the block's ds_read_b128, one behind each of its first MFMAs
+    constexpr int NREADS = 2 * MT + 4, NMFMA = 6 * MT;
+    constexpr int PAIRS = NREADS < NMFMA ? NREADS : NMFMA;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < PAIRS; ++i) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
       __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
     }
-    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+    if (NMFMA > PAIRS) __builtin_amdgcn_sched_group_barrier(0x008, NMFMA - PAIRS, 0);
   };
 
   // ---- prologue: patch 0, weight slabs 0 and 1 ----
@@ -303,14 +338,14 @@ __global__ __launch_bounds__(NT, 2) void k_conv3h(const Conv3hArgs a) {
   STAMP(2);
   STAMP_CLK(6);
 
-  Frags fA, fB;
+  FragsT fA, fB;
   frag_load(fA, 0, 0, 0, 0);
 
   // One step = (chunk, ky).  `cur` holds the operands of kx = 0 on entry; on exit `oth` holds
   // the operands of the NEXT step's kx = 0 (three blocks per step flip the roles).
   // The ring slot of step g = 3*chunk + ky is g % 3 = ky and the X buffer is chunk & 1: both are
   // compile-time constants at every call site below, so all LDS addresses are base + immediate.
-  auto step = [&](Frags& cur, Frags& oth, int chunk, int ky, int xbuf) __attribute__((always_inline)) {
+  auto step = [&](FragsT& cur, FragsT& oth, int chunk, int ky, int xbuf) __attribute__((always_inline)) {
     const int g = chunk * 3 + ky;
     const int slot = ky;
     const bool more_chunks = chunk + 1 < a.n_chunks;
@@ -361,14 +396,16 @@ __global__ __launch_bounds__(NT, 2) void k_conv3h(const Conv3hArgs a) {
     ds_epi::Args e;
     e.out = a.out; e.bias = a.bias; e.shift = a.shift; e.res1 = a.res1; e.res2 = a.res2; e.res1_up = a.res1_up;
     e.unscale = a.unscale; e.shift_stride = a.shift_stride;
-    e.b = b; e.co_base = cot * COT; e.y0 = y0 + wave_row; e.x0 = x0;
+    e.b = b; e.co_base = cot * COT + 32 * mh; e.y0 = y0 + wave_row; e.x0 = x0;
     e.Cout = a.Cout; e.H = a.H; e.W = a.W;
     e.tile_stats = a.tile_stats; e.tile = ty * a.tiles_x + tx; e.ntiles = a.tiles_x * a.tiles_y;
-    float* tile = reinterpret_cast<float*>(smem) + wv * (64 * 2 * 32);
-    ds_epi::store_tile<W16>(acc, tile, BS, e);
+    constexpr int WTILE = 32 * MT * 2 * 32;                           // floats of the wave's private transpose region
+    float* tile = reinterpret_cast<float*>(smem) + wv * WTILE;
+    ds_epi::store_tile<W16, MT>(acc, tile, BS + 32 * mh, e);
     if (a.tile_stats) {
       __syncthreads();
-      ds_epi::store_tile_stats(reinterpret_cast<const float*>(smem), 64 * 2 * 32, e);
+      e.co_base = cot * COT;
+      ds_epi::store_tile_stats<MT>(reinterpret_cast<const float*>(smem), WTILE, e);
     }
   }
 #ifdef DS_STAMP
@@ -400,19 +437,32 @@ __global__ void k_pack3h(_Float16* packed, const float* __restrict__ w, int Cout
   packed[i] = piece == 0 ? hi : lo;
 }
 
-template <int MODE, bool W16, bool PRE, bool CIRC>
-int launch_conv3h_c(const Conv3hArgs& a, hipStream_t s) {
+template <int MODE, bool W16, bool PRE, bool CIRC, int NW>
+int launch_conv3h_w(const Conv3hArgs& a, hipStream_t s) {
   {
-    const int rc = ds::ensure_dynamic_lds<&k_conv3h<MODE, W16, PRE, CIRC>>((int)(LDS_BYTES), "hipFuncSetAttribute(conv3h)");
+    const int rc = ds::ensure_dynamic_lds<&k_conv3h<MODE, W16, PRE, CIRC, NW>>((int)(LDS_BYTES), "hipFuncSetAttribute(conv3h)");
     if (rc != DS_OK) return rc;
   }
   const long long tiles = (long long)a.tiles_y * a.tiles_x;
   DS_REQUIRE(tiles > 0 && tiles < 65536 && a.B < 65536, DS_ERR_SHAPE,
              "ds_conv2d_h3: %lld pixel tiles x %d samples exceed the grid limits (65535 each)", tiles, a.B);
-  hipLaunchKernelGGL((k_conv3h<MODE, W16, PRE, CIRC>), dim3((unsigned)a.n_cot, (unsigned)tiles, (unsigned)a.B), dim3(NT),
+  hipLaunchKernelGGL((k_conv3h<MODE, W16, PRE, CIRC, NW>), dim3((unsigned)a.n_cot, (unsigned)tiles, (unsigned)a.B), dim3(64 * NW),
                      LDS_BYTES, s, a);
   DS_CHECK_LAUNCH("ds_conv2d_h3");
   return DS_OK;
+}
+
+// Waves per workgroup.  Default: eight for the fused norm+SiLU loader (its staging VALU work spreads over twice the
+// waves: 3-5 % faster at 64 and 128 channels), four otherwise (at 256 channels the extra LDS operand reads of the
+// eight-wave tiling cost 2-3 %: the kernel is power-limited).  DS_CONV_WAVES=4|8 forces one (A/B runs).
+inline int conv3h_waves(bool pre) {
+  static const int forced = [] { const char* e = getenv("DS_CONV_WAVES"); const int v = e ? atoi(e) : 0; return (v == 4 || v == 8) ? v : 0; }();
+  return forced ? forced : (pre ? 8 : 4);
+}
+
+template <int MODE, bool W16, bool PRE, bool CIRC>
+int launch_conv3h_c(const Conv3hArgs& a, hipStream_t s) {
+  return conv3h_waves(PRE) == 8 ? launch_conv3h_w<MODE, W16, PRE, CIRC, 8>(a, s) : launch_conv3h_w<MODE, W16, PRE, CIRC, 4>(a, s);
 }
 
 template <int MODE, bool W16, bool PRE>
@@ -483,6 +533,12 @@ int ds_conv2d_h3(float* out, const float* in, const void* w_packed, int wshift, 
   a.n_cot = (Cout + COT - 1) / COT;
   a.n_chunks = (Cin + KC - 1) / KC;
   a.tiles_x_magic = a.tiles_x == 1 ? 0u : (unsigned)((1ull << 32) / (unsigned)a.tiles_x) + 1u;   // tiles_x = 1 is special-cased in the kernel
+  {
+    // experiment knob: DS_CONV_STAGGER="ticks[,lo,hi]" (10 ns ticks; default range = the second resident workgroup of
+    // every CU under breadth-first dispatch: indices [256, 512))
+    static const struct Stg { unsigned ticks = 0, lo = 256, hi = 512; Stg() { const char* e = getenv("DS_CONV_STAGGER"); if (e) sscanf(e, "%u,%u,%u", &ticks, &lo, &hi); } } stg;
+    a.stagger_ticks = stg.ticks; a.stagger_lo = stg.lo; a.stagger_hi = stg.hi;
+  }
 #ifdef DS_STAMP
   a.stamps = g_stamps;
 #endif

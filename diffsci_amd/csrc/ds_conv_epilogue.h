@@ -49,16 +49,18 @@ __device__ __forceinline__ float row16_first(float v) {
 
 // W16 = false: the wave's 2 x 32 positions are 2 rows x 32 columns (row = y0 + r, column = x0 + x);
 // W16 = true (narrow feature maps): they are 4 rows x 16 columns (row = y0 + 2r + x/16, column = x0 + x%16).
-// tile:  wave-private LDS scratch of 64*2*32 floats (16 KiB), 16-byte aligned.
+// MT:    32-channel tiles the wave owns (2: the whole 64-channel tile; 1: half of it -- the 8-wave kernels; then
+//        e.co_base and bs point at the wave's own 32 channels).
+// tile:  wave-private LDS scratch of 32*MT*2*32 floats (16 KiB for MT = 2), 16-byte aligned.
 // bs:    LDS array [2][64]: bias and shift of the workgroup's 64 channels (zeros where absent),
 //        written by the caller before the last barrier of the main loop.
-template <bool W16 = false>
-__device__ __forceinline__ void store_tile(const f32x16 (&acc)[2][2], float* tile, const float* bs, const Args& e) {
+template <bool W16 = false, int MT = 2>
+__device__ __forceinline__ void store_tile(const f32x16 (&acc)[MT][2], float* tile, const float* bs, const Args& e) {
   const int lane = threadIdx.x & 63;
   const int li = lane & 31, lh = lane >> 5;
   // phase 1: accumulator layout -> [co][row][x]
 #pragma unroll
-  for (int m = 0; m < 2; ++m)
+  for (int m = 0; m < MT; ++m)
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
       const int co = 32 * m + (q & 3) + 8 * (q >> 2) + 4 * lh;
@@ -78,9 +80,9 @@ __device__ __forceinline__ void store_tile(const f32x16 (&acc)[2][2], float* til
   const size_t plane = (size_t)e.H * e.W;
   const bool stats = e.tile_stats != nullptr;
   if ((e.W & 3) == 0) {
-    float sK[16], ssum[16], ssq[16], scnt[16];        // per (half, k): channel 4*(4*half+k) + lane/16, valid in every lane of the row
+    float sK[8 * MT], ssum[8 * MT], ssq[8 * MT], scnt[8 * MT];   // per (half, k): channel 4*(4*half+k) + lane/16, valid in every lane of the row
 #pragma unroll
-    for (int half = 0; half < 4; ++half) {            // 4 batches of 4 wave-instructions
+    for (int half = 0; half < 2 * MT; ++half) {       // batches of 4 wave-instructions
       f32x4 v[4], r1[4], r2[4];
       size_t idx[4];
       bool ok[4];
@@ -141,10 +143,10 @@ __device__ __forceinline__ void store_tile(const f32x16 (&acc)[2][2], float* til
         }
       }
     }
-    if (stats) {                                      // all reads of the wave's tile are done: reuse its head as [64 co][4]
+    if (stats) {                                      // all reads of the wave's tile are done: reuse its head as [32*MT co][4]
       if ((lane & 15) == 0) {
 #pragma unroll
-        for (int it = 0; it < 16; ++it) {
+        for (int it = 0; it < 8 * MT; ++it) {
           f32x4 o = {sK[it], ssum[it], ssq[it], scnt[it]};
           *reinterpret_cast<f32x4*>(&tile[4 * (4 * it + (lane >> 4))]) = o;
         }
@@ -152,7 +154,7 @@ __device__ __forceinline__ void store_tile(const f32x16 (&acc)[2][2], float* til
     }
   } else {
     // ragged width: element-wise, compact loop (correctness path for odd shapes); one channel per iteration
-    for (int i = lane; i < 64 * 2 * 32; i += 64) {
+    for (int i = lane; i < 32 * MT * 2 * 32; i += 64) {
       const int co = i >> 6, r = (i >> 5) & 1, x = i & 31;
       const int gy = e.y0 + (W16 ? 2 * r + (x >> 4) : r), gxx = e.x0 + (W16 ? (x & 15) : x);
       float v = 0.f;
@@ -179,15 +181,18 @@ __device__ __forceinline__ void store_tile(const f32x16 (&acc)[2][2], float* til
   }
 }
 
-// Second half of the statistics: combine the four waves' [64][4] partials (at the head of each
+// Second half of the statistics: combine the four row-waves' partials of every channel (at the head of each
 // wave's tile region, `wave_stride` floats apart) about one shift and store them.  Call after a
-// __syncthreads().
+// __syncthreads().  MT = 2: four waves, each with [64][4]; MT = 1: eight waves, waves 4..7 hold channels 32..63
+// ([32][4] each).  e.co_base: first channel of the WORKGROUP's 64-channel tile.
+template <int MT = 2>
 __device__ __forceinline__ void store_tile_stats(const float* tiles, int wave_stride, const Args& e) {
   const int t = threadIdx.x;
   if (t < 64 && e.co_base + t < e.Cout) {
     f32x4 p[4];
+    const int w0 = MT == 1 ? 4 * (t >> 5) : 0, tl = MT == 1 ? (t & 31) : t;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) p[w] = *reinterpret_cast<const f32x4*>(&tiles[w * wave_stride + 4 * t]);
+    for (int w = 0; w < 4; ++w) p[w] = *reinterpret_cast<const f32x4*>(&tiles[(w0 + w) * wave_stride + 4 * tl]);
     const float K = p[0][0];                              // wave 0 owns the tile's first rows: valid if the tile is
     float S = 0.f, Q = 0.f, n = 0.f;
 #pragma unroll

@@ -224,7 +224,8 @@ class _Workspace:
             return lst.pop()
         if self.frozen:
             raise RuntimeError(f"workspace is frozen (graph captured) but a new buffer {shape} was requested")
-        t = torch.empty(shape, dtype=torch.float32, device=device)
+        with torch.inference_mode(False):    # a normal tensor even when the sampler runs under inference_mode: the pool
+            t = torch.empty(shape, dtype=torch.float32, device=device)   # outlives the call and serves eager forwards too
         self.bytes += t.numel() * 4
         return t
 
@@ -868,15 +869,15 @@ class PUNetGCond(PUNetG):
         # (shape, device); every call -- eager or as the refresh before a replay -- rewrites it.
         shape = (fields[0].shape[0], sum(f.shape[1] for f in fields)) + tuple(fields[0].shape[2:])
         key = (shape, str(fields[0].device))
-        with torch.inference_mode():     # the sampler runs under inference_mode; an eager forward() may not: one mode for the buffer
-            buf = self._ycat_static.get(key)
-            if buf is None:              # never evicted: captured plans keep reading the buffer of their shape
+        buf = self._ycat_static.get(key)
+        if buf is None:                  # never evicted: captured plans keep reading the buffer of their shape
+            with torch.inference_mode(False):          # a normal tensor: written under inference_mode and outside it
                 buf = torch.empty(shape, dtype=torch.float32, device=fields[0].device)
-                self._ycat_static[key] = buf
-            c0 = 0
-            for f in fields:
-                buf[:, c0:c0 + f.shape[1]].copy_(f)
-                c0 += f.shape[1]
+            self._ycat_static[key] = buf
+        c0 = 0
+        for f in fields:
+            buf[:, c0:c0 + f.shape[1]].copy_(f)
+            c0 += f.shape[1]
         return (rest if len(rest) else None), buf
 
     def _with_condition(self, x, ycat, ws):
