@@ -238,7 +238,69 @@ __global__ __launch_bounds__(256) void k_from_slices(float* y, const float* __re
   }
 }
 
+// AvgPool3d(2) / nearest x2 upsampling of volumes, the resampling of ADM blocks on volumes (adm.py:352-384: AvgPool3d,
+// Upsample(mode='nearest')).  One thread per output voxel; the pooling adds its 8 inputs in (z, y, x) order and divides
+// by 8, as torch's CPU kernel does.
+__global__ __launch_bounds__(256) void k_avgpool3d(float* __restrict__ out, const float* __restrict__ x, int Do, int Ho, int Wo,
+                                                  size_t total) {
+  const int Di = 2 * Do, Hi = 2 * Ho, Wi = 2 * Wo;
+  (void)Di;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int xo = (int)(i % Wo);
+    size_t t = i / Wo;
+    const int yo = (int)(t % Ho); t /= Ho;
+    const int zo = (int)(t % Do);
+    const size_t plane = t / Do;
+    const float* p = x + ((plane * (2 * Do) + 2 * zo) * (size_t)Hi + 2 * yo) * Wi + 2 * xo;
+    float s = 0.f;
+#pragma unroll
+    for (int dz = 0; dz < 2; ++dz)
+#pragma unroll
+      for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) s = s + p[((size_t)dz * Hi + dy) * Wi + dx];
+    out[i] = s / 8.0f;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_upsample3d(float* __restrict__ out, const float* __restrict__ x, int Di, int Hi, int Wi,
+                                                   size_t total) {
+  const int Ho = 2 * Hi, Wo = 2 * Wi, Do = 2 * Di;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int xo = (int)(i % Wo);
+    size_t t = i / Wo;
+    const int yo = (int)(t % Ho); t /= Ho;
+    const int zo = (int)(t % Do);
+    const size_t plane = t / Do;
+    out[i] = x[((plane * Di + (zo >> 1)) * (size_t)Hi + (yo >> 1)) * Wi + (xo >> 1)];
+  }
+}
+
 }  // namespace
+
+extern "C" int ds_avgpool3d(float* out, const float* x, int planes, int Do, int Ho, int Wo, void* stream) {
+  DS_REQUIRE(out && x, DS_ERR_NULL, "ds_avgpool3d: NULL pointer");
+  DS_REQUIRE(planes >= 0 && Do > 0 && Ho > 0 && Wo > 0, DS_ERR_SHAPE, "ds_avgpool3d: bad shape");
+  const size_t total = (size_t)planes * Do * Ho * Wo;
+  if (total == 0) return DS_OK;
+  size_t g = (total + 255) / 256;
+  if (g > 8192) g = 8192;
+  hipLaunchKernelGGL(k_avgpool3d, dim3((unsigned)g), dim3(256), 0, ds::as_stream(stream), out, x, Do, Ho, Wo, total);
+  DS_CHECK_LAUNCH("ds_avgpool3d");
+  return DS_OK;
+}
+
+extern "C" int ds_upsample3d(float* out, const float* x, int planes, int Di, int Hi, int Wi, void* stream) {
+  DS_REQUIRE(out && x, DS_ERR_NULL, "ds_upsample3d: NULL pointer");
+  DS_REQUIRE(planes >= 0 && Di > 0 && Hi > 0 && Wi > 0, DS_ERR_SHAPE, "ds_upsample3d: bad shape");
+  const size_t total = (size_t)planes * Di * Hi * Wi * 8;
+  if (total == 0) return DS_OK;
+  size_t g = (total + 255) / 256;
+  if (g > 8192) g = 8192;
+  hipLaunchKernelGGL(k_upsample3d, dim3((unsigned)g), dim3(256), 0, ds::as_stream(stream), out, x, Di, Hi, Wi, total);
+  DS_CHECK_LAUNCH("ds_upsample3d");
+  return DS_OK;
+}
 
 extern "C" int ds_volume_to_slices(float* slices, const float* x, int B, int C, int D, size_t HW, int depth_mode,
                                    int circular, void* stream) {

@@ -82,7 +82,9 @@ class ADMConfig(object):
 
     def unsupported_reason(self):
         checks = [
-            (self.dimension == 2, "only 2-D fields (dimension=2)"),
+            (self.dimension == 2, "only 2-D fields (dimension=2): the reference's own ADM cannot run on volumes (its stem and "
+                                  "output layers are Conv2d, adm.py:186-195); its 3-D capable part, the residual blocks, "
+                                  "is ADMEncoderBlock / ADMDecoderBlock(dimension=3)"),
             (self.convolution_type in ("default", "circular"), "convolution_type 'default' or 'circular'"),
             (self.first_resblock_norm in ("GroupLN", "GroupRMS") and self.second_resblock_norm in ("GroupLN", "GroupRMS"),
              "first/second_resblock_norm 'GroupLN' or 'GroupRMS' (the reference raises on anything else, adm.py:395,406)"),
@@ -115,6 +117,198 @@ class _Block(torch.nn.Module):
         self.convresidual = make_conv(cin, cout, 1, circular)
         if has_attn:
             self.attn = _Attn(cout)
+
+
+class ADMBaseBlock(torch.nn.Module):
+    """One ADM residual block as a module of its own -- the reference's ADMBaseBlock / ADMEncoderBlock / ADMDecoderBlock
+    (adm.py:218-540), which its tests drive directly, on 2-D fields AND 3-D volumes (tests/test_adm.py:7-70):
+
+        y = norm1(x) -> SiLU -> [AvgPool(2) | nearest x2] -> conv1 -> norm2 -> * te1 + te2 -> SiLU -> conv2
+            [+ convresidual(resample(x))] [-> attention]              with (te1, te2) = chunk(embed_linear(te), 2)
+
+    Same constructor arguments, defaults and state_dict keys.  Every tensor operation is a HIP launch (eager, standalone
+    norm kernels); the whole-network class ``ADM`` folds the norms into the convolutions and is captured as a graph.
+    Volumes: 3x3x3 convolutions as three 2-D matrix-core launches per convolution (ops.conv3d_mfma) or the direct
+    kernel for thin layers, the group-1 statistics over (C, D, H, W), AvgPool3d / nearest resampling by ds_avgpool3d /
+    the convolution loader / ds_upsample3d, attention over the flattened voxels.  (The reference's full ``ADM`` cannot
+    run with dimension=3 -- its stem is a Conv2d, adm.py:190 -- so only the blocks exist in 3-D there too.)"""
+
+    def __init__(self, channels_in: int, channels_out: int, channels_embed: int, channels_skip: int | None = None,
+                 conv_type: str = 'default', image_sample: str | None = None, has_residual: bool = False,
+                 has_attn: bool = False, first_norm: str = 'GroupLN', second_norm: str = 'GroupRMS',
+                 affine_norm: bool = True, dimension: int = 2, num_groups: int = 1, pdrop: float = 0.0,
+                 image_sample_type: str | None = None, image_sample_factor: int = 2, attn_type: str = 'default',
+                 attn_heads: int = 1, attn_residual: bool = True, skip_integration_type: str = 'concat'):
+        super().__init__()
+        bad = []
+        if dimension not in (2, 3):
+            bad.append("dimension 2 or 3")
+        if conv_type not in ("default", "circular"):
+            bad.append("conv_type 'default' or 'circular'")
+        if first_norm not in ("GroupLN", "GroupRMS") or second_norm not in ("GroupLN", "GroupRMS"):
+            bad.append("norms 'GroupLN' or 'GroupRMS'")
+        if num_groups != 1 or image_sample_factor != 2 or attn_heads != 1 or attn_type != "default":
+            bad.append("num_groups=1, image_sample_factor=2, one default attention head")
+        if image_sample not in (None, "downsample", "upsample"):
+            bad.append("image_sample None, 'downsample' or 'upsample'")
+        if image_sample == "downsample" and image_sample_type not in (None, "avg"):
+            bad.append("average pooling")
+        if image_sample == "upsample" and image_sample_type not in (None, "nearest"):
+            bad.append("nearest upsampling")
+        if skip_integration_type not in ("concat", "add"):
+            bad.append("skip_integration_type 'concat' or 'add'")
+        if bad:
+            raise NotImplementedError("diffsci_amd ADM blocks support: " + "; ".join(bad))
+        self.channels_in, self.channels_out, self.channels_embed = channels_in, channels_out, channels_embed
+        self.channels_skip, self.dimension, self.image_sample = channels_skip, dimension, image_sample
+        self.has_residual, self.has_attn, self.attn_residual = has_residual, has_attn, attn_residual
+        self.skip_integration_type, self.pdrop = skip_integration_type, pdrop
+        cin = channels_in + channels_skip if (channels_skip and skip_integration_type == "concat") else channels_in
+        self.channels_in_modified = cin
+        circ = conv_type == "circular"
+        self.circular = circ
+        self.norm1 = torch.nn.GroupNorm(1, cin, affine=affine_norm) if first_norm == "GroupLN" else _AffineHolder(cin, affine_norm)
+        self.norm2 = (torch.nn.GroupNorm(1, channels_out, affine=affine_norm) if second_norm == "GroupLN"
+                      else _AffineHolder(channels_out, affine_norm))
+        self.kinds = (0 if first_norm == "GroupLN" else 1, 0 if second_norm == "GroupLN" else 1)
+        self.conv1 = make_conv(cin, channels_out, 3, circ, True, dimension)
+        self.conv2 = make_conv(channels_out, channels_out, 3, circ, True, dimension)
+        self.embed_linear = torch.nn.Linear(channels_embed, 2 * channels_out)
+        if has_residual:
+            self.convresidual = make_conv(cin, channels_out, 1, circ, True, dimension)
+        if has_attn:
+            self.attn = _Attn(channels_out)
+        self.conv_precision = "fp16x3"
+        self._packed, self._packed_sig = None, None
+
+    def _packs(self):
+        convs = [self.conv1, self.conv2] + ([self.convresidual] if self.has_residual else [])
+        tracked = [m.weight for m in convs] + ([self.attn.mhattn.in_proj_weight, self.attn.mhattn.out_proj.weight] if self.has_attn else [])
+        sig = (self.conv_precision,) + tuple((t.data_ptr(), t._version) for t in tracked)
+        if self._packed is not None and sig == self._packed_sig:
+            return self._packed
+        pk = {}
+        with torch.no_grad():
+            for m in (self.conv1, self.conv2):
+                w = m.weight.detach()
+                if self.dimension == 2:
+                    pk[id(m)] = ops.pack_conv(w, self.conv_precision, upsampled=False)
+                elif self.conv_precision == "fp16x3" and min(w.shape[0], w.shape[1]) > 4:
+                    pk[id(m)] = ops.pack_conv3d(w)
+            prec = "fp16x3" if self.conv_precision == "fp16x3" else "fp32"
+            if self.has_residual:
+                w = self.convresidual.weight.detach()
+                pk[id(self.convresidual)] = ops.pack_conv(w.reshape(w.shape[0], w.shape[1], 1, 1).contiguous(), prec)
+            if self.has_attn:
+                m, E = self.attn.mhattn, self.attn.mhattn.embed_dim
+                pk["in"] = ops.pack_conv(m.in_proj_weight.detach().reshape(3 * E, E, 1, 1), prec)
+                pk["out"] = ops.pack_conv(m.out_proj.weight.detach().reshape(E, E, 1, 1), prec)
+        self._packed, self._packed_sig = pk, sig
+        return pk
+
+    def _conv3(self, m, x, pk, up=False, res1=None):
+        """3x3(x3) 'same' convolution of the block (with the nearest x2 upsampling in its loader when up)."""
+        mode = DS_LOAD_UPSAMPLE2 if up else DS_LOAD_PLAIN
+        if self.dimension == 2:
+            return ops.conv(x, pk[id(m)], bias=m.bias, circular=self.circular, load_mode=mode, res1=res1)
+        if id(m) in pk:
+            return ops.conv3d_mfma(x, pk[id(m)], bias=m.bias, circular=self.circular, load_mode=mode, res1=res1)
+        return ops.conv3d(x, m.weight, bias=m.bias, circular=self.circular, load_mode=mode, res1=res1)
+
+    @ops.device_guard
+    def forward(self, x, te, skip=None):
+        """adm.py:292-313.  x [B, Cin, (D,) H, W]; te [B or 1, Cembed]; skip [B, Cskip, ...] when the block has one."""
+        if self.training and self.pdrop:
+            raise NotImplementedError("dropout in training mode is outside the HIP sampling path: call .eval()")
+        ops.require_device(x, "x")
+        if x.dim() != 2 + self.dimension:
+            raise ValueError(f"a dimension={self.dimension} block takes {2 + self.dimension}-D tensors")
+        x = x.contiguous()
+        if self.channels_skip:
+            if skip is None:
+                raise ValueError("this block integrates a skip tensor")
+            x = ops.concat2(x, skip.contiguous()) if self.skip_integration_type == "concat" else ops.add(x, skip.contiguous())
+        B, Ci = x.shape[0], x.shape[1]
+        if Ci != self.channels_in_modified:
+            raise ValueError(f"expected {self.channels_in_modified} input channels, got {Ci}")
+        down, up = self.image_sample == "downsample", self.image_sample == "upsample"
+        pk = self._packs()
+        k1, k2 = self.kinds
+        Co = self.channels_out
+
+        def v4(t):                                   # the (C, spatial...) kernels see volumes as [B, C, D*H, W]
+            return t if t.dim() == 4 else t.view(t.shape[0], t.shape[1], -1, t.shape[-1])
+
+        def pool(t):                                 # AvgPool(2) of a field or a volume
+            if t.dim() == 4:
+                return ops.gnorm1_apply(t, None, None, None, 2, pool=True)
+            return ops.avgpool3d(t)
+
+        film = ops.linear(te.to(x).contiguous(), self.embed_linear.weight, self.embed_linear.bias)      # [B or 1, 2*Cout]
+        # first_block (adm.py:315-322): norm1 -> act -> resample -> conv1
+        st = ops.gnorm1_stats(x, k1, eps=1e-5)
+        fuse_pool = down and self.dimension == 2
+        a = ops.gnorm1_apply(v4(x), st, self.norm1.weight, self.norm1.bias, k1, pool=fuse_pool)
+        if down and self.dimension == 3:
+            a = ops.avgpool3d(a.view(x.shape))
+        elif self.dimension == 3:
+            a = a.view(x.shape)
+        y = self._conv3(self.conv1, a, pk, up=up)
+        # norm2 -> FiLM -> act -> conv2 (adm.py:306-308,324-329)
+        st2 = ops.gnorm1_stats(y, k2, eps=1e-5)
+        a2 = ops.gnorm1_apply(v4(y), st2, self.norm2.weight, self.norm2.bias, k2, film=film).view(y.shape)
+        r = None
+        if self.has_residual:                        # convresidual(resample(x)), adm.py:345-349
+            xr = pool(x) if down else x
+            m = self.convresidual
+            if up and self.dimension == 2:           # nearest x2 in the 1x1 convolution's loader
+                r = ops.conv(xr, pk[id(m)], bias=m.bias, load_mode=DS_LOAD_UPSAMPLE2)
+            else:
+                r = ops.conv(v4(xr), pk[id(m)], bias=m.bias).view((B, Co) + tuple(xr.shape[2:]))
+                if up:                               # a 1x1x1 convolution commutes with nearest upsampling: project at low resolution
+                    r = ops.upsample3d(r)
+        out = self._conv3(self.conv2, a2, pk, res1=r)
+        if self.has_attn:                            # N-dimensional attention over the flattened positions, attention.py:67-102
+            E, L = Co, out.numel() // (B * Co)
+            mh = self.attn.mhattn
+            qkv = ops.conv(v4(out), pk["in"], bias=mh.in_proj_bias)
+            o = ops.attention(qkv.view(B, 3 * E, L), E, precision=self.conv_precision)
+            out = ops.conv(o.view(v4(out).shape), pk["out"], bias=mh.out_proj.bias,
+                           res1=v4(out) if self.attn_residual else None).view(out.shape)
+        return out
+
+
+class ADMEncoderBlock(ADMBaseBlock):
+    """adm.py:455-498."""
+
+    def __init__(self, channels_in: int, channels_out: int, channels_embed: int, conv_type: str = 'default',
+                 has_downsample: bool = False, has_residual: bool = False, has_attn: bool = False,
+                 first_norm: str = 'GroupLN', second_norm: str = 'GroupRMS', dimension: int = 2, num_groups: int = 1,
+                 pdrop: float = 0.0, downsample_type: str = 'avg', downsample_factor: int = 2, attn_type: str = 'default',
+                 attn_heads: int = 1, attn_residual: bool = True):
+        super().__init__(channels_in, channels_out, channels_embed, channels_skip=None, conv_type=conv_type,
+                         image_sample='downsample' if has_downsample else None, has_residual=has_residual,
+                         has_attn=has_attn, first_norm=first_norm, second_norm=second_norm, dimension=dimension,
+                         num_groups=num_groups, pdrop=pdrop, image_sample_type=downsample_type,
+                         image_sample_factor=downsample_factor, attn_type=attn_type, attn_heads=attn_heads,
+                         attn_residual=attn_residual, skip_integration_type='concat')
+
+
+class ADMDecoderBlock(ADMBaseBlock):
+    """adm.py:498-540."""
+
+    def __init__(self, channels_in: int, channels_out: int, channels_embed: int, channels_skip: int | None = None,
+                 conv_type: str = 'default', has_upsample: bool = False, has_residual: bool = False,
+                 has_attn: bool = False, first_norm: str = 'GroupLN', second_norm: str = 'GroupRMS', dimension: int = 2,
+                 num_groups: int = 1, pdrop: float = 0.0, upsample_type: str = 'nearest', upsample_factor: int = 2,
+                 attn_type: str = 'default', attn_heads: int = 1, attn_residual: bool = True,
+                 skip_integration_type: str = 'concat'):
+        super().__init__(channels_in, channels_out, channels_embed, channels_skip=channels_skip, conv_type=conv_type,
+                         image_sample='upsample' if has_upsample else None, has_residual=has_residual, has_attn=has_attn,
+                         first_norm=first_norm, second_norm=second_norm, dimension=dimension, num_groups=num_groups,
+                         pdrop=pdrop, image_sample_type=upsample_type, image_sample_factor=upsample_factor,
+                         attn_type=attn_type, attn_heads=attn_heads, attn_residual=attn_residual,
+                         skip_integration_type=skip_integration_type)
 
 
 class _Layer(torch.nn.Module):

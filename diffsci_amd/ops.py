@@ -324,6 +324,28 @@ def conv3d_mfma(x, packs, bias=None, shift=None, res1=None, res2=None, load_mode
     return out
 
 
+def avgpool3d(x, out=None):
+    """AvgPool3d(2) of a volume [B, C, 2D, 2H, 2W]."""
+    require_device(x, "x")
+    B, C, Di, Hi, Wi = x.shape
+    if Di % 2 or Hi % 2 or Wi % 2:
+        raise ValueError("avgpool3d needs even D, H, W")
+    if out is None:
+        out = torch.empty((B, C, Di // 2, Hi // 2, Wi // 2), dtype=torch.float32, device=x.device)
+    N.check(N.lib().ds_avgpool3d(_p(out, "out"), _p(x, "x"), B * C, Di // 2, Hi // 2, Wi // 2, _stream()), "ds_avgpool3d")
+    return out
+
+
+def upsample3d(x, out=None):
+    """Nearest x2 upsampling of a volume [B, C, D, H, W]."""
+    require_device(x, "x")
+    B, C, Di, Hi, Wi = x.shape
+    if out is None:
+        out = torch.empty((B, C, 2 * Di, 2 * Hi, 2 * Wi), dtype=torch.float32, device=x.device)
+    N.check(N.lib().ds_upsample3d(_p(out, "out"), _p(x, "x"), B * C, Di, Hi, Wi, _stream()), "ds_upsample3d")
+    return out
+
+
 def gnorm1_stats(x, kind, eps=1e-5, stats=None, workspace=None):
     """Per-sample (mean, rstd) [kind 0] or (0, rms denominator) [kind 1] over (C, H, W)."""
     B, C = x.shape[0], x.shape[1]

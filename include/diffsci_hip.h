@@ -265,6 +265,13 @@ int ds_volume_to_slices(float* slices, const float* x, int B, int C, int D, size
 int ds_slices_to_volume(float* y, const float* slices, const float* res1, const float* res2, int B, int C, int D,
                         size_t HW, void* stream);
 
+/* Resampling of volumes in ADM blocks with dimension = 3 (make_downsample / make_upsample, adm.py:352-384):
+ *   ds_avgpool3d:  AvgPool3d(2): x [planes, 2Do, 2Ho, 2Wo] -> out [planes, Do, Ho, Wo] (sum of the 8 voxels in (z, y, x) order, / 8);
+ *   ds_upsample3d: Upsample(scale_factor=2, mode='nearest'): x [planes, Di, Hi, Wi] -> out [planes, 2Di, 2Hi, 2Wi].
+ * planes = B*C. */
+int ds_avgpool3d(float* out, const float* x, int planes, int Do, int Ho, int Wo, void* stream);
+int ds_upsample3d(float* out, const float* x, int planes, int Di, int Hi, int Wi, void* stream);
+
 /* 1x1 convolution in the fp16x3 scheme of ds_conv2d_h3 (same epilogue terms, same domain
  * |in| < 65504).  ADM's residual projection convresidual(resample(x)) (adm.py:345-349) with the
  * resampling folded into the load: load_mode PLAIN, UPSAMPLE2 (nearest x2, in is [B,Cin,H/2,W/2])

@@ -33,7 +33,8 @@ def group1_rms_norm(x, weight, bias, eps=1e-5):
     xg = x.view(B, 1, C, *x.shape[2:])
     xg = xg / torch.sqrt(xg.pow(2).mean(dim=tuple(range(2, xg.dim())), keepdim=True) + eps)
     x = xg.view(B, C, *xg.shape[3:])
-    return x * weight.view(1, C, 1, 1) + bias.view(1, C, 1, 1)
+    shape = (1, C) + (1,) * (x.dim() - 2)
+    return x * weight.view(shape) + bias.view(shape)
 
 
 def time_embedding(sd, t, ye=None):
@@ -57,24 +58,32 @@ def block_norm(kind, sd, p, x):
     return group1_rms_norm(x, w, b)
 
 
-def block(sd, p, x, te, sample=None, has_attn=False, attn_residual=True, circular=False, norms=("GroupLN", "GroupRMS")):
-    """ADMBaseBlock.forward for a block without its own skip input (adm.py:292-349).  circular: the block's
-    convolutions are CircularConv2d (conv_fn, adm.py:427-443; parameters under `.conv`)."""
+def block(sd, p, x, te, sample=None, has_attn=False, attn_residual=True, circular=False, norms=("GroupLN", "GroupRMS"),
+          skip=None, skip_integration_type="concat", has_residual=True):
+    """ADMBaseBlock.forward (adm.py:292-349) on fields [B, C, H, W] or volumes [B, C, D, H, W] (AvgPool3d / Conv3d /
+    attention over the flattened voxels).  circular: the block's convolutions are CircularConv2d / 3d (conv_fn,
+    adm.py:427-443; parameters under `.conv`).  skip: the block's own skip input (decoder blocks), joined first."""
+    if skip is not None:                                             # adm.py:297-304
+        x = torch.cat([x, skip], dim=1) if skip_integration_type == "concat" else x + skip
+    vol = x.dim() == 5
+
     def resample(v):
         if sample == "down":
-            return F.avg_pool2d(v, 2)
+            return (F.avg_pool3d if vol else F.avg_pool2d)(v, 2)
         if sample == "up":
             return F.interpolate(v, scale_factor=2.0, mode="nearest")
         return v
+    one = (1,) * (x.dim() - 2)
     y = F.silu(block_norm(norms[0], sd, p + "norm1.", x))
     y = conv3x3(sd, p + "conv1", resample(y), circular)
     y = block_norm(norms[1], sd, p + "norm2.", y)
     e = F.linear(te, sd[p + "embed_linear.weight"], sd[p + "embed_linear.bias"])
     te1, te2 = torch.chunk(e, 2, dim=-1)
-    y = y * te1[:, :, None, None] + te2[:, :, None, None]
+    y = y * te1.view(*te1.shape, *one) + te2.view(*te2.shape, *one)
     y = conv3x3(sd, p + "conv2", F.silu(y), circular)
-    rk = p + ("convresidual.conv." if circular else "convresidual.")
-    y = y + F.conv2d(resample(x), sd[rk + "weight"], sd[rk + "bias"])
+    if has_residual:
+        rk = p + ("convresidual.conv." if circular else "convresidual.")
+        y = y + (F.conv3d if vol else F.conv2d)(resample(x), sd[rk + "weight"], sd[rk + "bias"])
     if has_attn:
         y = attention_2d(sd, p + "attn.", y, attn_residual)
     return y

@@ -619,6 +619,47 @@ def adm():
         npz(f"adm8_{skip}", **arrs)
 
 
+def adm_blocks():
+    """ADM residual blocks driven on their own, on fields and on volumes, with the shapes of the reference's own test
+    (tests/test_adm.py:7-70: cin 16, cout 32, cembed 24, 14^2 / 14^3 inputs)."""
+    A = M.nets.adm
+    cases = {
+        "enc2d": (A.ADMEncoderBlock, dict(), (1, 16, 14, 14), None),
+        "enc2d_down": (A.ADMEncoderBlock, dict(has_downsample=True), (1, 16, 14, 14), None),
+        "enc3d": (A.ADMEncoderBlock, dict(dimension=3), (1, 16, 14, 14, 14), None),
+        "enc3d_full": (A.ADMEncoderBlock, dict(has_residual=True, has_attn=True, has_downsample=True, attn_residual=True,
+                                               dimension=3), (2, 16, 14, 14, 14), None),
+        "dec2d_skip": (A.ADMDecoderBlock, dict(channels_skip=12, has_residual=True, has_attn=True, has_upsample=True),
+                       (1, 16, 14, 14), (1, 12, 14, 14)),
+        "dec3d_skip_add": (A.ADMDecoderBlock, dict(channels_skip=16, has_residual=True, has_upsample=True, dimension=3,
+                                                   skip_integration_type="add", first_norm="GroupRMS", second_norm="GroupLN"),
+                           (2, 16, 6, 8, 10), (2, 16, 6, 8, 10)),
+        "enc3d_circ": (A.ADMEncoderBlock, dict(has_residual=True, has_downsample=True, dimension=3, conv_type="circular"),
+                       (1, 16, 8, 8, 8), None),
+    }
+    arrs = {}
+    for i, (tag, (cls, kw, xs, ss)) in enumerate(cases.items()):
+        torch.manual_seed(300 + i)
+        blk = cls(16, 32, 24, **kw).eval()
+        with torch.no_grad():
+            for k, v in blk.state_dict().items():
+                if "norm" in k or k.endswith("bias"):
+                    v.add_(0.25 * torch.randn_like(v))
+        x, te = torch.randn(*xs), torch.randn(xs[0], 24)
+        skip = None if ss is None else torch.randn(*ss)
+        with torch.inference_mode():
+            out = blk(x, te, skip) if skip is not None else blk(x, te)
+            b64 = cls(16, 32, 24, **kw).double().eval()
+            b64.load_state_dict({k: v.double() for k, v in blk.state_dict().items()})
+            out64 = b64(x.double(), te.double(), skip.double()) if skip is not None else b64(x.double(), te.double())
+        for k, v in blk.state_dict().items():
+            arrs[f"sd/{tag}/{k}"] = v.detach().numpy()
+        arrs[f"{tag}/x"], arrs[f"{tag}/te"], arrs[f"{tag}/out_f32"], arrs[f"{tag}/out_f64"] = x, te, out, out64
+        if skip is not None:
+            arrs[f"{tag}/skip"] = skip
+    npz("adm_blocks", **arrs)
+
+
 def variants():
     """PUNetG with magnitude-preserving layers (convolution_type='mp': normedlayers.py, the in-house
     attention of attention.py:110-247) and with the other norm choices of ResnetBlockC (commonlayers.py:882-899)."""
@@ -858,6 +899,6 @@ def latent():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["schedule", "toy", "punetg", "porosity", "inpaint", "vpve", "circular", "si", "punetgcond", "langevin", "adm", "variants", "latent", "adm_norms", "autoregressive", "si_latent", "si_inpaint", "volumes", "si_generic", "vp_karras"]
+    which = sys.argv[1:] or ["schedule", "toy", "punetg", "porosity", "inpaint", "vpve", "circular", "si", "punetgcond", "langevin", "adm", "variants", "latent", "adm_norms", "autoregressive", "si_latent", "si_inpaint", "volumes", "si_generic", "vp_karras", "adm_blocks"]
     for name in which:
         globals()[name]()

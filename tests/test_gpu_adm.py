@@ -215,3 +215,56 @@ def test_reference_adm_test_shape(M, dev):
     got = net.to(dev)(x.to(dev), t.to(dev)).cpu()
     assert got.shape == x.shape
     assert rel_l2(got, want) < REL
+
+
+ADM_BLOCK_CASES = {
+    "enc2d": ("ADMEncoderBlock", dict()),
+    "enc2d_down": ("ADMEncoderBlock", dict(has_downsample=True)),
+    "enc3d": ("ADMEncoderBlock", dict(dimension=3)),
+    "enc3d_full": ("ADMEncoderBlock", dict(has_residual=True, has_attn=True, has_downsample=True, attn_residual=True, dimension=3)),
+    "dec2d_skip": ("ADMDecoderBlock", dict(channels_skip=12, has_residual=True, has_attn=True, has_upsample=True)),
+    "dec3d_skip_add": ("ADMDecoderBlock", dict(channels_skip=16, has_residual=True, has_upsample=True, dimension=3,
+                                               skip_integration_type="add", first_norm="GroupRMS", second_norm="GroupLN")),
+    "enc3d_circ": ("ADMEncoderBlock", dict(has_residual=True, has_downsample=True, dimension=3, conv_type="circular")),
+}
+
+
+@pytest.mark.parametrize("precision", ["fp16x3", "fp32"])
+@pytest.mark.parametrize("tag", sorted(ADM_BLOCK_CASES))
+def test_adm_blocks_on_fields_and_volumes(M, dev, tag, precision):
+    """The reference drives ADM blocks on their own, on 2-D fields and 3-D volumes (tests/test_adm.py:7-70: cin 16,
+    cout 32, cembed 24, 14^2 / 14^3 inputs; AvgPool3d, attention over the 7^3 = 343 flattened voxels).  Same classes,
+    constructor arguments and state_dict keys here; outputs against the reference's."""
+    v, sd_all = load("adm_blocks")
+    sd = {k[len(tag) + 1:]: w for k, w in sd_all.items() if k.startswith(tag + "/")}
+    cls, kw = ADM_BLOCK_CASES[tag]
+    blk = getattr(M.nets, cls)(16, 32, 24, **kw)
+    r = blk.load_state_dict(sd, strict=True)
+    assert not r.missing_keys and not r.unexpected_keys
+    blk = blk.to(dev).eval()
+    blk.conv_precision = precision
+    args = [v[tag + "/x"].to(dev), v[tag + "/te"].to(dev)] + ([v[tag + "/skip"].to(dev)] if tag + "/skip" in v else [])
+    out = blk(*args).cpu()
+    assert out.shape == v[tag + "/out_f32"].shape
+    assert rel_l2(out, v[tag + "/out_f32"]) < REL
+    assert rel_l2(out, v[tag + "/out_f64"]) < max(4 * rel_l2(v[tag + "/out_f32"], v[tag + "/out_f64"]), 2e-6)
+
+
+def test_adm_block_shapes_of_the_reference_test(M, dev):
+    """tests/test_adm.py of the reference, lines 7-70, on the HIP blocks (shapes only, as there)."""
+    cin, cout, cembed = 16, 32, 24
+    E, D = M.nets.ADMEncoderBlock, M.nets.ADMDecoderBlock
+    x, te = torch.randn(1, cin, 14, 14, device=dev), torch.randn(1, cembed, device=dev)
+    assert E(cin, cout, cembed).to(dev)(x, te).shape == (1, cout, 14, 14)
+    assert E(cin, cout, cembed, has_downsample=True).to(dev)(x, te).shape == (1, cout, 7, 7)
+    x3 = torch.randn(1, cin, 14, 14, 14, device=dev)
+    assert E(cin, cout, cembed, dimension=3).to(dev)(x3, te).shape == (1, cout, 14, 14, 14)
+    assert E(cin, cout, cembed, has_residual=True, has_attn=True, has_downsample=True, attn_residual=True,
+             dimension=3).to(dev)(x3, te).shape == (1, cout, 7, 7, 7)
+    assert D(cin, cout, cembed).to(dev)(x, te).shape == (1, cout, 14, 14)
+    assert D(cin, cout, cembed, has_upsample=True).to(dev)(x, te).shape == (1, cout, 28, 28)
+    assert D(cin, cout, cembed, has_residual=True, has_attn=True, has_upsample=True).to(dev)(x, te).shape == (1, cout, 28, 28)
+    xskip = torch.randn(1, 12, 14, 14, device=dev)
+    assert D(cin, cout, cembed, 12, has_residual=True, has_attn=True, has_upsample=True).to(dev)(x, te, xskip).shape == (1, cout, 28, 28)
+    with pytest.raises(NotImplementedError, match="the reference's own ADM cannot run on volumes"):
+        M.ADM(M.ADMConfig(dimension=3))

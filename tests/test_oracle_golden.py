@@ -668,3 +668,30 @@ def test_philox_known_answers():
     z = P.normal(1234, 0, 1 << 18)
     assert abs(z.mean()) < 0.01 and abs(z.std() - 1) < 0.01 and np.isfinite(z).all()
     assert np.array_equal(P.normal(1234, 16, 64), P.normal(1234, 0, 128)[64:])          # offset = counter shift
+
+
+ADM_BLOCK_CASES = {
+    # tag: (sample, has_attn, has_residual, norms, skip_integration_type, circular)
+    "enc2d": (None, False, False, ("GroupLN", "GroupRMS"), "concat", False),
+    "enc2d_down": ("down", False, False, ("GroupLN", "GroupRMS"), "concat", False),
+    "enc3d": (None, False, False, ("GroupLN", "GroupRMS"), "concat", False),
+    "enc3d_full": ("down", True, True, ("GroupLN", "GroupRMS"), "concat", False),
+    "dec2d_skip": ("up", True, True, ("GroupLN", "GroupRMS"), "concat", False),
+    "dec3d_skip_add": ("up", False, True, ("GroupRMS", "GroupLN"), "add", False),
+    "enc3d_circ": ("down", False, True, ("GroupLN", "GroupRMS"), "concat", True),
+}
+
+
+@pytest.mark.parametrize("tag", sorted(ADM_BLOCK_CASES))
+def test_adm_blocks_on_fields_and_volumes(tag):
+    """ADM residual blocks called on their own as the reference's tests/test_adm.py does (14^2 fields, 14^3 volumes;
+    AvgPool3d, attention over 343 voxels, skip concat / add): the oracle's block against the reference's outputs."""
+    from oracle import adm_ref
+    v, sd_all = load("adm_blocks")
+    sd = {k[len(tag) + 1:]: w for k, w in sd_all.items() if k.startswith(tag + "/")}
+    sample, has_attn, has_res, norms, skip_type, circ = ADM_BLOCK_CASES[tag]
+    with torch.inference_mode():
+        got = adm_ref.block(sd, "", v[tag + "/x"], v[tag + "/te"], sample=sample, has_attn=has_attn, attn_residual=True,
+                            circular=circ, norms=norms, skip=v.get(tag + "/skip"), skip_integration_type=skip_type,
+                            has_residual=has_res)
+    assert_exact_or_rel(got, v[tag + "/out_f32"], tag, 2e-6)
