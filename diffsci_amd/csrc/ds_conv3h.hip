@@ -82,6 +82,7 @@ struct Conv3hArgs {
   int shift_stride;
   int res1_up;            // res1 is at half resolution (see ds_conv_epilogue.h)
   int circular;           // periodic padding in both dimensions (CircularConv2d, commonlayers.py:918-971)
+  int oy, ox;             // tap-origin offset: the 3x3 window is centred at (y + oy, x + ox) -- sub-kernels of larger kernels
   int B, Cin, Cout, H, W, Hin, Win;
   int tiles_x, tiles_y, n_cot, n_chunks;
   unsigned tiles_x_magic;   // floor(2^32 / tiles_x) + 1
@@ -176,7 +177,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_conv3h(const Conv3hArgs a) 
     const bool live = pos < NPOS;                      // the item exists
     const int r = pos / PW;
     const int col = pos - r * PW;
-    int gy = y0 + r - 1, gx = x0 + col - 1;
+    int gy = y0 + r - 1 + a.oy, gx = x0 + col - 1 + a.ox;
     if (CIRC) {
       // wrap instead of zero padding: one halo pixel on either side, so a compare-and-add per edge
       // (no integer division: that cost 2-3 % of the whole kernel in the prologue); rows / columns
@@ -500,7 +501,11 @@ int ds_conv2d_h3(float* out, const float* in, const void* w_packed, int wshift, 
              "ds_conv2d_h3: bad shape B=%d Cin=%d Cout=%d H=%d W=%d", B, Cin, Cout, H, W);
   const int circular = (load_mode & DS_PAD_CIRCULAR) ? 1 : 0;
   const int res1_up = (load_mode & DS_RES1_UPSAMPLED) ? 1 : 0;
-  load_mode &= ~(DS_PAD_CIRCULAR | DS_RES1_UPSAMPLED);
+  // tap-origin offset, two signed 4-bit fields (DS_TAP_OFFSET): 0 for a plain 3x3 convolution
+  const int oy = (int)((load_mode >> 8) & 15) - (((load_mode >> 8) & 8) ? 16 : 0);
+  const int ox = (int)((load_mode >> 12) & 15) - (((load_mode >> 12) & 8) ? 16 : 0);
+  load_mode &= ~(DS_PAD_CIRCULAR | DS_RES1_UPSAMPLED | 0xff00);
+  DS_REQUIRE(!(circular && (oy || ox)), DS_ERR_UNSUPPORTED, "ds_conv2d_h3: a tap offset cannot be combined with periodic padding");
   DS_REQUIRE(!res1_up || (res1 && H % 2 == 0 && W % 2 == 0), DS_ERR_SHAPE, "ds_conv2d_h3: RES1_UPSAMPLED needs res1 and even H, W");
   DS_REQUIRE(load_mode >= 0 && load_mode <= 2, DS_ERR_UNSUPPORTED, "ds_conv2d_h3: load_mode %d", load_mode);
   DS_REQUIRE(load_mode != DS_LOAD_UPSAMPLE2 || (H % 2 == 0 && W % 2 == 0), DS_ERR_SHAPE,
@@ -516,7 +521,7 @@ int ds_conv2d_h3(float* out, const float* in, const void* w_packed, int wshift, 
   DS_REQUIRE((reinterpret_cast<uintptr_t>(prenorm) & 15u) == 0, DS_ERR_SHAPE, "ds_conv2d_h3: prenorm must be 16-byte aligned");
   if (B == 0) return DS_OK;
   Conv3hArgs a;
-  a.prenorm = prenorm; a.tile_stats = tile_stats; a.circular = circular; a.res1_up = res1_up;
+  a.prenorm = prenorm; a.tile_stats = tile_stats; a.circular = circular; a.res1_up = res1_up; a.oy = oy; a.ox = ox;
   a.out = out; a.in = in; a.wp = reinterpret_cast<const u32x4*>(w_packed); a.bias = bias; a.shift = shift;
   a.res1 = res1; a.res2 = res2; a.shift_stride = shift_stride;
   a.unscale = ldexpf(1.0f, -wshift);

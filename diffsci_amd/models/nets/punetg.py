@@ -150,19 +150,19 @@ def make_conv(cin, cout, k, kind="default", bias=True, dim=2):
 class _ResBlock(torch.nn.Module):
     """ResnetBlockC parameters (commonlayers.py:766-807)."""
 
-    def __init__(self, C, embed, conv_kind="default", bias=True, norms=("GroupLN", "GroupRMS"), affine=True, dim=2):
+    def __init__(self, C, embed, conv_kind="default", bias=True, norms=("GroupLN", "GroupRMS"), affine=True, dim=2, k=3):
         super().__init__()
         self.gnorm1 = make_norm(norms[0], C, affine)
         self.gnorm2 = make_norm(norms[1], C, affine)
-        self.conv1 = make_conv(C, C, 3, conv_kind, bias, dim)
-        self.conv2 = make_conv(C, C, 3, conv_kind, bias, dim)
+        self.conv1 = make_conv(C, C, k, conv_kind, bias, dim)
+        self.conv2 = make_conv(C, C, k, conv_kind, bias, dim)
         self.timeblock = _TimeBlock(embed, C, mp=conv_kind == "mp")
 
 
 class _Sampler(torch.nn.Module):
-    def __init__(self, cin, cout, conv_kind="default", bias=True, dim=2):
+    def __init__(self, cin, cout, conv_kind="default", bias=True, dim=2, k=3):
         super().__init__()
-        self.conv = make_conv(cin, cout, 3, conv_kind, bias, dim)
+        self.conv = make_conv(cin, cout, k, conv_kind, bias, dim)
 
 
 class _Attn(torch.nn.Module):
@@ -267,11 +267,12 @@ class PUNetG(torch.nn.Module):
         if config.in_embedding:                           # fixed Fourier input embedding instead of a convolution, punetg.py:194-202
             self.convin = _FourierInput(config.input_channels + (0 if hb else 1), mc, config.input_projection_scale)
         else:
-            self.convin = make_conv(config.input_channels + (0 if hb else 1), mc, 3, circ, hb, dim)
-        self.convout = make_conv(mc, config.output_channels, 3, circ, hb, dim)
+            self.convin = make_conv(config.input_channels + (0 if hb else 1), mc, config.in_out_kernel_size, circ, hb, dim)
+        self.convout = make_conv(mc, config.output_channels, config.in_out_kernel_size, circ, hb, dim)
+        kres, ktr = config.kernel_size, config.transition_kernel_size
 
         def blocks(m, n):
-            bl = [_ResBlock(m * mc, mc, circ, hb, norms, bool(config.affine_norm), dim) for _ in range(n)]
+            bl = [_ResBlock(m * mc, mc, circ, hb, norms, bool(config.affine_norm), dim, kres) for _ in range(n)]
             if extra_residual is not None:
                 for b in bl:
                     b.extra_residual = extra_residual          # the reference registers the shared module in every block
@@ -280,12 +281,12 @@ class PUNetG(torch.nn.Module):
         self.downward_blocks = torch.nn.ModuleList(
             [blocks(mult[i], config.number_resnet_downward_block) for i in range(len(mult) - 1)])
         self.downsamplers = torch.nn.ModuleList(
-            [_Sampler(mult[i] * mc, mult[i + 1] * mc, circ, hb, dim) for i in range(len(mult) - 1)])
+            [_Sampler(mult[i] * mc, mult[i + 1] * mc, circ, hb, dim, ktr) for i in range(len(mult) - 1)])
         rmult = list(reversed(mult))
         self.upward_blocks = torch.nn.ModuleList(
             [blocks(rmult[i + 1], config.number_resnet_upward_block) for i in range(len(mult) - 1)])
         self.upsamplers = torch.nn.ModuleList(
-            [_Sampler(rmult[i] * mc, rmult[i + 1] * mc, circ, hb, dim) for i in range(len(mult) - 1)])
+            [_Sampler(rmult[i] * mc, rmult[i + 1] * mc, circ, hb, dim, ktr) for i in range(len(mult) - 1)])
         self.before_block = blocks(mult[-1], config.number_resnet_before_attn_block)
         self.after_block = blocks(mult[-1], config.number_resnet_after_attn_block)
         self.attn_resnet_block = blocks(mult[-1], config.number_resnet_attn_block)
@@ -522,7 +523,7 @@ class PUNetG(torch.nn.Module):
     def _out_conv(self, m, h, pk, out, circular):
         """The output layer: Cout <= 4 streams the input once through the direct fp32 kernel instead of
         padding Cout to a 64-channel MFMA tile."""
-        if m.out_channels <= 4 and getattr(self, "direct_out", True):
+        if m.out_channels <= 4 and getattr(self, "direct_out", True) and self.config.in_out_kernel_size == 3:
             return ops.conv_direct(h, pk.get((id(m), "eff"), m.weight), m.bias, circular=circular, out=out)
         return ops.conv(h, pk[id(m)], bias=m.bias, circular=circular, out=out)
 
@@ -557,7 +558,8 @@ class PUNetG(torch.nn.Module):
         k1, k2 = self.norm_kinds                           # 0 GroupLN, 1 GroupRMS, 2 none, 3 GroupPix (not a table)
         w1, b1 = getattr(blk.gnorm1, "weight", None), getattr(blk.gnorm1, "bias", None)
         w2, b2 = getattr(blk.gnorm2, "weight", None), getattr(blk.gnorm2, "bias", None)
-        if self._fused() and xs is not None and (C + 63) // 64 <= self.fuse_max_cot and k1 != 3 and k2 != 3:
+        if (self._fused() and xs is not None and (C + 63) // 64 <= self.fuse_max_cot and k1 != 3 and k2 != 3
+                and self.config.kernel_size == 3):                                  # the norm+SiLU loader is the 3x3 kernel's
             tab = ws.take((B, ops.table_channels(C), 4), dev)
             ops.inorm_table(xs, w1, b1, k1, H * W, eps=1e-5, out=tab)
             ys = self._stats_buf(ws, B, C, H, W, dev)

@@ -419,12 +419,14 @@ def pack_conv_weight(w):
 class PackedConv:
     """A convolution weight repacked for one of the MFMA kernels.
     kind: "fp32" (exact-fp32 MFMA), "bf16x6" or "fp16x3" (fp32 emulated on the 16-bit matrix cores)."""
-    __slots__ = ("data", "Cout", "Cin", "ks", "kind", "wshift", "up", "up_wshift")
+    __slots__ = ("data", "Cout", "Cin", "ks", "kind", "wshift", "up", "up_wshift", "subs")
 
-    def __init__(self, data, Cout, Cin, ks, kind, wshift=0, up=None, up_wshift=0):
+    def __init__(self, data, Cout, Cin, ks, kind, wshift=0, up=None, up_wshift=0, subs=None):
         self.data, self.Cout, self.Cin, self.ks, self.kind, self.wshift = data, Cout, Cin, ks, kind, wshift
         # fp16x3 3x3 only: the four 2x2 parity kernels of "upsample x2, then this convolution" and their scale
         self.up, self.up_wshift = up, up_wshift
+        # ks = 5, 7, ...: the kernel as ceil(ks/3)^2 zero-padded 3x3 blocks [(oy, ox, PackedConv 3x3)], see conv()
+        self.subs = subs
 
     @property
     def x6(self):
@@ -442,8 +444,24 @@ def pack_conv(w, precision="bf16x6", upsampled=False):
     require_device(w, "conv weight")
     if precision not in CONV_PRECISIONS:
         raise ValueError(f"unknown conv precision {precision!r}; choose from {CONV_PRECISIONS}")
-    Cout, Cin, k, _ = w.shape
+    Cout, Cin, k, k2 = w.shape
     w = w.contiguous()
+    if k != k2 or k % 2 == 0:
+        raise NotImplementedError(f"conv kernel {k}x{k2}: square kernels of odd size are implemented")
+    if k > 3:
+        # k x k = sum of ceil(k/3)^2 shifted 3x3 convolutions over zero-padded blocks of the taps (DS_TAP_OFFSET):
+        # block (gy, gx) holds taps [3gy, 3gy+3) x [3gx, 3gx+3); its centre tap 3g+1 sits at offset 3g + 1 - k//2
+        if precision != "fp16x3":
+            raise NotImplementedError(f"{k}x{k} kernels are implemented on the fp16x3 convolution only (conv_precision={precision!r})")
+        ng = (k + 2) // 3
+        wp = torch.zeros((Cout, Cin, 3 * ng, 3 * ng), dtype=torch.float32, device=w.device)
+        wp[:, :, :k, :k] = w
+        subs = []
+        for gy in range(ng):
+            for gx in range(ng):
+                blk = wp[:, :, 3 * gy:3 * gy + 3, 3 * gx:3 * gx + 3].contiguous()
+                subs.append((3 * gy + 1 - k // 2, 3 * gx + 1 - k // 2, pack_conv(blk, "fp16x3")))
+        return PackedConv(None, Cout, Cin, k, "fp16x3", subs=subs)
     if precision == "bf16x6" and k == 3:
         nbytes = N.lib().ds_conv2d_x6_packed_bytes(Cout, Cin)
         data = torch.empty(nbytes // 4, dtype=torch.float32, device=w.device)
@@ -473,8 +491,22 @@ def pack_conv(w, precision="bf16x6", upsampled=False):
 
 
 def conv(x, pw, **kw):
-    """Dispatch on the packing: ds_conv2d_h3, ds_conv2d_x6 or ds_conv2d."""
-    return conv2d(x, pw.data, pw.Cout, pw.ks, kind=pw.kind, wshift=pw.wshift, w_up=pw.up, up_wshift=pw.up_wshift, **kw)
+    """Dispatch on the packing: ds_conv2d_h3, ds_conv2d_x6 or ds_conv2d; kernels larger than 3x3 as a sum of shifted
+    3x3 blocks accumulated in place (the first launch carries bias / shift / residuals, the last one the statistics)."""
+    if pw.subs is None:
+        return conv2d(x, pw.data, pw.Cout, pw.ks, kind=pw.kind, wshift=pw.wshift, w_up=pw.up, up_wshift=pw.up_wshift, **kw)
+    if kw.get("circular", False):
+        raise NotImplementedError("periodic padding with kernels larger than 3x3")
+    if kw.get("res1_upsampled", False):
+        raise NotImplementedError("res1_upsampled with kernels larger than 3x3")
+    stats, out = kw.pop("tile_stats", None), kw.pop("out", None)
+    first = dict(bias=kw.pop("bias", None), shift=kw.pop("shift", None), res1=kw.pop("res1", None), res2=kw.pop("res2", None))
+    n = len(pw.subs)
+    for i, (oy, ox, sub) in enumerate(pw.subs):
+        extra = first if i == 0 else dict(res1=out)
+        out = conv2d(x, sub.data, sub.Cout, 3, kind="fp16x3", wshift=sub.wshift, tap_offset=(oy, ox), out=out,
+                     tile_stats=stats if i == n - 1 else None, **extra, **kw)
+    return out
 
 
 def conv_direct(x, w, bias=None, circular=False, out=None):
@@ -538,7 +570,7 @@ def gnorm1_table(stats_a, w, b, kind, count, stats_b=None, film=None, eps=1e-5, 
 
 def conv2d(x, w_packed, Cout, ks, bias=None, shift=None, res1=None, res2=None,
            load_mode=N.DS_LOAD_PLAIN, out=None, kind="fp32", wshift=0, prenorm=None, tile_stats=None, circular=False,
-           res1_upsampled=False, w_up=None, up_wshift=0):
+           res1_upsampled=False, w_up=None, up_wshift=0, tap_offset=None):
     """'same' zero-padded conv; x [B, Cin, Hin, Win]; shift [1 or B, Cout] or None.
     fp16x3 kernels only: prenorm [B, ceil16(Cin), 4] (3x3) applies SiLU((x-M)*A+C) in the loader; tile_stats
     [B, Cout, conv_tile_count(H, W), 4] receives per-tile (K, sum(x-K), sum((x-K)^2), n) of the output."""
@@ -584,6 +616,13 @@ def conv2d(x, w_packed, Cout, ks, bias=None, shift=None, res1=None, res2=None,
         raise ValueError(f"prenorm must be [B, ceil16(Cin), 4] on a 3x3 convolution; got {tuple(prenorm.shape)}")
     if tile_stats is not None and tuple(tile_stats.shape) != (B, Cout, conv_tile_count(H, W), 4):
         raise ValueError(f"tile_stats must be {(B, Cout, conv_tile_count(H, W), 4)}; got {tuple(tile_stats.shape)}")
+    tap = 0
+    if tap_offset is not None and tuple(tap_offset) != (0, 0):
+        oy, ox = (int(v) for v in tap_offset)
+        if kind != "fp16x3" or ks != 3 or circular or not (-8 <= oy <= 7 and -8 <= ox <= 7):
+            raise ValueError("tap_offset: fp16x3 3x3 convolution, zero padding, offsets in [-8, 7]")
+        tap = ((oy & 15) << 8) | ((ox & 15) << 12)                      # DS_TAP_OFFSET(oy, ox)
+        w_up = None                                                      # the parity kernel has no offset form
     if kind == "fp16x3" and ks == 1:
         N.check(N.lib().ds_conv1x1_h3(_p(out), _p(x), _p(w_packed), int(wshift), _p(bias), _p(shift), stride,
                                       _p(res1), _p(res2), B, Cin, Cout, H, W, load_mode, _p(tile_stats), _stream()),
@@ -599,7 +638,7 @@ def conv2d(x, w_packed, Cout, ks, bias=None, shift=None, res1=None, res2=None,
     elif kind == "fp16x3":
         N.check(N.lib().ds_conv2d_h3(_p(out), _p(x), _p(w_packed), int(wshift), _p(bias), _p(shift), stride,
                                      _p(res1), _p(res2), B, Cin, Cout, H, W,
-                                     load_mode | (N.DS_PAD_CIRCULAR if circular else 0) | (N.DS_RES1_UPSAMPLED if res1_upsampled else 0),
+                                     load_mode | tap | (N.DS_PAD_CIRCULAR if circular else 0) | (N.DS_RES1_UPSAMPLED if res1_upsampled else 0),
                                      _p(prenorm), _p(tile_stats),
                                      _stream()), "ds_conv2d_h3")
     elif kind == "bf16x6":

@@ -155,6 +155,11 @@ enum { DS_LOAD_PLAIN = 0, DS_LOAD_MAXPOOL2 = 1, DS_LOAD_UPSAMPLE2 = 2, DS_LOAD_A
                                  nearest-upsampled -- ADM's convresidual(upsample(x)) = upsample(convresidual(x)), adm.py:345-349 */,
        DS_PAD_CIRCULAR = 16 /* OR-ed into load_mode of ds_conv2d_h3: periodic instead of zero padding in H and W
                                (CircularConv2d, commonlayers.py:918-971; applied to the pooled / upsampled image) */ };
+/* OR-ed into load_mode of ds_conv2d_h3: the 3x3 window is centred at (y + oy, x + ox) instead of (y, x), -8 <= oy, ox <= 7
+ * (in the coordinates of the pooled / upsampled image; zero padding).  A k x k kernel with k = 5, 7, ... (kernel_size /
+ * in_out_kernel_size / transition_kernel_size of PUNetGConfig, punetg_config.py:19-25) is the sum of ceil(k/3)^2 such
+ * 3x3 convolutions over zero-padded blocks of its taps, accumulated through res1 = out. */
+#define DS_TAP_OFFSET(oy, ox) ((((oy) & 15) << 8) | (((ox) & 15) << 12))
 
 /* "same"-padded (zero) ks x ks convolution, ks in {1,3}, fp32 MFMA implicit GEMM.
  *   out[b,co,y,x] = sum w[co,ci,ky,kx]*src(b,ci,y+ky-ks/2,x+kx-ks/2) + bias[co]

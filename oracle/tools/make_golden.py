@@ -673,6 +673,9 @@ def variants():
         # parameter-free extra_residual module
         "fourier_in": dict(in_embedding=True, bias=False),
         "extra_res": dict(),
+        # kernel sizes other than 3 (punetg_config.py:19-25)
+        "k5": dict(kernel_size=5, in_out_kernel_size=1, transition_kernel_size=5),
+        "k7": dict(kernel_size=1, in_out_kernel_size=7, transition_kernel_size=7),
     }
     only = os.environ.get("VARIANTS_ONLY")
     for i, (tag, over) in enumerate(cases.items()):

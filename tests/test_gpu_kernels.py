@@ -679,3 +679,44 @@ def test_conv3d_on_the_matrix_cores(dev, case):
     one = ops.conv3d_mfma(x.to(dev), ops.pack_conv3d(w.to(dev)), bias=bias.to(dev), shift=shift[:1].to(dev), load_mode=mode,
                           circular=circ).cpu()                      # one shift row shared by the batch
     assert rel_l2(one, want - r1.double() - r2.double() + (shift[:1] - shift).double()[:, :, None, None, None]) < 5e-7
+
+
+@pytest.mark.parametrize("case", [
+    # B, Cin, Cout, H, W, k, mode (0 plain, 1 max-pool, 2 nearest-up)
+    (2, 24, 40, 20, 36, 5, 0),
+    (1, 64, 64, 32, 32, 5, 1),
+    (2, 16, 72, 16, 48, 5, 2),
+    (1, 8, 8, 11, 13, 7, 0),           # taps reach past a tiny, odd image on every side
+    (2, 32, 16, 16, 32, 7, 1),
+    (1, 40, 24, 24, 16, 7, 2),
+])
+def test_conv_kernels_larger_than_3x3(dev, case):
+    """kernel_size / in_out_kernel_size / transition_kernel_size of 5 and 7 (punetg_config.py:19-25): a k x k 'same'
+    convolution as ceil(k/3)^2 shifted 3x3 fp16x3 convolutions over zero-padded blocks of the taps (DS_TAP_OFFSET),
+    accumulated in place -- fp32-accurate against fp64, with the pooling / upsampling loaders and every epilogue term."""
+    ops = _ops()
+    B, Cin, Cout, H, W, k, mode = case
+    g = torch.Generator().manual_seed(sum(case))
+    Hin, Win = (2 * H, 2 * W) if mode == 1 else ((H // 2, W // 2) if mode == 2 else (H, W))
+    x = torch.randn(B, Cin, Hin, Win, generator=g) * 2.0
+    w = torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k)
+    bias, shift = torch.randn(Cout, generator=g), torch.randn(B, Cout, generator=g)
+    r1, r2 = torch.randn(B, Cout, H, W, generator=g), torch.randn(B, Cout, H, W, generator=g)
+    src = F.max_pool2d(x, 2) if mode == 1 else (F.interpolate(x, scale_factor=2.0, mode="nearest") if mode == 2 else x)
+    want = (F.conv2d(src.double(), w.double(), bias.double(), padding="same") + shift.double()[:, :, None, None]
+            + r1.double() + r2.double())
+    ref32 = F.conv2d(src, w, bias, padding="same") + shift[:, :, None, None] + r1 + r2
+    pw = ops.pack_conv(w.to(dev), "fp16x3")
+    assert pw.ks == k and len(pw.subs) == ((k + 2) // 3) ** 2
+    stats = torch.zeros(B, Cout, ops.conv_tile_count(H, W), 4, device=dev)
+    got = ops.conv(x.to(dev), pw, bias=bias.to(dev), shift=shift.to(dev), res1=r1.to(dev), res2=r2.to(dev), load_mode=mode,
+                   tile_stats=stats).cpu()
+    assert rel_l2(got, want) <= max(3 * rel_l2(ref32, want), 3e-7)
+    assert (got.double() - want).abs().max().item() <= max(4 * (ref32.double() - want).abs().max().item(), 1e-5)
+    # the statistics describe the final sum (written by the last block's launch)
+    s = stats.cpu().double()
+    n, mean = s[..., 3].sum(-1), (s[..., 0] * s[..., 3] + s[..., 1]).sum(-1) / s[..., 3].sum(-1)
+    assert torch.equal(n, torch.full_like(n, H * W))
+    torch.testing.assert_close(mean, want.mean(dim=(2, 3)), rtol=1e-5, atol=1e-5)
+    with pytest.raises(NotImplementedError, match="fp16x3 convolution only"):
+        ops.pack_conv(w.to(dev), "bf16x6")

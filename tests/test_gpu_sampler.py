@@ -638,6 +638,8 @@ def test_punetg_circular_convolutions(M, dev, grids):
     ("cosine", dict(attn_type="cosine")),
     ("fourier_in", dict(in_embedding=True, bias=False)),
     ("extra_res", dict()),
+    ("k5", dict(kernel_size=5, in_out_kernel_size=1, transition_kernel_size=5)),
+    ("k7", dict(kernel_size=1, in_out_kernel_size=7, transition_kernel_size=7)),
 ])
 def test_punetg_layer_variants(M, dev, grids, tag, over, fuse):
     """magnitude-preserving convolutions / linears / attention (weights folded when packed)

@@ -334,6 +334,8 @@ VARIANTS = {
     "cosine": dict(attn_type="cosine"),
     "fourier_in": dict(in_embedding=True, bias=False),      # ConvolutionalFourierProjection as convin (punetg.py:194-202)
     "extra_res": dict(),                                    # extra_residual = AvgPool2d(3, 1, 1) shared by every block
+    "k5": dict(kernel_size=5, in_out_kernel_size=1, transition_kernel_size=5),
+    "k7": dict(kernel_size=1, in_out_kernel_size=7, transition_kernel_size=7),
 }
 EXTRA_RES = torch.nn.AvgPool2d(3, stride=1, padding=1)
 
