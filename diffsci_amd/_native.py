@@ -74,6 +74,8 @@ _PROTOS = {
     "ds_attention": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     "ds_attention_generic": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     "ds_attention_h3": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
+    "ds_attention_h3_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "ds_attention_h3_ws": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P]),
     "ds_token_l2_normalize": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_float, c_float, _P]),
     "ds_linear": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "ds_fourier_features": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P]),

@@ -15,6 +15,12 @@
 // query, keys (r&3)+8(r>>2)+4h in register r of lane half h; packing pairs to fp16 and two
 // v_permlane32_swap per 16-key slab and piece turn that into the B operand of the next MFMA.
 //
+// Two staging forms.  IMG = false: every workgroup loads its K / V tiles as fp32, splits them and writes the LDS
+// images itself (no workspace; every tile is split once per 128-query block of the sample).  IMG = true: a pre-pass
+// (k_attn_images) splits K and V ONCE per sample into global images that already have the LDS layout, and the
+// attention kernel stages a tile with eight 1-KiB LDS-DMA instructions per wave and operand -- no staging registers,
+// no split VALU work in the loop.  At L = 4096 a tile is otherwise re-split by 32 workgroups.
+//
 // Workgroup = 4 waves x 32 queries; key tiles of 32.  K and V tiles are double-buffered in LDS
 // (4 x 32 KiB at E = 256) and staged one tile ahead through ONE set of 32 registers: the next K
 // tile is loaded under the S^T product and written out before the softmax, the next V tile is
@@ -54,8 +60,9 @@ __device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned&
 
 __device__ __forceinline__ f16x8 as_f16x8(u32x4 v) { return __builtin_bit_cast(f16x8, v); }
 
-template <int ET>
-__global__ __launch_bounds__(NT) void k_attn3h(float* out, const float* __restrict__ qkv, int L, float scale, float thr) {
+template <int ET, bool IMG>
+__global__ __launch_bounds__(NT) void k_attn3h(float* out, const float* __restrict__ qkv, const u32x4* __restrict__ kimg,
+                                               const u32x4* __restrict__ vimg, int L, float scale, float thr) {
   constexpr int E = 32 * ET;
   constexpr int NDG = E / 8;                         // d-groups of 8
   constexpr int NS = E / 16;                         // k-slabs of the S^T product
@@ -189,10 +196,28 @@ __global__ __launch_bounds__(NT) void k_attn3h(float* out, const float* __restri
   };
 
   const int nkb = L / KB;
-  k_load(0);
-  k_store(Kbuf);
-  v_load(0);
-  v_store(Vbuf);
+  // IMG: tile kb of sample b as LDS-ready images; a tile = KVEC (= VVEC = 8E) vectors = 2*ET 1-KiB pieces per wave
+  static_assert(KVEC == VVEC && KVEC % (64 * 4) == 0, "image tiles are whole LDS-DMA pieces per wave");
+  const u32x4* kimg_b = IMG ? kimg + (size_t)b * nkb * KVEC : nullptr;
+  const u32x4* vimg_b = IMG ? vimg + (size_t)b * nkb * VVEC : nullptr;
+  auto dma = [&](u32x4* dst, const u32x4* src) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < KVEC / 256; ++i) {
+      const int k = wv + 4 * i;                      // wave-uniform piece
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 64 * k + lane),
+                                       (__attribute__((address_space(3))) void*)(dst + 64 * k), 16, 0, 0);
+    }
+  };
+  if (IMG) {
+    dma(Kbuf, kimg_b);
+    dma(Vbuf, vimg_b);
+  } else {
+    k_load(0);
+    k_store(Kbuf);
+    v_load(0);
+    v_store(Vbuf);
+  }
+  if (IMG) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   for (int kb = 0; kb < nkb; ++kb) {
     const bool more = kb + 1 < nkb;
@@ -200,7 +225,13 @@ __global__ __launch_bounds__(NT) void k_attn3h(float* out, const float* __restri
     const u32x4* Vs = Vbuf + (kb & 1) * VVEC;
     u32x4* Kn = Kbuf + ((kb + 1) & 1) * KVEC;
     u32x4* Vn = Vbuf + ((kb + 1) & 1) * VVEC;
-    if (more) k_load((kb + 1) * KB);                 // flies under the S^T product
+    if (IMG) {
+      // both next-tile buffers were last read one iteration ago (before the barrier that ended it): the whole
+      // iteration covers the transfer, and the barrier at its end publishes it
+      if (more) { dma(Kn, kimg_b + (size_t)(kb + 1) * KVEC); dma(Vn, vimg_b + (size_t)(kb + 1) * VVEC); }
+    } else if (more) {
+      k_load((kb + 1) * KB);                         // flies under the S^T product
+    }
     f32x16 S;
     {
       // ---- S^T[key][query] ----
@@ -218,7 +249,7 @@ __global__ __launch_bounds__(NT) void k_attn3h(float* out, const float* __restri
         if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);
       }
     }
-    if (more) {
+    if (!IMG && more) {
       k_store(Kn);                                   // the other K buffer: last read two tiles ago
       v_load((kb + 1) * KB);                         // flies under the softmax and the O^T product
     }
@@ -282,8 +313,9 @@ __global__ __launch_bounds__(NT) void k_attn3h(float* out, const float* __restri
         if ((t & 1) == 1) __builtin_amdgcn_sched_barrier(0);
       }
     }
-    if (more) v_store(Vn);
-    __syncthreads();
+    if (!IMG && more) v_store(Vn);
+    if (IMG) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA pieces have landed ...
+    __syncthreads();                                            // ... and so have everyone's
   }
   if (active) {
     const float inv = 1.0f / l_run;
@@ -298,39 +330,103 @@ __global__ __launch_bounds__(NT) void k_attn3h(float* out, const float* __restri
   }
 }
 
+// Pre-pass of the IMG form: one workgroup per (key tile, sample) writes the tile's K and V images
+//   K [piece][d-group][key 32][8 d]   V [piece][key-group][d][8 keys]        (the LDS layouts above)
+// with the split every attention workgroup would otherwise redo.  Reads K, V once (8 B/elt), writes as many bytes.
 template <int ET>
-int launch_attn3h(float* out, const float* qkv, int B, int L, float scale, hipStream_t s) {
+__global__ __launch_bounds__(NT) void k_attn_images(u32x4* __restrict__ kimg, u32x4* __restrict__ vimg,
+                                                   const float* __restrict__ qkv, int L) {
+  constexpr int E = 32 * ET, NDG = E / 8;
+  constexpr int KITEMS = NDG * KB, VITEMS = E * 4;
+  const int tid = threadIdx.x, kb = blockIdx.x, b = blockIdx.y, nkb = L / KB;
+  const float* Kt = qkv + ((size_t)b * 3 + 1) * E * L + (size_t)kb * KB;
+  const float* Vt = Kt + (size_t)E * L;
+  u32x4* Kd = kimg + ((size_t)b * nkb + kb) * (2 * KITEMS);
+  u32x4* Vd = vimg + ((size_t)b * nkb + kb) * (2 * VITEMS);
+  for (int e = tid; e < KITEMS; e += NT) {
+    const int dg = e / KB, key = e % KB;
+    u32x4 h, l;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      unsigned a, c;
+      split2(Kt[(size_t)(8 * dg + 2 * k) * L + key], Kt[(size_t)(8 * dg + 2 * k + 1) * L + key], a, c);
+      h[k] = a; l[k] = c;
+    }
+    Kd[e] = h;
+    Kd[KITEMS + e] = l;
+  }
+  for (int e = tid; e < VITEMS; e += NT) {
+    const int d = e >> 2, kg = e & 3;
+    const float* p = Vt + (size_t)d * L + 8 * kg;
+    const f32x4 v0 = *reinterpret_cast<const f32x4*>(p), v1 = *reinterpret_cast<const f32x4*>(p + 4);
+    u32x4 h, l;
+    unsigned a, c;
+    split2(v0[0], v0[1], a, c); h[0] = a; l[0] = c;
+    split2(v0[2], v0[3], a, c); h[1] = a; l[1] = c;
+    split2(v1[0], v1[1], a, c); h[2] = a; l[2] = c;
+    split2(v1[2], v1[3], a, c); h[3] = a; l[3] = c;
+    Vd[kg * E + d] = h;
+    Vd[VITEMS + kg * E + d] = l;
+  }
+}
+
+template <int ET, bool IMG>
+int launch_attn3h(float* out, const float* qkv, void* workspace, int B, int L, float scale, hipStream_t s) {
   constexpr int E = 32 * ET;
   const size_t lds = (size_t)2 * (2 * (E / 8) * KB + 2 * 4 * E) * 16;    // K and V, double-buffered
   if (lds > 48 * 1024) {
-    const int rc = ds::ensure_dynamic_lds<&k_attn3h<ET>>((int)lds, "hipFuncSetAttribute(attn3h)");
+    const int rc = ds::ensure_dynamic_lds<&k_attn3h<ET, IMG>>((int)lds, "hipFuncSetAttribute(attn3h)");
     if (rc != DS_OK) return rc;
+  }
+  u32x4* kimg = nullptr;
+  u32x4* vimg = nullptr;
+  if (IMG) {
+    kimg = reinterpret_cast<u32x4*>(workspace);
+    vimg = kimg + (size_t)B * L * (E / 4);                                // K images: B * (L/32) tiles * 8E vectors
+    hipLaunchKernelGGL((k_attn_images<ET>), dim3(L / KB, B), dim3(NT), 0, s, kimg, vimg, qkv, L);
+    DS_CHECK_LAUNCH("ds_attention_h3 (images)");
   }
   dim3 g((L + 127) / 128, B);
   static const float thr = [] { const char* e = getenv("DS_ATTN_T"); return e ? (float)atof(e) : RESCALE_T; }();   // diagnostic knob
-  hipLaunchKernelGGL((k_attn3h<ET>), g, dim3(NT), lds, s, out, qkv, L, scale, thr);
+  hipLaunchKernelGGL((k_attn3h<ET, IMG>), g, dim3(NT), lds, s, out, qkv, kimg, vimg, L, scale, thr);
   DS_CHECK_LAUNCH("ds_attention_h3");
   return DS_OK;
+}
+
+template <bool IMG>
+int attention_h3(float* out, const float* qkv, void* workspace, int B, int E, int L, void* stream) {
+  DS_REQUIRE(out && qkv, DS_ERR_NULL, "ds_attention_h3: NULL pointer");
+  DS_REQUIRE(B >= 0 && E > 0 && L > 0, DS_ERR_SHAPE, "ds_attention_h3: bad shape B=%d E=%d L=%d", B, E, L);
+  DS_REQUIRE(L % 32 == 0, DS_ERR_UNSUPPORTED, "ds_attention_h3: L=%d must be a multiple of 32", L);
+  DS_REQUIRE(B < 65536 && L / 32 < 65536 * 32, DS_ERR_SHAPE, "ds_attention_h3: B=%d exceeds grid.y", B);
+  DS_REQUIRE((reinterpret_cast<uintptr_t>(qkv) & 15u) == 0, DS_ERR_SHAPE, "ds_attention_h3: qkv must be 16-byte aligned");
+  DS_REQUIRE(!IMG || (workspace && (reinterpret_cast<uintptr_t>(workspace) & 15u) == 0), DS_ERR_NULL,
+             "ds_attention_h3_ws: a 16-byte aligned workspace of ds_attention_h3_workspace_bytes(B, E, L) bytes is required");
+  if (B == 0) return DS_OK;
+  const float scale = (float)sqrt(1.0 / (double)E);
+  hipStream_t s = ds::as_stream(stream);
+  switch (E) {
+    case 32: return launch_attn3h<1, IMG>(out, qkv, workspace, B, L, scale, s);
+    case 64: return launch_attn3h<2, IMG>(out, qkv, workspace, B, L, scale, s);
+    case 128: return launch_attn3h<4, IMG>(out, qkv, workspace, B, L, scale, s);
+    case 256: return launch_attn3h<8, IMG>(out, qkv, workspace, B, L, scale, s);
+    default:
+      ds::set_error("ds_attention_h3: E=%d unsupported (32, 64, 128, 256)", E);
+      return DS_ERR_UNSUPPORTED;
+  }
 }
 
 }  // namespace
 
 extern "C" int ds_attention_h3(float* out, const float* qkv, int B, int E, int L, void* stream) {
-  DS_REQUIRE(out && qkv, DS_ERR_NULL, "ds_attention_h3: NULL pointer");
-  DS_REQUIRE(B >= 0 && E > 0 && L > 0, DS_ERR_SHAPE, "ds_attention_h3: bad shape B=%d E=%d L=%d", B, E, L);
-  DS_REQUIRE(L % 32 == 0, DS_ERR_UNSUPPORTED, "ds_attention_h3: L=%d must be a multiple of 32", L);
-  DS_REQUIRE(B < 65536, DS_ERR_SHAPE, "ds_attention_h3: B=%d exceeds grid.y", B);
-  DS_REQUIRE((reinterpret_cast<uintptr_t>(qkv) & 15u) == 0, DS_ERR_SHAPE, "ds_attention_h3: qkv must be 16-byte aligned");
-  if (B == 0) return DS_OK;
-  const float scale = (float)sqrt(1.0 / (double)E);
-  hipStream_t s = ds::as_stream(stream);
-  switch (E) {
-    case 32: return launch_attn3h<1>(out, qkv, B, L, scale, s);
-    case 64: return launch_attn3h<2>(out, qkv, B, L, scale, s);
-    case 128: return launch_attn3h<4>(out, qkv, B, L, scale, s);
-    case 256: return launch_attn3h<8>(out, qkv, B, L, scale, s);
-    default:
-      ds::set_error("ds_attention_h3: E=%d unsupported (32, 64, 128, 256)", E);
-      return DS_ERR_UNSUPPORTED;
-  }
+  return attention_h3<false>(out, qkv, nullptr, B, E, L, stream);
+}
+
+extern "C" size_t ds_attention_h3_workspace_bytes(int B, int E, int L) {
+  if (B <= 0 || E <= 0 || L <= 0) return 0;
+  return (size_t)B * L * E * 8;                      // K and V images: 2 pieces x 2 bytes per element, each
+}
+
+extern "C" int ds_attention_h3_ws(float* out, const float* qkv, void* workspace, int B, int E, int L, void* stream) {
+  return attention_h3<true>(out, qkv, workspace, B, E, L, stream);
 }

@@ -568,8 +568,12 @@ class ADM(torch.nn.Module):
         L = Hh * Ww
         m = att.mhattn
         qkv = ops.conv(x, pk[(id(att), "in")], bias=m.in_proj_bias, out=ws.take((B, 3 * E, Hh, Ww), x.device))
+        nws = ops.attention_workspace_floats(B, E, L, self.conv_precision)
+        aws = ws.take((nws,), x.device) if nws else None
         o = ops.attention(qkv.view(B, 3 * E, L), E, out=ws.take((B, E, L), x.device),
-                          precision=self.conv_precision)
+                          precision=self.conv_precision, workspace=aws)
+        if aws is not None:
+            ws.give(aws)
         y = ops.conv(o.view(B, E, Hh, Ww), pk[(id(att), "out")], bias=m.out_proj.bias,
                      res1=x if self.config.attn_residual else None, tile_stats=tile_stats,
                      out=ws.take(x.shape, x.device))

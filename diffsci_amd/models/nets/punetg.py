@@ -828,8 +828,12 @@ class PUNetG(torch.nn.Module):
             # attention kernels scale by 1/sqrt(E), which the queries' gain cancels
             ops.token_l2_normalize(qkv.view(B, 3 * E, L), 0, E, eps=1e-8, gain=math.sqrt(E))
             ops.token_l2_normalize(qkv.view(B, 3 * E, L), E, E, eps=1e-8, gain=1.0)
+        nws = ops.attention_workspace_floats(B, E, L, self.conv_precision)
+        aws = ws.take((nws,), x.device) if nws else None
         o = ops.attention(qkv.view(B, 3 * E, L), E, out=ws.take((B, E, L), x.device),
-                          precision=self.conv_precision)
+                          precision=self.conv_precision, workspace=aws)
+        if aws is not None:
+            ws.give(aws)
         res1 = x if self.config.attn_residual else None
         y = ops.conv(o.view(B, E, Hh, Ww), pk[(id(att), "out")], bias=out_bias,
                      res1=res1, res2=res2, tile_stats=tile_stats, out=ws.take(x.shape, x.device))

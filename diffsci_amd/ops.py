@@ -659,9 +659,20 @@ def token_l2_normalize(x, c0, C, eps=1e-8, gain=1.0):
     return x
 
 
-def attention(qkv, E, out=None, precision="fp32"):
+ATTN_IMAGES_MIN_L = 512      # from this many tokens on the pre-split K / V images pay (a tile is split L/128 times without)
+
+
+def attention_workspace_floats(B, E, L, precision="fp16x3"):
+    """Floats of scratch attention() can use (0: none) -- for callers that keep buffers in a pool."""
+    if precision == "fp16x3" and E <= 256 and E in (32, 64, 128, 256) and L % 32 == 0 and L >= ATTN_IMAGES_MIN_L:
+        return N.lib().ds_attention_h3_workspace_bytes(B, E, L) // 4
+    return 0
+
+
+def attention(qkv, E, out=None, precision="fp32", workspace=None):
     """qkv [B, 3E, L] channel-major -> out [B, E, L].  precision "fp16x3": split-fp16 MFMA
-    (fp32-level accuracy, |operands| < 65504, E <= 256); anything else, or wider heads: exact-fp32 MFMA."""
+    (fp32-level accuracy, |operands| < 65504, E <= 256); anything else, or wider heads: exact-fp32 MFMA.
+    workspace: float tensor of attention_workspace_floats(...) elements; allocated here when needed and not given."""
     B, E3, L = qkv.shape
     if E3 != 3 * E:
         raise ValueError("qkv must be [B, 3E, L]")
@@ -669,6 +680,13 @@ def attention(qkv, E, out=None, precision="fp32"):
         out = torch.empty((B, E, L), dtype=torch.float32, device=qkv.device)
     if L % 32 != 0 or E not in (32, 64, 128, 256, 384, 512):
         N.check(N.lib().ds_attention_generic(_p(out), _p(qkv), B, E, L, _stream()), "ds_attention_generic")
+    elif precision == "fp16x3" and E <= 256 and L >= ATTN_IMAGES_MIN_L:
+        need = attention_workspace_floats(B, E, L)
+        if workspace is None:
+            workspace = torch.empty(need, dtype=torch.float32, device=qkv.device)
+        elif workspace.numel() < need:
+            raise ValueError("attention workspace too small")
+        N.check(N.lib().ds_attention_h3_ws(_p(out), _p(qkv), _p(workspace, "workspace"), B, E, L, _stream()), "ds_attention_h3_ws")
     elif precision == "fp16x3" and E <= 256:
         N.check(N.lib().ds_attention_h3(_p(out), _p(qkv), B, E, L, _stream()), "ds_attention_h3")
     else:

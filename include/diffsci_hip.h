@@ -307,6 +307,12 @@ int ds_token_l2_normalize(float* x, int B, int Ctot, int c0, int C, int L, float
  * ds_conv2d_h3 (operands split into fp16 hi + lo, three products, fp32 accumulation and fp32
  * softmax statistics): fp32-level accuracy for |q|, |k|, |v| < 65504. Same layouts; E <= 256. */
 int ds_attention_h3(float* out, const float* qkv, int B, int E, int L, void* stream);
+/* The same with a caller-provided workspace of ds_attention_h3_workspace_bytes(B, E, L) bytes (16-byte aligned): a
+ * pre-pass splits K and V once per sample into images that have the kernel's LDS layout, and the attention kernel
+ * stages its key tiles by LDS-DMA instead of re-splitting them in every 128-query workgroup -- the form for long
+ * sequences (L = 4096 tokens at a 64 x 64 bottleneck: every tile is otherwise split 32 times).  Same results bit for bit. */
+size_t ds_attention_h3_workspace_bytes(int B, int E, int L);
+int ds_attention_h3_ws(float* out, const float* qkv, void* workspace, int B, int E, int L, void* stream);
 
 /* y[m, n] = act(sum_k x[m,k]*w[n,k] + b[n]); act 0 none, 1 SiLU, 2 ReLU.  torch Linear layout.
  * ResnetTimeBlock (commonlayers.py:516-522) and MLPUncond (mlp.py:30-37). b may be NULL. */
