@@ -208,6 +208,94 @@ __global__ __launch_bounds__(NT) void k_attn3h(float* out, const float* __restri
                                        (__attribute__((address_space(3))) void*)(dst + 64 * k), 16, 0, 0);
     }
   };
+  // ---- the two matrix products and the softmax between them, shared by both staging forms ----
+  auto qk = [&](const u32x4* Ks) __attribute__((always_inline)) {                    // S^T[key][query]
+    f32x16 S;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) S[r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const f16x8 ah = as_f16x8(Ks[(2 * s + lh) * KB + li]);
+      const f16x8 al = as_f16x8(Ks[NDG * KB + (2 * s + lh) * KB + li]);
+      S = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, as_f16x8(qh[s]), S, 0, 0, 0);
+      S = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, as_f16x8(ql[s]), S, 0, 0, 0);
+      S = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, as_f16x8(qh[s]), S, 0, 0, 0);
+    }
+    return S;
+  };
+  if constexpr (IMG) {
+    // Software pipeline (one wave per SIMD: nothing else hides the softmax): iteration kb issues the matrix
+    // instructions of S(kb+1) and the vector instructions of softmax(S(kb)) as independent streams, then the O^T
+    // product of tile kb.  K therefore runs one tile ahead of V: K(kb+2) -> K buffer kb&1 (last read for S(kb) in
+    // iteration kb-1), V(kb+1) -> V buffer (kb+1)&1 (last read in iteration kb-1).
+    dma(Kbuf, kimg_b);
+    dma(Vbuf, vimg_b);
+    if (nkb > 1) dma(Kbuf + KVEC, kimg_b + KVEC);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    f32x16 S = qk(Kbuf);
+    for (int kb = 0; kb < nkb; ++kb) {
+      const u32x4* Vs = Vbuf + (kb & 1) * VVEC;
+      if (kb + 2 < nkb) dma(Kbuf + (kb & 1) * KVEC, kimg_b + (size_t)(kb + 2) * KVEC);
+      if (kb + 1 < nkb) dma(Vbuf + ((kb + 1) & 1) * VVEC, vimg_b + (size_t)(kb + 1) * VVEC);
+      f32x16 Sn;
+      if (kb + 1 < nkb) Sn = qk(Kbuf + ((kb + 1) & 1) * KVEC);       // matrix pipe: independent of everything below up to the O^T product
+      // ---- online softmax of tile kb (vector pipe) ----
+      float mx = S[0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) mx = fmaxf(mx, S[r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      if (__any(mx > m_run + thr)) {
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = expf(m_run - m_new);
+        l_run = l_run * alpha;
+        m_run = m_new;
+#pragma unroll
+        for (int t = 0; t < ET; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) O[t][r] *= alpha;
+      }
+      float rs = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        S[r] = expf(S[r] - m_run);
+        rs += S[r];
+      }
+      rs += __shfl_xor(rs, 32, 64);
+      l_run = l_run + rs;
+      u32x4 ph[2], pl[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        unsigned h[4], l[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) split2(S[8 * t + 2 * k], S[8 * t + 2 * k + 1], h[k], l[k]);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          u32x2 r = __builtin_amdgcn_permlane32_swap(h[k], h[2 + k], false, false);
+          h[k] = r[0]; h[2 + k] = r[1];
+          r = __builtin_amdgcn_permlane32_swap(l[k], l[2 + k], false, false);
+          l[k] = r[0]; l[2 + k] = r[1];
+        }
+        ph[t] = u32x4{h[0], h[1], h[2], h[3]};
+        pl[t] = u32x4{l[0], l[1], l[2], l[3]};
+      }
+#pragma unroll
+      for (int t = 0; t < ET; ++t) {
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl) {
+          const f16x8 vh = as_f16x8(Vs[(2 * sl + lh) * E + 32 * t + li]);
+          const f16x8 vl = as_f16x8(Vs[4 * E + (2 * sl + lh) * E + 32 * t + li]);
+          O[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, as_f16x8(ph[sl]), O[t], 0, 0, 0);
+          O[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, as_f16x8(pl[sl]), O[t], 0, 0, 0);
+          O[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, as_f16x8(ph[sl]), O[t], 0, 0, 0);
+        }
+        if ((t & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+      }
+      if (kb + 1 < nkb) S = Sn;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+  } else {
   if (IMG) {
     dma(Kbuf, kimg_b);
     dma(Vbuf, vimg_b);
@@ -317,6 +405,7 @@ __global__ __launch_bounds__(NT) void k_attn3h(float* out, const float* __restri
     if (IMG) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA pieces have landed ...
     __syncthreads();                                            // ... and so have everyone's
   }
+  }   // staging form
   if (active) {
     const float inv = 1.0f / l_run;
     float* ob = out + (size_t)b * E * L;

@@ -659,12 +659,22 @@ def token_l2_normalize(x, c0, C, eps=1e-8, gain=1.0):
     return x
 
 
-ATTN_IMAGES_MIN_L = 512      # from this many tokens on the pre-split K / V images pay (a tile is split L/128 times without)
+# Pre-split K / V images + LDS-DMA staging (ds_attention_h3_ws) against staging in every workgroup (ds_attention_h3),
+# measured on MI355X (tools/attn_time.py): E = 256: 332 vs 353 us at L = 1024 (B = 64), 975 vs 1181 us at L = 4096
+# (B = 16); E = 128 / 64 at L = 1024: 162 vs 160 / 91 vs 85 us.  A tile is re-split L/128 times without the images.
+ATTN_IMAGES_MIN_L = 2048     # any head width
+ATTN_IMAGES_MIN_L_WIDE = 1024    # E = 256
+
+
+def _attention_uses_images(E, L, precision):
+    if precision != "fp16x3" or E not in (32, 64, 128, 256) or L % 32:
+        return False
+    return L >= ATTN_IMAGES_MIN_L or (E == 256 and L >= ATTN_IMAGES_MIN_L_WIDE)
 
 
 def attention_workspace_floats(B, E, L, precision="fp16x3"):
     """Floats of scratch attention() can use (0: none) -- for callers that keep buffers in a pool."""
-    if precision == "fp16x3" and E <= 256 and E in (32, 64, 128, 256) and L % 32 == 0 and L >= ATTN_IMAGES_MIN_L:
+    if _attention_uses_images(E, L, precision):
         return N.lib().ds_attention_h3_workspace_bytes(B, E, L) // 4
     return 0
 
@@ -680,7 +690,7 @@ def attention(qkv, E, out=None, precision="fp32", workspace=None):
         out = torch.empty((B, E, L), dtype=torch.float32, device=qkv.device)
     if L % 32 != 0 or E not in (32, 64, 128, 256, 384, 512):
         N.check(N.lib().ds_attention_generic(_p(out), _p(qkv), B, E, L, _stream()), "ds_attention_generic")
-    elif precision == "fp16x3" and E <= 256 and L >= ATTN_IMAGES_MIN_L:
+    elif _attention_uses_images(E, L, precision):
         need = attention_workspace_floats(B, E, L)
         if workspace is None:
             workspace = torch.empty(need, dtype=torch.float32, device=qkv.device)

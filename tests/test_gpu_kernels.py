@@ -720,3 +720,25 @@ def test_conv_kernels_larger_than_3x3(dev, case):
     torch.testing.assert_close(mean, want.mean(dim=(2, 3)), rtol=1e-5, atol=1e-5)
     with pytest.raises(NotImplementedError, match="fp16x3 convolution only"):
         ops.pack_conv(w.to(dev), "bf16x6")
+
+
+@pytest.mark.parametrize("B,E,L", [(2, 256, 1024), (1, 64, 2048), (3, 32, 96), (2, 128, 160)])
+def test_attention_presplit_images_match_in_kernel_staging(dev, B, E, L):
+    """ds_attention_h3_ws (K / V split once per sample into LDS-layout images, tiles staged by LDS-DMA, S(k+1) issued
+    beside softmax(k)) computes exactly what ds_attention_h3 (every workgroup stages and splits its own tiles) does."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(B + E + L)
+    qkv = (torch.randn(B, 3 * E, L, generator=g) * 1.5).to(dev)
+    old = ops.ATTN_IMAGES_MIN_L, ops.ATTN_IMAGES_MIN_L_WIDE
+    try:
+        ops.ATTN_IMAGES_MIN_L = ops.ATTN_IMAGES_MIN_L_WIDE = 1 << 30
+        assert ops.attention_workspace_floats(B, E, L) == 0
+        a = ops.attention(qkv, E, precision="fp16x3")
+        ops.ATTN_IMAGES_MIN_L = ops.ATTN_IMAGES_MIN_L_WIDE = 0
+        assert ops.attention_workspace_floats(B, E, L) == 2 * B * E * L
+        b = ops.attention(qkv, E, precision="fp16x3")
+        with pytest.raises(ValueError, match="workspace too small"):
+            ops.attention(qkv, E, precision="fp16x3", workspace=torch.empty(16, device=dev))
+    finally:
+        ops.ATTN_IMAGES_MIN_L, ops.ATTN_IMAGES_MIN_L_WIDE = old
+    assert torch.equal(a, b)

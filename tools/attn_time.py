@@ -13,7 +13,7 @@ for (B, E, L) in [(64, 256, 1024), (16, 256, 4096), (64, 128, 1024), (64, 64, 10
     for name, min_l in (("staged", 1 << 30), ("images", 0)):
         if E > 256 and name == "images":
             continue
-        ops.ATTN_IMAGES_MIN_L = min_l
+        ops.ATTN_IMAGES_MIN_L = ops.ATTN_IMAGES_MIN_L_WIDE = min_l
         out = torch.empty(B, E, L, device=dev)
         nws = ops.attention_workspace_floats(B, E, L)
         ws = torch.empty(nws, device=dev) if nws else None
