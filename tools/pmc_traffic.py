@@ -25,7 +25,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("fetch")
     ap.add_argument("write")
-    ap.add_argument("--last", type=int, default=30)
+    ap.add_argument("--last", type=int, default=29)
     ap.add_argument("--write-json", action="store_true")
     a = ap.parse_args()
     f, nf, rows = last_sum(a.fetch, "FETCH_SIZE", a.last)
@@ -35,8 +35,8 @@ def main():
     write = w * 1024 / a.last
     print(f"fetch {fetch/1e6:.1f} MB + write {write/1e6:.1f} MB = {(fetch+write)/1e6:.1f} MB per launch over {a.last} launches")
     if a.write_json:
-        p = os.path.join(ROOT, "profiles", "r01_dominant_kernel_traffic.json")
-        j = json.load(open(p))
+        p = os.path.join(ROOT, "profiles", "r02_dominant_kernel_traffic.json")
+        j = json.load(open(p)) if os.path.exists(p) else json.load(open(os.path.join(ROOT, "profiles", "r01_dominant_kernel_traffic.json")))
         j.update(fetch_size_kib_sum=f, write_size_kib_sum=w, fetch_bytes_per_launch_corrected=int(fetch),
                  write_bytes_per_launch=int(write), hbm_bytes_per_launch=int(fetch + write), launches=a.last)
         json.dump(j, open(p, "w"), indent=1)
