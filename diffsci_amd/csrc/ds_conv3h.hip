@@ -86,9 +86,9 @@ struct Conv3hArgs {
   int B, Cin, Cout, H, W, Hin, Win;
   int tiles_x, tiles_y, n_cot, n_chunks;
   unsigned tiles_x_magic;   // floor(2^32 / tiles_x) + 1
-  unsigned stagger_lo, stagger_hi, stagger_ticks;   // workgroups with dispatch index in [lo, hi) start `ticks` x 10 ns late (see launch)
 #ifdef DS_STAMP
   unsigned long long* stamps;   // diagnostic build only (tools/conv3h_stamp.hip)
+  unsigned stagger_lo, stagger_hi, stagger_ticks;   // experiment: workgroups with dispatch index in [lo, hi) start `ticks` x 10 ns late
 #endif
 };
 
@@ -142,14 +142,16 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_conv3h(const Conv3hArgs a) 
     b_u = rest / ny;
   }
   STAMP_PLACE();
+#ifdef DS_STAMP
   if (a.stagger_ticks) {
-    // Phase offset between the two workgroups that share a CU (see launch_conv3h_c): speed only, never correctness.
+    // Experiment (profiles/r02_stamps_stagger.log: no effect): a phase offset between the two workgroups that share a CU.
     const unsigned id = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
     if (id >= a.stagger_lo && id < a.stagger_hi) {
       const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
       while (__builtin_amdgcn_s_memrealtime() - t0 < a.stagger_ticks) __builtin_amdgcn_s_sleep(8);
     }
   }
+#endif
   const int cot = (int)cot_u;
   const int tile_id = (int)tile_u;
   const int b = (int)b_u;
@@ -538,12 +540,14 @@ int ds_conv2d_h3(float* out, const float* in, const void* w_packed, int wshift, 
   a.n_cot = (Cout + COT - 1) / COT;
   a.n_chunks = (Cin + KC - 1) / KC;
   a.tiles_x_magic = a.tiles_x == 1 ? 0u : (unsigned)((1ull << 32) / (unsigned)a.tiles_x) + 1u;   // tiles_x = 1 is special-cased in the kernel
+#ifdef DS_STAMP
   {
-    // experiment knob: DS_CONV_STAGGER="ticks[,lo,hi]" (10 ns ticks; default range = the second resident workgroup of
-    // every CU under breadth-first dispatch: indices [256, 512))
+    // experiment knob of the stamp build: DS_CONV_STAGGER="ticks[,lo,hi]" (10 ns ticks; default range = the second resident
+    // workgroup of every CU under breadth-first dispatch: indices [256, 512))
     static const struct Stg { unsigned ticks = 0, lo = 256, hi = 512; Stg() { const char* e = getenv("DS_CONV_STAGGER"); if (e) sscanf(e, "%u,%u,%u", &ticks, &lo, &hi); } } stg;
     a.stagger_ticks = stg.ticks; a.stagger_lo = stg.lo; a.stagger_hi = stg.hi;
   }
+#endif
 #ifdef DS_STAMP
   a.stamps = g_stamps;
 #endif

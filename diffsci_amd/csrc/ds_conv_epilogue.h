@@ -64,14 +64,9 @@ __device__ __forceinline__ void store_tile(const f32x16 (&acc)[MT][2], float* ti
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
       const int co = 32 * m + (q & 3) + 8 * (q >> 2) + 4 * lh;
-      const float bv = bs[co], sv = bs[64 + co];
+      const float bsv = bs[co] + bs[64 + co];          // bias + shift, added once per channel (the kernel is vector-issue / power bound)
 #pragma unroll
-      for (int r = 0; r < 2; ++r) {
-        float v = acc[m][r][q] * e.unscale;
-        v = v + bv;
-        v = v + sv;
-        tile[(co * 2 + r) * 32 + li] = v;
-      }
+      for (int r = 0; r < 2; ++r) tile[(co * 2 + r) * 32 + li] = acc[m][r][q] * e.unscale + bsv;
     }
   // phase 2: 16 bytes per lane; lane -> (segment = 8*it + lane/8, quarter = lane%8)
   const int p4 = 4 * (lane & 7);
@@ -80,6 +75,13 @@ __device__ __forceinline__ void store_tile(const f32x16 (&acc)[MT][2], float* ti
   const size_t plane = (size_t)e.H * e.W;
   const bool stats = e.tile_stats != nullptr;
   if ((e.W & 3) == 0) {
+    // lane-constant parts of the 16 store instructions: segment 8*j + lane/8 -> channel 4*j + lane/16, row (lane/8)&1
+    const int r_lane = (lane >> 3) & 1;
+    const int gy_lane = e.y0 + (W16 ? 2 * r_lane + yq : r_lane);
+    const bool pix_ok = gy_lane < e.H && gx < e.W;
+    const size_t idx_lane = ((size_t)e.b * e.Cout + e.co_base + (lane >> 4)) * plane + (size_t)gy_lane * e.W + gx;
+    const size_t idx_step = 4 * plane;                 // four channels per instruction
+    const float cnt_row = stats ? row16_sum(pix_ok ? 4.f : 0.f) : 0.f;     // valid pixels of a channel in this wave: the same for every channel
     float sK[8 * MT], ssum[8 * MT], ssq[8 * MT], scnt[8 * MT];   // per (half, k): channel 4*(4*half+k) + lane/16, valid in every lane of the row
 #pragma unroll
     for (int half = 0; half < 2 * MT; ++half) {       // batches of 4 wave-instructions
@@ -88,11 +90,11 @@ __device__ __forceinline__ void store_tile(const f32x16 (&acc)[MT][2], float* ti
       bool ok[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const int seg = (half * 4 + k) * 8 + (lane >> 3);
-        const int co = seg >> 1, r = seg & 1;
-        const int gy = e.y0 + (W16 ? 2 * r + yq : r);
-        ok[k] = (e.co_base + co < e.Cout) && gy < e.H && gx < e.W;
-        idx[k] = ok[k] ? ((size_t)e.b * e.Cout + e.co_base + co) * plane + (size_t)gy * e.W + gx : (size_t)0;
+        const int j = half * 4 + k;
+        const int seg = j * 8 + (lane >> 3);
+        const int co = seg >> 1;
+        ok[k] = pix_ok && (e.co_base + co < e.Cout);
+        idx[k] = ok[k] ? idx_lane + (size_t)j * idx_step : (size_t)0;
         v[k] = *reinterpret_cast<const f32x4*>(&tile[seg * 32 + p4]);
       }
       if (e.res1) {
@@ -139,7 +141,7 @@ __device__ __forceinline__ void store_tile(const f32x16 (&acc)[MT][2], float* ti
           sK[half * 4 + k] = K;
           ssum[half * 4 + k] = row16_sum(sv);
           ssq[half * 4 + k] = row16_sum(qv);
-          scnt[half * 4 + k] = row16_sum(ok[k] ? 4.f : 0.f);
+          scnt[half * 4 + k] = (e.co_base + ((half * 4 + k) * 4 + (lane >> 4)) < e.Cout) ? cnt_row : 0.f;
         }
       }
     }
