@@ -63,10 +63,17 @@ template <bool W16> struct Geo {
   static constexpr int XBUF_VEC = 2 * 2 * NPOS;                      // 16-byte vectors per X buffer
 };
 constexpr int XBUF_VEC = Geo<false>::XBUF_VEC;              // LDS is sized for the larger geometry: 1360
+// 16x16x32 variant: the two 8-channel halves of a piece sit a multiple of 256 B apart (its operand reads put both
+// halves into one ds_read_b128 lane group): 12 pad vectors between them, 24 per X buffer
+constexpr int HPAD16 = 12;
+constexpr int XBUF_VEC16 = XBUF_VEC + 2 * HPAD16;
 constexpr int WSLAB_VEC = 2 * 3 * 2 * COT;                  // 16-byte vectors per (chunk, ky) slab: 768
 constexpr int WPIECES = WSLAB_VEC / 64;                     // LDS-DMA wave-instructions per slab: 12
 constexpr int STAGE_BYTES = (2 * XBUF_VEC + 3 * WSLAB_VEC) * 16;   // 80,384
 constexpr int LDS_BYTES = STAGE_BYTES + 128 * 4;              // + bias / shift of the channel tile = 80,896
+constexpr int STAGE_BYTES16 = (2 * XBUF_VEC16 + 3 * WSLAB_VEC) * 16;   // 81,152
+constexpr int LDS_BYTES16 = STAGE_BYTES16 + 128 * 4;                   // 81,664: two workgroups still fit 160 KiB
+static_assert(2 * LDS_BYTES16 <= 160 * 1024, "two workgroups per CU");
 
 struct Conv3hArgs {
   float* out;
@@ -101,16 +108,26 @@ template <int MT> struct Frags { f16x8 a[2][MT]; f16x8 b[2][2]; };   // [piece][
 //         the matrix pipe busy through its own loader / staging / barrier gaps (stamped: 43 % while its partner
 //         workgroup is in its prologue or epilogue, 91 % when both are in the main loop); with four waves per SIMD
 //         one of them almost always has MFMAs ready.  Costs: 1.5x the LDS operand reads per MFMA.
-template <int MODE, bool W16, bool PRE, bool CIRC, int NW>
+// S16 (NW = 4, an even number of 16-channel chunks): the same tiling on v_mfma_f32_16x16x32_f16 -- the chip holds a
+//         higher clock on that shape (tools/mfma_shape_bench.hip: +8-11 % FLOP/s in a bare loop).  K = 32 of one
+//         instruction = two TAPS x 16 channels: lane group g = l>>4 reads channels 8(g&1).. of tap g>>1, so the LDS images
+//         and the weight packing are unchanged.  The 18 taps of two chunks pair up as
+//           (0,0)+(0,1) | (0,2)+(1,0) | (1,1)+(1,2) | (2,0)+(2,1) | (2,2)+(0,0)' | (0,1)'+(0,2)' | (1,0)'+(1,1)' | (1,2)'+(2,0)' | (2,1)'+(2,2)'
+//         (' = the next chunk, whose patch and first weight slab are already resident when its (0,0) tap is consumed).
+template <int MODE, bool W16, bool PRE, bool CIRC, int NW, bool S16 = false>
 __global__ __launch_bounds__(64 * NW, NW / 2) void k_conv3h(const Conv3hArgs a) {
+  static_assert(!S16 || NW == 4, "the 16x16x32 variant is a four-wave kernel");
   constexpr int TH = Geo<W16>::TH, TW = Geo<W16>::TW, PW = Geo<W16>::PW, NPOS = Geo<W16>::NPOS;
   constexpr int NTH = 64 * NW;                                       // threads
   constexpr int MT = 8 / NW;                                         // 32-channel tiles per wave: 2 or 1
   constexpr int XI = (Geo<W16>::XITEMS + NTH - 1) / NTH;             // staging items per thread: 3 or 2
+  constexpr int HS = S16 ? NPOS + HPAD16 : NPOS;                     // vectors between the h = 0 and h = 1 images of a piece
+  constexpr int PS = S16 ? 2 * NPOS + HPAD16 : 2 * NPOS;             // ... between the two pieces
+  constexpr int XBV = S16 ? XBUF_VEC16 : XBUF_VEC;                   // ... between the two X buffers
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   u32x4* Xs = reinterpret_cast<u32x4*>(smem);                        // [buf][piece][h][pos]
-  u32x4* Ws = Xs + 2 * XBUF_VEC;                                     // [slot][piece][kx][h][co]
-  float* BS = reinterpret_cast<float*>(smem + STAGE_BYTES);           // [2][64] bias, shift
+  u32x4* Ws = Xs + 2 * XBV;                                          // [slot][piece][kx][h][co]
+  float* BS = reinterpret_cast<float*>(smem + (S16 ? STAGE_BYTES16 : STAGE_BYTES));   // [2][64] bias, shift
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -195,7 +212,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_conv3h(const Conv3hArgs a) 
     else if (MODE == DS_LOAD_MAXPOOL2) off = (2 * gy) * a.Win + 2 * gx;
     else off = (gy >> 1) * a.Win + (gx >> 1);
     xoff[i] = ok ? off : 0;
-    xlds[i] = h * NPOS + pos;
+    xlds[i] = h * HS + pos;
     if (ok) xvalid |= (1u << i);
     if (live) xlive |= (1u << i);
   }
@@ -248,7 +265,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_conv3h(const Conv3hArgs a) 
     for (int k = 0; k < 8; ++k) xr[i][k] = fast_silu((xr[i][k] - p[k][0]) * p[k][1] + p[k][2]);
   };
   auto x_store = [&](int buf) __attribute__((always_inline)) {                       // [normalise + SiLU,] split to fp16 pieces, write the LDS image
-    u32x4* xb = Xs + buf * XBUF_VEC;
+    u32x4* xb = Xs + buf * XBV;
     if (PRE) {
 #pragma unroll
       for (int i = 0; i < XI; ++i) x_activate(i);
@@ -268,7 +285,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_conv3h(const Conv3hArgs a) 
           qh[k] = ph; ql[k] = pl;
         }
         xb[xlds[i]] = qh;                // piece 0: [h][pos]
-        xb[2 * NPOS + xlds[i]] = ql;     // piece 1
+        xb[PS + xlds[i]] = ql;           // piece 1
       }
     }
   };
@@ -297,7 +314,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_conv3h(const Conv3hArgs a) 
   // operand fetch for (weight slot, X buffer, ky, kx)
   auto frag_load = [&](FragsT& f, int slot, int xbuf, int ky, int kx) __attribute__((always_inline)) {
     const u32x4* wb = Ws + slot * WSLAB_VEC;
-    const u32x4* xb = Xs + xbuf * XBUF_VEC;
+    const u32x4* xb = Xs + xbuf * XBV;
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
 #pragma unroll
@@ -305,7 +322,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_conv3h(const Conv3hArgs a) 
         f.a[p][m] = *reinterpret_cast<const f16x8*>(&wb[((p * 3 + kx) * 2 + lh) * COT + 32 * (m + mh) + li]);
 #pragma unroll
       for (int r = 0; r < 2; ++r)
-        f.b[p][r] = *reinterpret_cast<const f16x8*>(&xb[(p * 2 + lh) * NPOS + (wave_row + ROWS_PER_R * r + ky) * PW + lane_pos + kx]);
+        f.b[p][r] = *reinterpret_cast<const f16x8*>(&xb[p * PS + lh * HS + (wave_row + ROWS_PER_R * r + ky) * PW + lane_pos + kx]);
     }
   };
   auto frag_mma = [&](const FragsT& f) __attribute__((always_inline)) {              // lo*hi, hi*lo, hi*hi
@@ -341,6 +358,66 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_conv3h(const Conv3hArgs a) 
   STAMP(2);
   STAMP_CLK(6);
 
+  f32x4 acc16[4][4];                                   // S16: [16-channel tile][16-position tile]
+  if constexpr (S16) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc16[m][n][q] = 0.f;
+    const int i16 = lane & 15, h16 = (lane >> 4) & 1;
+    const bool tapB = lane >= 32;                        // lane groups 2, 3 read the pair's second tap
+    // lane part of the operand addresses: weights [piece][kx][h][co], input [piece][h][position]
+    const int wlane = h16 * COT + i16;
+    int xlane[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+      xlane[n] = h16 * HS + (wave_row + ROWS_PER_R * (n >> 1)) * PW + (W16 ? (n & 1) * PW + i16 : 16 * (n & 1) + i16);
+    struct F16 { f16x8 a[2][4]; f16x8 b[2][4]; };
+    // one K = 32 group: taps (slot, ky, kx, X buffer) A and B of the pair; every argument is a compile-time constant
+    auto pair = [&](int slotA, int kyA, int kxA, int xbA, int slotB, int kyB, int kxB, int xbB) __attribute__((always_inline)) {
+      const int wofs = (tapB ? slotB * WSLAB_VEC + kxB * 2 * COT : slotA * WSLAB_VEC + kxA * 2 * COT) + wlane;
+      const int xofs = tapB ? xbB * XBV + kyB * PW + kxB : xbA * XBV + kyA * PW + kxA;
+      F16 f;
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) f.a[p][m] = *reinterpret_cast<const f16x8*>(&Ws[wofs + p * 6 * COT + 16 * m]);
+#pragma unroll
+        for (int n = 0; n < 4; ++n) f.b[p][n] = *reinterpret_cast<const f16x8*>(&Xs[xofs + p * PS + xlane[n]]);
+      }
+      constexpr int PA[3] = {1, 0, 0};
+      constexpr int PB[3] = {0, 1, 0};
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int n = 0; n < 4; ++n)
+            acc16[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.a[PA[t]][m], f.b[PB[t]][n], acc16[m][n], 0, 0, 0);
+    };
+    // staging of a step (weights two steps ahead, the next patch at ky = 0 / 1), as in the 32x32x16 schedule
+    auto stage_in = [&](int chunk, int ky) __attribute__((always_inline)) {
+      const int g = chunk * 3 + ky;
+      if (g + 2 < n_steps) w_fetch(g + 2, (ky + 2) % 3);
+      if (ky == 0 && chunk + 1 < a.n_chunks) x_fetch(chunk + 1);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    auto stage_out = [&](int chunk, int ky, int xbuf) __attribute__((always_inline)) {
+      __builtin_amdgcn_sched_barrier(0);
+      if (ky == 1 && chunk + 1 < a.n_chunks) x_store(xbuf ^ 1);
+      __syncthreads();
+    };
+    for (int chunk = 0; chunk < a.n_chunks; chunk += 2) {          // n_chunks is even (checked by the launcher)
+      stage_in(chunk, 0);     pair(0, 0, 0, 0, 0, 0, 1, 0); pair(0, 0, 2, 0, 1, 1, 0, 0);   stage_out(chunk, 0, 0);
+      stage_in(chunk, 1);     pair(1, 1, 1, 0, 1, 1, 2, 0);                                 stage_out(chunk, 1, 0);
+      stage_in(chunk, 2);     pair(2, 2, 0, 0, 2, 2, 1, 0); pair(2, 2, 2, 0, 0, 0, 0, 1);   stage_out(chunk, 2, 0);
+      stage_in(chunk + 1, 0); pair(0, 0, 1, 1, 0, 0, 2, 1);                                 stage_out(chunk + 1, 0, 1);
+      stage_in(chunk + 1, 1); pair(1, 1, 0, 1, 1, 1, 1, 1); pair(1, 1, 2, 1, 2, 2, 0, 1);   stage_out(chunk + 1, 1, 1);
+      stage_in(chunk + 1, 2); pair(2, 2, 1, 1, 2, 2, 2, 1);                                 stage_out(chunk + 1, 2, 1);
+    }
+  } else {
   FragsT fA, fB;
   frag_load(fA, 0, 0, 0, 0);
 
@@ -391,6 +468,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_conv3h(const Conv3hArgs a) 
     step(fA, fB, chunk, 2, 0);
   }
 
+  }   // MFMA shape
   STAMP(3);
   STAMP_CLK(7);
   // ---- epilogue (ds_conv_epilogue.h): LDS transpose -> 16-byte stores.  The staging buffers are
@@ -404,7 +482,12 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_conv3h(const Conv3hArgs a) 
     e.tile_stats = a.tile_stats; e.tile = ty * a.tiles_x + tx; e.ntiles = a.tiles_x * a.tiles_y;
     constexpr int WTILE = 32 * MT * 2 * 32;                           // floats of the wave's private transpose region
     float* tile = reinterpret_cast<float*>(smem) + wv * WTILE;
-    ds_epi::store_tile<W16, MT>(acc, tile, BS + 32 * mh, e);
+    if constexpr (S16) {
+      ds_epi::store_tile16_phase1(acc16, tile, BS, e.unscale);
+      ds_epi::store_tile_rows<W16, 2>(tile, e);
+    } else {
+      ds_epi::store_tile<W16, MT>(acc, tile, BS + 32 * mh, e);
+    }
     if (a.tile_stats) {
       __syncthreads();
       e.co_base = cot * COT;
@@ -440,19 +523,28 @@ __global__ void k_pack3h(_Float16* packed, const float* __restrict__ w, int Cout
   packed[i] = piece == 0 ? hi : lo;
 }
 
-template <int MODE, bool W16, bool PRE, bool CIRC, int NW>
+template <int MODE, bool W16, bool PRE, bool CIRC, int NW, bool S16 = false>
 int launch_conv3h_w(const Conv3hArgs& a, hipStream_t s) {
+  constexpr int LDSB = S16 ? LDS_BYTES16 : LDS_BYTES;
   {
-    const int rc = ds::ensure_dynamic_lds<&k_conv3h<MODE, W16, PRE, CIRC, NW>>((int)(LDS_BYTES), "hipFuncSetAttribute(conv3h)");
+    const int rc = ds::ensure_dynamic_lds<&k_conv3h<MODE, W16, PRE, CIRC, NW, S16>>(LDSB, "hipFuncSetAttribute(conv3h)");
     if (rc != DS_OK) return rc;
   }
   const long long tiles = (long long)a.tiles_y * a.tiles_x;
   DS_REQUIRE(tiles > 0 && tiles < 65536 && a.B < 65536, DS_ERR_SHAPE,
              "ds_conv2d_h3: %lld pixel tiles x %d samples exceed the grid limits (65535 each)", tiles, a.B);
-  hipLaunchKernelGGL((k_conv3h<MODE, W16, PRE, CIRC, NW>), dim3((unsigned)a.n_cot, (unsigned)tiles, (unsigned)a.B), dim3(64 * NW),
-                     LDS_BYTES, s, a);
+  hipLaunchKernelGGL((k_conv3h<MODE, W16, PRE, CIRC, NW, S16>), dim3((unsigned)a.n_cot, (unsigned)tiles, (unsigned)a.B), dim3(64 * NW),
+                     LDSB, s, a);
   DS_CHECK_LAUNCH("ds_conv2d_h3");
   return DS_OK;
+}
+
+// MFMA shape: v_mfma_f32_16x16x32_f16 wherever the layer has an even number of 16-channel chunks (measured on MI355X,
+// profiles/r02_stamps_shape16.log: 190 -> 173 us at 256 channels, 236 -> 215 us at 128 channels with the fused loader;
+// bench.py 72.8 -> 76.7 samples/s), v_mfma_f32_32x32x16_f16 otherwise.  DS_CONV_SHAPE=32 forces the latter (A/B runs).
+inline bool conv3h_shape16() {
+  static const bool on = [] { const char* e = getenv("DS_CONV_SHAPE"); return !(e && atoi(e) == 32); }();
+  return on;
 }
 
 // Waves per workgroup.  Default: eight for the fused norm+SiLU loader (its staging VALU work spreads over twice the
@@ -465,6 +557,7 @@ inline int conv3h_waves(bool pre) {
 
 template <int MODE, bool W16, bool PRE, bool CIRC>
 int launch_conv3h_c(const Conv3hArgs& a, hipStream_t s) {
+  if (conv3h_shape16() && a.n_chunks % 2 == 0) return launch_conv3h_w<MODE, W16, PRE, CIRC, 4, true>(a, s);
   return conv3h_waves(PRE) == 8 ? launch_conv3h_w<MODE, W16, PRE, CIRC, 8>(a, s) : launch_conv3h_w<MODE, W16, PRE, CIRC, 4>(a, s);
 }
 

@@ -54,6 +54,10 @@ __device__ __forceinline__ float row16_first(float v) {
 // tile:  wave-private LDS scratch of 32*MT*2*32 floats (16 KiB for MT = 2), 16-byte aligned.
 // bs:    LDS array [2][64]: bias and shift of the workgroup's 64 channels (zeros where absent),
 //        written by the caller before the last barrier of the main loop.
+// Phase 2 of the epilogue, from a wave-private LDS tile laid out [co][row r][32 positions] (see store_tile).
+template <bool W16, int MT>
+__device__ __forceinline__ void store_tile_rows(float* tile, const Args& e);
+
 template <bool W16 = false, int MT = 2>
 __device__ __forceinline__ void store_tile(const f32x16 (&acc)[MT][2], float* tile, const float* bs, const Args& e) {
   const int lane = threadIdx.x & 63;
@@ -68,6 +72,28 @@ __device__ __forceinline__ void store_tile(const f32x16 (&acc)[MT][2], float* ti
 #pragma unroll
       for (int r = 0; r < 2; ++r) tile[(co * 2 + r) * 32 + li] = acc[m][r][q] * e.unscale + bsv;
     }
+  store_tile_rows<W16, MT>(tile, e);
+}
+
+// The same for the 16x16 accumulator tiles of v_mfma_f32_16x16x32_f16: acc[m][n], m = 16-channel tile, n = 16-position
+// tile (positions 16*(n&1) .. +15 of row r = n>>1); register q of lane l holds channel 16m + 4(l>>4) + q, position l&15.
+__device__ __forceinline__ void store_tile16_phase1(const f32x4 (&acc)[4][4], float* tile, const float* bs, float unscale) {
+  const int lane = threadIdx.x & 63;
+  const int i = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int co = 16 * m + 4 * g + q;
+      const float bsv = bs[co] + bs[64 + co];
+#pragma unroll
+      for (int n = 0; n < 4; ++n) tile[(co * 2 + (n >> 1)) * 32 + 16 * (n & 1) + i] = acc[m][n][q] * unscale + bsv;
+    }
+}
+
+template <bool W16, int MT>
+__device__ __forceinline__ void store_tile_rows(float* tile, const Args& e) {
+  const int lane = threadIdx.x & 63;
   // phase 2: 16 bytes per lane; lane -> (segment = 8*it + lane/8, quarter = lane%8)
   const int p4 = 4 * (lane & 7);
   const int gx = e.x0 + (W16 ? (p4 & 15) : p4);
