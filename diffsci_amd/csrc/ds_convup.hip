@@ -48,6 +48,14 @@ constexpr int EPI_BYTES = 4 * 64 * 2 * 32 * 4;                     // the epilog
 constexpr int MAIN_BYTES = STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES;
 constexpr int STAT_BYTES = 4 * 64 * 4 * 4;                         // per wave [64 co][K, S, Q, n]
 constexpr int LDS_BYTES = MAIN_BYTES + 128 * 4 + STAT_BYTES;       // 70,144
+// 16x16x32 variant (S16): K = 32 of one instruction = the step's two column taps x 16 channels, so a step is ONE group of
+// 48 MFMAs.  As in ds_conv3h.hip the two 8-channel halves of a piece must sit a multiple of 256 B apart (both land in one
+// ds_read_b128 lane group): 14 pad vectors after each 306-position image.
+constexpr int HS16 = 320;
+constexpr int XBUF_VEC16 = 2 * 2 * HS16;
+constexpr int STAGE_BYTES16 = (2 * XBUF_VEC16 + 3 * WSLAB_VEC) * 16;   // 65,536
+constexpr int LDS_BYTES16 = STAGE_BYTES16 + 128 * 4 + STAT_BYTES;      // 71,936
+static_assert(STAGE_BYTES16 >= EPI_BYTES && 2 * LDS_BYTES16 <= 160 * 1024, "two workgroups per CU");
 
 struct UpArgs {
   float* out;
@@ -74,6 +82,11 @@ struct Frags { f16x8 a[2][2]; f16x8 b[2][2]; };   // [piece][m] weights, [piece]
 //   W16 = false: (r, p) -> low-resolution row y0 + r,            output column 2*x0 + p        (p = 2*li + b < 64)
 //   W16 = true:            low-resolution row y0 + 2r + (p >> 5), output column 2*x0 + (p & 31)
 // Per-channel shifted statistics of the stored values go to stat[(32m + co)*4 .. +3] = (K, S, Q, n).
+//   SWZ (the 16x16x32 accumulators' phase 1): segments of channels with bit 2 set hold their two 32-float halves swapped, which
+//   spreads that layout's four 16-lane write groups over both halves of the banks.
+template <bool W16, bool SWZ>
+__device__ __forceinline__ void store_half_rows(int m, const float* tile, float* stat, const ds_epi::Args& e);
+
 template <bool W16>
 __device__ __forceinline__ void store_half(const f32x16 (&acc0)[2], const f32x16 (&acc1)[2], int m, float* tile,
                                            const float* bs, float* stat, const ds_epi::Args& e) {
@@ -92,6 +105,38 @@ __device__ __forceinline__ void store_half(const f32x16 (&acc0)[2], const f32x16
       *reinterpret_cast<f32x2_t*>(&tile[((co * 2 + r) * 32 + li) * 2]) = f32x2_t{v0, v1};
     }
   }
+  store_half_rows<W16, false>(m, tile, stat, e);
+}
+
+// The same for the 16x16x32 accumulators acc[column parity][m16 4][n 4]: lane l holds channels 16*m16 + 4*(l >> 4) + q of pixel
+// l & 15 of pixel group n, where n = (r, 16-pixel half of the 32-pixel segment) -- the 32x32 form's (r, li) with li = 16*(n & 1) + l%16.
+template <bool W16>
+__device__ __forceinline__ void store_half16(const f32x4 (&acc0)[4][4], const f32x4 (&acc1)[4][4], int m, float* tile,
+                                             const float* bs, float* stat, const ds_epi::Args& e) {
+  const int lane = threadIdx.x & 63;
+  const int l16 = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int co = 16 * mm + 4 * g + q;                             // within the half; (co >> 2) & 1 == g & 1
+      const float bv = bs[32 * m + co], sv = bs[64 + 32 * m + co];
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        float v0 = acc0[2 * m + mm][n][q] * e.unscale, v1 = acc1[2 * m + mm][n][q] * e.unscale;
+        v0 = v0 + bv; v1 = v1 + bv;
+        v0 = v0 + sv; v1 = v1 + sv;
+        const int li = (16 * (n & 1) + l16) ^ (16 * (g & 1));
+        typedef float f32x2_t __attribute__((ext_vector_type(2)));
+        *reinterpret_cast<f32x2_t*>(&tile[((co * 2 + (n >> 1)) * 32 + li) * 2]) = f32x2_t{v0, v1};
+      }
+    }
+  store_half_rows<W16, true>(m, tile, stat, e);
+}
+
+template <bool W16, bool SWZ>
+__device__ __forceinline__ void store_half_rows(int m, const float* tile, float* stat, const ds_epi::Args& e) {
+  const int lane = threadIdx.x & 63;
   // 16 lanes per (co, r) segment of 64 floats; lane -> (segment = 4*it + lane/16, vector = lane%16)
   const int vq = lane & 15;
   const int p4 = 4 * vq;
@@ -107,7 +152,7 @@ __device__ __forceinline__ void store_half(const f32x16 (&acc0)[2], const f32x16
     const int gy = 2 * gyl + e.pa;
     const bool ok = e.co_base + 32 * m + co < e.Cout;
     const size_t idx = ok ? ((size_t)e.b * e.Cout + e.co_base + 32 * m + co) * plane + (size_t)gy * e.W + gx : (size_t)0;
-    f32x4 v = *reinterpret_cast<const f32x4*>(&tile[seg * 64 + p4]);
+    f32x4 v = *reinterpret_cast<const f32x4*>(&tile[seg * 64 + (SWZ ? p4 ^ (32 * ((co >> 2) & 1)) : p4)]);
     if (e.res1) {
       if (e.res1_up) {                                              // [B, Cout, H/2, W/2]: two low-resolution columns
         const size_t lidx = ok ? (((size_t)e.b * e.Cout + e.co_base + 32 * m + co) * (e.H >> 1) + gyl) * (e.W >> 1) + (gx >> 1) : (size_t)0;
@@ -138,15 +183,17 @@ __device__ __forceinline__ void store_half(const f32x16 (&acc0)[2], const f32x16
   }
 }
 
-template <bool W16, bool PRE, bool CIRC>
+template <bool W16, bool PRE, bool CIRC, bool S16>
 __global__ __launch_bounds__(NT, 2) void k_convup(const UpArgs a) {
   constexpr int TH = Geo<W16>::TH, TW = Geo<W16>::TW, PW = Geo<W16>::PW, NPOS = Geo<W16>::NPOS;
   constexpr int XI = 3;
   static_assert(NPOS > NT && NPOS - NT <= NT / 2, "staging plan assumes 256 < NPOS <= 384");
+  constexpr int HS = S16 ? HS16 : NPOS;                              // vectors between the two channel halves of a piece
+  constexpr int XBV = S16 ? XBUF_VEC16 : XBUF_VEC;                   // ... between the two X buffers
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   u32x4* Xs = reinterpret_cast<u32x4*>(smem);                        // [buf][piece][h][pos]
-  u32x4* Ws = Xs + 2 * XBUF_VEC;                                     // [slot][piece][t][h][co]
-  float* BS = reinterpret_cast<float*>(smem + MAIN_BYTES);            // [2][64] bias, shift
+  u32x4* Ws = Xs + 2 * XBV;                                          // [slot][piece][t][h][co]
+  float* BS = reinterpret_cast<float*>(smem + (S16 ? STAGE_BYTES16 : MAIN_BYTES));   // [2][64] bias, shift
   float* ST = BS + 128;                                               // [4 waves][64 co][4]
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -199,7 +246,7 @@ __global__ __launch_bounds__(NT, 2) void k_convup(const UpArgs a) {
     }
     const bool ok = live && gy >= 0 && gy < a.Hl && gx >= 0 && gx < a.Wl;
     xoff[i] = ok ? gy * a.Wl + gx : 0;
-    xlds[i] = h * NPOS + pos;
+    xlds[i] = h * HS + pos;
     if (ok) xvalid |= (1u << i);
     if (live) xlive |= (1u << i);
   }
@@ -237,7 +284,7 @@ __global__ __launch_bounds__(NT, 2) void k_convup(const UpArgs a) {
     for (int k = 0; k < 8; ++k) xr[i][k] = fast_silu((xr[i][k] - p[k][0]) * p[k][1] + p[k][2]);
   };
   auto x_store = [&](int buf) __attribute__((always_inline)) {
-    u32x4* xb = Xs + buf * XBUF_VEC;
+    u32x4* xb = Xs + buf * XBV;
     if (PRE) { x_activate(0); x_activate(1); x_activate(2); }
 #pragma unroll
     for (int i = 0; i < XI; ++i) {
@@ -254,7 +301,7 @@ __global__ __launch_bounds__(NT, 2) void k_convup(const UpArgs a) {
           qh[k] = ph; ql[k] = pl;
         }
         xb[xlds[i]] = qh;
-        xb[2 * NPOS + xlds[i]] = ql;
+        xb[2 * HS + xlds[i]] = ql;
       }
     }
   };
@@ -270,6 +317,82 @@ __global__ __launch_bounds__(NT, 2) void k_convup(const UpArgs a) {
     }
   };
 
+  // ---- prologue: patch 0, weight slabs 0 and 1 ----
+  ds_epi::load_bias_shift(BS, a.bias, a.shift, a.shift_stride, b, cot * COT, a.Cout);
+  x_fetch(0);
+  w_fetch(0, 0);
+  w_fetch(1, 1);                                                 // n_steps >= 4 always
+  x_store(0);
+  __syncthreads();
+
+  ds_epi::Args e;
+  e.out = a.out; e.bias = a.bias; e.shift = a.shift; e.res1 = a.res1; e.res2 = a.res2; e.res1_up = a.res1_up;
+  e.unscale = a.unscale; e.shift_stride = a.shift_stride;
+  e.b = b; e.co_base = cot * COT; e.y0 = y0 + wave_row; e.x0 = x0;
+  e.Cout = a.Cout; e.H = 2 * a.Hl; e.W = 2 * a.Wl;
+  e.pa = pa; e.pb = 0;
+  // statistics: this workgroup covers the two column-parity "tiles" of its row parity; all 512 pixels are
+  // accounted in the first entry, the second one is empty
+  e.tile_stats = a.tile_stats; e.tile = (ty * a.tiles_x + tx) * 4 + pa * 2; e.ntiles = a.tiles_x * a.tiles_y * 4;
+  float* tile = reinterpret_cast<float*>(smem) + wv * (64 * 2 * 32);
+  float* stat = ST + wv * 256;
+
+  if constexpr (S16) {
+    f32x4 acc16[2][4][4];                                          // [column parity b][m16][n]
+#pragma unroll
+    for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc16[pb][m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // lane group g = lane / 16: channel half g & 1 of column tap g >> 1
+    const int l16 = lane & 15, gh = (lane >> 4) & 1, gt = lane >> 5;
+    const int wlane = (gt * 2 + gh) * COT + l16;
+    int xlane[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+      xlane[n] = gh * HS + (wave_row + (W16 ? 2 * (n >> 1) + (n & 1) : (n >> 1))) * PW + (W16 ? 0 : 16 * (n & 1)) + l16 + gt;
+    auto step16 = [&](int chunk, int k, int slot) __attribute__((always_inline)) {
+      const int g = chunk * 4 + k;
+      const int s = k >> 1, pb = k & 1;
+      const int xbuf = chunk & 1;
+      if (g + 2 < n_steps) w_fetch(g + 2, slot >= 1 ? slot - 1 : 2);      // (slot + 2) % 3
+      if (k == 0 && chunk + 1 < a.n_chunks) x_fetch(chunk + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      const int wofs = slot * WSLAB_VEC + wlane;
+      const int xofs = xbuf * XBV + s * PW + pb;
+      f16x8 fa[2][4], fb[2][4];
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) fa[p][m] = *reinterpret_cast<const f16x8*>(&Ws[wofs + p * 4 * COT + 16 * m]);
+#pragma unroll
+        for (int n = 0; n < 4; ++n) fb[p][n] = *reinterpret_cast<const f16x8*>(&Xs[xofs + p * 2 * HS + xlane[n]]);
+      }
+      constexpr int PA[3] = {1, 0, 0};
+      constexpr int PB[3] = {0, 1, 0};
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int n = 0; n < 4; ++n)
+            acc16[pb][m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[PA[t]][m], fb[PB[t]][n], acc16[pb][m][n], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (k == 2 && chunk + 1 < a.n_chunks) x_store(xbuf ^ 1);            // published by this step's barrier
+      __syncthreads();
+    };
+    int chunk = 0;
+    for (; chunk + 2 < a.n_chunks; chunk += 3) {
+      step16(chunk, 0, 0); step16(chunk, 1, 1); step16(chunk, 2, 2); step16(chunk, 3, 0);
+      step16(chunk + 1, 0, 1); step16(chunk + 1, 1, 2); step16(chunk + 1, 2, 0); step16(chunk + 1, 3, 1);
+      step16(chunk + 2, 0, 2); step16(chunk + 2, 1, 0); step16(chunk + 2, 2, 1); step16(chunk + 2, 3, 2);
+    }
+    if (chunk < a.n_chunks) { step16(chunk, 0, 0); step16(chunk, 1, 1); step16(chunk, 2, 2); step16(chunk, 3, 0); ++chunk; }
+    if (chunk < a.n_chunks) { step16(chunk, 0, 1); step16(chunk, 1, 2); step16(chunk, 2, 0); step16(chunk, 3, 1); }
+    store_half16<W16>(acc16[0], acc16[1], 0, tile, BS, stat, e);
+    store_half16<W16>(acc16[0], acc16[1], 1, tile, BS, stat, e);
+  } else {
   f32x16 acc[2][2][2];                                             // [column parity b][m][r]
 #pragma unroll
   for (int pb = 0; pb < 2; ++pb)
@@ -314,14 +437,6 @@ __global__ __launch_bounds__(NT, 2) void k_convup(const UpArgs a) {
     __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
   };
 
-  // ---- prologue: patch 0, weight slabs 0 and 1 ----
-  ds_epi::load_bias_shift(BS, a.bias, a.shift, a.shift_stride, b, cot * COT, a.Cout);
-  x_fetch(0);
-  w_fetch(0, 0);
-  w_fetch(1, 1);                                                 // n_steps >= 4 always
-  x_store(0);
-  __syncthreads();
-
   Frags fA, fB;
   frag_load(fA, 0, 0, 0, 0, 0);
 
@@ -360,20 +475,10 @@ __global__ __launch_bounds__(NT, 2) void k_convup(const UpArgs a) {
   if (chunk < a.n_chunks) { step(chunk, 0, 0); step(chunk, 1, 1); step(chunk, 2, 2); step(chunk, 3, 0); ++chunk; }
   if (chunk < a.n_chunks) { step(chunk, 0, 1); step(chunk, 1, 2); step(chunk, 2, 0); step(chunk, 3, 1); }
 
-  {
-    ds_epi::Args e;
-    e.out = a.out; e.bias = a.bias; e.shift = a.shift; e.res1 = a.res1; e.res2 = a.res2; e.res1_up = a.res1_up;
-    e.unscale = a.unscale; e.shift_stride = a.shift_stride;
-    e.b = b; e.co_base = cot * COT; e.y0 = y0 + wave_row; e.x0 = x0;
-    e.Cout = a.Cout; e.H = 2 * a.Hl; e.W = 2 * a.Wl;
-    e.pa = pa; e.pb = 0;
-    // statistics: this workgroup covers the two column-parity "tiles" of its row parity; all 512 pixels are
-    // accounted in the first entry, the second one is empty
-    e.tile_stats = a.tile_stats; e.tile = (ty * a.tiles_x + tx) * 4 + pa * 2; e.ntiles = a.tiles_x * a.tiles_y * 4;
-    float* tile = reinterpret_cast<float*>(smem) + wv * (64 * 2 * 32);
-    float* stat = ST + wv * 256;
     store_half<W16>(acc[0][0], acc[1][0], 0, tile, BS, stat, e);
     store_half<W16>(acc[0][1], acc[1][1], 1, tile, BS, stat, e);
+  }
+  {
     if (a.tile_stats) {
       __syncthreads();
       ds_epi::store_tile_stats(ST, 256, e);
@@ -418,19 +523,31 @@ __global__ void k_pack_up(_Float16* packed, const float* __restrict__ w, int Cou
   packed[i] = piece == 0 ? hi : lo;
 }
 
-template <bool W16, bool PRE, bool CIRC>
-int launch_up(const UpArgs& a, hipStream_t s) {
+// DS_CONV_SHAPE=32 keeps the 32x32x16 form (A/B measurements); default: 16x16x32
+bool up_shape16() {
+  static const bool v = [] { const char* e = getenv("DS_CONV_SHAPE"); return !(e && atoi(e) == 32); }();
+  return v;
+}
+
+template <bool W16, bool PRE, bool CIRC, bool S16>
+int launch_up_shape(const UpArgs& a, hipStream_t s) {
+  constexpr int LDS = S16 ? LDS_BYTES16 : LDS_BYTES;
   {
-    const int rc = ds::ensure_dynamic_lds<&k_convup<W16, PRE, CIRC>>((int)(LDS_BYTES), "hipFuncSetAttribute(convup)");
+    const int rc = ds::ensure_dynamic_lds<&k_convup<W16, PRE, CIRC, S16>>(LDS, "hipFuncSetAttribute(convup)");
     if (rc != DS_OK) return rc;
   }
   const long long tiles = (long long)a.tiles_y * a.tiles_x;
   DS_REQUIRE(tiles > 0 && tiles < 65536 && a.B < 65536, DS_ERR_SHAPE,
              "ds_conv2d_h3_up: %lld pixel tiles x %d samples exceed the grid limits (65535 each)", tiles, a.B);
-  hipLaunchKernelGGL((k_convup<W16, PRE, CIRC>), dim3((unsigned)a.n_cot * 2u, (unsigned)tiles, (unsigned)a.B), dim3(NT),
-                     LDS_BYTES, s, a);
+  hipLaunchKernelGGL((k_convup<W16, PRE, CIRC, S16>), dim3((unsigned)a.n_cot * 2u, (unsigned)tiles, (unsigned)a.B), dim3(NT),
+                     LDS, s, a);
   DS_CHECK_LAUNCH("ds_conv2d_h3_up");
   return DS_OK;
+}
+
+template <bool W16, bool PRE, bool CIRC>
+int launch_up(const UpArgs& a, hipStream_t s) {
+  return up_shape16() ? launch_up_shape<W16, PRE, CIRC, true>(a, s) : launch_up_shape<W16, PRE, CIRC, false>(a, s);
 }
 
 // 0: unsupported, 1: 8 x 32 tiles, 2: 16 x 16 tiles
