@@ -187,13 +187,14 @@ __global__ __launch_bounds__(NT, 2) void k_conv1h(const Conv1hArgs a) {
 
   float R0[KC], R1[KC];
   u32x4 W0, W1;
-  ds_epi::load_bias_shift(BS, a.bias, a.shift, a.shift_stride, b, cot * COT, a.Cout);
+  const float bias_shift = ds_epi::fetch_bias_shift(a.bias, a.shift, a.shift_stride, b, cot * COT, a.Cout);
   w_fetch(W0, 0);
   x_fetch(R0, 0);
   w_fetch(W1, n > 1 ? 1 : 0);
   x_fetch(R1, n > 1 ? 1 : 0);
   w_store(W0, 0);
   x_store(R0, 0);
+  ds_epi::commit_bias_shift(BS, bias_shift);
   __syncthreads();
 
   // chunk k: fetched into R[k & 1] at step k-2, split into image k % 3 at step k-1, used at step k

@@ -348,12 +348,13 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_conv3h(const Conv3hArgs a) 
   };
 
   // ---- prologue: patch 0, weight slabs 0 and 1 ----
-  ds_epi::load_bias_shift(BS, a.bias, a.shift, a.shift_stride, b, cot * COT, a.Cout);
   x_fetch(0);
+  const float bias_shift = ds_epi::fetch_bias_shift(a.bias, a.shift, a.shift_stride, b, cot * COT, a.Cout);
   w_fetch(0, 0);
   if (n_steps > 1) w_fetch(1, 1);
   STAMP(1);
   x_store(0);
+  ds_epi::commit_bias_shift(BS, bias_shift);
   __syncthreads();
   STAMP(2);
   STAMP_CLK(6);
@@ -483,8 +484,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_conv3h(const Conv3hArgs a) 
     constexpr int WTILE = 32 * MT * 2 * 32;                           // floats of the wave's private transpose region
     float* tile = reinterpret_cast<float*>(smem) + wv * WTILE;
     if constexpr (S16) {
-      ds_epi::store_tile16_phase1(acc16, tile, BS, e.unscale);
-      ds_epi::store_tile_rows<W16, 2>(tile, e);
+      ds_epi::store_tile16<W16>(acc16, tile, BS, e);
     } else {
       ds_epi::store_tile<W16, MT>(acc, tile, BS + 32 * mh, e);
     }

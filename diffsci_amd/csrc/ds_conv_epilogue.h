@@ -55,13 +55,66 @@ __device__ __forceinline__ float row16_first(float v) {
 // bs:    LDS array [2][64]: bias and shift of the workgroup's 64 channels (zeros where absent),
 //        written by the caller before the last barrier of the main loop.
 // Phase 2 of the epilogue, from a wave-private LDS tile laid out [co][row r][32 positions] (see store_tile).
+// The residual vectors of phase 2, loaded BEFORE phase 1 so that their latency hides behind the transposition (loaded inside
+// the row loop they cost one to two serial memory round trips per batch of four store instructions: a level-0 launch with a
+// residual took 284 us against 261 us without).  Whole-tile kernels only (MT = 2): 64 registers per residual.
+template <int MT> struct Residuals {
+  f32x4 r1[8 * MT], r2[8 * MT];          // res1_up: .xy = the two low-resolution columns
+};
+template <> struct Residuals<0> {};
+
+// lane-constant parts of phase 2's 16 store instructions: segment 8*j + lane/8 -> channel 4*j + lane/16, row (lane/8) & 1
+template <bool W16> struct RowPlan {
+  int p4, gx, yq, gy_lane;
+  bool pix_ok;
+  size_t idx_lane, idx_step;
+  __device__ __forceinline__ RowPlan(const Args& e) {
+    const int lane = threadIdx.x & 63;
+    p4 = 4 * (lane & 7);
+    gx = e.x0 + (W16 ? (p4 & 15) : p4);
+    yq = W16 ? (p4 >> 4) : 0;
+    const int r_lane = (lane >> 3) & 1;
+    gy_lane = e.y0 + (W16 ? 2 * r_lane + yq : r_lane);
+    pix_ok = gy_lane < e.H && gx < e.W;
+    const size_t plane = (size_t)e.H * e.W;
+    idx_lane = ((size_t)e.b * e.Cout + e.co_base + (lane >> 4)) * plane + (size_t)gy_lane * e.W + gx;
+    idx_step = 4 * plane;                 // four channels per instruction
+  }
+};
+
 template <bool W16, int MT>
-__device__ __forceinline__ void store_tile_rows(float* tile, const Args& e);
+__device__ __forceinline__ void load_residuals(Residuals<MT>& R, const Args& e) {
+  if ((e.W & 3) != 0 || (!e.res1 && !e.res2)) return;
+  const int lane = threadIdx.x & 63;
+  const RowPlan<W16> rp(e);
+#pragma unroll
+  for (int j = 0; j < 8 * MT; ++j) {
+    const bool ok = rp.pix_ok && (e.co_base + 4 * j + (lane >> 4) < e.Cout);
+    const size_t idx = ok ? rp.idx_lane + (size_t)j * rp.idx_step : (size_t)0;
+    if (e.res1) {
+      if (e.res1_up) {                              // 4 output columns = 2 low-resolution columns
+        const size_t lidx = ok ? (((size_t)e.b * e.Cout + e.co_base + 4 * j + (lane >> 4)) * (e.H >> 1) + (rp.gy_lane >> 1)) * (e.W >> 1) + (rp.gx >> 1) : (size_t)0;
+        typedef float f32x2_t __attribute__((ext_vector_type(2)));
+        const f32x2_t lo = *reinterpret_cast<const f32x2_t*>(e.res1 + lidx);
+        R.r1[j] = f32x4{lo[0], lo[1], 0.f, 0.f};
+      } else {
+        R.r1[j] = *reinterpret_cast<const f32x4*>(e.res1 + idx);
+      }
+    }
+    if (e.res2) R.r2[j] = *reinterpret_cast<const f32x4*>(e.res2 + idx);
+  }
+}
+
+template <bool W16, int MT, bool PREFETCHED>
+__device__ __forceinline__ void store_tile_rows(float* tile, const Args& e, const Residuals<PREFETCHED ? MT : 0>& R);
 
 template <bool W16 = false, int MT = 2>
 __device__ __forceinline__ void store_tile(const f32x16 (&acc)[MT][2], float* tile, const float* bs, const Args& e) {
   const int lane = threadIdx.x & 63;
   const int li = lane & 31, lh = lane >> 5;
+  constexpr bool PF = MT == 2;
+  Residuals<PF ? MT : 0> R;
+  if constexpr (PF) load_residuals<W16, MT>(R, e);
   // phase 1: accumulator layout -> [co][row][x]
 #pragma unroll
   for (int m = 0; m < MT; ++m)
@@ -72,14 +125,18 @@ __device__ __forceinline__ void store_tile(const f32x16 (&acc)[MT][2], float* ti
 #pragma unroll
       for (int r = 0; r < 2; ++r) tile[(co * 2 + r) * 32 + li] = acc[m][r][q] * e.unscale + bsv;
     }
-  store_tile_rows<W16, MT>(tile, e);
+  store_tile_rows<W16, MT, PF>(tile, e, R);
 }
 
 // The same for the 16x16 accumulator tiles of v_mfma_f32_16x16x32_f16: acc[m][n], m = 16-channel tile, n = 16-position
 // tile (positions 16*(n&1) .. +15 of row r = n>>1); register q of lane l holds channel 16m + 4(l>>4) + q, position l&15.
-__device__ __forceinline__ void store_tile16_phase1(const f32x4 (&acc)[4][4], float* tile, const float* bs, float unscale) {
+template <bool W16>
+__device__ __forceinline__ void store_tile16(const f32x4 (&acc)[4][4], float* tile, const float* bs, const Args& e) {
   const int lane = threadIdx.x & 63;
   const int i = lane & 15, g = lane >> 4;
+  const float unscale = e.unscale;
+  Residuals<2> R;
+  load_residuals<W16, 2>(R, e);
 #pragma unroll
   for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -89,24 +146,20 @@ __device__ __forceinline__ void store_tile16_phase1(const f32x4 (&acc)[4][4], fl
 #pragma unroll
       for (int n = 0; n < 4; ++n) tile[(co * 2 + (n >> 1)) * 32 + 16 * (n & 1) + i] = acc[m][n][q] * unscale + bsv;
     }
+  store_tile_rows<W16, 2, true>(tile, e, R);
 }
 
-template <bool W16, int MT>
-__device__ __forceinline__ void store_tile_rows(float* tile, const Args& e) {
+template <bool W16, int MT, bool PREFETCHED>
+__device__ __forceinline__ void store_tile_rows(float* tile, const Args& e, const Residuals<PREFETCHED ? MT : 0>& R) {
   const int lane = threadIdx.x & 63;
   // phase 2: 16 bytes per lane; lane -> (segment = 8*it + lane/8, quarter = lane%8)
-  const int p4 = 4 * (lane & 7);
-  const int gx = e.x0 + (W16 ? (p4 & 15) : p4);
-  const int yq = W16 ? (p4 >> 4) : 0;
+  const RowPlan<W16> rp(e);
+  const int p4 = rp.p4, gx = rp.gx, yq = rp.yq;
   const size_t plane = (size_t)e.H * e.W;
   const bool stats = e.tile_stats != nullptr;
   if ((e.W & 3) == 0) {
-    // lane-constant parts of the 16 store instructions: segment 8*j + lane/8 -> channel 4*j + lane/16, row (lane/8)&1
-    const int r_lane = (lane >> 3) & 1;
-    const int gy_lane = e.y0 + (W16 ? 2 * r_lane + yq : r_lane);
-    const bool pix_ok = gy_lane < e.H && gx < e.W;
-    const size_t idx_lane = ((size_t)e.b * e.Cout + e.co_base + (lane >> 4)) * plane + (size_t)gy_lane * e.W + gx;
-    const size_t idx_step = 4 * plane;                 // four channels per instruction
+    const bool pix_ok = rp.pix_ok;
+    const size_t idx_lane = rp.idx_lane, idx_step = rp.idx_step;
     const float cnt_row = stats ? row16_sum(pix_ok ? 4.f : 0.f) : 0.f;     // valid pixels of a channel in this wave: the same for every channel
     float sK[8 * MT], ssum[8 * MT], ssq[8 * MT], scnt[8 * MT];   // per (half, k): channel 4*(4*half+k) + lane/16, valid in every lane of the row
 #pragma unroll
@@ -123,6 +176,21 @@ __device__ __forceinline__ void store_tile_rows(float* tile, const Args& e) {
         idx[k] = ok[k] ? idx_lane + (size_t)j * idx_step : (size_t)0;
         v[k] = *reinterpret_cast<const f32x4*>(&tile[seg * 32 + p4]);
       }
+      if constexpr (PREFETCHED) {
+        if (e.res1) {
+          if (e.res1_up) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const f32x4 lo = R.r1[half * 4 + k]; r1[k] = f32x4{lo[0], lo[0], lo[1], lo[1]}; }
+          } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) r1[k] = R.r1[half * 4 + k];
+          }
+        }
+        if (e.res2) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) r2[k] = R.r2[half * 4 + k];
+        }
+      } else {
       if (e.res1) {
         if (e.res1_up) {                              // 4 output columns = 2 low-resolution columns
 #pragma unroll
@@ -143,6 +211,7 @@ __device__ __forceinline__ void store_tile_rows(float* tile, const Args& e) {
       if (e.res2) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) r2[k] = *reinterpret_cast<const f32x4*>(e.res2 + idx[k]);
+      }
       }
       if (e.res1) {
 #pragma unroll
@@ -235,19 +304,22 @@ __device__ __forceinline__ void store_tile_stats(const float* tiles, int wave_st
   }
 }
 
-// Fill bs[0..63] = bias (or 0), bs[64..127] = shift row (or 0) for the workgroup's channel tile.
-__device__ __forceinline__ void load_bias_shift(float* bs, const float* bias, const float* shift, int shift_stride,
-                                                int b, int co_base, int Cout) {
+// bs[0..63] = bias (or 0), bs[64..127] = shift row (or 0) for the workgroup's channel tile, in two halves so that the load
+// rides behind the first patch's loads instead of in front of them (a load + wait + LDS store at the top of the kernel put one
+// more memory round trip into every workgroup's prologue: 2.8 us before the patch loads were even issued at level 0).
+__device__ __forceinline__ float fetch_bias_shift(const float* bias, const float* shift, int shift_stride, int b, int co_base,
+                                                   int Cout) {
   const int t = threadIdx.x;
-  if (t < 128) {
-    const int co = co_base + (t & 63);
-    float v = 0.f;
-    if (co < Cout) {
-      if (t < 64) v = bias ? bias[co] : 0.f;
-      else v = shift ? shift[(size_t)b * shift_stride + co] : 0.f;
-    }
-    bs[t] = v;
+  const int co = co_base + (t & 63);
+  float v = 0.f;
+  if (t < 128 && co < Cout) {
+    if (t < 64) v = bias ? bias[co] : 0.f;
+    else v = shift ? shift[(size_t)b * shift_stride + co] : 0.f;
   }
+  return v;
+}
+__device__ __forceinline__ void commit_bias_shift(float* bs, float v) {
+  if (threadIdx.x < 128) bs[threadIdx.x] = v;
 }
 
 }  // namespace ds_epi

@@ -318,11 +318,12 @@ __global__ __launch_bounds__(NT, 2) void k_convup(const UpArgs a) {
   };
 
   // ---- prologue: patch 0, weight slabs 0 and 1 ----
-  ds_epi::load_bias_shift(BS, a.bias, a.shift, a.shift_stride, b, cot * COT, a.Cout);
   x_fetch(0);
+  const float bias_shift = ds_epi::fetch_bias_shift(a.bias, a.shift, a.shift_stride, b, cot * COT, a.Cout);
   w_fetch(0, 0);
   w_fetch(1, 1);                                                 // n_steps >= 4 always
   x_store(0);
+  ds_epi::commit_bias_shift(BS, bias_shift);
   __syncthreads();
 
   ds_epi::Args e;
