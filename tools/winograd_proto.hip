@@ -34,44 +34,50 @@ constexpr int NT = 512, KC = 16, COT = 64;
 constexpr int PR = 18;                         // patch rows / columns
 constexpr int PC2 = 10;                        // columns per parity (9 used): two patch rows = 640 B = 128 mod 256
 constexpr int CG_VEC = PR * 2 * PC2;           // 16-byte vectors per 4-channel group: 360
-constexpr int PATCH_VEC = 4 * CG_VEC;          // 1440 (23,040 B)
-constexpr int ESTRIDE = 72;                    // epilogue exchange: [p 16][co 8][72 (64 tiles used)] floats
-constexpr int EPI_BYTES = 16 * 8 * ESTRIDE * 4;   // 36,864
-constexpr int LDS_BYTES = 2 * PATCH_VEC * 16;     // 46,080
-static_assert(EPI_BYTES <= LDS_BYTES, "epilogue aliases the patch buffers");
+constexpr int PATCH_USED = 4 * CG_VEC;         // 1440
+constexpr int PATCH_VEC = 1536;                // padded to 96 LDS-DMA instructions of 16 vectors (12 per wave)
+constexpr int NBUF = 3, NDMA = 12;
+constexpr int ES = 72;                         // epilogue exchange: [p 16][co 32][72 (64 tiles used)] floats per pass
+constexpr int EPI_BYTES = 16 * 32 * ES * 4;        // 147,456
+constexpr int STAGE_BYTES = NBUF * PATCH_VEC * 16; // 73,728
+constexpr int LDS_BYTES = EPI_BYTES > STAGE_BYTES ? EPI_BYTES : STAGE_BYTES;
 
 struct Args {
   float* out;
   const float* in;
-  const u32x4* U;          // [cot][chunk][wave 8][pt 2][piece 2][mt 2][lane 64] 16-byte fragments
+  const u32x4* U;          // [cot][chunk][wave 8][pt 2][piece 2][mt 2][lane 64] 16-byte fragments, point signs folded in
   const float* bias;
   float unscale;
   int B, Cin, Cout, H, W;
   int tiles_x, tiles_y, n_chunks, n_cot;
+  unsigned long long* stamps;      // [workgroup][8] s_memrealtime (100 MHz) of wave 0: start, prologue done, sum of the chunks' construct phases (to the barrier), sum of their matrix phases (to the barrier), main loop done, epilogue done
 };
 
+// fp32 pair -> fp16 hi pair + fp16 lo pair (lo = a - hi, exact in fp32, one rounding to fp16): three instructions
 __device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned& lo) {
-  f16x2 h = {(_Float16)a, (_Float16)b};
-  unsigned hp = __builtin_bit_cast(unsigned, h);
-  asm volatile("" : "+v"(hp));
-  const f16x2 hq = __builtin_bit_cast(f16x2, hp);
-  f16x2 l = {(_Float16)(a - (float)hq[0]), (_Float16)(b - (float)hq[1])};
+  unsigned hp, lp;
+  asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hp) : "v"(a), "v"(b));
+  asm volatile("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(lp) : "v"(hp), "v"(a));
+  asm volatile("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lp) : "v"(hp), "v"(b));
   hi = hp;
-  lo = __builtin_bit_cast(unsigned, l);
+  lo = lp;
 }
 
-// VARIANT bits (timing experiments; results are wrong unless 0): 1 = one epilogue pass instead of eight, 2 = B operand from
+// VARIANT bits (timing experiments; results are wrong unless 0): 1 = one epilogue pass instead of two, 2 = B operand from
 // registers (no LDS reads, no transform, no split), 4 = the first chunk's weights for every chunk (no L2 stream),
-// 8 = the first chunk's patch for every chunk (no staging)
+// 8 = no patch staging after the prologue
 template <int VARIANT>
 __global__ __launch_bounds__(NT, 1) void k_wino(const Args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  f32x4* P = reinterpret_cast<f32x4*>(smem);                  // [buf 2][cg 4][row 18][parity 2][10] x 4 channels fp32
+  f32x4* P = reinterpret_cast<f32x4*>(smem);                  // [buf 3][cg 4][row 18][parity 2][10] x 4 channels fp32
+  float* Pf = reinterpret_cast<float*>(smem);
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n = lane & 31, lh = lane >> 5;
 
+  const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+  unsigned long long t_compute = 0, t_wait = 0, t_c = 0, t_w = 0, t_m = 0;
   const int cot = blockIdx.x;
   const int tile_id = blockIdx.y;
   const int b = blockIdx.z;
@@ -79,58 +85,56 @@ __global__ __launch_bounds__(NT, 1) void k_wino(const Args a) {
   const int y0 = by * 16, x0 = bx * 16;
   const int HW = a.H * a.W;
 
-  // ---- staging plan: items = (4-channel group, patch pixel); thread handles items tid, tid + 512, tid + 1024 ----
-  int xoff[3], xlds[3];
-  unsigned xvalid = 0, xlive = 0;
+  // ---- LDS-DMA plan: instruction k = wv + 8 i moves 64 dwords = 16 (pixel slot) x 4 channels; lane = 4 * slot + channel.
+  //      Every lane always reads a valid address (clamped); lanes whose pixel is outside the image zero their own dword
+  //      after their own wait (zero padding), so the number of outstanding operations is the same for every wave. ----
+  int doff[NDMA];
+  unsigned dzero = 0;
 #pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    const int item = tid + NT * i;
-    const bool live = item < 4 * PR * PR;
-    const int cg = item / (PR * PR);
-    const int pix = item - cg * (PR * PR);
-    const int r = pix / PR, c = pix - r * PR;
-    const int gy = y0 - 1 + r, gx = x0 - 1 + c;
-    const bool ok = live && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-    xoff[i] = ok ? (cg * 4) * HW + gy * a.W + gx : 0;
-    xlds[i] = ((cg * PR + r) * 2 + (c & 1)) * PC2 + (c >> 1);
-    if (ok) xvalid |= 1u << i;
-    if (live) xlive |= 1u << i;
+  for (int i = 0; i < NDMA; ++i) {
+    const int s = 16 * (wv + 8 * i) + (lane >> 2), ci = lane & 3;
+    const int cg = s / CG_VEC, rem = s - cg * CG_VEC;
+    const int row = rem / (2 * PC2), r2 = rem - row * (2 * PC2);
+    const int par = r2 / PC2, col2 = r2 - par * PC2;
+    const int col = 2 * col2 + par;
+    const bool live = s < PATCH_USED && col2 < 9;
+    const int gy = y0 - 1 + row, gx = x0 - 1 + col;
+    const bool inimg = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+    const int cy = gy < 0 ? 0 : (gy >= a.H ? a.H - 1 : gy), cx = gx < 0 ? 0 : (gx >= a.W ? a.W - 1 : gx);
+    doff[i] = ((cg > 3 ? 3 : cg) * 4 + ci) * HW + cy * a.W + cx;
+    if (live && !inimg) dzero |= 1u << i;
   }
   const float* in_b = a.in + (size_t)b * a.Cin * HW;
-  float xr[3][4];
-  auto x_fetch = [&](int chunk) __attribute__((always_inline)) {
+  auto dma = [&](int chunk, int buf) __attribute__((always_inline)) {
     const float* src = in_b + (size_t)chunk * KC * HW;
+    float* dst = Pf + buf * (PATCH_VEC * 4) + 64 * wv;
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-      for (int k = 0; k < 4; ++k) xr[i][k] = src[xoff[i] + k * HW];
+    for (int i = 0; i < NDMA; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + doff[i]),
+                                       (__attribute__((address_space(3))) void*)(dst + 512 * i), 4, 0, 0);
   };
-  auto x_store = [&](int buf) __attribute__((always_inline)) {
-    f32x4* pb = P + buf * PATCH_VEC;
+  auto zero_fix = [&](int buf) __attribute__((always_inline)) {
+    if (dzero) {
+      float* dst = Pf + buf * (PATCH_VEC * 4) + 64 * wv + lane;
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
-      if ((xlive >> i) & 1u) {
-        const bool ok = (xvalid >> i) & 1u;
-        pb[xlds[i]] = ok ? f32x4{xr[i][0], xr[i][1], xr[i][2], xr[i][3]} : f32x4{0.f, 0.f, 0.f, 0.f};
-      }
+      for (int i = 0; i < NDMA; ++i)
+        if ((dzero >> i) & 1u) dst[512 * i] = 0.f;
+    }
   };
 
-  // ---- the wave's two points: p = 4i + j; B^T row i = (k_a, s_a), (k_b, s_b) ----
-  //   i = 0: (0,+)(2,-)   1: (1,+)(2,+)   2: (1,-)(2,+)   3: (1,+)(3,-)
-  int poff[2][4];          // LDS vector offsets of the four pixels (a,c) (a,d) (b,c) (b,d) relative to the tile's patch origin
-  float psgn[2][4];
+  // ---- the wave's two points: row i = wv >> 1 of B^T, columns j0, j0 + 1 with j0 = 2 (wv & 1); point signs are folded
+  //      into U.  r_l = d[ka][l] + beta d[kb][l] for three columns l = c0 .. c0 + 2, then
+  //      j0 = 0: V_a = r0 - r2, V_b = r1 + r2;   j0 = 2: V_a = r0 - r1, V_b = r0 - r2 ----
+  const int irow = wv >> 1, j0 = 2 * (wv & 1);
+  const int ka = irow == 0 ? 0 : 1, kb = irow == 3 ? 3 : 2;
+  const float beta = irow == 1 ? 1.f : -1.f;
+  int oa[3], ob[3];
 #pragma unroll
-  for (int pt = 0; pt < 2; ++pt) {
-    const int p = 2 * wv + pt, i = p >> 2, j = p & 3;
-    const int ka = i == 0 ? 0 : 1, kb = i == 3 ? 3 : 2;
-    const float sa = i == 2 ? -1.f : 1.f, sb = (i == 0 || i == 3) ? -1.f : 1.f;
-    const int lc = j == 0 ? 0 : 1, ld = j == 3 ? 3 : 2;
-    const float sc = j == 2 ? -1.f : 1.f, sd = (j == 0 || j == 3) ? -1.f : 1.f;
-    const int oc = (lc & 1) * PC2 + (lc >> 1), od = (ld & 1) * PC2 + (ld >> 1);
-    poff[pt][0] = 2 * PC2 * ka + oc; psgn[pt][0] = sa * sc;
-    poff[pt][1] = 2 * PC2 * ka + od; psgn[pt][1] = sa * sd;
-    poff[pt][2] = 2 * PC2 * kb + oc; psgn[pt][2] = sb * sc;
-    poff[pt][3] = 2 * PC2 * kb + od; psgn[pt][3] = sb * sd;
+  for (int t = 0; t < 3; ++t) {
+    const int l = (j0 == 0 ? 0 : 1) + t;
+    const int co = (l & 1) * PC2 + (l >> 1);
+    oa[t] = 2 * PC2 * ka + co;
+    ob[t] = 2 * PC2 * kb + co;
   }
   // lane part: tile t = 32 nb + n -> (ty, tx) = (t >> 3, t & 7); channel groups 2 lh, 2 lh + 1
   int lbase[2];
@@ -160,102 +164,148 @@ __global__ __launch_bounds__(NT, 1) void k_wino(const Args a) {
       for (int mt = 0; mt < 2; ++mt) A[pt][piece][mt] = __builtin_bit_cast(f16x8, src[(piece * 2 + mt) * 64]);
   };
 
-  x_fetch(0);
-  a_fetch(0, 0);
-  a_fetch(0, 1);
-  x_store(0);
-  __syncthreads();
-
-  for (int chunk = 0; chunk < a.n_chunks; ++chunk) {
-    const bool more = chunk + 1 < a.n_chunks;
-    if (more && !(VARIANT & 8)) x_fetch(chunk + 1);
-    const f32x4* pb = P + ((VARIANT & 8) ? 0 : (chunk & 1)) * PATCH_VEC;
+  f16x8 Bh[2][2], Bl[2][2];                                  // [nb][pt]
+  const bool late = wv >= 4;
+  auto construct = [&](const f32x4* pb) __attribute__((always_inline)) {
 #pragma unroll
-    for (int pt = 0; pt < 2; ++pt) {
-#pragma unroll
-      for (int nb = 0; nb < 2; ++nb) {
-        // V = s0 d_ac + s1 d_ad + s2 d_bc + s3 d_bd for the lane's 8 channels, then the fp16 split
-        f32x4 v[2];
-        if (VARIANT & 2) {
-          v[0] = f32x4{1.f, 2.f, 3.f, 4.f} * psgn[pt][nb]; v[1] = v[0];
-        } else
+    for (int nb = 0; nb < 2; ++nb) {
+      f32x4 va[2], vb[2];
+      if (VARIANT & 2) {
+        va[0] = f32x4{1.f, 2.f, 3.f, 4.f} * beta; va[1] = va[0]; vb[0] = va[0]; vb[1] = va[0];
+      } else {
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
           const f32x4* q = pb + lbase[nb] + g * CG_VEC;
-          f32x4 t = q[poff[pt][0]] * psgn[pt][0];
-          t = t + q[poff[pt][1]] * psgn[pt][1];
-          t = t + q[poff[pt][2]] * psgn[pt][2];
-          t = t + q[poff[pt][3]] * psgn[pt][3];
-          v[g] = t;
+          const f32x4 r0 = q[oa[0]] + q[ob[0]] * beta;
+          const f32x4 r1 = q[oa[1]] + q[ob[1]] * beta;
+          const f32x4 r2 = q[oa[2]] + q[ob[2]] * beta;
+          if (j0 == 0) { va[g] = r0 - r2; vb[g] = r1 + r2; }
+          else { va[g] = r0 - r1; vb[g] = r0 - r2; }
         }
+      }
+#pragma unroll
+      for (int pt = 0; pt < 2; ++pt) {
+        const f32x4 v0 = pt == 0 ? va[0] : vb[0], v1 = pt == 0 ? va[1] : vb[1];
         unsigned h0, h1, h2, h3, l0, l1, l2, l3;
-        if (VARIANT & 2) {
-          h0 = h1 = h2 = h3 = __builtin_bit_cast(unsigned, v[0][0]) | 0x3c003c00u; l0 = l1 = l2 = l3 = h0 ^ 0x00010001u;
-        } else {
-        split2(v[0][0], v[0][1], h0, l0);
-        split2(v[0][2], v[0][3], h1, l1);
-        split2(v[1][0], v[1][1], h2, l2);
-        split2(v[1][2], v[1][3], h3, l3);
-        }
+        split2(v0[0], v0[1], h0, l0);
+        split2(v0[2], v0[3], h1, l1);
+        split2(v1[0], v1[1], h2, l2);
+        split2(v1[2], v1[3], h3, l3);
         const u32x4 bh = {h0, h1, h2, h3}, bl = {l0, l1, l2, l3};
-        const f16x8 Bh = __builtin_bit_cast(f16x8, bh), Bl = __builtin_bit_cast(f16x8, bl);
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-          acc[pt][mt][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[pt][1][mt], Bh, acc[pt][mt][nb], 0, 0, 0);
-          acc[pt][mt][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[pt][0][mt], Bl, acc[pt][mt][nb], 0, 0, 0);
-          acc[pt][mt][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[pt][0][mt], Bh, acc[pt][mt][nb], 0, 0, 0);
-        }
+        Bh[nb][pt] = __builtin_bit_cast(f16x8, bh); Bl[nb][pt] = __builtin_bit_cast(f16x8, bl);
       }
-      if (more && !(VARIANT & 4)) a_fetch(chunk + 1, pt);    // this point's weights are dead: fetch the next chunk's
     }
-    if (more && !(VARIANT & 8)) x_store((chunk + 1) & 1);
-    __syncthreads();
-  }
+  };
+  // the 24 matrix instructions of the fragments in Bh / Bl, each point's weights for chunk `next` fetched right behind its last use
+  auto matrix_phase = [&](int next, bool fetch) __attribute__((always_inline)) {
+#pragma unroll
+    for (int pt = 0; pt < 2; ++pt) {
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt)
+            acc[pt][mt][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[pt][t == 0 ? 1 : 0][mt], t == 1 ? Bl[nb][pt] : Bh[nb][pt], acc[pt][mt][nb], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (fetch && !(VARIANT & 4)) a_fetch(next, pt);
+    }
+  };
 
-  // ---- epilogue: 8 passes of 8 channels (mt, g): channel 32 mt + 8 g + (q & 3) + 4 lh ----
+  // ---- prologue ----
+  dma(0, 0);
+  if (a.n_chunks > 1) dma(1, 1);
+  a_fetch(0, 0);
+  a_fetch(0, 1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  zero_fix(0);
+  if (a.n_chunks > 1) zero_fix(1);
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+  const unsigned long long t_pro = __builtin_amdgcn_s_memrealtime();
+  // Two phases per chunk and wave: CONSTRUCT (LDS reads, transform, split: vector pipe) and MATRIX (24 MFMAs), a barrier
+  // behind each.  The two waves of a SIMD (w and w + 4) run them in antiphase: waves 4..7 pass one extra barrier before the
+  // loop (waves 0..3 one after it), so barrier k releases waves 0..3 into their matrix phase and waves 4..7 into their
+  // construct phase, or the reverse -- one wave's vector work overlaps the other's matrix work with ONE copy of the loop
+  // (in lockstep the phases of the two waves serialise: 1.4 + 1.0 us per chunk against 0.37 us of matrix time per wave).
+  //   buffer i + 1 is read after barrier 2i + 1 (waves 0..3) / 2i + 2 (waves 4..7); its DMA parts are waited for before
+  //   barrier 2i / 2i + 1; DMA (i + 2) overwrites buffer i - 1 after barrier 2i - 1 / 2i, its last reader (waves 4..7,
+  //   construct i - 1) arrived at barrier 2i - 1.
+  if (late) asm volatile("s_barrier" ::: "memory");
+  for (int chunk = 0; chunk < a.n_chunks; ++chunk) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    if (chunk + 2 < a.n_chunks && !(VARIANT & 8)) dma(chunk + 2, (chunk + 2) % NBUF);
+    construct(P + ((VARIANT & 8) ? 0 : chunk % NBUF) * PATCH_VEC);
+    const unsigned long long tc = __builtin_amdgcn_s_memrealtime();
+    // this wave's part of the next chunk's patch (and this chunk's weights) has landed once everything older than this
+    // iteration's DMA (12) has
+    if (chunk + 1 < a.n_chunks && !(VARIANT & 8)) {
+      if (chunk + 2 < a.n_chunks) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      zero_fix((chunk + 1) % NBUF);
+    }
+    const unsigned long long tw = __builtin_amdgcn_s_memrealtime();
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
+    matrix_phase(chunk + 1, chunk + 1 < a.n_chunks);
+    const unsigned long long tm = __builtin_amdgcn_s_memrealtime();
+    t_c += tc - t0; t_w += tw - tc; t_m += tm - t1;
+    asm volatile("s_barrier" ::: "memory");
+    const unsigned long long t2 = __builtin_amdgcn_s_memrealtime();
+    t_compute += t1 - t0; t_wait += t2 - t1;
+  }
+  if (!late) asm volatile("s_barrier" ::: "memory");
+  const unsigned long long t_main = __builtin_amdgcn_s_memrealtime();
+
+  // ---- epilogue: two passes of 32 channels (mt); every wave parks its two points' 32 x 64 blocks in LDS, then each thread
+  //      gathers the 16 points of two (channel, tile pair) items, applies A^T . A and stores 2 rows x 4 pixels ----
   float* E = reinterpret_cast<float*>(smem);
-  const int co8 = tid >> 6, tl = tid & 63;                   // reader: one (channel, tile) per thread
-  const int ty = tl >> 3, tx = tl & 7;
-  const int gy = y0 + 2 * ty, gx = x0 + 2 * tx;
 #pragma unroll
-  for (int mt = 0; mt < ((VARIANT & 1) ? 1 : 2); ++mt)
-#pragma unroll
-    for (int g = 0; g < ((VARIANT & 1) ? 1 : 4); ++g) {
-      if (VARIANT & 1) {                                       // keep every accumulator alive
-#pragma unroll
-        for (int pt = 0; pt < 2; ++pt)
-#pragma unroll
-          for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-            for (int q = 1; q < 16; ++q) acc[pt][0][nb][q & 3] += acc[pt][0][nb][q] + acc[pt][1][nb][q];
-      }
+  for (int mt = 0; mt < ((VARIANT & 1) ? 1 : 2); ++mt) {
+    if (VARIANT & 1) {                                       // keep every accumulator alive
 #pragma unroll
       for (int pt = 0; pt < 2; ++pt)
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-          for (int qq = 0; qq < 4; ++qq)
-            E[((2 * wv + pt) * 8 + qq + 4 * lh) * ESTRIDE + 32 * nb + n] = acc[pt][mt][nb][4 * g + qq];
-      __syncthreads();
-      float m[16];
+          for (int q = 0; q < 16; ++q) acc[pt][0][nb][q] += acc[pt][1][nb][q];
+    }
 #pragma unroll
-      for (int p = 0; p < 16; ++p) m[p] = E[(p * 8 + co8) * ESTRIDE + tl];
-      // Y = A^T M A, A^T = [1 1 1 0; 0 1 -1 -1]
-      float r0[4], r1[4];                                      // rows of A^T M
+    for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+          E[((2 * wv + pt) * 32 + (q & 3) + 8 * (q >> 2) + 4 * lh) * ES + 32 * nb + n] = acc[pt][mt][nb][q];
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int item = tid + NT * it;
+      const int co32 = item >> 5, ty = (item >> 2) & 7, txp = item & 3;
+      f32x2 m[16];
+#pragma unroll
+      for (int p = 0; p < 16; ++p) m[p] = *reinterpret_cast<const f32x2*>(&E[(p * 32 + co32) * ES + 8 * ty + 2 * txp]);
+      // Y = A^T M A, A^T = [1 1 1 0; 0 1 -1 -1], for the two tiles at once
+      f32x2 r0[4], r1[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         r0[j] = (m[j] + m[4 + j]) + m[8 + j];
         r1[j] = (m[4 + j] - m[8 + j]) - m[12 + j];
       }
-      const int co = cot * COT + 32 * mt + 8 * g + co8;
+      const int co = cot * COT + 32 * mt + co32;
       const float bv = a.bias ? a.bias[co] : 0.f;
-      f32x2 o0 = {((r0[0] + r0[1]) + r0[2]) * a.unscale + bv, ((r0[1] - r0[2]) - r0[3]) * a.unscale + bv};
-      f32x2 o1 = {((r1[0] + r1[1]) + r1[2]) * a.unscale + bv, ((r1[1] - r1[2]) - r1[3]) * a.unscale + bv};
-      float* dst = a.out + ((size_t)b * a.Cout + co) * HW + (size_t)gy * a.W + gx;
-      *reinterpret_cast<f32x2*>(dst) = o0;
-      *reinterpret_cast<f32x2*>(dst + a.W) = o1;
-      __syncthreads();
+      const f32x2 y00 = ((r0[0] + r0[1]) + r0[2]) * a.unscale + bv, y01 = ((r0[1] - r0[2]) - r0[3]) * a.unscale + bv;
+      const f32x2 y10 = ((r1[0] + r1[1]) + r1[2]) * a.unscale + bv, y11 = ((r1[1] - r1[2]) - r1[3]) * a.unscale + bv;
+      float* dst = a.out + ((size_t)b * a.Cout + co) * HW + (size_t)(y0 + 2 * ty) * a.W + x0 + 4 * txp;
+      *reinterpret_cast<f32x4*>(dst) = f32x4{y00[0], y01[0], y00[1], y01[1]};
+      *reinterpret_cast<f32x4*>(dst + a.W) = f32x4{y10[0], y11[0], y10[1], y11[1]};
     }
+    if (mt == 0 && !(VARIANT & 1)) __syncthreads();
+  }
+  if (a.stamps && tid == 0) {
+    unsigned long long* st = a.stamps + 8 * ((size_t)blockIdx.x + gridDim.x * (blockIdx.y + (size_t)gridDim.y * blockIdx.z));
+    st[0] = t_start; st[1] = t_pro; st[2] = t_compute; st[3] = t_wait; st[4] = t_main; st[5] = __builtin_amdgcn_s_memrealtime(); st[6] = t_c; st[7] = t_w | (t_m << 32);
+  }
 }
 
 }  // namespace wino
@@ -277,7 +327,8 @@ static void pack_U(std::vector<_Float16>& packed, const std::vector<float>& w, i
       const int chunk = ci / 16, lh = (ci % 16) / 8, e = ci % 8;
       const int lane = lh * 32 + m;
       for (int p = 0; p < 16; ++p) {
-        const float v = (float)(U[p >> 2][p & 3] * scale);
+        const double sgn = (((p >> 2) == 2) != ((p & 3) == 2)) ? -1.0 : 1.0;     // sigma_i sigma_j (see k_wino)
+        const float v = (float)(sgn * U[p >> 2][p & 3] * scale);
         const _Float16 hi = (_Float16)v, lo = (_Float16)(v - (float)hi);
         const int wvi = p >> 1, pt = p & 1;
         for (int piece = 0; piece < 2; ++piece) {
@@ -288,12 +339,13 @@ static void pack_U(std::vector<_Float16>& packed, const std::vector<float>& w, i
     }
 }
 
+static unsigned long long* g_stamps = nullptr;
 template <int VARIANT>
 static int launch_wino_v(float* out, const float* in, const void* U, const float* bias, float unscale, int B, int Cin, int Cout, int S) {
   wino::Args a;
   a.out = out; a.in = in; a.U = reinterpret_cast<const u32x4*>(U); a.bias = bias; a.unscale = unscale;
   a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = S; a.W = S;
-  a.tiles_x = S / 16; a.tiles_y = S / 16; a.n_chunks = Cin / 16; a.n_cot = Cout / 64;
+  a.tiles_x = S / 16; a.tiles_y = S / 16; a.n_chunks = Cin / 16; a.n_cot = Cout / 64; a.stamps = g_stamps;
   static bool attr = false;
   if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wino::k_wino<VARIANT>), hipFuncAttributeMaxDynamicSharedMemorySize, wino::LDS_BYTES); attr = true; }
   hipLaunchKernelGGL(wino::k_wino<VARIANT>, dim3(a.n_cot, a.tiles_x * a.tiles_y, B), dim3(wino::NT), wino::LDS_BYTES, 0, a);
@@ -385,6 +437,27 @@ int main(int argc, char** argv) {
       hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms_d, e0, e1);
       printf("round %d  B=%d C=%d %dx%d: winograd %.1f us   direct (ds_conv2d_h3) %.1f us   ratio %.2f\n", round, B, C, S, S,
              ms_w * 1e3 / reps, ms_d * 1e3 / reps, ms_d / ms_w);
+      {
+        const int nwg = (C / 64) * (S / 16) * (S / 16) * B;
+        hipMalloc(&g_stamps, (size_t)nwg * 64);
+        launch_wino(out, in, U, nullptr, 1.f / wscale, B, C, C, S);
+        hipDeviceSynchronize();
+        std::vector<unsigned long long> h((size_t)nwg * 8);
+        hipMemcpy(h.data(), g_stamps, h.size() * 8, hipMemcpyDeviceToHost);
+        double pro = 0, comp = 0, wait = 0, epi = 0, life = 0, sc = 0, sw = 0, sm = 0;
+        unsigned long long tmin = ~0ull, tmax = 0;
+        for (int w = 0; w < nwg; ++w) {
+          pro += h[w * 8 + 1] - h[w * 8]; comp += h[w * 8 + 2]; wait += h[w * 8 + 3]; epi += h[w * 8 + 5] - h[w * 8 + 4]; life += h[w * 8 + 5] - h[w * 8];
+          sc += h[w * 8 + 6]; sw += h[w * 8 + 7] & 0xffffffffull; sm += h[w * 8 + 7] >> 32;
+          tmin = std::min(tmin, h[w * 8]); tmax = std::max(tmax, h[w * 8 + 5]);
+        }
+        printf("    %d workgroups, span %.1f us; per workgroup (us): prologue %.2f, construct phases %.2f (%.2f each), matrix phases %.2f (%.2f each), epilogue %.2f, life %.2f\n",
+               nwg, (tmax - tmin) / 100.0, pro / nwg / 100, comp / nwg / 100, comp / nwg / 100 / (C / 16), wait / nwg / 100, wait / nwg / 100 / (C / 16),
+               epi / nwg / 100, life / nwg / 100);
+        printf("    per chunk (us): DMA issue + construct %.2f, wait for landed loads + zero fix %.2f, barrier %.2f | matrix issue %.2f, barrier %.2f\n",
+               sc / nwg / 100 / (C / 16), sw / nwg / 100 / (C / 16), (comp - sc - sw) / nwg / 100 / (C / 16), sm / nwg / 100 / (C / 16), (wait - sm) / nwg / 100 / (C / 16));
+        hipFree(g_stamps); g_stamps = nullptr;
+      }
       hipFree(in); hipFree(out); hipFree(w); hipFree(U); hipFree(wp);
     }
   return 0;
