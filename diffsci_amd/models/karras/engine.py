@@ -68,6 +68,8 @@ class ModuleSource:
         self.cfg = self.conditional and self.guidance != 1.0
         self.planned = bool(getattr(self.model, "forward_with_shifts", None)) and getattr(self.model, "capturable", True) and (
             like.dim() == 4 or (like.dim() == 5 and getattr(self.model, "dim", 2) == 3))
+        if self.planned and self.conditional and getattr(self.model, "condition_is_field", None) and self.model.condition_is_field(y):
+            self.planned = False                 # per-pixel time shifts are computed inside every evaluation
         self._out = {}
         self.shifts_c = self.shifts_u = None
 

@@ -328,11 +328,16 @@ class PUNetG(torch.nn.Module):
         """punetg.py:389-416.  x [B, Cin, H, W]; t [B] noise conditioning; y optional condition."""
         ops.require_device(x, "x")
         B = x.shape[0]
-        if t is None:
-            te = torch.zeros(B, self.config.model_channels, device=x.device)
+        ye = self.embed_condition(y)
+        if ye is not None and ye.dim() > 2:                       # a field of embeddings: per-pixel time shifts
+            te = self.embed_time_field(None if t is None else t.reshape(-1).to(x), ye, B)
+            shifts = self.time_shift_fields(te)
         else:
-            te = self.embed_time(t.reshape(-1).to(x), self.embed_condition(y))
-        shifts = self.time_shifts(te)
+            if t is None:
+                te = torch.zeros(B, self.config.model_channels, device=x.device)
+            else:
+                te = self.embed_time(t.reshape(-1).to(x), ye)
+            shifts = self.time_shifts(te)
         out = self.forward_with_shifts(x.contiguous(), shifts, row=None)
         if precision.needs_escalation(self, out, x, te):
             precision.escalate(self)
@@ -345,9 +350,59 @@ class PUNetG(torch.nn.Module):
         if y is None:
             return None
         ye = y if self.conditional_embedding is None else self.conditional_embedding(y)
-        if ye.ndim != 2:
-            raise NotImplementedError("spatial conditional embeddings (ye.ndim > 2) are not implemented")
+        if ye.dim() == 2 + self.dim and self.dim == 2:            # punetg.py:405-407: a field [B or 1, C, H, W]
+            if ye.shape[1] != self.config.model_channels:
+                raise ValueError("a field-valued conditional embedding must have model_channels channels")
+            ops.require_device(ye, "conditional embedding")
+            return ye.to(torch.float32).contiguous()
+        if ye.dim() != 2:
+            raise NotImplementedError("field-valued conditional embeddings are implemented for 2-D networks ([B, C, H, W])")
         return ye.to(torch.float32).contiguous()
+
+    def condition_is_field(self, y):
+        """True when conditional_embedding(y) is a field: every evaluation then computes per-pixel time shifts, which are not
+        tabulated per run (the sampler evaluates such a network eagerly, engine.ModuleSource)."""
+        ye = None if y is None else self.embed_condition(y)
+        return ye is not None and ye.dim() > 2
+
+    def embed_time_field(self, t, ye, B):
+        """te.reshape(B, C, 1, 1) + ye (punetg.py:405-410) -> [B, C, He, We]."""
+        if ye.shape[0] not in (1, B):
+            raise ValueError("conditional embedding batch must be 1 or match x")
+        if t is None:
+            te = torch.zeros(B, self.config.model_channels, device=ye.device)
+        else:
+            te = ops.fourier_features(t.contiguous(), self.time_projection.W)
+            if te.shape[0] not in (1, B):
+                raise ValueError("time batch must be 1 or match x")
+        return (te[:, :, None, None] + ye).expand(B, -1, -1, -1).contiguous()
+
+    def time_shift_fields(self, te):
+        """ResnetTimeBlock on a field (commonlayers.py:537-546): the three linears as 1x1 convolutions on the matrix cores,
+        one [B, C_block, He, We] shift per block; _res brings it to the block's resolution."""
+        pk = self._timeblock_convs()
+        out = []
+        for blk in self._resblocks():
+            n = blk.timeblock.net
+            h = ops.conv(te, pk[id(n[0])], bias=n[0].bias)
+            ops.inorm_silu(h, None, None, kind=2, out=h)
+            h2 = ops.conv(h, pk[id(n[2])], bias=n[2].bias)
+            ops.inorm_silu(h2, None, None, kind=2, out=h2)
+            out.append(ops.conv(h2, pk[id(n[4])], bias=n[4].bias))
+        return out
+
+    def _timeblock_convs(self):
+        lins = list(self._timeblock_linears())
+        sig = (self.conv_precision,) + tuple((l.weight.data_ptr(), l.weight._version) for l in lins)
+        if getattr(self, "_tb_packed_sig", None) != sig:
+            with torch.no_grad():
+                self._tb_packed = {}
+                for l in lins:
+                    w = mp_weight(l.weight.detach()) if self.mp else l.weight.detach()
+                    self._tb_packed[id(l)] = ops.pack_conv(w.reshape(w.shape[0], w.shape[1], 1, 1).contiguous(),
+                                                           "fp16x3" if self.conv_precision == "fp16x3" else "fp32")
+            self._tb_packed_sig = sig
+        return self._tb_packed
 
     def embed_time(self, t, ye=None):
         """te = GaussianFourierProjection(t) [+ ye]  (punetg.py:396-410)."""
@@ -555,6 +610,9 @@ class PUNetG(torch.nn.Module):
             if res2 is not None:
                 ops.add(y, res2, out=y)                             # x + xa of bottom_forward, after the block as in the reference
             return y, None                                          # no tile statistics of the sum: the consumer normalises standalone
+        yt = None
+        if shift is not None and shift.dim() == 4:         # a field of time shifts: conv1's epilogue adds it as a residual
+            yt, shift = self._rescale_shift_field(shift, H, W), None
         k1, k2 = self.norm_kinds                           # 0 GroupLN, 1 GroupRMS, 2 none, 3 GroupPix (not a table)
         w1, b1 = getattr(blk.gnorm1, "weight", None), getattr(blk.gnorm1, "bias", None)
         w2, b2 = getattr(blk.gnorm2, "weight", None), getattr(blk.gnorm2, "bias", None)
@@ -563,7 +621,7 @@ class PUNetG(torch.nn.Module):
             tab = ws.take((B, ops.table_channels(C), 4), dev)
             ops.inorm_table(xs, w1, b1, k1, H * W, eps=1e-5, out=tab)
             ys = self._stats_buf(ws, B, C, H, W, dev)
-            y = self._conv(blk.conv1, x, pk, shift=shift, prenorm=tab, tile_stats=ys, out=ws.take(x.shape, dev))
+            y = self._conv(blk.conv1, x, pk, shift=shift, res1=yt, prenorm=tab, tile_stats=ys, out=ws.take(x.shape, dev))
             ops.inorm_table(ys, w2, b2, k2, H * W, eps=1e-5, out=tab)
             os_ = self._stats_buf(ws, B, C, H, W, dev) if want_stats else None
             out = self._conv(blk.conv2, y, pk, res1=x, res2=res2, prenorm=tab, tile_stats=os_, out=ws.take(x.shape, dev))
@@ -572,12 +630,28 @@ class PUNetG(torch.nn.Module):
             ws.give(tab)
             return out, os_
         a = ops.inorm_silu(x, w1, b1, kind=k1, eps=1e-5, out=ws.take(x.shape, dev))
-        y = self._conv(blk.conv1, a, pk, shift=shift, out=ws.take(x.shape, dev))
+        y = self._conv(blk.conv1, a, pk, shift=shift, res1=yt, out=ws.take(x.shape, dev))
         ops.inorm_silu(y, w2, b2, kind=k2, eps=1e-5, out=a)
         os_ = self._stats_buf(ws, B, C, H, W, dev) if want_stats else None
         self._conv(blk.conv2, a, pk, res1=x, res2=res2, tile_stats=os_, out=y)
         ws.give(a)
         return y, os_
+
+    @staticmethod
+    def _rescale_shift_field(yt, H, W):
+        """ResnetBlockC.rescale_yt (commonlayers.py:838-869): the top-left corner of every window (CornerPool2d) when the
+        field is finer than the block.  A coarser field takes the reference through torch.nn.Upsample(shape_factor), whose
+        first argument is the output size -- it fails there unless the block's side equals the factor; not reproduced."""
+        h, w = yt.shape[2:]
+        if (h, w) == (H, W):
+            return yt
+        if h > H:
+            f = h // H
+            if H * f != h or W * f != w:
+                raise ValueError(f"yt_dims {(h, w)} and y_dims {(H, W)} are not compatible")
+            return yt[:, :, ::f, ::f].contiguous()
+        raise NotImplementedError("a conditional-embedding field coarser than a block's resolution (the reference's "
+                                  "upscaling branch passes the factor as torch.nn.Upsample's size and fails as well)")
 
     def forward_with_shifts(self, x, shifts, row=None, out=None):
         """UNet body given the per-block time shifts.  shifts[k] is [M, C_k]; row selects one row
@@ -595,6 +669,8 @@ class PUNetG(torch.nn.Module):
 
         def sh():
             s = shifts[next(it)]
+            if s.dim() == 4:                           # [B, C, He, We]: a field of shifts (eager evaluation only)
+                return s
             if row is not None:
                 if s.dim() == 3:                       # [n_evals, B, C]: per-sample conditions in the planned sampler
                     if s.shape[1] != B:

@@ -89,12 +89,38 @@ def time_shift(sd, prefix, te, mp=False, ndim=2):
     def w(i):
         wt = sd[prefix + f"net.{i}.weight"]
         return mp_effective(wt) if mp else wt
+    spatial = te.dim() - 2 == ndim                            # commonlayers.py:537-546: a field of embeddings, one MLP per pixel
+    if spatial:
+        shape = te.shape
+        te = te.movedim(1, -1).reshape(-1, shape[1])          # 'nbatch embed s.. -> (nbatch s..) embed'
     h = F.linear(te, w(0), sd[prefix + "net.0.bias"])
     h = F.silu(h)
     h = F.linear(h, w(2), sd[prefix + "net.2.bias"])
     h = F.silu(h)
     h = F.linear(h, w(4), sd[prefix + "net.4.bias"])
+    if spatial:
+        return h.reshape(shape[0], *shape[2:], h.shape[1]).movedim(-1, 1)
     return h.view(*h.shape, *([1] * ndim))
+
+
+def rescale_yt(yt, y):
+    """ResnetBlockC.rescale_yt, commonlayers.py:838-869: a field-valued time shift follows the block's resolution by
+    taking the top-left corner of every window (CornerPool, :1035-1098).  The upscaling branch of the reference builds
+    torch.nn.Upsample(shape_factor), whose first argument is the output SIZE, so it only works when the block's
+    resolution equals the factor; it is restated as written."""
+    yt_dims, y_dims = tuple(yt.shape[2:]), tuple(y.shape[2:])
+    if yt_dims == (1,) * len(y_dims) or yt_dims == y_dims:
+        return yt
+    factor = yt_dims[0] / y_dims[0]
+    if factor > 1:
+        f = int(factor)
+        if any(dy * f != dyt for dy, dyt in zip(y_dims, yt_dims)):
+            raise ValueError(f"yt_dims {yt_dims} and y_dims {y_dims} are not compatible")
+        return yt[(Ellipsis,) + (slice(None, None, f),) * len(y_dims)]
+    f = int(1 / factor)
+    if any(dyt * f != dy for dy, dyt in zip(y_dims, yt_dims)):
+        raise ValueError(f"yt_dims {yt_dims} and y_dims {y_dims} are not compatible")
+    return F.interpolate(yt, size=f, mode="nearest")
 
 
 def block_norm(kind, sd, prefix, x):
@@ -122,7 +148,7 @@ def resnet_block(sd, prefix, x, te, circular=False, norms=("GroupLN", "GroupRMS"
     here), added after the residual connection."""
     h = block_norm(norms[0], sd, prefix + "gnorm1.", x)
     y = conv3x3(sd, prefix + "conv1", F.silu(h), circular)
-    y = y + time_shift(sd, prefix + "timeblock.", te, mp=circular == "mp", ndim=x.dim() - 2)   # [B, C, 1, 1(, 1)]
+    y = y + rescale_yt(time_shift(sd, prefix + "timeblock.", te, mp=circular == "mp", ndim=x.dim() - 2), y)   # [B, C, 1, 1(, 1)] or a field
     h = block_norm(norms[1], sd, prefix + "gnorm2.", y)
     y = conv3x3(sd, prefix + "conv2", F.silu(h), circular)
     y = y + x
@@ -210,6 +236,8 @@ def punetg_forward(sd, cfg, x, t, ye=None):
     else:
         te = fourier_features(t, sd["time_projection.W"])
     if ye is not None:
+        if ye.dim() > te.dim():                                      # punetg.py:405-407: a field of embeddings
+            te = te.reshape(list(te.shape) + [1] * (ye.dim() - te.dim()))
         te = te + ye
     skips = []
     for lv in range(nlev):                                           # encode, punetg.py:356-365

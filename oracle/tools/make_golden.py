@@ -718,6 +718,51 @@ def variants():
         npz(f"punetg8_{tag}", **arrs)
 
 
+def spatial_cond():
+    """punetg.py:405-407 + commonlayers.py:537-546,838-869: a conditional embedding that is a FIELD ([B, C, H, W], here a
+    user 1x1 convolution of a two-channel condition): the time embedding becomes a field, every block runs its time MLP per
+    pixel and CornerPools the result to its own resolution."""
+    import warnings
+    torch.manual_seed(170)
+    cfg = M.nets.PUNetGConfig(model_channels=8)
+    emb = torch.nn.Conv2d(2, 8, kernel_size=1)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        net = M.nets.PUNetG(cfg, conditional_embedding=emb).eval()
+    with torch.no_grad():
+        for k, v in net.state_dict().items():
+            if "gnorm" in k or k.endswith(".bias"):
+                v.add_(0.25 * torch.randn_like(v))
+    sd = net.state_dict()
+    torch.manual_seed(171)
+    x = torch.randn(2, 1, 32, 32)
+    y = torch.randn(2, 2, 32, 32)
+    t = torch.tensor([0.3, -1.1])
+    arrs = dict(sd_arrays(sd), x=x, y=y, t=t)
+    with torch.inference_mode():
+        arrs["out_f32"] = net(x, t, y)
+        arrs["out_uncond_f32"] = net(x, t)
+        te = net.time_projection(t).reshape(2, 8, 1, 1) + emb(y)
+        blk = net.downward_blocks[1][0]
+        h = torch.randn(2, 16, 16, 16)
+        arrs["resblock_in"] = h
+        arrs["resblock_te"] = te
+        arrs["resblock_l1"] = blk(h, te)                      # CornerPool2d(2) of the per-pixel shift
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        net64 = M.nets.PUNetG(cfg, conditional_embedding=torch.nn.Conv2d(2, 8, kernel_size=1)).double().eval()
+    net64.load_state_dict({k: v.double() for k, v in sd.items()})
+    with torch.inference_mode():
+        arrs["out_f64"] = net64(x.double(), t.double(), y.double())
+    module = M.KarrasModule(net, M.KarrasModuleConfig.from_edm(), conditional=True).eval()
+    wn = torch.randn(2, 1, 32, 32)
+    arrs["white_noise"] = wn
+    # the sampler's condition is un-batched (karrasmodule.py:916-917 unsqueezes it): one field shared by the batch
+    arrs["hist_heun_N4_g1_f32"] = module.propagate_white_noise(wn, y=y[0], guidance=1.0, nsteps=4, record_history=True)
+    arrs["hist_heun_N4_g2_f32"] = module.propagate_white_noise(wn, y=y[0], guidance=2.0, nsteps=4, record_history=True)
+    npz("punetg8_spatial_cond", **arrs)
+
+
 def adm_norms():
     """ADM with the other norm choices of make_norm_layers (adm.py:385-406): RMS first / LN second (+FiLM), and LN / LN
     with affine_norm=False -- which the reference's ADM silently ignores (the flag is not forwarded to the blocks)."""
@@ -902,6 +947,6 @@ def latent():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["schedule", "toy", "punetg", "porosity", "inpaint", "vpve", "circular", "si", "punetgcond", "langevin", "adm", "variants", "latent", "adm_norms", "autoregressive", "si_latent", "si_inpaint", "volumes", "si_generic", "vp_karras", "adm_blocks"]
+    which = sys.argv[1:] or ["schedule", "toy", "punetg", "porosity", "inpaint", "vpve", "circular", "si", "punetgcond", "langevin", "adm", "variants", "latent", "adm_norms", "autoregressive", "si_latent", "si_inpaint", "volumes", "si_generic", "vp_karras", "adm_blocks", "spatial_cond"]
     for name in which:
         globals()[name]()

@@ -434,6 +434,45 @@ def test_porosity_conditional_cfg_dict_y(M, dev, grids):
         assert rel_l2(o, v["out_cond_g1_N4_f32"]) < REL
 
 
+def test_field_valued_conditional_embedding(M, dev, grids):
+    """punetg.py:405-407 / commonlayers.py:537-546, 838-869: a conditional embedding that is a FIELD (here a user 1x1
+    convolution of a two-channel condition) turns every block's time shift into a field -- the time MLP per pixel as 1x1
+    convolutions on the matrix cores, CornerPooled to the block's resolution and added through conv1's epilogue.  Such a
+    network is evaluated eagerly inside the sampler (no per-run table of shifts)."""
+    from diffsci_amd.models.karras import engine
+    v, sd = load("punetg8_spatial_cond")
+    net = M.PUNetG(M.PUNetGConfig(model_channels=8), conditional_embedding=torch.nn.Conv2d(2, 8, kernel_size=1))
+    r = net.load_state_dict(sd, strict=True)
+    assert not r.missing_keys and not r.unexpected_keys
+    net = net.to(dev).eval()
+    x, t, y = v["x"].to(dev), v["t"].to(dev), v["y"].to(dev)
+    assert net.condition_is_field(y) and not net.condition_is_field(None)
+    for fuse in (True, False):
+        net.fuse_norm = fuse
+        out = net(x, t, y).cpu()
+        assert rel_l2(out, v["out_f32"]) < REL
+        assert rel_l2(out.double(), v["out_f64"]) < 4 * max(rel_l2(v["out_f32"].double(), v["out_f64"]), 2.5e-6)
+    net.fuse_norm = True
+    assert rel_l2(net(x, t).cpu(), v["out_uncond_f32"]) < REL
+    # one block at level 1: the per-pixel shift of a 32 x 32 field, CornerPooled to 16 x 16
+    te = v["resblock_te"].to(dev)
+    shifts = net.time_shift_fields(te)
+    k = len(net.downward_blocks[0])                                   # first block of level 1
+    pk, ws = net.packed_weights(), net._ws
+    got, _ = net._res(net.downward_blocks[1][0], v["resblock_in"].to(dev), shifts[k], pk, ws, xs=None)
+    assert rel_l2(got.cpu(), v["resblock_l1"]) < REL
+    with pytest.raises(NotImplementedError):
+        net._rescale_shift_field(torch.zeros(1, 8, 8, 8, device=dev), 16, 16)
+    module = M.KarrasModule(net, M.KarrasModuleConfig.from_edm(), conditional=True).to(dev)
+    _pin_grid(module, grids)
+    src = engine.ModuleSource(module, y[:1], 1.0, 2, x)
+    assert not src.planned
+    wn = v["white_noise"].to(dev)
+    for g in (1.0, 2.0):
+        h = module.propagate_white_noise(wn, y=y[0], guidance=g, nsteps=4, record_history=True).cpu()
+        assert rel_l2(h, v[f"hist_heun_N4_g{int(g)}_f32"]) < REL
+
+
 def test_fused_and_standalone_norms_agree(M, net8, dev):
     """fuse_norm folds GroupNorm/GroupRMSNorm + SiLU into the convolutions around them (statistics
     from the producer's epilogue, activation in the consumer's loader); the standalone-kernel route

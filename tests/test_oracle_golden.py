@@ -374,6 +374,31 @@ def test_punetg_layer_variants(tag):
         assert_exact_or_rel(hist, v["hist_heun_N6_f32"], tag + " hist_heun_N6_f32", 2e-6)
 
 
+def _spatial_embed(sd):
+    w, b = sd["conditional_embedding.weight"], sd["conditional_embedding.bias"]
+    return lambda y: torch.nn.functional.conv2d(y if y.dim() == 4 else y[None], w, b)
+
+
+def test_punetg_spatial_conditional_embedding():
+    """punetg.py:405-407, commonlayers.py:537-546, 838-869: a conditional embedding that is a field makes the time shift of
+    every block a field (time MLP per pixel, CornerPool to the block's resolution)."""
+    v, sd = load("punetg8_spatial_cond")
+    cfg = punetg_ref.default_config(model_channels=8)
+    embed = _spatial_embed(sd)
+    with torch.inference_mode():
+        r = punetg_ref.resnet_block(sd, "downward_blocks.1.0.", v["resblock_in"], v["resblock_te"])
+        assert_exact_or_rel(r, v["resblock_l1"], "level-1 block with a CornerPooled shift", 1e-6)
+        net = punetg_ref.make_net(sd, cfg, embed)
+        assert_exact_or_rel(net(v["x"], v["t"], v["y"]), v["out_f32"], "out_f32", 2e-6)
+        assert_exact_or_rel(net(v["x"], v["t"]), v["out_uncond_f32"], "out_uncond_f32", 2e-6)
+        sd64 = {k: t.double() for k, t in sd.items()}
+        out64 = punetg_ref.make_net(sd64, cfg, _spatial_embed(sd64))(v["x"].double(), v["t"].double(), v["y"].double())
+        assert rel_l2(out64, v["out_f64"]) < 1e-13
+        for g in (1.0, 2.0):
+            hist = K.propagate_white_noise(net, v["white_noise"], 4, y=v["y"][0], guidance=g, conditional=True, record_history=True)
+            assert_exact_or_rel(hist, v[f"hist_heun_N4_g{int(g)}_f32"], f"history g={g}", 2e-6)
+
+
 def test_si_latent_boundary_and_single_step():
     """SIModule with an autoencoder and the batch-norm initial_norm (flowfield.py:300-345, 742-747), and its
     single-step entry point integration_step (:749-781)."""
