@@ -238,6 +238,117 @@ __global__ __launch_bounds__(256) void k_from_slices(float* y, const float* __re
   }
 }
 
+// ---- the same two copies with the block's normalisation folded in (round 2) ----
+// k_to_slices_act: the copy applies SiLU((x - M) A + C) from a per-(sample, channel) table (ds_inorm_table's rows) -- the
+// standalone norm pass over the volume disappears; pad slices stay exactly zero.  Same expf / IEEE division as the
+// standalone norm kernels (ds_norm.hip).
+__global__ __launch_bounds__(256) void k_to_slices_act(float* S, const float* __restrict__ x, const float* __restrict__ table,
+                                                      int C, int Cpad, int D, size_t HW) {
+  const int zp = blockIdx.y % (D + 2);
+  const int b = blockIdx.y / (D + 2);
+  const int c = blockIdx.z;
+  float* dst = S + (((size_t)b * (D + 2) + zp) * C + c) * HW;
+  const int z = zp - 1;
+  const bool zero = z < 0 || z >= D;
+  const float4 t = reinterpret_cast<const float4*>(table)[(size_t)b * Cpad + c];
+  const float* src = x + (((size_t)b * C + c) * D + (zero ? 0 : z)) * HW;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < HW; i += (size_t)gridDim.x * 256) {
+    float v = 0.f;
+    if (!zero) {
+      const float u = (src[i] - t.x) * t.y + t.z;
+      v = u / (1.0f + expf(-u));
+    }
+    dst[i] = v;
+  }
+}
+
+// k_from_slices_stats: the copy back also leaves the shifted partial sums (K, S, Q, n) of what it stores, one entry per
+// workgroup, in ds_conv_epilogue.h's tile-statistics format: stats[(b*C + c)*(D*gx) + z*gx + blockIdx.x] -- the next
+// block's first norm needs no pass of its own over the volume.
+__global__ __launch_bounds__(256) void k_from_slices_stats(float* y, const float* __restrict__ S, const float* __restrict__ r1,
+                                                          const float* __restrict__ r2, float* __restrict__ stats, int C,
+                                                          int D, size_t HW) {
+  __shared__ float sk;
+  __shared__ float red[3][4];
+  const int z = blockIdx.y % D;
+  const int b = blockIdx.y / D;
+  const int c = blockIdx.z;
+  const float* src = S + (((size_t)b * (D + 2) + z + 1) * C + c) * HW;
+  const size_t o = (((size_t)b * C + c) * D + z) * HW;
+  const size_t first = (size_t)blockIdx.x * 256;
+  if (threadIdx.x == 0) {
+    float v = first < HW ? src[first] : 0.f;
+    if (first < HW && r1) v = v + r1[o + first];
+    if (first < HW && r2) v = v + r2[o + first];
+    sk = v;
+  }
+  __syncthreads();
+  const float K = sk;
+  float s1 = 0.f, s2 = 0.f, n = 0.f;
+  for (size_t i = first + threadIdx.x; i < HW; i += (size_t)gridDim.x * 256) {
+    float v = src[i];
+    if (r1) v = v + r1[o + i];
+    if (r2) v = v + r2[o + i];
+    y[o + i] = v;
+    const float d = v - K;
+    s1 += d; s2 += d * d; n += 1.f;
+  }
+  for (int k = 32; k > 0; k >>= 1) { s1 += __shfl_xor(s1, k, 64); s2 += __shfl_xor(s2, k, 64); n += __shfl_xor(n, k, 64); }
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s1; red[1][threadIdx.x >> 6] = s2; red[2][threadIdx.x >> 6] = n; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float S1 = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    const float S2 = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    const float Nn = (red[2][0] + red[2][1]) + (red[2][2] + red[2][3]);
+    reinterpret_cast<float4*>(stats)[((size_t)b * C + c) * ((size_t)D * gridDim.x) + (size_t)z * gridDim.x + blockIdx.x] =
+        make_float4(K, S1, S2, Nn);
+  }
+}
+
+// k_slice_tables: the norm table of a volume that STAYS slice-major between the two convolutions of a block.  Input: the
+// tile statistics the last depth-tap launch left, [2-D sample j = slice - 1][c][tile]; a sample's D real slices are
+// combined (fp64, fixed order) into one (M, A, C) row, written for each of them; pad slices get zero rows -- whatever the
+// tap launches computed there becomes SiLU(0) = 0 in the consumer's loader, i.e. the zero padding of the depth axis.
+// 16 lanes per (b, c).
+__global__ __launch_bounds__(256) void k_slice_tables(float* table, const float* __restrict__ ts, const float* __restrict__ w,
+                                                     const float* __restrict__ bias, int B, int C, int Cpad, int D, int ntiles,
+                                                     double inv_n, float eps, int kind) {
+  const int row = blockIdx.x * 16 + (threadIdx.x >> 4);
+  const int l = threadIdx.x & 15;
+  const int b = row / Cpad, c = row - b * Cpad;
+  if (b >= B) return;
+  const bool real = c < C;
+  double s = 0.0, q = 0.0;
+  if (real) {
+    for (int z = 0; z < D; ++z) {
+      const float4* p = reinterpret_cast<const float4*>(ts) + (((size_t)b * (D + 2) + z) * C + c) * ntiles;
+      for (int t = l; t < ntiles; t += 16) {
+        const float4 v = p[t];
+        const double K = v.x, S = v.y, Q = v.z, n = v.w;
+        s += n * K + S;
+        q += Q + 2.0 * K * S + n * K * K;
+      }
+    }
+  }
+  for (int o = 8; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+  float4 o4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (real) {
+    float M = 0.f, rs = 1.0f;
+    if (kind == 0) {
+      const double mean = s * inv_n;
+      double var = q * inv_n - mean * mean;
+      if (var < 0.0) var = 0.0;
+      M = (float)mean;
+      rs = 1.0f / sqrtf((float)var + eps);
+    } else if (kind == 1) {
+      rs = 1.0f / sqrtf((float)(q * inv_n) + eps);
+    }
+    o4 = make_float4(M, rs * ((w && kind != 2) ? w[c] : 1.f), (bias && kind != 2) ? bias[c] : 0.f, 0.f);
+  }
+  for (int zp = l; zp < D + 2; zp += 16)
+    reinterpret_cast<float4*>(table)[((size_t)b * (D + 2) + zp) * Cpad + c] = (zp >= 1 && zp <= D) ? o4 : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
 // AvgPool3d(2) / nearest x2 upsampling of volumes, the resampling of ADM blocks on volumes (adm.py:352-384: AvgPool3d,
 // Upsample(mode='nearest')).  One thread per output voxel; the pooling adds its 8 inputs in (z, y, x) order and divides
 // by 8, as torch's CPU kernel does.
@@ -328,5 +439,55 @@ extern "C" int ds_slices_to_volume(float* y, const float* slices, const float* r
   hipLaunchKernelGGL(k_from_slices, dim3((unsigned)(gx > 64 ? 64 : gx), (unsigned)(B * D), (unsigned)C), dim3(256), 0,
                      ds::as_stream(stream), y, slices, res1, res2, C, D, HW);
   DS_CHECK_LAUNCH("ds_slices_to_volume");
+  return DS_OK;
+}
+
+static unsigned slice_copy_blocks(size_t HW) {
+  const size_t gx = (HW + 1023) / 1024;
+  return (unsigned)(gx > 64 ? 64 : gx);
+}
+
+extern "C" int ds_volume_stat_tiles(int D, size_t HW) { return D <= 0 || HW == 0 ? 0 : D * (int)slice_copy_blocks(HW); }
+
+extern "C" int ds_volume_to_slices_act(float* slices, const float* x, const float* table, int B, int C, int D, size_t HW,
+                                       void* stream) {
+  DS_REQUIRE(slices && x && table, DS_ERR_NULL, "ds_volume_to_slices_act: NULL pointer");
+  DS_REQUIRE(B >= 0 && C > 0 && D > 0 && HW > 0, DS_ERR_SHAPE, "ds_volume_to_slices_act: bad arguments B=%d C=%d D=%d", B, C, D);
+  DS_REQUIRE((long long)B * (D + 2) < 65536 && C < 65536, DS_ERR_SHAPE, "ds_volume_to_slices_act: B*(D+2) and C must stay below 65536");
+  DS_REQUIRE((reinterpret_cast<uintptr_t>(table) & 15u) == 0, DS_ERR_SHAPE, "ds_volume_to_slices_act: table must be 16-byte aligned");
+  if (B == 0) return DS_OK;
+  hipLaunchKernelGGL(k_to_slices_act, dim3(slice_copy_blocks(HW), (unsigned)(B * (D + 2)), (unsigned)C), dim3(256), 0,
+                     ds::as_stream(stream), slices, x, table, C, (C + 15) / 16 * 16, D, HW);
+  DS_CHECK_LAUNCH("ds_volume_to_slices_act");
+  return DS_OK;
+}
+
+extern "C" int ds_slices_to_volume_stats(float* y, const float* slices, const float* res1, const float* res2, float* stats,
+                                         int B, int C, int D, size_t HW, void* stream) {
+  DS_REQUIRE(y && slices && stats, DS_ERR_NULL, "ds_slices_to_volume_stats: NULL pointer");
+  DS_REQUIRE(B >= 0 && C > 0 && D > 0 && HW > 0, DS_ERR_SHAPE, "ds_slices_to_volume_stats: bad shape");
+  DS_REQUIRE((long long)B * D < 65536 && C < 65536, DS_ERR_SHAPE, "ds_slices_to_volume_stats: B*D and C must stay below 65536");
+  DS_REQUIRE((reinterpret_cast<uintptr_t>(stats) & 15u) == 0, DS_ERR_SHAPE, "ds_slices_to_volume_stats: stats must be 16-byte aligned");
+  if (B == 0) return DS_OK;
+  hipLaunchKernelGGL(k_from_slices_stats, dim3(slice_copy_blocks(HW), (unsigned)(B * D), (unsigned)C), dim3(256), 0,
+                     ds::as_stream(stream), y, slices, res1, res2, stats, C, D, HW);
+  DS_CHECK_LAUNCH("ds_slices_to_volume_stats");
+  return DS_OK;
+}
+
+extern "C" int ds_slice_tables(float* table, const float* tile_stats, const float* w, const float* b, int B, int C, int D,
+                               int ntiles, long long count, float eps, int kind, void* stream) {
+  DS_REQUIRE(table && tile_stats, DS_ERR_NULL, "ds_slice_tables: NULL pointer");
+  DS_REQUIRE(B >= 0 && C > 0 && D > 0 && ntiles > 0 && count > 0, DS_ERR_SHAPE, "ds_slice_tables: bad shape");
+  DS_REQUIRE(kind >= 0 && kind <= 2, DS_ERR_UNSUPPORTED, "ds_slice_tables: kind %d (0 GroupLN, 1 GroupRMS, 2 none)", kind);
+  DS_REQUIRE((reinterpret_cast<uintptr_t>(table) & 15u) == 0 && (reinterpret_cast<uintptr_t>(tile_stats) & 15u) == 0,
+             DS_ERR_SHAPE, "ds_slice_tables: misaligned pointer");
+  if (B == 0) return DS_OK;
+  const int Cpad = (C + 15) / 16 * 16;
+  const long long rows = (long long)B * Cpad;
+  DS_REQUIRE(rows < (1ll << 31), DS_ERR_SHAPE, "ds_slice_tables: too many rows");
+  hipLaunchKernelGGL(k_slice_tables, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, ds::as_stream(stream), table, tile_stats,
+                     w, b, B, C, Cpad, D, ntiles, 1.0 / (double)count, eps, kind);
+  DS_CHECK_LAUNCH("ds_slice_tables");
   return DS_OK;
 }

@@ -792,8 +792,21 @@ class PUNetG(torch.nn.Module):
                 raise ValueError("time embedding batch does not match x")
             return s
 
-        def conv(m, h, load_mode=0, dst=None, fresh=False, **kw):
-            """Every buffer comes from the workspace (a captured loop must not allocate); fresh: the caller's result."""
+        # Norm folding on volumes (round 2; fp16x3, zero padding, 3x3x3 kernels): every activation travels with the partial
+        # sums its producer's slice -> volume copy left (hs); a block whose input has them runs ops.resblock3d_fused --
+        # norm1 inside the volume -> slice copy, the intermediate slice-major with norm2 in conv2's loader -- 20 instead of
+        # 52 bytes per element of norm / copy traffic per block.  Without statistics (after the thin input layer or the
+        # attention) the block runs the standalone norms and leaves statistics for its successor.
+        fold = (self._fused() and not self.circular and self.extra_residual is None and k1 != 3 and k2 != 3
+                and cfg.kernel_size == 3)
+
+        def stats_buf(shape):
+            Bc, C, D, H, W = shape
+            return ws.take((Bc, C, ops.volume_stat_tiles(D, H * W), 4), dev)
+
+        def conv(m, h, load_mode=0, dst=None, fresh=False, want_stats=False, **kw):
+            """-> (tensor, statistics or None).  Every buffer comes from the workspace (a captured loop must not allocate);
+            fresh: the caller's result."""
             f = {0: (1, 1), DS_LOAD_MAXPOOL2: (1, 2), DS_LOAD_UPSAMPLE2: (2, 1)}[load_mode]
             shape = (h.shape[0], m.out_channels) + tuple(v * f[0] // f[1] for v in h.shape[2:])
             if dst is None and not fresh:
@@ -802,25 +815,42 @@ class PUNetG(torch.nn.Module):
             # fp16x3 (default): three 2-D MFMA launches per convolution -- 0.30 vs 1.33 ms at 64 -> 64 channels, 8 x 32^3;
             # the thin input / output layers stay on the direct kernel (0.08 vs 0.14 ms for 1 -> 64)
             if packs is not None and m.out_channels > 4 and m.in_channels > 4:
-                return ops.conv3d_mfma(h, packs, bias=m.bias, circular=self.circular, load_mode=load_mode, out=dst, ws=ws, **kw)
+                st = stats_buf(shape) if (fold and want_stats) else None
+                return ops.conv3d_mfma(h, packs, bias=m.bias, circular=self.circular, load_mode=load_mode, out=dst, ws=ws,
+                                       out_stats=st, **kw), st
             return ops.conv3d(h, pk.get((id(m), "eff"), m.weight), bias=m.bias, circular=self.circular, load_mode=load_mode,
-                              out=dst, **kw)
+                              out=dst, **kw), None
 
-        def res(blk, h, res2=None):                                               # ResnetBlockC.forward; h untouched
+        def give(t, ts=None):
+            ws.give(t)
+            if ts is not None:
+                ws.give(ts)
+
+        def res(blk, h, hs, res2=None, want_stats=True):                          # ResnetBlockC.forward; h untouched
             w1, b1 = getattr(blk.gnorm1, "weight", None), getattr(blk.gnorm1, "bias", None)
             w2, b2 = getattr(blk.gnorm2, "weight", None), getattr(blk.gnorm2, "bias", None)
+            C = h.shape[1]
+            p1, p2 = pk.get((id(blk.conv1), "3d")), pk.get((id(blk.conv2), "3d"))
+            if fold and hs is not None and p1 is not None and p2 is not None and C > 4 and (C + 63) // 64 <= self.fuse_max_cot:
+                tab = ops.inorm_table(hs, w1, b1, k1, h[0, 0].numel(), eps=1e-5, out=ws.take((B, ops.table_channels(C), 4), dev))
+                os_ = stats_buf(h.shape) if want_stats else None
+                y = ops.resblock3d_fused(h, tab, p1, blk.conv1.bias, sh(), p2, blk.conv2.bias, w2, b2, k2, res2=res2,
+                                         out=ws.take(h.shape, dev), out_stats=os_, ws=ws)
+                ws.give(tab)
+                return y, os_
             a = ops.inorm_silu(h, w1, b1, kind=k1, eps=1e-5, out=ws.take(h.shape, dev))
-            y = conv(blk.conv1, a, shift=sh())
+            y, _ = conv(blk.conv1, a, shift=sh())
             ops.inorm_silu(y, w2, b2, kind=k2, eps=1e-5, out=a)
             if self.extra_residual is None:
-                conv(blk.conv2, a, res1=h, res2=res2, dst=y)
+                _, os_ = conv(blk.conv2, a, res1=h, res2=res2, dst=y, want_stats=want_stats)
             else:
                 conv(blk.conv2, a, res1=h, dst=y)
                 ops.add(y, self.extra_residual(h).contiguous(), out=y)
                 if res2 is not None:
                     ops.add(y, res2, out=y)
+                os_ = None
             ws.give(a)
-            return y
+            return y, os_
 
         def attn(att, h, res2=None):                                              # ThreeDimensionalAttention
             Bq, E, D, H, W = h.shape
@@ -839,56 +869,61 @@ class PUNetG(torch.nn.Module):
             xe = ops.concat2(x, ones, out=ws.take((B, x.shape[1] + 1) + tuple(x.shape[2:]), dev))
             ws.give(ones)
             x = xe
+        hs = None
         if isinstance(self.convin, _FourierInput):
             h = ops.fourier_channels(x, self.convin.W, out=ws.take((B, cfg.model_channels) + tuple(x.shape[2:]), dev))
         else:
-            h = conv(self.convin, x)
+            h, hs = conv(self.convin, x, want_stats=True)
         if xe is not None:
             ws.give(xe)
         skips = []
         for lv, blocks in enumerate(self.downward_blocks):
             for blk in blocks:
-                h2 = res(blk, h)
-                ws.give(h)
-                h = h2
+                h2, hs2 = res(blk, h, hs)
+                give(h, hs)
+                h, hs = h2, hs2
             skips.append(h)
-            h = conv(self.downsamplers[lv].conv, h, load_mode=DS_LOAD_MAXPOOL2)
+            if hs is not None:
+                ws.give(hs)                                                      # the skip is only added, never normalised
+            h, hs = conv(self.downsamplers[lv].conv, h, load_mode=DS_LOAD_MAXPOOL2, want_stats=True)
         for blk in self.before_block:
-            h2 = res(blk, h)
-            ws.give(h)
-            h = h2
-        xa = h
+            h2, hs2 = res(blk, h, hs)
+            give(h, hs)
+            h, hs = h2, hs2
+        xa, xas = h, hs
         nattn = len(self.attn_resnet_block)
         for i, blk in enumerate(self.attn_resnet_block):
             last = i == nattn - 1
-            xa2 = res(blk, xa, res2=h if (last and i >= len(self.attn_block)) else None)
+            xa2, xas2 = res(blk, xa, xas, res2=h if (last and i >= len(self.attn_block)) else None)
             if xa is not h:
-                ws.give(xa)
-            xa = xa2
+                give(xa, xas)
+            xa, xas = xa2, xas2
             if i < len(self.attn_block):
                 xa2 = attn(self.attn_block[i], xa, res2=h if last else None)
-                ws.give(xa)
-                xa = xa2
+                give(xa, xas)
+                xa, xas = xa2, None
         if nattn == 0:
-            xa = ops.add(h, h, out=ws.take(h.shape, dev))
-        ws.give(h)
-        h = xa
+            xa, xas = ops.add(h, h, out=ws.take(h.shape, dev)), None
+        give(h, hs if xas is not hs else None)
+        h, hs = xa, xas
         for blk in self.after_block:
-            h2 = res(blk, h)
-            ws.give(h)
-            h = h2
+            h2, hs2 = res(blk, h, hs)
+            give(h, hs)
+            h, hs = h2, hs2
+        nup = len(self.upward_blocks)
         for lv, blocks in enumerate(self.upward_blocks):
             skip = skips.pop()
-            h2 = conv(self.upsamplers[lv].conv, h, load_mode=DS_LOAD_UPSAMPLE2, res1=skip)
-            ws.give(h)
+            h2, hs2 = conv(self.upsamplers[lv].conv, h, load_mode=DS_LOAD_UPSAMPLE2, res1=skip, want_stats=True)
+            give(h, hs)
             ws.give(skip)
-            h = h2
-            for blk in blocks:
-                h2 = res(blk, h)
-                ws.give(h)
-                h = h2
-        y = conv(self.convout, h, dst=out, fresh=out is None)
-        ws.give(h)
+            h, hs = h2, hs2
+            for j, blk in enumerate(blocks):
+                final = lv == nup - 1 and j == len(blocks) - 1                    # feeds convout: no norm follows
+                h2, hs2 = res(blk, h, hs, want_stats=not final)
+                give(h, hs)
+                h, hs = h2, hs2
+        y, _ = conv(self.convout, h, dst=out, fresh=out is None)
+        give(h, hs)
         return y
 
     def _attention(self, att, x, pk, ws, res2=None, tile_stats=None):

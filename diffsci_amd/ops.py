@@ -275,12 +275,90 @@ def pack_conv3d(w, upsampled=False):
     return [pack_conv(w[:, :, kz].contiguous(), "fp16x3", upsampled=upsampled) for kz in range(3)]
 
 
+def volume_stat_tiles(D, HW):
+    """Entries per (sample, channel) of the statistics ds_slices_to_volume_stats leaves for a [.., D, H, W] volume."""
+    return N.lib().ds_volume_stat_tiles(int(D), int(HW))
+
+
+def _slice_rows(shift, B, D, Cout):
+    """Per-slice rows of a per-sample time shift for the 2-D batch of all slices but the outermost two."""
+    if shift is None:
+        return None
+    if shift.dim() != 2 or shift.shape[1] != Cout or shift.shape[0] not in (1, B):
+        raise ValueError(f"shift must be [1 or B, Cout]; got {tuple(shift.shape)}")
+    ns = B * (D + 2)
+    return shift if shift.shape[0] == 1 else shift.repeat_interleave(D + 2, dim=0)[1:ns - 1].contiguous()
+
+
+def _depth_taps(s_in, s_out, packs, bias, rows, load_mode, circular, prenorm=None, tile_stats=None):
+    """The three depth-tap launches of a 3x3x3 convolution over slice-major volumes: the centre tap initialises the
+    accumulator (all slices of s_out but the outermost two), the others add to it; prenorm: per-SLICE table
+    [B*(D+2), ceil16(Cin), 4] (ds_slice_tables) for the fused norm + SiLU loader; tile_stats: filled by the last launch."""
+    ns = s_in.shape[0]
+    acc = s_out[1:ns - 1]
+    for n, dz in enumerate((0, -1, 1)):
+        conv(s_in[1 + dz:ns - 1 + dz], packs[dz + 1], bias=bias if n == 0 else None, shift=rows if n == 0 else None,
+             res1=None if n == 0 else acc, load_mode=load_mode, circular=circular, out=acc,
+             prenorm=None if prenorm is None else prenorm[1 + dz:ns - 1 + dz], tile_stats=tile_stats if n == 2 else None)
+    return acc
+
+
+def _from_slices(out, s_out, res1, res2, B, C, D, HW, out_stats=None):
+    if out_stats is None:
+        N.check(N.lib().ds_slices_to_volume(_p(out), _p(s_out), _p(res1), _p(res2), B, C, D, HW, _stream()), "ds_slices_to_volume")
+    else:
+        if tuple(out_stats.shape) != (B, C, volume_stat_tiles(D, HW), 4):
+            raise ValueError(f"out_stats must be {(B, C, volume_stat_tiles(D, HW), 4)}")
+        N.check(N.lib().ds_slices_to_volume_stats(_p(out), _p(s_out), _p(res1), _p(res2), _p(out_stats), B, C, D, HW, _stream()),
+                "ds_slices_to_volume_stats")
+    return out
+
+
+def resblock3d_fused(h, tab1, packs1, bias1, shift, packs2, bias2, w2, b2, kind2, res2=None, out=None, out_stats=None,
+                     ws=None, eps=1e-5):
+    """ResnetBlockC on a volume (commonlayers.py:824-833) with both norms folded and the intermediate kept slice-major:
+        S1 = SiLU(norm1(h))         by the volume -> slice copy (tab1 = ds_inorm_table rows of h's statistics)
+        S2 = conv1(S1) + shift      three depth-tap launches; the last one leaves S2's tile statistics
+        T  = per-slice table of norm2 over the sample's real slices, zero rows for the pad slices (ds_slice_tables)
+        S3 = conv2(SiLU(norm2(S2))) three launches with the fused loader reading S2 in place
+        out = S3 + h [+ res2]       by the slice -> volume copy, which also leaves out's statistics (out_stats)
+    against norm, copy, 3 launches, copy, norm, copy, 3 launches, copy.  Zero padding, plain loads, fp16x3 packings."""
+    require_device(h, "h")
+    B, C, D, H, W = h.shape
+    if packs1[0].Cout != C or packs2[0].Cout != C:
+        raise ValueError("resblock3d_fused keeps the channel count")
+    ns, dev = B * (D + 2), h.device
+
+    def take(shape):
+        return torch.empty(shape, dtype=torch.float32, device=dev) if ws is None else ws.take(shape, dev)
+    if out is None:
+        out = torch.empty_like(h)
+    s1 = take((ns, C, H, W))
+    N.check(N.lib().ds_volume_to_slices_act(_p(s1), _p(h.contiguous()), _p(tab1), B, C, D, H * W, _stream()),
+            "ds_volume_to_slices_act")
+    s2 = take((ns, C, H, W))
+    s2[0].zero_()                                           # the outermost pad slices are never written by the launches
+    s2[ns - 1].zero_()
+    ts = take((ns - 2, C, conv_tile_count(H, W), 4))
+    _depth_taps(s1, s2, packs1, bias1, _slice_rows(shift, B, D, C), N.DS_LOAD_PLAIN, False, tile_stats=ts)
+    tab2 = take((ns, table_channels(C), 4))
+    N.check(N.lib().ds_slice_tables(_p(tab2), _p(ts), _p(w2), _p(b2), B, C, D, ts.shape[2], D * H * W, float(eps), int(kind2),
+                                    _stream()), "ds_slice_tables")
+    _depth_taps(s2, s1, packs2, bias2, None, N.DS_LOAD_PLAIN, False, prenorm=tab2)          # S1 is dead: reuse it for S3
+    _from_slices(out, s1, h, res2, B, C, D, H * W, out_stats)
+    if ws is not None:
+        for t in (s1, s2, ts, tab2):
+            ws.give(t)
+    return out
+
+
 def conv3d_mfma(x, packs, bias=None, shift=None, res1=None, res2=None, load_mode=N.DS_LOAD_PLAIN, circular=False, out=None,
-                ws=None):
+                ws=None, out_stats=None):
     """3x3x3 'same' convolution of a volume on the matrix cores: three 2-D fp16x3 convolutions (one per depth tap) over
     a slice-major, depth-padded copy of the volume (ds_volume_to_slices / ds_slices_to_volume).  Same arguments and
     fusions as conv3d; packs = pack_conv3d(weight).  ws: an optional buffer pool (take(shape, device) / give(tensor)) for
-    the two slice copies, so that a captured loop allocates nothing."""
+    the two slice copies, so that a captured loop allocates nothing.  out_stats: [B, Cout, volume_stat_tiles(D, H*W), 4],
+    filled with the result's shifted partial sums (the consumer's norm table, ds_inorm_table with count D*H*W)."""
     require_device(x, "x")
     B, Cin, Din, Hi, Wi = x.shape
     Cout = packs[0].Cout
@@ -307,17 +385,8 @@ def conv3d_mfma(x, packs, bias=None, shift=None, res1=None, res2=None, load_mode
     N.check(N.lib().ds_volume_to_slices(_p(s_in), _p(x.contiguous()), B, Cin, D, Hi * Wi, depth_mode, 1 if circular else 0,
                                         _stream()), "ds_volume_to_slices")
     s_out = take((ns, Cout, H, W))
-    acc = s_out[1:ns - 1]                                   # every slice but the outermost two pads: the 2-D "batch"
-    rows = None
-    if shift is not None:
-        if shift.dim() != 2 or shift.shape[1] != Cout or shift.shape[0] not in (1, B):
-            raise ValueError(f"shift must be [1 or B, Cout]; got {tuple(shift.shape)}")
-        rows = shift if shift.shape[0] == 1 else shift.repeat_interleave(D + 2, dim=0)[1:ns - 1].contiguous()
-    for n, dz in enumerate((0, -1, 1)):                     # centre tap first: it initialises the accumulator
-        conv(s_in[1 + dz:ns - 1 + dz], packs[dz + 1], bias=bias if n == 0 else None, shift=rows if n == 0 else None,
-             res1=None if n == 0 else acc, load_mode=load_mode, circular=circular, out=acc)
-    N.check(N.lib().ds_slices_to_volume(_p(out), _p(s_out), _p(res1), _p(res2), B, Cout, D, H * W, _stream()),
-            "ds_slices_to_volume")
+    _depth_taps(s_in, s_out, packs, bias, _slice_rows(shift, B, D, Cout), load_mode, circular)
+    _from_slices(out, s_out, res1, res2, B, Cout, D, H * W, out_stats)
     if ws is not None:
         ws.give(s_in)
         ws.give(s_out)

@@ -316,3 +316,56 @@ def test_sample_sharded_on_a_one_rank_rccl_group(M, net8, dev, grids):
         assert got.shape == (5, 1, 32, 32) and torch.equal(got, want)
     finally:
         dist.destroy_process_group()
+
+
+def test_volume_norm_folding(M, dev):
+    """Round 2: the norms of a residual block on volumes are folded into the copies and the convolutions around them
+    (ops.resblock3d_fused: norm1 in the volume -> slice copy, the intermediate slice-major with norm2 in conv2's loader,
+    statistics from the slice -> volume copy).  Pieces against torch on the same tensors, the network against the
+    standalone-norm route and the reference's golden."""
+    from diffsci_amd import ops
+    from tests.golden_util import load, rel_l2
+    torch.manual_seed(11)
+    B, C, D, H, W = 2, 8, 6, 16, 16
+    h = torch.randn(B, C, D, H, W, device=dev) * 1.7 + 0.4
+    w1, b1 = torch.randn(C, device=dev), torch.randn(C, device=dev)
+    # the copy's statistics -> table -> activated slices
+    s_plain = torch.empty(B * (D + 2), C, H, W, device=dev)
+    ops.N.check(ops.N.lib().ds_volume_to_slices(ops._p(s_plain), ops._p(h), B, C, D, H * W, 0, 0, ops._stream()), "to_slices")
+    back = torch.empty_like(h)
+    st = torch.empty(B, C, ops.volume_stat_tiles(D, H * W), 4, device=dev)
+    r1 = torch.randn_like(h)
+    ops._from_slices(back, s_plain, r1, None, B, C, D, H * W, st)
+    assert torch.equal(back, h + r1)
+    tab = ops.inorm_table(st, w1, b1, 0, D * H * W)
+    v = (h + r1).double()
+    mean, var = v.mean(dim=(2, 3, 4)), v.var(dim=(2, 3, 4), unbiased=False)
+    assert torch.allclose(tab[:, :C, 0].double(), mean, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(tab[:, :C, 1].double(), w1.double() / torch.sqrt(var + 1e-5), rtol=1e-5)
+    s_act = torch.empty_like(s_plain)
+    ops.N.check(ops.N.lib().ds_volume_to_slices_act(ops._p(s_act), ops._p(back), ops._p(tab), B, C, D, H * W, ops._stream()), "to_slices_act")
+    want = torch.nn.functional.silu(torch.nn.functional.group_norm(back, C, w1, b1, 1e-5))
+    got = s_act.view(B, D + 2, C, H, W)
+    assert float(got[:, 0].abs().max()) == 0.0 and float(got[:, D + 1].abs().max()) == 0.0
+    assert rel_l2(got[:, 1:D + 1].permute(0, 2, 1, 3, 4).cpu(), want.cpu()) < 2e-6
+    # the network: folded against standalone norms and the reference
+    g, sd = load("punetg8_3d")
+    net = M.PUNetG(M.PUNetGConfig(model_channels=8, dimension=3))
+    net.load_state_dict(sd, strict=True)
+    net = net.to(dev).eval()
+    x, t = g["x"].to(dev), g["t"].to(dev)
+    calls = []
+    orig = ops.resblock3d_fused
+    ops.resblock3d_fused = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    try:
+        folded = net(x, t).cpu()
+    finally:
+        ops.resblock3d_fused = orig
+    assert len(calls) >= 8, "the folded block did not run"
+    net.fuse_norm = False
+    plain = net(x, t).cpu()
+    net.fuse_norm = True
+    assert rel_l2(folded, plain) < 3e-6
+    assert rel_l2(folded, g["out_f32"]) < 1e-5
+    assert rel_l2(folded, g["out_f64"]) < max(4 * rel_l2(g["out_f32"], g["out_f64"]), 2e-6)
+
