@@ -40,7 +40,8 @@ constexpr int NBUF = 3, NDMA = 12;
 constexpr int ES = 72;                         // epilogue exchange: [p 16][co 32][72 (64 tiles used)] floats per pass
 constexpr int EPI_BYTES = 16 * 32 * ES * 4;        // 147,456
 constexpr int STAGE_BYTES = NBUF * PATCH_VEC * 16; // 73,728
-constexpr int LDS_BYTES = EPI_BYTES > STAGE_BYTES ? EPI_BYTES : STAGE_BYTES;
+constexpr int PLAN_BYTES = NDMA * NT * 4;           // 24,576
+constexpr int LDS_BYTES = EPI_BYTES > STAGE_BYTES + PLAN_BYTES ? EPI_BYTES : STAGE_BYTES + PLAN_BYTES;
 
 struct Args {
   float* out;
@@ -56,9 +57,9 @@ struct Args {
 // fp32 pair -> fp16 hi pair + fp16 lo pair (lo = a - hi, exact in fp32, one rounding to fp16): three instructions
 __device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned& lo) {
   unsigned hp, lp;
-  asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hp) : "v"(a), "v"(b));
-  asm volatile("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(lp) : "v"(hp), "v"(a));
-  asm volatile("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lp) : "v"(hp), "v"(b));
+  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hp) : "v"(a), "v"(b));
+  asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(lp) : "v"(hp), "v"(a));
+  asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lp) : "v"(hp), "v"(b));
   hi = hp;
   lo = lp;
 }
@@ -88,7 +89,7 @@ __global__ __launch_bounds__(NT, 1) void k_wino(const Args a) {
   // ---- LDS-DMA plan: instruction k = wv + 8 i moves 64 dwords = 16 (pixel slot) x 4 channels; lane = 4 * slot + channel.
   //      Every lane always reads a valid address (clamped); lanes whose pixel is outside the image zero their own dword
   //      after their own wait (zero padding), so the number of outstanding operations is the same for every wave. ----
-  int doff[NDMA];
+  int* DT = reinterpret_cast<int*>(smem + STAGE_BYTES);      // [12][512] source offsets of the DMA plan: parked in LDS, the main loop has no registers to spare
   unsigned dzero = 0;
 #pragma unroll
   for (int i = 0; i < NDMA; ++i) {
@@ -101,7 +102,7 @@ __global__ __launch_bounds__(NT, 1) void k_wino(const Args a) {
     const int gy = y0 - 1 + row, gx = x0 - 1 + col;
     const bool inimg = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
     const int cy = gy < 0 ? 0 : (gy >= a.H ? a.H - 1 : gy), cx = gx < 0 ? 0 : (gx >= a.W ? a.W - 1 : gx);
-    doff[i] = ((cg > 3 ? 3 : cg) * 4 + ci) * HW + cy * a.W + cx;
+    DT[i * NT + tid] = ((cg > 3 ? 3 : cg) * 4 + ci) * HW + cy * a.W + cx;
     if (live && !inimg) dzero |= 1u << i;
   }
   const float* in_b = a.in + (size_t)b * a.Cin * HW;
@@ -110,7 +111,7 @@ __global__ __launch_bounds__(NT, 1) void k_wino(const Args a) {
     float* dst = Pf + buf * (PATCH_VEC * 4) + 64 * wv;
 #pragma unroll
     for (int i = 0; i < NDMA; ++i)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + doff[i]),
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + DT[i * NT + tid]),
                                        (__attribute__((address_space(3))) void*)(dst + 512 * i), 4, 0, 0);
   };
   auto zero_fix = [&](int buf) __attribute__((always_inline)) {
@@ -128,10 +129,14 @@ __global__ __launch_bounds__(NT, 1) void k_wino(const Args a) {
   const int irow = wv >> 1, j0 = 2 * (wv & 1);
   const int ka = irow == 0 ? 0 : 1, kb = irow == 3 ? 3 : 2;
   const float beta = irow == 1 ? 1.f : -1.f;
+  // three patch columns per wave, ordered so that V_a = r[0] - r[1] for both kinds of wave and V_b = r[2] + gamma * r_d:
+  //   j0 = 0: columns (0, 2, 1), r_d = r[1], gamma = +1 (V_0 = d0 - d2, V_1 = d1 + d2)
+  //   j0 = 2: columns (1, 2, 3), r_d = r[0], gamma = -1 (-V_2 = d1 - d2, -V_3 = d3 - d1; the signs live in U)
   int oa[3], ob[3];
+  const float gamma = j0 == 0 ? 1.f : -1.f;
 #pragma unroll
   for (int t = 0; t < 3; ++t) {
-    const int l = (j0 == 0 ? 0 : 1) + t;
+    const int l = j0 == 0 ? (t == 0 ? 0 : (t == 1 ? 2 : 1)) : 1 + t;
     const int co = (l & 1) * PC2 + (l >> 1);
     oa[t] = 2 * PC2 * ka + co;
     ob[t] = 2 * PC2 * kb + co;
@@ -164,97 +169,108 @@ __global__ __launch_bounds__(NT, 1) void k_wino(const Args a) {
       for (int mt = 0; mt < 2; ++mt) A[pt][piece][mt] = __builtin_bit_cast(f16x8, src[(piece * 2 + mt) * 64]);
   };
 
-  f16x8 Bh[2][2], Bl[2][2];                                  // [nb][pt]
-  const bool late = wv >= 4;
-  auto construct = [&](const f32x4* pb) __attribute__((always_inline)) {
+  // ---- main loop, software-pipelined inside every wave: a STEP = the 12 matrix instructions of one half of the tiles (nb)
+  //      interleaved with building the B fragments of the NEXT step -- 12 ds_read_b128 behind the first four MFMAs, the
+  //      transform and the split behind the other eight -- so the vector / LDS work hides under the wave's own matrix time
+  //      (as separate phases it took 1.1-1.25 us per chunk against 0.43 us of matrix issue).
+  //      chunk c: step 0 = MFMA(c, nb 0) | build (c, nb 1);  barrier;  step 1 = MFMA(c, nb 1) | build (c + 1, nb 0), the next
+  //      chunk's weights behind each point's last use, then the patch DMA three chunks ahead (issued AFTER the weight loads:
+  //      vmcnt retires in order, and the weights are consumed first).
+  struct BFr { f16x8 h[2], l[2]; };                          // [pt]
+  auto build = [&](BFr& Bn, const f32x4* pb, int nb) __attribute__((always_inline)) {       // the prologue's, not scheduled
+    f32x4 va[2], vb[2];
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb) {
-      f32x4 va[2], vb[2];
-      if (VARIANT & 2) {
-        va[0] = f32x4{1.f, 2.f, 3.f, 4.f} * beta; va[1] = va[0]; vb[0] = va[0]; vb[1] = va[0];
-      } else {
-#pragma unroll
-        for (int g = 0; g < 2; ++g) {
-          const f32x4* q = pb + lbase[nb] + g * CG_VEC;
-          const f32x4 r0 = q[oa[0]] + q[ob[0]] * beta;
-          const f32x4 r1 = q[oa[1]] + q[ob[1]] * beta;
-          const f32x4 r2 = q[oa[2]] + q[ob[2]] * beta;
-          if (j0 == 0) { va[g] = r0 - r2; vb[g] = r1 + r2; }
-          else { va[g] = r0 - r1; vb[g] = r0 - r2; }
-        }
-      }
-#pragma unroll
-      for (int pt = 0; pt < 2; ++pt) {
-        const f32x4 v0 = pt == 0 ? va[0] : vb[0], v1 = pt == 0 ? va[1] : vb[1];
-        unsigned h0, h1, h2, h3, l0, l1, l2, l3;
-        split2(v0[0], v0[1], h0, l0);
-        split2(v0[2], v0[3], h1, l1);
-        split2(v1[0], v1[1], h2, l2);
-        split2(v1[2], v1[3], h3, l3);
-        const u32x4 bh = {h0, h1, h2, h3}, bl = {l0, l1, l2, l3};
-        Bh[nb][pt] = __builtin_bit_cast(f16x8, bh); Bl[nb][pt] = __builtin_bit_cast(f16x8, bl);
-      }
+    for (int g = 0; g < 2; ++g) {
+      const f32x4* q = pb + lbase[nb] + g * CG_VEC;
+      const f32x4 r0 = q[oa[0]] + q[ob[0]] * beta, r1 = q[oa[1]] + q[ob[1]] * beta, r2 = q[oa[2]] + q[ob[2]] * beta;
+      va[g] = r0 - r1;
+      vb[g] = r2 + (j0 == 0 ? r1 : r0) * gamma;
     }
-  };
-  // the 24 matrix instructions of the fragments in Bh / Bl, each point's weights for chunk `next` fetched right behind its last use
-  auto matrix_phase = [&](int next, bool fetch) __attribute__((always_inline)) {
 #pragma unroll
     for (int pt = 0; pt < 2; ++pt) {
-#pragma unroll
-      for (int t = 0; t < 3; ++t)
-#pragma unroll
-        for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-          for (int mt = 0; mt < 2; ++mt)
-            acc[pt][mt][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[pt][t == 0 ? 1 : 0][mt], t == 1 ? Bl[nb][pt] : Bh[nb][pt], acc[pt][mt][nb], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      if (fetch && !(VARIANT & 4)) a_fetch(next, pt);
+      const f32x4 v0 = pt == 0 ? va[0] : vb[0], v1 = pt == 0 ? va[1] : vb[1];
+      unsigned h0, h1, h2, h3, l0, l1, l2, l3;
+      split2(v0[0], v0[1], h0, l0); split2(v0[2], v0[3], h1, l1); split2(v1[0], v1[1], h2, l2); split2(v1[2], v1[3], h3, l3);
+      const u32x4 bh = {h0, h1, h2, h3}, bl = {l0, l1, l2, l3};
+      Bn.h[pt] = __builtin_bit_cast(f16x8, bh); Bn.l[pt] = __builtin_bit_cast(f16x8, bl);
     }
   };
+  // One step, scheduled by hand (sched_barrier(0) pins every group behind "its" MFMA): MFMA i of the current fragments, then
+  // a slice of the next fragments' construction.  i = 6 pt + 2 t + mt; the weights of point 0 are dead after MFMA 5.
+  auto step = [&](const BFr& Bc, int nbc, BFr& Bn, const f32x4* pbn, int nbn, bool do_build, int fetch_chunk)
+      __attribute__((always_inline)) {
+    f32x4 ra[2][3], rb[2][3], va[2], vb[2];
+    unsigned hh[2][4], ll[2][4];
+    auto MF = [&](int i) __attribute__((always_inline)) {
+      const int pt = i / 6, t = (i % 6) >> 1, mt = i & 1;
+      acc[pt][mt][nbc] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[pt][t == 0 ? 1 : 0][mt], t == 1 ? Bc.l[pt] : Bc.h[pt],
+                                                                acc[pt][mt][nbc], 0, 0, 0);
+    };
+    auto reads = [&](int g) __attribute__((always_inline)) {
+      const f32x4* q = pbn + lbase[nbn] + g * CG_VEC;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { ra[g][c] = q[oa[c]]; rb[g][c] = q[ob[c]]; }
+    };
+    auto transform = [&](int g) __attribute__((always_inline)) {
+      const f32x4 r0 = ra[g][0] + rb[g][0] * beta, r1 = ra[g][1] + rb[g][1] * beta, r2 = ra[g][2] + rb[g][2] * beta;
+      va[g] = r0 - r1;
+      vb[g] = r2 + (j0 == 0 ? r1 : r0) * gamma;
+    };
+    auto splits = [&](int pt, int half) __attribute__((always_inline)) {          // half: channel group g = half
+      const f32x4 v = pt == 0 ? va[half] : vb[half];
+      split2(v[0], v[1], hh[pt][2 * half], ll[pt][2 * half]);
+      split2(v[2], v[3], hh[pt][2 * half + 1], ll[pt][2 * half + 1]);
+    };
+    auto finish = [&](int pt) __attribute__((always_inline)) {
+      const u32x4 bh = {hh[pt][0], hh[pt][1], hh[pt][2], hh[pt][3]}, bl = {ll[pt][0], ll[pt][1], ll[pt][2], ll[pt][3]};
+      Bn.h[pt] = __builtin_bit_cast(f16x8, bh); Bn.l[pt] = __builtin_bit_cast(f16x8, bl);
+    };
+#define SB __builtin_amdgcn_sched_barrier(0)
+    SB; MF(0); if (do_build) reads(0);
+    SB; MF(1); if (do_build) transform(0);
+    SB; MF(2); if (do_build) reads(1);
+    SB; MF(3); if (do_build) splits(0, 0);
+    SB; MF(4); if (do_build) transform(1);
+    SB; MF(5); if (do_build) splits(1, 0);
+    SB; if (fetch_chunk >= 0 && !(VARIANT & 4)) a_fetch(fetch_chunk, 0);
+    SB; MF(6); if (do_build) { splits(0, 1); finish(0); }
+    SB; MF(7); if (do_build) { splits(1, 1); finish(1); }
+    SB; MF(8);
+    SB; MF(9);
+    SB; MF(10);
+    SB; MF(11);
+    SB; if (fetch_chunk >= 0 && !(VARIANT & 4)) a_fetch(fetch_chunk, 1);
+    SB;
+#undef SB
+  };
 
-  // ---- prologue ----
+  // ---- prologue: three patches, the first weights, the first fragments ----
   dma(0, 0);
   if (a.n_chunks > 1) dma(1, 1);
+  if (a.n_chunks > 2) dma(2, 2);
   a_fetch(0, 0);
   a_fetch(0, 1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   zero_fix(0);
   if (a.n_chunks > 1) zero_fix(1);
+  if (a.n_chunks > 2) zero_fix(2);
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-
+  BFr B0, B1;
+  build(B0, P, 0);
   const unsigned long long t_pro = __builtin_amdgcn_s_memrealtime();
-  // Two phases per chunk and wave: CONSTRUCT (LDS reads, transform, split: vector pipe) and MATRIX (24 MFMAs), a barrier
-  // behind each.  The two waves of a SIMD (w and w + 4) run them in antiphase: waves 4..7 pass one extra barrier before the
-  // loop (waves 0..3 one after it), so barrier k releases waves 0..3 into their matrix phase and waves 4..7 into their
-  // construct phase, or the reverse -- one wave's vector work overlaps the other's matrix work with ONE copy of the loop
-  // (in lockstep the phases of the two waves serialise: 1.4 + 1.0 us per chunk against 0.37 us of matrix time per wave).
-  //   buffer i + 1 is read after barrier 2i + 1 (waves 0..3) / 2i + 2 (waves 4..7); its DMA parts are waited for before
-  //   barrier 2i / 2i + 1; DMA (i + 2) overwrites buffer i - 1 after barrier 2i - 1 / 2i, its last reader (waves 4..7,
-  //   construct i - 1) arrived at barrier 2i - 1.
-  if (late) asm volatile("s_barrier" ::: "memory");
+
   for (int chunk = 0; chunk < a.n_chunks; ++chunk) {
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    if (chunk + 2 < a.n_chunks && !(VARIANT & 8)) dma(chunk + 2, (chunk + 2) % NBUF);
-    construct(P + ((VARIANT & 8) ? 0 : chunk % NBUF) * PATCH_VEC);
-    const unsigned long long tc = __builtin_amdgcn_s_memrealtime();
-    // this wave's part of the next chunk's patch (and this chunk's weights) has landed once everything older than this
-    // iteration's DMA (12) has
-    if (chunk + 1 < a.n_chunks && !(VARIANT & 8)) {
-      if (chunk + 2 < a.n_chunks) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    const bool more = chunk + 1 < a.n_chunks;
+    step(B0, 0, B1, P + (chunk % NBUF) * PATCH_VEC, 1, true, -1);
+    if (more) {
+      if (chunk + 2 < a.n_chunks) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");   // all but the DMA issued one iteration ago
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       zero_fix((chunk + 1) % NBUF);
     }
-    const unsigned long long tw = __builtin_amdgcn_s_memrealtime();
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
-    matrix_phase(chunk + 1, chunk + 1 < a.n_chunks);
-    const unsigned long long tm = __builtin_amdgcn_s_memrealtime();
-    t_c += tc - t0; t_w += tw - tc; t_m += tm - t1;
-    asm volatile("s_barrier" ::: "memory");
-    const unsigned long long t2 = __builtin_amdgcn_s_memrealtime();
-    t_compute += t1 - t0; t_wait += t2 - t1;
+    step(B1, 1, B0, P + ((chunk + 1) % NBUF) * PATCH_VEC, 0, more, more ? chunk + 1 : -1);
+    if (chunk + 3 < a.n_chunks && !(VARIANT & 8)) dma(chunk + 3, chunk % NBUF);
   }
-  if (!late) asm volatile("s_barrier" ::: "memory");
   const unsigned long long t_main = __builtin_amdgcn_s_memrealtime();
 
   // ---- epilogue: two passes of 32 channels (mt); every wave parks its two points' 32 x 64 blocks in LDS, then each thread
@@ -327,7 +343,7 @@ static void pack_U(std::vector<_Float16>& packed, const std::vector<float>& w, i
       const int chunk = ci / 16, lh = (ci % 16) / 8, e = ci % 8;
       const int lane = lh * 32 + m;
       for (int p = 0; p < 16; ++p) {
-        const double sgn = (((p >> 2) == 2) != ((p & 3) == 2)) ? -1.0 : 1.0;     // sigma_i sigma_j (see k_wino)
+        const double sgn = (((p >> 2) == 2) != ((p & 3) >= 2)) ? -1.0 : 1.0;     // point signs folded into U (see k_wino: rows i = 2, columns j = 2, 3)
         const float v = (float)(sgn * U[p >> 2][p & 3] * scale);
         const _Float16 hi = (_Float16)v, lo = (_Float16)(v - (float)hi);
         const int wvi = p >> 1, pt = p & 1;
@@ -451,11 +467,10 @@ int main(int argc, char** argv) {
           sc += h[w * 8 + 6]; sw += h[w * 8 + 7] & 0xffffffffull; sm += h[w * 8 + 7] >> 32;
           tmin = std::min(tmin, h[w * 8]); tmax = std::max(tmax, h[w * 8 + 5]);
         }
-        printf("    %d workgroups, span %.1f us; per workgroup (us): prologue %.2f, construct phases %.2f (%.2f each), matrix phases %.2f (%.2f each), epilogue %.2f, life %.2f\n",
-               nwg, (tmax - tmin) / 100.0, pro / nwg / 100, comp / nwg / 100, comp / nwg / 100 / (C / 16), wait / nwg / 100, wait / nwg / 100 / (C / 16),
-               epi / nwg / 100, life / nwg / 100);
-        printf("    per chunk (us): DMA issue + construct %.2f, wait for landed loads + zero fix %.2f, barrier %.2f | matrix issue %.2f, barrier %.2f\n",
-               sc / nwg / 100 / (C / 16), sw / nwg / 100 / (C / 16), (comp - sc - sw) / nwg / 100 / (C / 16), sm / nwg / 100 / (C / 16), (wait - sm) / nwg / 100 / (C / 16));
+        double mainl = 0;
+        for (int w = 0; w < nwg; ++w) mainl += h[w * 8 + 4] - h[w * 8 + 1];
+        printf("    %d workgroups, span %.1f us; per workgroup (us): prologue %.2f, main loop %.2f (%.2f per chunk), epilogue %.2f, life %.2f\n",
+               nwg, (tmax - tmin) / 100.0, pro / nwg / 100, mainl / nwg / 100, mainl / nwg / 100 / (C / 16), epi / nwg / 100, life / nwg / 100);
         hipFree(g_stamps); g_stamps = nullptr;
       }
       hipFree(in); hipFree(out); hipFree(w); hipFree(U); hipFree(wp);
