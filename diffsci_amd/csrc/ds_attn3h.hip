@@ -48,6 +48,10 @@ constexpr float RESCALE_T = 8.0f;
 // stored pair with v_cvt_pk_f16_f32 and the remainder's reference with v_cvt_f16_f32, and the two
 // disagree on exact ties (measured on gfx950: hi + lo off by one fp16 ulp, 2^-11 relative, for one
 // value in ~8000).  Deriving the reference from the packed bits removes the second rounding.
+// e^x for the softmax numerators (x <= RESCALE_T): one FMA and the hardware exp2 (1 ulp; the argument's rounding adds
+// |x| * 2^-24 relative, i.e. < 1e-6 wherever the result is not negligible) instead of libm's range-reduced expf
+constexpr float LOG2E = 1.44269504088896341f;
+
 __device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned& lo) {
   // three instructions per pair: the packed conversion, then lo = fp16(a - hi) by the mixed-precision FMA reading the stored
   // high piece itself (a - hi is exact in fp32; one rounding to fp16)
@@ -211,18 +215,24 @@ __global__ __launch_bounds__(NT) void k_attn3h(float* out, const float* __restri
   };
   // ---- the two matrix products and the softmax between them, shared by both staging forms ----
   auto qk = [&](const u32x4* Ks) __attribute__((always_inline)) {                    // S^T[key][query]
-    f32x16 S;
+    // two accumulation chains (even / odd 16-wide d slabs), summed at the end: consecutive matrix instructions are independent
+    f32x16 S, S1;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) S[r] = 0.f;
+    for (int r = 0; r < 16; ++r) { S[r] = 0.f; S1[r] = 0.f; }
 #pragma unroll
-    for (int s = 0; s < NS; ++s) {
+    for (int s = 0; s < NS; s += 2) {
       const f16x8 ah = as_f16x8(Ks[(2 * s + lh) * KB + li]);
       const f16x8 al = as_f16x8(Ks[NDG * KB + (2 * s + lh) * KB + li]);
+      const f16x8 bh = as_f16x8(Ks[(2 * s + 2 + lh) * KB + li]);
+      const f16x8 bl = as_f16x8(Ks[NDG * KB + (2 * s + 2 + lh) * KB + li]);
       S = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, as_f16x8(qh[s]), S, 0, 0, 0);
+      S1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl, as_f16x8(qh[s + 1]), S1, 0, 0, 0);
       S = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, as_f16x8(ql[s]), S, 0, 0, 0);
+      S1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, as_f16x8(ql[s + 1]), S1, 0, 0, 0);
       S = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, as_f16x8(qh[s]), S, 0, 0, 0);
+      S1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, as_f16x8(qh[s + 1]), S1, 0, 0, 0);
     }
-    return S;
+    return S + S1;
   };
   if constexpr (IMG) {
     // Software pipeline (one wave per SIMD: nothing else hides the softmax): iteration kb issues the matrix
@@ -257,9 +267,10 @@ __global__ __launch_bounds__(NT) void k_attn3h(float* out, const float* __restri
           for (int r = 0; r < 16; ++r) O[t][r] *= alpha;
       }
       float rs = 0.f;
+      const float mneg = -m_run * LOG2E;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        S[r] = expf(S[r] - m_run);
+        S[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(S[r], LOG2E, mneg));     // e^(S - m): one FMA and the hardware exp2
         rs += S[r];
       }
       rs += __shfl_xor(rs, 32, 64);
@@ -323,20 +334,27 @@ __global__ __launch_bounds__(NT) void k_attn3h(float* out, const float* __restri
     }
     f32x16 S;
     {
-      // ---- S^T[key][query] ----
+      // ---- S^T[key][query]: the same two chains, in the same order, as qk() above (the two forms agree bit for bit) ----
+      f32x16 S1;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) S[r] = 0.f;
+      for (int r = 0; r < 16; ++r) { S[r] = 0.f; S1[r] = 0.f; }
 #pragma unroll
-      for (int s = 0; s < NS; ++s) {
+      for (int s = 0; s < NS; s += 2) {
         const f16x8 ah = as_f16x8(Ks[(2 * s + lh) * KB + li]);
         const f16x8 al = as_f16x8(Ks[NDG * KB + (2 * s + lh) * KB + li]);
+        const f16x8 bh = as_f16x8(Ks[(2 * s + 2 + lh) * KB + li]);
+        const f16x8 bl = as_f16x8(Ks[NDG * KB + (2 * s + 2 + lh) * KB + li]);
         S = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, as_f16x8(qh[s]), S, 0, 0, 0);
+        S1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl, as_f16x8(qh[s + 1]), S1, 0, 0, 0);
         S = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, as_f16x8(ql[s]), S, 0, 0, 0);
+        S1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, as_f16x8(ql[s + 1]), S1, 0, 0, 0);
         S = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, as_f16x8(qh[s]), S, 0, 0, 0);
+        S1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, as_f16x8(qh[s + 1]), S1, 0, 0, 0);
         // bound the operand look-ahead: without a fence the scheduler hoists all 2*NS fragment
         // reads (128 registers at E = 256) in front of the first MFMA
-        if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        if ((s & 2) == 2) __builtin_amdgcn_sched_barrier(0);
       }
+      S = S + S1;
     }
     if (!IMG && more) {
       k_store(Kn);                                   // the other K buffer: last read two tiles ago
@@ -363,9 +381,10 @@ __global__ __launch_bounds__(NT) void k_attn3h(float* out, const float* __restri
           for (int r = 0; r < 16; ++r) O[t][r] *= alpha;
       }
       float rs = 0.f;
+      const float mneg = -m_run * LOG2E;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        S[r] = expf(S[r] - m_run);
+        S[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(S[r], LOG2E, mneg));     // e^(S - m): one FMA and the hardware exp2
         rs += S[r];
       }
       rs += __shfl_xor(rs, 32, 64);
