@@ -14,14 +14,13 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 // disagree on exact ties (measured on gfx950: hi + lo off by one fp16 ulp, 2^-11 relative, for one
 // value in ~8000).  Deriving the reference from the packed bits removes the second rounding.
 __device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned& lo) {
-  // three instructions per pair: the packed conversion, then lo = fp16(a - hi) by the mixed-precision FMA reading the stored
-  // high piece itself (a - hi is exact in fp32; one rounding to fp16)
-  unsigned hp, lp;
-  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hp) : "v"(a), "v"(b));
-  asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(lp) : "v"(hp), "v"(a));
-  asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lp) : "v"(hp), "v"(b));
+  f16x2 h = {(_Float16)a, (_Float16)b};
+  unsigned hp = __builtin_bit_cast(unsigned, h);
+  asm volatile("" : "+v"(hp));                       // opaque: both uses below see these exact bits
+  const f16x2 hq = __builtin_bit_cast(f16x2, hp);
+  f16x2 l = {(_Float16)(a - (float)hq[0]), (_Float16)(b - (float)hq[1])};
   hi = hp;
-  lo = lp;
+  lo = __builtin_bit_cast(unsigned, l);
 }
 
 // x * sigmoid(x) with the hardware exp2 / rcp (1 ulp each): the fused-normalisation loader's
