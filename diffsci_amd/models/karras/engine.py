@@ -163,7 +163,7 @@ class Loop:
 
     Usage: loop.load(x0[, scale]); loop.set_noise(eps); loop.launch(); loop.result()."""
 
-    def __init__(self, table: StepTable, source, like, record_history=False, injected_noise=False):
+    def __init__(self, table: StepTable, source, like, record_history=False, injected_noise=False, noise_shard=None):
         ops.require_device(like, "x")
         self.table, self.source, self.record_history = table, source, record_history
         n = len(table.rows)
@@ -179,7 +179,15 @@ class Loop:
         self.tmp = new() if (not source.wants_xin or table.kind == "karras") else None
         self.tmp2 = new() if (not source.wants_xin and table.kind == "karras") else None
         self.eps = self.rng = None
-        self.counters_per_step = ops.philox_counters(like.numel())
+        # noise_shard = (first element, total elements): this state is rows [lo, hi) of a larger batch sampled by several
+        # ranks (parallel.sample_sharded).  The in-kernel stream is then addressed as the single process would address it --
+        # element e of step i reads counter base + i * ceil(total / 4) + (first + e) / 4 -- so the shards of a stochastic
+        # run draw disjoint noise from one seed and reproduce the unsharded run.
+        first, total = (0, like.numel()) if noise_shard is None else (int(noise_shard[0]), int(noise_shard[1]))
+        if first % 4 or first < 0 or first + like.numel() > total:
+            raise ValueError("noise_shard: the shard must start at a multiple of 4 elements and lie inside the total")
+        self.counters_per_step = ops.philox_counters(total)
+        self.noise_base = first // 4
         if table.needs_noise:
             if injected_noise:
                 self.eps = torch.empty((n,) + shape, dtype=torch.float32, device=dev)
@@ -224,7 +232,7 @@ class Loop:
         """The eps of step i as a tensor (generator mode regenerates it from the counters: tests / diagnostics)."""
         if self.eps is not None:
             return self.eps[i]
-        return ops.philox_normal(self.rng, i * self.counters_per_step, self.x.shape)
+        return ops.philox_normal(self.rng, i * self.counters_per_step + self.noise_base, self.x.shape)
 
     def launch(self):
         table, source = self.table, self.source
@@ -245,7 +253,7 @@ class Loop:
             xin_next = xin if chain else None
             base = cur
             eps_i = eps[i] if eps is not None else None
-            philox_i = (self.rng, i * self.counters_per_step) if (self.rng is not None) else None
+            philox_i = (self.rng, i * self.counters_per_step + self.noise_base) if (self.rng is not None) else None
             if karras:
                 base = tmp                                           # x_hat, integrators.py:104-105
                 ops.churn(cur, eps_i, row.churn_coef, xhat_out=base, xin_out=xin, c_in=row.first.c_in, philox=philox_i)

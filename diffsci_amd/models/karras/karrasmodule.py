@@ -140,6 +140,9 @@ class KarrasModule(torch.nn.Module, LatentSpaceAutoregressive):
         self.edm_batch_norm = (edmbatchnorm.DimensionAgnosticBatchNorm(sigma=config.extra_args.get("sigma_data", 0.5))
                                if config.has_edm_batch_norm else None)
         self.use_graph = True          # capture the loop as a hipGraph for HIP-native networks
+        # (first element, total elements) of this process' rows inside a batch sampled by several ranks: set by
+        # parallel.sample_sharded around a run so that the in-kernel noise of the stochastic integrators is the unsharded run's
+        self.noise_shard = None
         self._plans = PlanCache()
 
     # ---------------------------------------------------------------- bookkeeping
@@ -352,12 +355,12 @@ class KarrasModule(torch.nn.Module, LatentSpaceAutoregressive):
             src = ModuleSource(self, y, guidance, x.shape[0], x)
 
             def make_loop():
-                return Loop(table, src, x, record_history, injected_noise=injected)
+                return Loop(table, src, x, record_history, injected_noise=injected, noise_shard=self.noise_shard)
 
             if src.planned and self.use_graph:
                 key = (tuple(x.shape), str(x.device), nsteps, i0, i1, record_history, table.kind, injected,
                        (integ.s_schurn, integ.s_tmin, integ.s_tmax, integ.s_noise) if table.kind == "karras" else None,
-                       float(guidance), condition_signature(y), float(sch.langevin_const), repr(sch.langevin_interval),
+                       float(guidance), condition_signature(y), float(sch.langevin_const), repr(sch.langevin_interval), self.noise_shard,
                        tuple(float(v) for v in table.t.tolist()),
                        tuple((p.data_ptr(), p._version) for p in self.model.parameters()),
                        tuple(getattr(self.model, a, None) for a in ("conv_precision", "fuse_norm", "fuse_max_cot", "direct_out", "upsample_parity")))

@@ -60,7 +60,17 @@ def sample_sharded(module, nsamples, shape, nsteps=100, seed=0, y=None, guidance
     else:
         local = white_noise[lo:hi]
     local = local.to(module.device)
-    out = module.propagate_white_noise(local, y=y, guidance=guidance, nsteps=nsteps, integrator=integrator)
+    # stochastic integrators: every rank addresses the in-kernel noise stream as the single process would (engine.Loop), so with
+    # the same torch.manual_seed on every rank the shards draw disjoint noise and the gathered batch is the unsharded run's
+    per_row = local[0].numel() if local.shape[0] else 1
+    shard = (lo * per_row, nsamples * per_row) if (world > 1 and per_row % 4 == 0 and hasattr(module, "noise_shard")) else None
+    if shard is not None:
+        module.noise_shard = shard
+    try:
+        out = module.propagate_white_noise(local, y=y, guidance=guidance, nsteps=nsteps, integrator=integrator)
+    finally:
+        if shard is not None:
+            module.noise_shard = None
     if not gather or not dist.is_initialized():
         return out
     return gather_samples(out, nsamples)

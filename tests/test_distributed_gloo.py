@@ -15,8 +15,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 class _StandIn:
     device = torch.device("cpu")
+    noise_shard = None          # KarrasModule's attribute: (first element, total elements) of this rank's rows
+    seen = None
 
     def propagate_white_noise(self, x, y=None, guidance=1.0, nsteps=100, integrator=None):
+        type(self).seen = self.noise_shard
         return torch.tanh(x) * nsteps + x.flatten(1).sum(1).view(-1, 1, 1, 1)   # per-sample, deterministic
 
 
@@ -26,7 +29,13 @@ def _worker(rank, world, port, nsamples, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from diffsci_amd.parallel import sample_sharded
     out = sample_sharded(_StandIn(), nsamples, [1, 4, 4], nsteps=3, seed=7, gather=True)
-    local = sample_sharded(_StandIn(), nsamples, [1, 4, 4], nsteps=3, seed=7, gather=False)
+    m = _StandIn()
+    local = sample_sharded(m, nsamples, [1, 4, 4], nsteps=3, seed=7, gather=False)
+    # the in-kernel noise of the stochastic integrators is addressed as the unsharded run's: the module is told where
+    # this rank's rows start and how long the whole batch is, and the setting does not outlive the call
+    from diffsci_amd.parallel import shard_rows
+    lo, _ = shard_rows(nsamples, world, rank)
+    assert _StandIn.seen == (lo * 16, nsamples * 16) and m.noise_shard is None
     q.put((rank, out.clone(), local.clone()))
     dist.barrier()
     dist.destroy_process_group()

@@ -369,3 +369,42 @@ def test_volume_norm_folding(M, dev):
     assert rel_l2(folded, g["out_f32"]) < 1e-5
     assert rel_l2(folded, g["out_f64"]) < max(4 * rel_l2(g["out_f32"], g["out_f64"]), 2e-6)
 
+
+@pytest.mark.parametrize("integrator", ["karras", "euler-maruyama"])
+def test_sharded_stochastic_run_reproduces_the_unsharded_one(M, dev, integrator):
+    """parallel.sample_sharded tells the module where its rows sit in the global batch (KarrasModule.noise_shard); the
+    in-kernel Philox stream is then addressed by GLOBAL element index, so two shards run one after the other from the same
+    generator state are the unsharded run's rows bit for bit (and ranks seeded alike draw disjoint noise)."""
+    from tests.golden_util import load
+    _, sd = load("punetg8_forward")
+    net = M.PUNetG(M.PUNetGConfig(model_channels=8))
+    net.load_state_dict(sd, strict=True)
+    module = M.KarrasModule(net, M.KarrasModuleConfig.from_edm()).to(dev)
+    if integrator == "euler-maruyama":
+        module.config.noisescheduler.langevin_const = 0.3
+    torch.manual_seed(3)
+    wn = torch.randn(4, 1, 32, 32, device=dev)
+    per_row = wn[0].numel()
+    for use_graph in (False, True):
+        module.use_graph = use_graph
+        torch.manual_seed(11)
+        full = module.propagate_white_noise(wn, nsteps=5, integrator=integrator)
+        parts = []
+        for lo, hi in ((0, 1), (1, 4)):                          # a ragged split
+            torch.manual_seed(11)                                 # every rank holds the same generator state
+            module.noise_shard = (lo * per_row, 4 * per_row)
+            try:
+                parts.append(module.propagate_white_noise(wn[lo:hi], nsteps=5, integrator=integrator))
+            finally:
+                module.noise_shard = None
+        assert torch.equal(torch.cat(parts), full)
+        torch.manual_seed(11)
+        alone = module.propagate_white_noise(wn[1:4], nsteps=5, integrator=integrator)     # unsharded addressing: other noise
+        assert not torch.equal(alone, full[1:4])
+    with pytest.raises(ValueError, match="noise_shard"):
+        module.noise_shard = (2, 4 * per_row)
+        try:
+            module.propagate_white_noise(wn[:1], nsteps=5, integrator=integrator)
+        finally:
+            module.noise_shard = None
+
