@@ -333,8 +333,10 @@ class PUNetG(torch.nn.Module):
             te = self.embed_time_field(None if t is None else t.reshape(-1).to(x), ye, B)
             shifts = self.time_shift_fields(te)
         else:
-            if t is None:
+            if t is None:                                          # punetg.py:398-399, 410: zeros (+ ye)
                 te = torch.zeros(B, self.config.model_channels, device=x.device)
+                if ye is not None:
+                    te = te + ye
             else:
                 te = self.embed_time(t.reshape(-1).to(x), ye)
             shifts = self.time_shifts(te)

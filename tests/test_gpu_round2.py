@@ -408,3 +408,22 @@ def test_sharded_stochastic_run_reproduces_the_unsharded_one(M, dev, integrator)
         finally:
             module.noise_shard = None
 
+
+def test_no_time_input_with_a_condition(M, dev):
+    """punetg.py:396-410: t = None means a zero time embedding, to which the embedded condition is still added."""
+    from oracle import punetg_ref
+    from tests.golden_util import load, rel_l2
+    v, sd = load("punetg8_forward")
+    net = M.PUNetG(M.PUNetGConfig(model_channels=8))
+    net.load_state_dict(sd, strict=True)
+    net = net.to(dev).eval()
+    torch.manual_seed(2)
+    ye = torch.randn(2, 8)
+    cfg = punetg_ref.default_config(model_channels=8)
+    with torch.inference_mode():
+        want = punetg_ref.punetg_forward(sd, cfg, v["x"], None, ye)
+        zero = punetg_ref.punetg_forward(sd, cfg, v["x"], None, None)
+    assert rel_l2(net(v["x"].to(dev), None, ye.to(dev)).cpu(), want) < 1e-5
+    assert rel_l2(net(v["x"].to(dev)).cpu(), zero) < 1e-5
+    assert rel_l2(want, zero) > 1e-3
+
