@@ -427,3 +427,29 @@ def test_no_time_input_with_a_condition(M, dev):
     assert rel_l2(net(v["x"].to(dev)).cpu(), zero) < 1e-5
     assert rel_l2(want, zero) > 1e-3
 
+
+def test_batched_classifier_free_guidance_is_bit_identical(M, dev):
+    """engine.ModuleSource runs the conditional and the unconditional evaluation of a guided step as one evaluation of batch
+    2B (tabulated time shifts: rows B.. are the unconditional half).  Every kernel treats samples independently, so the
+    result is the two-evaluation result bit for bit -- eagerly, captured, and after a condition change under the plan."""
+    from tests.golden_util import load
+    v, sd = load("punetg8_porosity")
+    net = M.PUNetG(M.PUNetGConfig(model_channels=8, input_channels=4, output_channels=4),
+                   conditional_embedding=M.nets.PorosityEmbedder(dembed=8))
+    net.load_state_dict(sd, strict=True)
+    module = M.KarrasModule(net, M.KarrasModuleConfig.from_edm(), conditional=True).to(dev)
+    wn = v["white_noise"].to(dev)
+    ys = [{"porosity": v["porosity"].to(dev)}, {"porosity": (v["porosity"] * 0.5 + 0.1).to(dev)}]
+    outs = {}
+    for batched in (False, True):
+        module.batch_cfg = batched
+        for use_graph in (False, True):
+            module.use_graph = use_graph
+            outs[(batched, use_graph)] = [module.propagate_white_noise(wn, y=y, guidance=2.0, nsteps=4, record_history=True).clone()
+                                          for y in ys + ys[:1]]
+    ref = outs[(False, False)]
+    assert not torch.equal(ref[0], ref[1]) and torch.equal(ref[0], ref[2])
+    for key, got in outs.items():
+        for a, b in zip(got, ref):
+            assert torch.equal(a, b), key
+

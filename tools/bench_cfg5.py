@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--reps", type=int, default=2)
     ap.add_argument("--guidance", type=float, default=2.0)
     ap.add_argument("--precision", default="fp16x3")
+    ap.add_argument("--no-batch-cfg", action="store_true", help="two evaluations per guided step instead of one of twice the batch")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-fuse-norm", action="store_true")
     a = ap.parse_args()
@@ -34,6 +35,7 @@ def main():
     net.conv_precision = a.precision
     net.fuse_norm = not a.no_fuse_norm
     module = M.KarrasModule(net, M.KarrasModuleConfig.from_edm(), conditional=True).to(dev).eval()
+    module.batch_cfg = not a.no_batch_cfg
     module.use_graph = not a.no_graph
     wn = torch.randn(a.batch, 4, a.size, a.size, device=dev)
     y = {"porosity": torch.tensor([0.2], device=dev)}
