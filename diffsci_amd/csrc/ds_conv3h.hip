@@ -116,7 +116,7 @@ template <int MT> struct Frags { f16x8 a[2][MT]; f16x8 b[2][2]; };   // [piece][
 //         (' = the next chunk, whose patch and first weight slab are already resident when its (0,0) tap is consumed).
 template <int MODE, bool W16, bool PRE, bool CIRC, int NW, bool S16 = false>
 __global__ __launch_bounds__(64 * NW, NW / 2) void k_conv3h(const Conv3hArgs a) {
-  static_assert(!S16 || NW == 4, "the 16x16x32 variant is a four-wave kernel");
+  constexpr int M16 = 16 / NW;                                       // S16: 16-channel tiles per wave (4, or 2 with eight waves)
   constexpr int TH = Geo<W16>::TH, TW = Geo<W16>::TW, PW = Geo<W16>::PW, NPOS = Geo<W16>::NPOS;
   constexpr int NTH = 64 * NW;                                       // threads
   constexpr int MT = 8 / NW;                                         // 32-channel tiles per wave: 2 or 1
@@ -359,10 +359,10 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_conv3h(const Conv3hArgs a) 
   STAMP(2);
   STAMP_CLK(6);
 
-  f32x4 acc16[4][4];                                   // S16: [16-channel tile][16-position tile]
+  f32x4 acc16[M16][4];                                 // S16: [16-channel tile][16-position tile]
   if constexpr (S16) {
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+    for (int m = 0; m < M16; ++m)
 #pragma unroll
       for (int n = 0; n < 4; ++n)
 #pragma unroll
@@ -370,12 +370,12 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_conv3h(const Conv3hArgs a) 
     const int i16 = lane & 15, h16 = (lane >> 4) & 1;
     const bool tapB = lane >= 32;                        // lane groups 2, 3 read the pair's second tap
     // lane part of the operand addresses: weights [piece][kx][h][co], input [piece][h][position]
-    const int wlane = h16 * COT + i16;
+    const int wlane = h16 * COT + i16 + 32 * mh;        // eight waves: the wave's 32-channel half
     int xlane[4];
 #pragma unroll
     for (int n = 0; n < 4; ++n)
       xlane[n] = h16 * HS + (wave_row + ROWS_PER_R * (n >> 1)) * PW + (W16 ? (n & 1) * PW + i16 : 16 * (n & 1) + i16);
-    struct F16 { f16x8 a[2][4]; f16x8 b[2][4]; };
+    struct F16 { f16x8 a[2][M16]; f16x8 b[2][4]; };
     // one K = 32 group: taps (slot, ky, kx, X buffer) A and B of the pair; every argument is a compile-time constant
     auto pair = [&](int slotA, int kyA, int kxA, int xbA, int slotB, int kyB, int kxB, int xbB) __attribute__((always_inline)) {
       const int wofs = (tapB ? slotB * WSLAB_VEC + kxB * 2 * COT : slotA * WSLAB_VEC + kxA * 2 * COT) + wlane;
@@ -384,7 +384,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_conv3h(const Conv3hArgs a) 
 #pragma unroll
       for (int p = 0; p < 2; ++p) {
 #pragma unroll
-        for (int m = 0; m < 4; ++m) f.a[p][m] = *reinterpret_cast<const f16x8*>(&Ws[wofs + p * 6 * COT + 16 * m]);
+        for (int m = 0; m < M16; ++m) f.a[p][m] = *reinterpret_cast<const f16x8*>(&Ws[wofs + p * 6 * COT + 16 * m]);
 #pragma unroll
         for (int n = 0; n < 4; ++n) f.b[p][n] = *reinterpret_cast<const f16x8*>(&Xs[xofs + p * PS + xlane[n]]);
       }
@@ -393,7 +393,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_conv3h(const Conv3hArgs a) 
 #pragma unroll
       for (int t = 0; t < 3; ++t)
 #pragma unroll
-        for (int m = 0; m < 4; ++m)
+        for (int m = 0; m < M16; ++m)
 #pragma unroll
           for (int n = 0; n < 4; ++n)
             acc16[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.a[PA[t]][m], f.b[PB[t]][n], acc16[m][n], 0, 0, 0);
@@ -484,7 +484,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_conv3h(const Conv3hArgs a) 
     constexpr int WTILE = 32 * MT * 2 * 32;                           // floats of the wave's private transpose region
     float* tile = reinterpret_cast<float*>(smem) + wv * WTILE;
     if constexpr (S16) {
-      ds_epi::store_tile16<W16>(acc16, tile, BS, e);
+      ds_epi::store_tile16<W16, MT>(acc16, tile, BS + 32 * mh, e);
     } else {
       ds_epi::store_tile<W16, MT>(acc, tile, BS + 32 * mh, e);
     }
@@ -555,9 +555,22 @@ inline int conv3h_waves(bool pre) {
   return forced ? forced : (pre ? 8 : 4);
 }
 
+// Waves of the 16x16x32 variant with the fused loader.  Eight (the staging's vector work spread over twice the waves, as in the
+// 32x32x16 kernel) measured 75.5 -> 76.0 samples/s on one box and 79.6 -> 79.0 on another, ADM-128 33.3 -> 33.45 ms per
+// evaluation: noise.  Default four; DS_CONV_WAVES16=8 selects eight up to 128 input channels (A/B runs).
+inline int conv3h_waves16() {
+  static const int v = [] { const char* e = getenv("DS_CONV_WAVES16"); return (e && atoi(e) == 8) ? 8 : 4; }();
+  return v;
+}
+
 template <int MODE, bool W16, bool PRE, bool CIRC>
 int launch_conv3h_c(const Conv3hArgs& a, hipStream_t s) {
-  if (conv3h_shape16() && a.n_chunks % 2 == 0) return launch_conv3h_w<MODE, W16, PRE, CIRC, 4, true>(a, s);
+  if (conv3h_shape16() && a.n_chunks % 2 == 0) {
+    if constexpr (PRE && MODE == DS_LOAD_PLAIN) {
+      if (conv3h_waves16() == 8 && a.n_chunks <= 8) return launch_conv3h_w<MODE, W16, PRE, CIRC, 8, true>(a, s);   // up to 128 input channels
+    }
+    return launch_conv3h_w<MODE, W16, PRE, CIRC, 4, true>(a, s);
+  }
   return conv3h_waves(PRE) == 8 ? launch_conv3h_w<MODE, W16, PRE, CIRC, 8>(a, s) : launch_conv3h_w<MODE, W16, PRE, CIRC, 4>(a, s);
 }
 

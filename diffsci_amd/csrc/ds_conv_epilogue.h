@@ -130,15 +130,17 @@ __device__ __forceinline__ void store_tile(const f32x16 (&acc)[MT][2], float* ti
 
 // The same for the 16x16 accumulator tiles of v_mfma_f32_16x16x32_f16: acc[m][n], m = 16-channel tile, n = 16-position
 // tile (positions 16*(n&1) .. +15 of row r = n>>1); register q of lane l holds channel 16m + 4(l>>4) + q, position l&15.
-template <bool W16>
-__device__ __forceinline__ void store_tile16(const f32x4 (&acc)[4][4], float* tile, const float* bs, const Args& e) {
+// MT: 32-channel tiles of the wave (2: all 64 channels; 1: the eight-wave kernels, bs / e.co_base at the wave's own 32)
+template <bool W16, int MT = 2>
+__device__ __forceinline__ void store_tile16(const f32x4 (&acc)[2 * MT][4], float* tile, const float* bs, const Args& e) {
   const int lane = threadIdx.x & 63;
   const int i = lane & 15, g = lane >> 4;
   const float unscale = e.unscale;
-  Residuals<2> R;
-  load_residuals<W16, 2>(R, e);
+  constexpr bool PF = MT == 2;
+  Residuals<PF ? MT : 0> R;
+  if constexpr (PF) load_residuals<W16, MT>(R, e);
 #pragma unroll
-  for (int m = 0; m < 4; ++m)
+  for (int m = 0; m < 2 * MT; ++m)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int co = 16 * m + 4 * g + q;
@@ -146,7 +148,7 @@ __device__ __forceinline__ void store_tile16(const f32x4 (&acc)[4][4], float* ti
 #pragma unroll
       for (int n = 0; n < 4; ++n) tile[(co * 2 + (n >> 1)) * 32 + 16 * (n & 1) + i] = acc[m][n][q] * unscale + bsv;
     }
-  store_tile_rows<W16, 2, true>(tile, e, R);
+  store_tile_rows<W16, MT, PF>(tile, e, R);
 }
 
 template <bool W16, int MT, bool PREFETCHED>
