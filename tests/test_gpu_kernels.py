@@ -468,14 +468,19 @@ def test_conv_direct_small_cout(dev, case):
         ops.conv_direct(x.to(dev), torch.randn(5, Cin, 3, 3, device=dev))
 
 
-def test_convolution_family_fuzz():
-    """A short run of tools/conv_fuzz.py: random shapes through every load / padding / fusion combination."""
+@pytest.mark.parametrize("env", [{}, {"DS_CONV_SHAPE": "32"}, {"DS_CONV_WAVES16": "8"}],
+                         ids=["shipped", "mfma-32x32x16", "16x16x32-eight-waves"])
+def test_convolution_family_fuzz(env):
+    """A short run of tools/conv_fuzz.py: random shapes through every load / padding / fusion combination -- with the
+    shipped kernel selection and with the two alternatives the library keeps behind environment switches (the 32x32x16
+    instruction shape incl. its eight-wave fused-loader instances; the eight-wave form of the 16x16x32 variant), which are
+    read once per process: hence the subprocess."""
     import subprocess
     import sys
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "conv_fuzz.py"), "--n", "80", "--seed", "7"],
-                       capture_output=True, text=True, timeout=600)
+                       capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "all 80 cases passed" in r.stdout
 
