@@ -280,14 +280,21 @@ def volume_stat_tiles(D, HW):
     return N.lib().ds_volume_stat_tiles(int(D), int(HW))
 
 
-def _slice_rows(shift, B, D, Cout):
-    """Per-slice rows of a per-sample time shift for the 2-D batch of all slices but the outermost two."""
+def _slice_rows(shift, B, D, Cout, ws=None):
+    """Per-slice rows of a per-sample time shift for the 2-D batch of all slices but the outermost two -> (rows, buffer to give
+    back to ws or None).  With a pool the expansion lands in a pool buffer (a captured loop must not allocate)."""
     if shift is None:
-        return None
+        return None, None
     if shift.dim() != 2 or shift.shape[1] != Cout or shift.shape[0] not in (1, B):
         raise ValueError(f"shift must be [1 or B, Cout]; got {tuple(shift.shape)}")
+    if shift.shape[0] == 1:
+        return shift, None
     ns = B * (D + 2)
-    return shift if shift.shape[0] == 1 else shift.repeat_interleave(D + 2, dim=0)[1:ns - 1].contiguous()
+    if ws is None:
+        return shift.repeat_interleave(D + 2, dim=0)[1:ns - 1].contiguous(), None
+    buf = ws.take((B, D + 2, Cout), shift.device)
+    buf.copy_(shift[:, None, :].expand(B, D + 2, Cout))
+    return buf.view(ns, Cout)[1:ns - 1], buf
 
 
 def _depth_taps(s_in, s_out, packs, bias, rows, load_mode, circular, prenorm=None, tile_stats=None):
@@ -340,15 +347,17 @@ def resblock3d_fused(h, tab1, packs1, bias1, shift, packs2, bias2, w2, b2, kind2
     s2[0].zero_()                                           # the outermost pad slices are never written by the launches
     s2[ns - 1].zero_()
     ts = take((ns - 2, C, conv_tile_count(H, W), 4))
-    _depth_taps(s1, s2, packs1, bias1, _slice_rows(shift, B, D, C), N.DS_LOAD_PLAIN, False, tile_stats=ts)
+    rows, rows_buf = _slice_rows(shift, B, D, C, ws)
+    _depth_taps(s1, s2, packs1, bias1, rows, N.DS_LOAD_PLAIN, False, tile_stats=ts)
     tab2 = take((ns, table_channels(C), 4))
     N.check(N.lib().ds_slice_tables(_p(tab2), _p(ts), _p(w2), _p(b2), B, C, D, ts.shape[2], D * H * W, float(eps), int(kind2),
                                     _stream()), "ds_slice_tables")
     _depth_taps(s2, s1, packs2, bias2, None, N.DS_LOAD_PLAIN, False, prenorm=tab2)          # S1 is dead: reuse it for S3
     _from_slices(out, s1, h, res2, B, C, D, H * W, out_stats)
     if ws is not None:
-        for t in (s1, s2, ts, tab2):
-            ws.give(t)
+        for t in (s1, s2, ts, tab2, rows_buf):
+            if t is not None:
+                ws.give(t)
     return out
 
 
@@ -385,8 +394,11 @@ def conv3d_mfma(x, packs, bias=None, shift=None, res1=None, res2=None, load_mode
     N.check(N.lib().ds_volume_to_slices(_p(s_in), _p(x.contiguous()), B, Cin, D, Hi * Wi, depth_mode, 1 if circular else 0,
                                         _stream()), "ds_volume_to_slices")
     s_out = take((ns, Cout, H, W))
-    _depth_taps(s_in, s_out, packs, bias, _slice_rows(shift, B, D, Cout), load_mode, circular)
+    rows, rows_buf = _slice_rows(shift, B, D, Cout, ws)
+    _depth_taps(s_in, s_out, packs, bias, rows, load_mode, circular)
     _from_slices(out, s_out, res1, res2, B, Cout, D, H * W, out_stats)
+    if rows_buf is not None:
+        ws.give(rows_buf)
     if ws is not None:
         ws.give(s_in)
         ws.give(s_out)

@@ -453,3 +453,28 @@ def test_batched_classifier_free_guidance_is_bit_identical(M, dev):
         for a, b in zip(got, ref):
             assert torch.equal(a, b), key
 
+
+def test_volume_sampler_with_per_sample_conditions_is_captured(M, dev):
+    """PUNetG(dimension=3) under the captured sampler with one embedded-condition row per sample: the per-slice expansion of
+    the time-shift rows lands in a workspace buffer (a capture must not allocate), graph and eager runs agree bit for bit, and
+    every sample equals the run of that sample alone with its own label."""
+    from tests.golden_util import load
+    g, sd = load("punetg8_3d")
+    torch.manual_seed(4)
+    net = M.PUNetG(M.PUNetGConfig(model_channels=8, dimension=3), conditional_embedding=_TableEmbedding(10, 8))
+    net.load_state_dict(sd, strict=False)
+    module = M.KarrasModule(net, M.KarrasModuleConfig.from_edm(), conditional=True).to(dev).eval()
+    wn = g["white_noise"].to(dev)
+    B = wn.shape[0]
+    labels = (torch.arange(B, device=dev) * 3 % 10).float()
+    outs = []
+    for use_graph in (False, True, True):
+        module.use_graph = use_graph
+        outs.append(module.propagate_white_noise(wn, y=labels, guidance=1.0, nsteps=3).clone())
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
+    assert len(module._plans.plans) == 1
+    module.use_graph = False
+    for b in range(B):
+        alone = module.propagate_white_noise(wn[b:b + 1], y=labels[b:b + 1], guidance=1.0, nsteps=3)
+        assert torch.equal(alone[0], outs[0][b])
+    assert not torch.equal(outs[0][0], module.propagate_white_noise(wn[:1], y=labels[1:2], guidance=1.0, nsteps=3)[0])
