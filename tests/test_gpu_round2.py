@@ -478,3 +478,13 @@ def test_volume_sampler_with_per_sample_conditions_is_captured(M, dev):
         alone = module.propagate_white_noise(wn[b:b + 1], y=labels[b:b + 1], guidance=1.0, nsteps=3)
         assert torch.equal(alone[0], outs[0][b])
     assert not torch.equal(outs[0][0], module.propagate_white_noise(wn[:1], y=labels[1:2], guidance=1.0, nsteps=3)[0])
+    # guided: one evaluation of batch 2B on volumes, against two evaluations, eagerly and captured
+    res = {}
+    for batched in (False, True):
+        module.batch_cfg = batched
+        for use_graph in (False, True):
+            module.use_graph = use_graph
+            res[(batched, use_graph)] = module.propagate_white_noise(wn, y=labels, guidance=2.0, nsteps=3).clone()
+    for got in res.values():
+        assert torch.equal(got, res[(False, False)])
+    assert not torch.equal(res[(False, False)], outs[0])
