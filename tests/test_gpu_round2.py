@@ -488,3 +488,27 @@ def test_volume_sampler_with_per_sample_conditions_is_captured(M, dev):
     for got in res.values():
         assert torch.equal(got, res[(False, False)])
     assert not torch.equal(res[(False, False)], outs[0])
+
+
+def test_adm_guided_sampling_batched(M, dev):
+    """ADM under classifier-free guidance: the batched evaluation (FiLM rows of the unconditional half behind the conditional
+    ones) against two evaluations, eagerly and captured, with one condition row per sample."""
+    from tests.golden_util import load
+    v, sd = load("adm8_concat")
+    torch.manual_seed(6)
+    net = M.ADM(M.ADMConfig(model_channels=8, time_embed_dim=8, output_embed_dim=16), conditional_embedding=_TableEmbedding(10, 16))
+    net.load_state_dict(sd, strict=False)
+    module = M.KarrasModule(net, M.KarrasModuleConfig.from_edm(), conditional=True).to(dev).eval()
+    wn = torch.randn(3, 1, 32, 32, device=dev)
+    labels = torch.tensor([1.0, 7.0, 4.0], device=dev)
+    res = {}
+    for batched in (False, True):
+        module.batch_cfg = batched
+        for use_graph in (False, True):
+            module.use_graph = use_graph
+            res[(batched, use_graph)] = module.propagate_white_noise(wn, y=labels, guidance=2.0, nsteps=3).clone()
+    for got in res.values():
+        assert torch.isfinite(got).all() and torch.equal(got, res[(False, False)])
+    module.batch_cfg = True
+    assert not torch.equal(res[(True, True)], module.propagate_white_noise(wn, y=labels, guidance=1.0, nsteps=3))
+
