@@ -23,6 +23,13 @@
  *   - the elementwise stepper entry points take any element count and any 4-byte-aligned
  *     pointers (16-byte-aligned operands run the float4 path, others a scalar path with
  *     identical arithmetic): the reference accepts any tensor shape.
+ *
+ * Environment (read once per process; measurement switches, results are identical up to fp32 rounding of the accumulation
+ * order): DIFFSCI_HIP_LIB = path of another build of this library (A/B runs, diffsci_amd/_native.py); DS_CONV_SHAPE=32 =
+ * the v_mfma_f32_32x32x16_f16 form of ds_conv2d_h3 / ds_conv2d_h3_up everywhere (default: 16x16x32 wherever the layer has
+ * an even number of 16-channel chunks); DS_CONV_WAVES=4|8 = waves per workgroup of the 32x32x16 form (default: 8 with the
+ * fused loader); DS_CONV_WAVES16=8 = eight waves for the 16x16x32 form with the fused loader (default 4); DS_ATTN_T =
+ * rescaling threshold of ds_attention_h3's online softmax (default 8).
  */
 #ifndef DIFFSCI_HIP_H
 #define DIFFSCI_HIP_H
