@@ -96,6 +96,7 @@ struct Conv3hArgs {
 #ifdef DS_STAMP
   unsigned long long* stamps;   // diagnostic build only (tools/conv3h_stamp.hip)
   unsigned stagger_lo, stagger_hi, stagger_ticks;   // experiment: workgroups with dispatch index in [lo, hi) start `ticks` x 10 ns late
+  unsigned no_stage;                                // experiment (wrong results): 1 = the patches after the first are neither fetched nor split / stored, 2 = not fetched
 #endif
 };
 
@@ -402,12 +403,22 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_conv3h(const Conv3hArgs a) 
     auto stage_in = [&](int chunk, int ky) __attribute__((always_inline)) {
       const int g = chunk * 3 + ky;
       if (g + 2 < n_steps) w_fetch(g + 2, (ky + 2) % 3);
-      if (ky == 0 && chunk + 1 < a.n_chunks) x_fetch(chunk + 1);
+#ifdef DS_STAMP
+      const bool fetch = !a.no_stage;
+#else
+      constexpr bool fetch = true;
+#endif
+      if (fetch && ky == 0 && chunk + 1 < a.n_chunks) x_fetch(chunk + 1);
       __builtin_amdgcn_sched_barrier(0);
     };
     auto stage_out = [&](int chunk, int ky, int xbuf) __attribute__((always_inline)) {
       __builtin_amdgcn_sched_barrier(0);
-      if (ky == 1 && chunk + 1 < a.n_chunks) x_store(xbuf ^ 1);
+#ifdef DS_STAMP
+      const bool store = a.no_stage != 1;
+#else
+      constexpr bool store = true;
+#endif
+      if (store && ky == 1 && chunk + 1 < a.n_chunks) x_store(xbuf ^ 1);
       __syncthreads();
     };
     for (int chunk = 0; chunk < a.n_chunks; chunk += 2) {          // n_chunks is even (checked by the launcher)
@@ -652,6 +663,9 @@ int ds_conv2d_h3(float* out, const float* in, const void* w_packed, int wshift, 
     // workgroup of every CU under breadth-first dispatch: indices [256, 512))
     static const struct Stg { unsigned ticks = 0, lo = 256, hi = 512; Stg() { const char* e = getenv("DS_CONV_STAGGER"); if (e) sscanf(e, "%u,%u,%u", &ticks, &lo, &hi); } } stg;
     a.stagger_ticks = stg.ticks; a.stagger_lo = stg.lo; a.stagger_hi = stg.hi;
+    // DS_CONV_NOSTAGE=1|2 (16x16x32 variant): what does staging the input patches cost?  (profiles/r02_stamps_nostage.log)
+    static const unsigned nostage = [] { const char* e = getenv("DS_CONV_NOSTAGE"); return e ? (unsigned)atoi(e) : 0u; }();
+    a.no_stage = nostage;
   }
 #endif
 #ifdef DS_STAMP
