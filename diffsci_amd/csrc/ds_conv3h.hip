@@ -25,6 +25,7 @@
 //   * operand fragments are double-buffered per kx block, their ds_read_b128 slotted between the
 //     MFMAs of the previous block.  One barrier per step, nothing waits on it.
 #include "ds_common.h"
+#include <cstring>
 #include "ds_conv_epilogue.h"
 #include "ds_h3_common.h"
 
@@ -115,9 +116,14 @@ template <int MT> struct Frags { f16x8 a[2][MT]; f16x8 b[2][2]; };   // [piece][
 //         and the weight packing are unchanged.  The 18 taps of two chunks pair up as
 //           (0,0)+(0,1) | (0,2)+(1,0) | (1,1)+(1,2) | (2,0)+(2,1) | (2,2)+(0,0)' | (0,1)'+(0,2)' | (1,0)'+(1,1)' | (1,2)'+(2,0)' | (2,1)'+(2,2)'
 //         (' = the next chunk, whose patch and first weight slab are already resident when its (0,0) tap is consumed).
-template <int MODE, bool W16, bool PRE, bool CIRC, int NW, bool S16 = false>
+// IMGIN: the input arrives as pre-split fp16 hi / lo images in the LDS layout (ds_inorm_silu_images: [b][chunk][piece][h][H+2][W+2]
+// vectors of 8 channels, zero border) and is staged by LDS-DMA -- no staging registers, no split in this kernel.  Staging the
+// patches from fp32 costs 16-29 % of the kernel (profiles/r02_stamps_nostage.log), and at four channel tiles every element is
+// split 5.3 times; the producer splits it once.  16x16x32 variant, four waves, plain load, zero padding, no fused norm.
+template <int MODE, bool W16, bool PRE, bool CIRC, int NW, bool S16 = false, bool IMGIN = false>
 __global__ __launch_bounds__(64 * NW, NW / 2) void k_conv3h(const Conv3hArgs a) {
   constexpr int M16 = 16 / NW;                                       // S16: 16-channel tiles per wave (4, or 2 with eight waves)
+  static_assert(!IMGIN || (S16 && NW == 4 && MODE == DS_LOAD_PLAIN && !PRE && !CIRC), "image input: plain 16x16x32 four-wave kernel");
   constexpr int TH = Geo<W16>::TH, TW = Geo<W16>::TW, PW = Geo<W16>::PW, NPOS = Geo<W16>::NPOS;
   constexpr int NTH = 64 * NW;                                       // threads
   constexpr int MT = 8 / NW;                                         // 32-channel tiles per wave: 2 or 1
@@ -348,13 +354,54 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_conv3h(const Conv3hArgs a) 
     if (NMFMA > PAIRS) __builtin_amdgcn_sched_group_barrier(0x008, NMFMA - PAIRS, 0);
   };
 
+  // ---- IMGIN: an X buffer is one linear region of XBV vectors holding four images (piece, h) at 0, HS, PS, PS + HS; it is
+  //      filled by NINST 64-lane DMA instructions, instruction k = wv + 4 i at vector 64 k -- the last one moved back so that it
+  //      ends with the buffer (it rewrites a few vectors of its predecessor with the same data).  Lane -> linear index ->
+  //      (image, position); the pad vectors behind the h = 0 images read the patch's last position (never used). ----
+  constexpr int NINST = IMGIN ? (XBV + 63) / 64 : 0;
+  static_assert(!IMGIN || NINST <= 24, "six instructions per wave");
+  int doff[IMGIN ? 6 : 1];
+  const int Wp = a.W + 2, Hp = a.H + 2;
+  if constexpr (IMGIN) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int k = wv + 4 * i;
+      const int L = (k < NINST - 1 ? 64 * k : XBV - 64) + lane;
+      const int piece = L >= PS ? 1 : 0, Lp = L - piece * PS;
+      const int hh = Lp >= HS ? 1 : 0;
+      const int q = 2 * piece + hh;                        // image
+      int pos = Lp - hh * HS;
+      pos = pos < NPOS ? pos : NPOS - 1;
+      const int r = pos / PW, col = pos - r * PW;
+      int py = y0 + r, px = x0 + col;                      // padded coordinates: patch origin (y0 - 1, x0 - 1) + 1
+      py = py < Hp ? py : Hp - 1;                          // ragged tiles: the zero border
+      px = px < Wp ? px : Wp - 1;
+      doff[i] = (q * Hp + py) * Wp + px;
+    }
+  }
+  const u32x4* img_b = IMGIN ? reinterpret_cast<const u32x4*>(a.in) + (size_t)b * a.n_chunks * 4 * Hp * Wp : nullptr;
+  auto x_dma = [&](int chunk, int buf) __attribute__((always_inline)) {
+    if constexpr (IMGIN) {
+      const u32x4* src = img_b + (size_t)chunk * 4 * Hp * Wp;
+      u32x4* dst = Xs + buf * XBV;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        const int k = wv + 4 * i;                          // wave-uniform
+        if (k < NINST)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + doff[i]),
+                                           (__attribute__((address_space(3))) void*)(dst + (k < NINST - 1 ? 64 * k : XBV - 64)), 16, 0, 0);
+      }
+    }
+  };
+
   // ---- prologue: patch 0, weight slabs 0 and 1 ----
+  if constexpr (IMGIN) x_dma(0, 0); else
   x_fetch(0);
   const float bias_shift = ds_epi::fetch_bias_shift(a.bias, a.shift, a.shift_stride, b, cot * COT, a.Cout);
   w_fetch(0, 0);
   if (n_steps > 1) w_fetch(1, 1);
   STAMP(1);
-  x_store(0);
+  if constexpr (!IMGIN) x_store(0);
   ds_epi::commit_bias_shift(BS, bias_shift);
   __syncthreads();
   STAMP(2);
@@ -408,6 +455,11 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_conv3h(const Conv3hArgs a) 
 #else
       constexpr bool fetch = true;
 #endif
+      if constexpr (IMGIN) {
+        // the next patch straight into the other buffer: last read before the barrier that ended the previous step, landed
+        // by the barrier that ends the step after this one (__syncthreads waits for the wave's outstanding DMA)
+        if (ky == 0 && chunk + 1 < a.n_chunks) x_dma(chunk + 1, (chunk + 1) & 1);
+      } else
       if (fetch && ky == 0 && chunk + 1 < a.n_chunks) x_fetch(chunk + 1);
       __builtin_amdgcn_sched_barrier(0);
     };
@@ -418,6 +470,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_conv3h(const Conv3hArgs a) 
 #else
       constexpr bool store = true;
 #endif
+      if constexpr (!IMGIN)
       if (store && ky == 1 && chunk + 1 < a.n_chunks) x_store(xbuf ^ 1);
       __syncthreads();
     };
@@ -534,17 +587,17 @@ __global__ void k_pack3h(_Float16* packed, const float* __restrict__ w, int Cout
   packed[i] = piece == 0 ? hi : lo;
 }
 
-template <int MODE, bool W16, bool PRE, bool CIRC, int NW, bool S16 = false>
+template <int MODE, bool W16, bool PRE, bool CIRC, int NW, bool S16 = false, bool IMGIN = false>
 int launch_conv3h_w(const Conv3hArgs& a, hipStream_t s) {
   constexpr int LDSB = S16 ? LDS_BYTES16 : LDS_BYTES;
   {
-    const int rc = ds::ensure_dynamic_lds<&k_conv3h<MODE, W16, PRE, CIRC, NW, S16>>(LDSB, "hipFuncSetAttribute(conv3h)");
+    const int rc = ds::ensure_dynamic_lds<&k_conv3h<MODE, W16, PRE, CIRC, NW, S16, IMGIN>>(LDSB, "hipFuncSetAttribute(conv3h)");
     if (rc != DS_OK) return rc;
   }
   const long long tiles = (long long)a.tiles_y * a.tiles_x;
   DS_REQUIRE(tiles > 0 && tiles < 65536 && a.B < 65536, DS_ERR_SHAPE,
              "ds_conv2d_h3: %lld pixel tiles x %d samples exceed the grid limits (65535 each)", tiles, a.B);
-  hipLaunchKernelGGL((k_conv3h<MODE, W16, PRE, CIRC, NW, S16>), dim3((unsigned)a.n_cot, (unsigned)tiles, (unsigned)a.B), dim3(64 * NW),
+  hipLaunchKernelGGL((k_conv3h<MODE, W16, PRE, CIRC, NW, S16, IMGIN>), dim3((unsigned)a.n_cot, (unsigned)tiles, (unsigned)a.B), dim3(64 * NW),
                      LDSB, s, a);
   DS_CHECK_LAUNCH("ds_conv2d_h3");
   return DS_OK;
@@ -682,6 +735,48 @@ int ds_conv2d_h3(float* out, const float* in, const void* w_packed, int wshift, 
   if (load_mode == DS_LOAD_MAXPOOL2) return launch_conv3h<DS_LOAD_MAXPOOL2, false, false>(a, s);
   return DS_L3(DS_LOAD_UPSAMPLE2, false);
 #undef DS_L3
+}
+
+size_t ds_conv_images_bytes(int B, int C, int H, int W) {
+  if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return 0;
+  return (size_t)B * ((C + KC - 1) / KC) * 4 * (size_t)(H + 2) * (W + 2) * 16;
+}
+
+int ds_conv2d_h3_img(float* out, const void* images, const void* w_packed, int wshift, const float* bias, const float* shift,
+                     int shift_stride, const float* res1, const float* res2, int B, int Cin, int Cout, int H, int W,
+                     float* tile_stats, void* stream) {
+  DS_REQUIRE(out && images && w_packed, DS_ERR_NULL, "ds_conv2d_h3_img: NULL pointer");
+  DS_REQUIRE(B >= 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, DS_ERR_SHAPE,
+             "ds_conv2d_h3_img: bad shape B=%d Cin=%d Cout=%d H=%d W=%d", B, Cin, Cout, H, W);
+  DS_REQUIRE(((Cin + KC - 1) / KC) % 2 == 0, DS_ERR_UNSUPPORTED,
+             "ds_conv2d_h3_img: the image-input kernel is the 16x16x32 variant: an even number of 16-channel chunks (Cin = %d)", Cin);
+  DS_REQUIRE(shift == nullptr || shift_stride == 0 || shift_stride >= Cout, DS_ERR_SHAPE,
+             "ds_conv2d_h3_img: shift_stride %d < Cout %d", shift_stride, Cout);
+  DS_REQUIRE((reinterpret_cast<uintptr_t>(w_packed) & 15u) == 0 && (reinterpret_cast<uintptr_t>(images) & 15u) == 0, DS_ERR_SHAPE,
+             "ds_conv2d_h3_img: images and w_packed must be 16-byte aligned");
+  DS_REQUIRE(wshift >= -40 && wshift <= 40, DS_ERR_SHAPE, "ds_conv2d_h3_img: wshift %d out of range", wshift);
+  DS_REQUIRE((long long)4 * (H + 2) * (W + 2) < (1ll << 27), DS_ERR_SHAPE, "ds_conv2d_h3_img: image planes too large");
+  if (B == 0) return DS_OK;
+  Conv3hArgs a;
+  memset(&a, 0, sizeof(a));
+  a.out = out; a.in = reinterpret_cast<const float*>(images); a.wp = reinterpret_cast<const u32x4*>(w_packed);
+  a.bias = bias; a.shift = shift; a.res1 = res1; a.res2 = res2; a.shift_stride = shift_stride; a.tile_stats = tile_stats;
+  a.unscale = ldexpf(1.0f, -wshift);
+  a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.Hin = H; a.Win = W;
+  const long long pad32 = (long long)((W + 31) / 32 * 32) * ((H + 7) / 8 * 8);
+  const long long pad16 = (long long)((W + 15) / 16 * 16) * ((H + 15) / 16 * 16);
+  const bool w16 = pad16 < pad32;
+  const int TW = w16 ? 16 : 32, TH = w16 ? 16 : 8;
+  a.tiles_x = (W + TW - 1) / TW; a.tiles_y = (H + TH - 1) / TH;
+  a.n_cot = (Cout + COT - 1) / COT;
+  a.n_chunks = (Cin + KC - 1) / KC;
+  a.tiles_x_magic = a.tiles_x == 1 ? 0u : (unsigned)((1ull << 32) / (unsigned)a.tiles_x) + 1u;
+#ifdef DS_STAMP
+  a.stamps = g_stamps;
+#endif
+  hipStream_t s = ds::as_stream(stream);
+  return w16 ? launch_conv3h_w<DS_LOAD_PLAIN, true, false, false, 4, true, true>(a, s)
+             : launch_conv3h_w<DS_LOAD_PLAIN, false, false, false, 4, true, true>(a, s);
 }
 
 }  // extern "C"

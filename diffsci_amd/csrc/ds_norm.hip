@@ -236,6 +236,122 @@ __global__ __launch_bounds__(256) void k_pointwise_silu(float* out, const float*
   }
 }
 
+// ---- norm + SiLU written as the consuming convolution's pre-split fp16 hi / lo images (ds_conv2d_h3_img) ----------------------
+// images [B][chunk][piece 2][half 2][H+2][W+2] vectors of 8 channels (c = 16 chunk + 8 half + 0..7), zero border, zero channels
+// past C: the same 8 bytes per element as ds_inorm_silu moves, but the convolution then stages its patches by LDS-DMA and no
+// workgroup splits anything (with four channel tiles and the halo every element used to be split 5.3 times).
+// One workgroup of 8 waves per 8-channel group: wave k normalises channel k exactly as k_inorm_wave does (same loads, same
+// summation order, same activation: bit-identical values), parks its plane in LDS, then all threads gather the 8 channels of a
+// pixel, split and store two vectors.
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void split2_img(float a, float b, unsigned& hi, unsigned& lo) {      // ds_h3_common.h's split2
+  f16x2_t h = {(_Float16)a, (_Float16)b};
+  unsigned hp = __builtin_bit_cast(unsigned, h);
+  asm volatile("" : "+v"(hp));
+  const f16x2_t hq = __builtin_bit_cast(f16x2_t, hp);
+  f16x2_t l = {(_Float16)(a - (float)hq[0]), (_Float16)(b - (float)hq[1])};
+  hi = hp;
+  lo = __builtin_bit_cast(unsigned, l);
+}
+
+template <int KIND, int VPT>
+__global__ __launch_bounds__(512) void k_inorm_images(u32x4_t* __restrict__ img, const float* __restrict__ x,
+                                                     const float* __restrict__ w, const float* __restrict__ b, int C, int nchunk,
+                                                     int H, int W, int hw4, float inv_hw, float eps) {
+  __shared__ __attribute__((aligned(16))) float act[8][1024];
+  const int lane = threadIdx.x & 63, k = threadIdx.x >> 6;
+  const int g = blockIdx.x;
+  const int h = g & 1, chunk = (g >> 1) % nchunk, bb = (g >> 1) / nchunk;
+  const int c = 16 * chunk + 8 * h + k;
+  float4 v[VPT];
+  if (c < C) {
+    const size_t plane = (size_t)bb * C + c;
+    const float4* src = reinterpret_cast<const float4*>(x) + plane * hw4;
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+      int idx = lane + 64 * i;
+      v[i] = idx < hw4 ? src[idx] : make_float4(0, 0, 0, 0);
+    }
+    float mean = 0.f, sod;
+    if (KIND == 0) {
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < VPT; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+      mean = wave_sum(s) * inv_hw;
+      float q = 0.f;
+#pragma unroll
+      for (int i = 0; i < VPT; ++i) {
+        if (lane + 64 * i < hw4) {
+          float a0 = v[i].x - mean, a1 = v[i].y - mean, a2 = v[i].z - mean, a3 = v[i].w - mean;
+          q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+        }
+      }
+      float var = wave_sum(q) * inv_hw;
+      sod = 1.0f / sqrtf(var + eps);
+    } else {
+      float q = 0.f;
+#pragma unroll
+      for (int i = 0; i < VPT; ++i) q += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+      sod = sqrtf(wave_sum(q) * inv_hw + eps);
+    }
+    const float wc = w ? w[c] : 1.0f, bc = b ? b[c] : 0.0f;
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {                              // activated in place: the plane stays in registers
+      v[i].x = apply_one<KIND>(v[i].x, mean, sod, wc, bc);
+      v[i].y = apply_one<KIND>(v[i].y, mean, sod, wc, bc);
+      v[i].z = apply_one<KIND>(v[i].z, mean, sod, wc, bc);
+      v[i].w = apply_one<KIND>(v[i].w, mean, sod, wc, bc);
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) v[i] = make_float4(0, 0, 0, 0);
+  }
+  const int Hp = H + 2, Wp = W + 2, HW = 4 * hw4;
+  u32x4_t* hi_img = img + ((((size_t)bb * nchunk + chunk) * 2 + 0) * 2 + h) * Hp * Wp;
+  u32x4_t* lo_img = img + ((((size_t)bb * nchunk + chunk) * 2 + 1) * 2 + h) * Hp * Wp;
+  // slabs of 1024 pixels (= 256 float4 = registers 4 s .. 4 s + 3 of every lane) through LDS: gather the 8 channels of a
+  // pixel, split, store two vectors
+  constexpr int NSLAB = (VPT + 3) / 4;
+#pragma unroll
+  for (int sl = 0; sl < NSLAB; ++sl) {
+    if (sl > 0) __syncthreads();
+#pragma unroll
+    for (int i = 4 * sl; i < 4 * sl + 4 && i < VPT; ++i) {
+      const int idx = lane + 64 * i;
+      if (idx < hw4) reinterpret_cast<float4*>(act[k])[idx - 256 * sl] = v[i];
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < 1024; j += 512) {
+      const int i = 1024 * sl + j;
+      if (i < HW) {
+        const int y = i / W, xx = i - y * W;
+        u32x4_t qh, ql;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          unsigned ph, pl;
+          split2_img(act[2 * t][j], act[2 * t + 1][j], ph, pl);
+          qh[t] = ph; ql[t] = pl;
+        }
+        const size_t o = (size_t)(y + 1) * Wp + xx + 1;
+        hi_img[o] = qh;
+        lo_img[o] = ql;
+      }
+    }
+  }
+  const int nb = 2 * Wp + 2 * H;                                   // the zero border (the convolution's padding)
+  const u32x4_t z = {0u, 0u, 0u, 0u};
+  for (int j = threadIdx.x; j < nb; j += 512) {
+    size_t o;
+    if (j < Wp) o = j;
+    else if (j < 2 * Wp) o = (size_t)(Hp - 1) * Wp + (j - Wp);
+    else { const int r = j - 2 * Wp; o = (size_t)(1 + (r >> 1)) * Wp + ((r & 1) ? Wp - 1 : 0); }
+    hi_img[o] = z;
+    lo_img[o] = z;
+  }
+}
+
 }  // namespace
 
 extern "C" int ds_inorm_silu(float* out, const float* x, const float* w, const float* b, int B, int C, int HW,
@@ -258,3 +374,39 @@ extern "C" int ds_inorm_silu(float* out, const float* x, const float* w, const f
   }
   return kind == 0 ? launch_inorm<0>(out, x, w, b, B, C, HW, eps, s) : launch_inorm<1>(out, x, w, b, B, C, HW, eps, s);
 }
+
+extern "C" int ds_inorm_silu_images_supported(int H, int W) {
+  const long long hw = (long long)H * W;
+  return H > 0 && W > 0 && hw % 4 == 0 && hw <= 4096;
+}
+
+extern "C" int ds_inorm_silu_images(void* images, const float* x, const float* w, const float* b, int B, int C, int H, int W,
+                                    float eps, int kind, void* stream) {
+  DS_REQUIRE(images && x, DS_ERR_NULL, "ds_inorm_silu_images: NULL pointer");
+  DS_REQUIRE(B >= 0 && C > 0 && H > 0 && W > 0, DS_ERR_SHAPE, "ds_inorm_silu_images: bad shape");
+  DS_REQUIRE(kind == 0 || kind == 1, DS_ERR_UNSUPPORTED, "ds_inorm_silu_images: kind must be 0 (GroupLN) or 1 (GroupRMS)");
+  DS_REQUIRE(ds_inorm_silu_images_supported(H, W), DS_ERR_UNSUPPORTED,
+             "ds_inorm_silu_images: planes of H*W <= 4096 floats, H*W a multiple of 4 (got %d x %d)", H, W);
+  DS_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(images)) & 15u) == 0, DS_ERR_SHAPE,
+             "ds_inorm_silu_images: x and images must be 16-byte aligned");
+  if (B == 0) return DS_OK;
+  const int nchunk = (C + 15) / 16, hw4 = H * W / 4;
+  DS_REQUIRE((long long)B * nchunk * 2 < (1ll << 31), DS_ERR_SHAPE, "ds_inorm_silu_images: too many channel groups");
+  const float inv = 1.0f / (float)(H * W);
+  hipStream_t s = ds::as_stream(stream);
+  const dim3 g((unsigned)(B * nchunk * 2)), t(512);
+  u32x4_t* img = reinterpret_cast<u32x4_t*>(images);
+#define DS_LI(K) \
+  do { \
+    if (hw4 <= 64) hipLaunchKernelGGL((k_inorm_images<K, 1>), g, t, 0, s, img, x, w, b, C, nchunk, H, W, hw4, inv, eps); \
+    else if (hw4 <= 128) hipLaunchKernelGGL((k_inorm_images<K, 2>), g, t, 0, s, img, x, w, b, C, nchunk, H, W, hw4, inv, eps); \
+    else if (hw4 <= 256) hipLaunchKernelGGL((k_inorm_images<K, 4>), g, t, 0, s, img, x, w, b, C, nchunk, H, W, hw4, inv, eps); \
+    else if (hw4 <= 512) hipLaunchKernelGGL((k_inorm_images<K, 8>), g, t, 0, s, img, x, w, b, C, nchunk, H, W, hw4, inv, eps); \
+    else hipLaunchKernelGGL((k_inorm_images<K, 16>), g, t, 0, s, img, x, w, b, C, nchunk, H, W, hw4, inv, eps); \
+  } while (0)
+  if (kind == 0) DS_LI(0); else DS_LI(1);
+#undef DS_LI
+  DS_CHECK_LAUNCH("ds_inorm_silu_images");
+  return DS_OK;
+}
+

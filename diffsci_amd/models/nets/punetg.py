@@ -14,6 +14,7 @@ operation of the forward pass is a launch into libdiffsci_hip.so:
   x + xa (punetg.py:385)                                    folded into the preceding conv epilogue
 """
 import math
+import os
 from typing import Any
 
 import torch
@@ -308,6 +309,9 @@ class PUNetG(torch.nn.Module):
         # tiles every tile's workgroup would redo the activation of the same input patch (5.3x the transcendental
         # work of a standalone pass at Cout = 256), and the standalone kernel wins
         self.fuse_max_cot = 2
+        # Standalone norms hand their convolutions pre-split fp16 images (ops.inorm_silu_images / ops.conv_img) where the layer
+        # qualifies (_norm_images_ok); DIFFSCI_NORM_IMAGES=0 keeps the fp32 route (A/B runs)
+        self.norm_images = os.environ.get("DIFFSCI_NORM_IMAGES", "1") != "0"
         self._packed = None
         self._packed_sig = None
         self._ws = _Workspace()
@@ -631,6 +635,18 @@ class PUNetG(torch.nn.Module):
             ws.give(ys)
             ws.give(tab)
             return out, os_
+        if self._norm_images_ok(blk, C, H, W, k1, k2):
+            # standalone norms (the 256-channel level): written as the convolution's pre-split fp16 images, which it stages by
+            # LDS-DMA -- same bytes as the fp32 result, bit-identical values, no split in the convolution (ops.conv_img)
+            img = ops.inorm_silu_images(x, w1, b1, k1, eps=1e-5, out=ws.take((ops.conv_images_floats(B, C, H, W),), dev))
+            y = ops.conv_img(img, pk[id(blk.conv1)], B, C, H, W, bias=blk.conv1.bias, shift=shift, res1=yt, out=ws.take(x.shape, dev))
+            ops.inorm_silu_images(y, w2, b2, k2, eps=1e-5, out=img)
+            os_ = self._stats_buf(ws, B, C, H, W, dev) if want_stats else None
+            out = ops.conv_img(img, pk[id(blk.conv2)], B, C, H, W, bias=blk.conv2.bias, res1=x, res2=res2, tile_stats=os_,
+                               out=ws.take(x.shape, dev))
+            ws.give(img)
+            ws.give(y)
+            return out, os_
         a = ops.inorm_silu(x, w1, b1, kind=k1, eps=1e-5, out=ws.take(x.shape, dev))
         y = self._conv(blk.conv1, a, pk, shift=shift, res1=yt, out=ws.take(x.shape, dev))
         ops.inorm_silu(y, w2, b2, kind=k2, eps=1e-5, out=a)
@@ -638,6 +654,14 @@ class PUNetG(torch.nn.Module):
         self._conv(blk.conv2, a, pk, res1=x, res2=res2, tile_stats=os_, out=y)
         ws.give(a)
         return y, os_
+
+    def _norm_images_ok(self, blk, C, H, W, k1, k2):
+        """The standalone norms of this block can hand their convolutions pre-split images: fp16x3 3x3 convolutions with zero
+        padding that keep the channel count, an even number of 16-channel chunks, GroupLN / GroupRMS, planes the image kernel
+        takes."""
+        return (getattr(self, "norm_images", True) and self.conv_precision == "fp16x3" and not self.circular
+                and self.config.kernel_size == 3 and k1 in (0, 1) and k2 in (0, 1) and ((C + 15) // 16) % 2 == 0
+                and blk.conv1.out_channels == C and blk.conv2.out_channels == C and ops.inorm_silu_images_supported(H, W))
 
     @staticmethod
     def _rescale_shift_field(yt, H, W):

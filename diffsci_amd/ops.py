@@ -731,6 +731,59 @@ def conv2d(x, w_packed, Cout, ks, bias=None, shift=None, res1=None, res2=None,
     return out
 
 
+def conv_images_floats(B, C, H, W):
+    """Floats of the pre-split image buffer of a [B, C, H, W] activation (ds_inorm_silu_images / conv_img)."""
+    return N.lib().ds_conv_images_bytes(int(B), int(C), int(H), int(W)) // 4
+
+
+def inorm_silu_images_supported(H, W):
+    return bool(N.lib().ds_inorm_silu_images_supported(int(H), int(W)))
+
+
+def inorm_silu_images(x, w, b, kind, eps=1e-5, out=None):
+    """inorm_silu with the result written as the consuming convolution's pre-split fp16 hi / lo images (conv_img)."""
+    require_device(x, "x")
+    B, C, H, W = x.shape
+    n = conv_images_floats(B, C, H, W)
+    if out is None:
+        out = torch.empty(n, dtype=torch.float32, device=x.device)
+    elif out.numel() != n:
+        raise ValueError("images buffer size does not match x")
+    if w is not None and (w.numel() != C or b.numel() != C):
+        raise ValueError("norm affine parameters must have C entries")
+    N.check(N.lib().ds_inorm_silu_images(_p(out), _p(x), _p(w), _p(b), B, C, H, W, float(eps), int(kind), _stream()),
+            "ds_inorm_silu_images")
+    return out
+
+
+def conv_img(images, pw, B, Cin, H, W, bias=None, shift=None, res1=None, res2=None, tile_stats=None, out=None):
+    """3x3 'same' zero-padded fp16x3 convolution whose input is given as pre-split fp16 hi / lo images (the layout
+    ds_inorm_silu_images writes): patches are staged by LDS-DMA, no split in the kernel.  pw = pack_conv(weight, "fp16x3")."""
+    require_device(images, "images")
+    if pw.kind != "fp16x3" or pw.ks != 3 or pw.subs is not None:
+        raise ValueError("conv_img: a 3x3 fp16x3 packing")
+    Cout = pw.Cout
+    if images.numel() != conv_images_floats(B, Cin, H, W):
+        raise ValueError("images size does not match (B, Cin, H, W)")
+    if out is None:
+        out = torch.empty((B, Cout, H, W), dtype=torch.float32, device=images.device)
+    elif tuple(out.shape) != (B, Cout, H, W):
+        raise ValueError(f"out has shape {tuple(out.shape)}, expected {(B, Cout, H, W)}")
+    stride = 0
+    if shift is not None:
+        if shift.dim() != 2 or shift.shape[1] != Cout or shift.shape[0] not in (1, B):
+            raise ValueError(f"shift must be [1 or B, Cout]; got {tuple(shift.shape)}")
+        stride = 0 if shift.shape[0] == 1 else Cout
+    for r in (res1, res2):
+        if r is not None and tuple(r.shape) != (B, Cout, H, W):
+            raise ValueError("residual shape mismatch")
+    if tile_stats is not None and tuple(tile_stats.shape) != (B, Cout, conv_tile_count(H, W), 4):
+        raise ValueError(f"tile_stats must be {(B, Cout, conv_tile_count(H, W), 4)}")
+    N.check(N.lib().ds_conv2d_h3_img(_p(out), _p(images), _p(pw.data), int(pw.wshift), _p(bias), _p(shift), stride, _p(res1),
+                                     _p(res2), B, Cin, Cout, H, W, _p(tile_stats), _stream()), "ds_conv2d_h3_img")
+    return out
+
+
 def token_l2_normalize(x, c0, C, eps=1e-8, gain=1.0):
     """In place: channels [c0, c0+C) of x [B, Ctot, L] divided by (per-token L2 norm + eps), times gain."""
     require_device(x, "x")

@@ -224,6 +224,23 @@ int ds_conv_tile_count(int H, int W);
  * tile: the count equals ds_conv_tile_count(2Hl, 2Wl)) as ds_conv2d_h3.  flags: DS_PAD_CIRCULAR and/or
  * DS_RES1_UPSAMPLED.  Only for inputs that are whole 8x32 or 16x16 tiles (ds_conv2d_h3_up_supported); other
  * shapes use ds_conv2d_h3 with DS_LOAD_UPSAMPLE2. */
+/* The same convolution with its input given as pre-split fp16 hi / lo IMAGES in the kernel's LDS layout -- what
+ * ds_inorm_silu_images writes: [B][ceil(Cin/16)][piece 2][half 2][H+2][W+2] 16-byte vectors of 8 channels, zero border (the
+ * convolution's zero padding), zero channels past Cin.  Patches are staged by LDS-DMA: no staging registers, no split in the
+ * kernel (16-29 % of ds_conv2d_h3; with several channel tiles every element used to be split once per tile).  Plain load, zero
+ * padding, no fused norm; Cin must give an even number of 16-channel chunks (DS_ERR_UNSUPPORTED otherwise).  Epilogue terms and
+ * tile_stats as ds_conv2d_h3.  Replaces conv(SiLU(norm(x))) of commonlayers.py:824-833 where the norm is not folded. */
+/* The producer of those images: ds_inorm_silu (GroupNorm(C,C) / GroupRMSNorm(C,C) + SiLU, commonlayers.py:766-770, 372-384, 824,
+ * 829) with the result written pre-split instead of as fp32 -- the same 8 bytes per element, values bit-identical to ds_inorm_silu's for planes of up to 1024 floats (beyond that the statistics are summed in
+ * another order).  Planes of H*W <= 4096 floats, H*W a multiple of 4: ds_inorm_silu_images_supported. */
+int ds_inorm_silu_images_supported(int H, int W);
+int ds_inorm_silu_images(void* images, const float* x, const float* w, const float* b, int B, int C, int H, int W, float eps,
+                         int kind, void* stream);
+size_t ds_conv_images_bytes(int B, int C, int H, int W);
+int ds_conv2d_h3_img(float* out, const void* images, const void* w_packed, int wshift, const float* bias, const float* shift,
+                     int shift_stride, const float* res1, const float* res2, int B, int Cin, int Cout, int H, int W,
+                     float* tile_stats, void* stream);
+
 int ds_conv2d_h3_up_supported(int Hl, int Wl);
 size_t ds_conv2d_h3_up_packed_bytes(int Cout, int Cin);
 int ds_conv2d_h3_up_pack_weights(void* packed, const float* w, int Cout, int Cin, int wshift, void* stream);
