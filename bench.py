@@ -126,6 +126,9 @@ def dominant_kernel_roofline(module, args, dev, reps=40):
     conv2s = {id(blk.conv2) for blk in net._resblocks()}
     shift = {c: torch.randn(1, c, device=dev) for c in {m.out_channels for m in mods}}
     fused = net._fused()
+    blk_of = {id(c): blk for blk in net._resblocks() for c in (blk.conv1, blk.conv2)}
+    k1, k2 = net.norm_kinds
+    imgs = {}
     tabs, stats = {}, {}
     if fused:
         for m, cin, cout, s in launches:
@@ -135,9 +138,25 @@ def dominant_kernel_roofline(module, args, dev, reps=40):
                 tabs[(cin, s)] = t
             stats[(cout, s)] = torch.empty(B, cout, ops.conv_tile_count(s, s), 4, device=dev)
 
+    def use_images(m, cin, s):      # the standalone-norm blocks hand their convolutions pre-split images (punetg._res)
+        blk = blk_of.get(id(m))
+        folded = fused and (cin + 63) // 64 <= net.fuse_max_cot
+        return blk is not None and not folded and net._norm_images_ok(blk, cin, s, s, k1, k2)
+
+    for m, cin, cout, s in launches:
+        if use_images(m, cin, s) and (cin, s) not in imgs:
+            ones = torch.ones(cin, device=dev)
+            imgs[(cin, s)] = ops.inorm_silu_images(buf(cin, s), ones, torch.zeros(cin, device=dev), 0)
+
     def run():      # the same loaders / epilogues as in the network
         for m, cin, cout, s in launches:
             block = (id(m) in conv1s or id(m) in conv2s) and (cin + 63) // 64 <= net.fuse_max_cot
+            if use_images(m, cin, s):
+                ops.conv_img(imgs[(cin, s)], pk[id(m)], B, cin, s, s, bias=m.bias,
+                             shift=shift[cout] if id(m) in conv1s else None,
+                             res1=buf(cout, s, "res") if id(m) in conv2s else None,
+                             tile_stats=stats[(cout, s)] if fused else None, out=outs[(cout, s)])
+                continue
             ops.conv(buf(cin, s), pk[id(m)], bias=m.bias,
                      shift=shift[cout] if id(m) in conv1s else None,
                      res1=buf(cout, s, "res") if id(m) in conv2s else None,
@@ -158,8 +177,8 @@ def dominant_kernel_roofline(module, args, dev, reps=40):
     ms = e0.elapsed_time(e1) / reps
     n = len(launches)
     kname, peak = {
-        "fp16x3": ("k_conv3h<PLAIN> (ds_conv2d_h3, 3x3, fp32 via 3 fp16 MFMA products"
-                   + (", norm+SiLU in the loader, tile statistics in the epilogue)" if fused else ")"), BF16_PEAK_TFLOPS / 3.0),
+        "fp16x3": ("k_conv3h<PLAIN> (ds_conv2d_h3 / ds_conv2d_h3_img, 3x3, fp32 via 3 fp16 MFMA products"
+                   + (", norm+SiLU in the loader or pre-split image input, tile statistics in the epilogue)" if fused else ")"), BF16_PEAK_TFLOPS / 3.0),
         "bf16x6": ("k_conv6<PLAIN> (ds_conv2d_x6, 3x3, fp32 via 6 bf16 MFMA products)", BF16_PEAK_TFLOPS / 6.0),
         "fp32": ("k_conv<3,PLAIN> (ds_conv2d 3x3, exact-fp32 MFMA)", MFMA_F32_PEAK_TFLOPS)}[net.conv_precision]
     achieved = flops / (ms * 1e-3) / 1e12
