@@ -69,7 +69,8 @@ _PROTOS = {
     "ds_conv_images_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "ds_inorm_silu_images_supported": (c_int, [c_int, c_int]),
     "ds_inorm_silu_images": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_int, _P]),
-    "ds_conv2d_h3_img": (c_int, [_P, _P, _P, c_int, _P, _P, c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
+    "ds_conv2d_h3_img": (c_int, [_P, _P, _P, c_int, _P, _P, c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P]),
+    "ds_gnorm1_apply_images": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "ds_volume_stat_tiles": (c_int, [c_int, c_size_t]),
     "ds_volume_to_slices_act": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_size_t, _P]),
     "ds_slices_to_volume_stats": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_size_t, _P]),

@@ -744,8 +744,11 @@ size_t ds_conv_images_bytes(int B, int C, int H, int W) {
 
 int ds_conv2d_h3_img(float* out, const void* images, const void* w_packed, int wshift, const float* bias, const float* shift,
                      int shift_stride, const float* res1, const float* res2, int B, int Cin, int Cout, int H, int W,
-                     float* tile_stats, void* stream) {
+                     int flags, float* tile_stats, void* stream) {
   DS_REQUIRE(out && images && w_packed, DS_ERR_NULL, "ds_conv2d_h3_img: NULL pointer");
+  DS_REQUIRE((flags & ~DS_RES1_UPSAMPLED) == 0, DS_ERR_UNSUPPORTED, "ds_conv2d_h3_img: flags %d (DS_RES1_UPSAMPLED only)", flags);
+  DS_REQUIRE(!(flags & DS_RES1_UPSAMPLED) || (res1 && H % 2 == 0 && W % 2 == 0 && (reinterpret_cast<uintptr_t>(res1) & 7u) == 0),
+             DS_ERR_SHAPE, "ds_conv2d_h3_img: RES1_UPSAMPLED needs res1 [B, Cout, H/2, W/2] (8-byte aligned) and even H, W");
   DS_REQUIRE(B >= 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, DS_ERR_SHAPE,
              "ds_conv2d_h3_img: bad shape B=%d Cin=%d Cout=%d H=%d W=%d", B, Cin, Cout, H, W);
   DS_REQUIRE(((Cin + KC - 1) / KC) % 2 == 0, DS_ERR_UNSUPPORTED,
@@ -761,6 +764,7 @@ int ds_conv2d_h3_img(float* out, const void* images, const void* w_packed, int w
   memset(&a, 0, sizeof(a));
   a.out = out; a.in = reinterpret_cast<const float*>(images); a.wp = reinterpret_cast<const u32x4*>(w_packed);
   a.bias = bias; a.shift = shift; a.res1 = res1; a.res2 = res2; a.shift_stride = shift_stride; a.tile_stats = tile_stats;
+  a.res1_up = (flags & DS_RES1_UPSAMPLED) ? 1 : 0;
   a.unscale = ldexpf(1.0f, -wshift);
   a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.Hin = H; a.Win = W;
   const long long pad32 = (long long)((W + 31) / 32 * 32) * ((H + 7) / 8 * 8);

@@ -156,6 +156,76 @@ __global__ __launch_bounds__(NT) void k_g1_apply(float* out, const float* __rest
 #undef DS_A
 }
 
+// k_g1_apply with the result written as the consuming convolution's pre-split fp16 hi / lo images (ds_conv2d_h3_img; layout and
+// rationale: ds_norm.hip, k_inorm_images).  One thread = one position of the padded image of one 8-channel group: border
+// positions store zeros, the others apply the same arithmetic as k_g1_apply (bit-identical values) to their 8 channels and split.
+typedef _Float16 g1_f16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned g1_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void g1_split2(float a, float b, unsigned& hi, unsigned& lo) {        // ds_h3_common.h's split2
+  g1_f16x2 h = {(_Float16)a, (_Float16)b};
+  unsigned hp = __builtin_bit_cast(unsigned, h);
+  asm volatile("" : "+v"(hp));
+  const g1_f16x2 hq = __builtin_bit_cast(g1_f16x2, hp);
+  g1_f16x2 l = {(_Float16)(a - (float)hq[0]), (_Float16)(b - (float)hq[1])};
+  hi = hp;
+  lo = __builtin_bit_cast(unsigned, l);
+}
+
+template <int KIND, int POOL>
+__global__ __launch_bounds__(NT) void k_g1_apply_images(g1_u32x4* __restrict__ img, const float* __restrict__ x,
+                                                        const float* __restrict__ stats, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, const float* __restrict__ film1,
+                                                        const float* __restrict__ film2, int film_stride, int C, int nchunk,
+                                                        int Ho, int Wo, size_t total) {
+  const size_t i = (size_t)blockIdx.x * NT + threadIdx.x;
+  if (i >= total) return;
+  const int Hp = Ho + 2, Wp = Wo + 2;
+  const int px = (int)(i % Wp);
+  size_t t = i / Wp;
+  const int py = (int)(t % Hp); t /= Hp;
+  const int h = (int)(t & 1); t >>= 1;
+  const int chunk = (int)(t % nchunk);
+  const int b = (int)(t / nchunk);
+  g1_u32x4* hi_img = img + ((((size_t)b * nchunk + chunk) * 2 + 0) * 2 + h) * Hp * Wp;
+  g1_u32x4* lo_img = img + ((((size_t)b * nchunk + chunk) * 2 + 1) * 2 + h) * Hp * Wp;
+  const size_t o = (size_t)py * Wp + px;
+  g1_u32x4 qh = {0u, 0u, 0u, 0u}, ql = {0u, 0u, 0u, 0u};
+  if (py >= 1 && py <= Ho && px >= 1 && px <= Wo) {
+    const int y = py - 1, xq = px - 1;
+    const float mean = stats[2 * b], sd = stats[2 * b + 1];
+    const bool film = film1 != nullptr;
+    float a[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int c = 16 * chunk + 8 * h + k;
+      if (c < C) {
+        const float wc = w ? w[c] : 1.f, bc = bias ? bias[c] : 0.f;
+        float f1 = 1.f, f2 = 0.f;
+        if (film) { f1 = film1[(size_t)b * film_stride + c]; f2 = film2[(size_t)b * film_stride + c]; }
+#define DS_A(v) apply1<KIND>(v, mean, sd, wc, bc, film, f1, f2)
+        if (POOL == 0) {
+          a[k] = DS_A(x[(((size_t)b * C + c) * Ho + y) * Wo + xq]);
+        } else {
+          const int Wi = 2 * Wo;
+          const float* r0 = x + (((size_t)b * C + c) * (2 * Ho) + 2 * y) * Wi + 2 * xq;
+          a[k] = (((DS_A(r0[0]) + DS_A(r0[1])) + DS_A(r0[Wi])) + DS_A(r0[Wi + 1])) / 4.0f;      // torch avg_pool2d's order
+        }
+#undef DS_A
+      } else {
+        a[k] = 0.f;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      unsigned ph, pl;
+      g1_split2(a[2 * j], a[2 * j + 1], ph, pl);
+      qh[j] = ph; ql[j] = pl;
+    }
+  }
+  hi_img[o] = qh;
+  lo_img[o] = ql;
+}
+
 __global__ __launch_bounds__(NT) void k_concat2(float* out, const float* __restrict__ a, const float* __restrict__ b,
                                                 size_t na4, size_t nb4, size_t total4) {
   const size_t i = (size_t)blockIdx.x * NT + threadIdx.x;
@@ -229,6 +299,29 @@ int ds_gnorm1_apply(float* out, const float* x, const float* stats, const float*
 #undef LV
 #undef L
   DS_CHECK_LAUNCH("ds_gnorm1_apply");
+  return DS_OK;
+}
+
+int ds_gnorm1_apply_images(void* images, const float* x, const float* stats, const float* w, const float* b,
+                           const float* film_scale, const float* film_shift, int film_stride, int B, int C, int Ho, int Wo,
+                           int kind, int pool, void* stream) {
+  DS_REQUIRE(images && x && stats, DS_ERR_NULL, "ds_gnorm1_apply_images: NULL pointer");
+  DS_REQUIRE(B >= 0 && C > 0 && Ho > 0 && Wo > 0, DS_ERR_SHAPE, "ds_gnorm1_apply_images: bad shape");
+  DS_REQUIRE(kind == 0 || kind == 1, DS_ERR_UNSUPPORTED, "ds_gnorm1_apply_images: kind must be 0 (GroupNorm(1,C)) or 1 (GroupRMSNorm(1,C))");
+  DS_REQUIRE((film_scale == nullptr) == (film_shift == nullptr), DS_ERR_NULL, "ds_gnorm1_apply_images: FiLM needs scale and shift");
+  DS_REQUIRE((reinterpret_cast<uintptr_t>(images) & 15u) == 0, DS_ERR_SHAPE, "ds_gnorm1_apply_images: images must be 16-byte aligned");
+  if (B == 0) return DS_OK;
+  const int nchunk = (C + 15) / 16;
+  const size_t total = (size_t)B * nchunk * 2 * (Ho + 2) * (Wo + 2);
+  DS_REQUIRE((total + NT - 1) / NT < (1ull << 31), DS_ERR_SHAPE, "ds_gnorm1_apply_images: too many positions");
+  g1_u32x4* img = reinterpret_cast<g1_u32x4*>(images);
+  dim3 g((unsigned)((total + NT - 1) / NT)), t(NT);
+  hipStream_t s = ds::as_stream(stream);
+#define L(K, P) hipLaunchKernelGGL((k_g1_apply_images<K, P>), g, t, 0, s, img, x, stats, w, b, film_scale, film_shift, film_stride, C, nchunk, Ho, Wo, total)
+  if (kind == 0) { if (pool) L(0, 1); else L(0, 0); }
+  else { if (pool) L(1, 1); else L(1, 0); }
+#undef L
+  DS_CHECK_LAUNCH("ds_gnorm1_apply_images");
   return DS_OK;
 }
 

@@ -17,6 +17,8 @@ parameter containers only; every tensor operation is a launch into libdiffsci_hi
 from typing import Any
 import pathlib
 
+import os
+
 import torch
 import yaml
 
@@ -385,6 +387,7 @@ class ADM(torch.nn.Module):
         # (the 512-1024-channel layers would redo the activation once per 64-channel tile).
         self.fuse_norm = True
         self.fuse_max_cot = 4
+        self.norm_images = os.environ.get("DIFFSCI_NORM_IMAGES", "1") != "0"      # see PUNetG.norm_images
         self._packed = None
         self._packed_sig = None
         self._ws = _Workspace()
@@ -481,6 +484,13 @@ class ADM(torch.nn.Module):
             return None
         return ws.take((B, C, ops.conv_tile_count(H, W), 4), dev)
 
+    def _norm_images_ok(self, conv, pk, Cin):
+        """A standalone norm may hand this convolution pre-split images: 3x3 fp16x3 packing, zero padding, an even number
+        of 16-channel chunks."""
+        p = pk[id(conv)]
+        return (self.norm_images and not isinstance(conv, _CircConv) and p.kind == "fp16x3" and p.ks == 3 and p.subs is None
+                and ((Cin + 15) // 16) % 2 == 0)
+
     def _block(self, blk, x, film, pk, ws, xs=None, want_stats=True):
         """ADMBaseBlock.forward (adm.py:292-349); returns (fresh buffer, its tile statistics); x untouched.
         xs: tile statistics of x -- one buffer, or a pair when x is the channel concatenation of two
@@ -510,10 +520,18 @@ class ADM(torch.nn.Module):
             stats = ws.take((B, 2), dev)
             scratch = ws.take((ops.N.lib().ds_gnorm1_workspace_bytes(B) // 4,), dev)
             ops.gnorm1_stats(x, k1, eps=1e-5, stats=stats, workspace=scratch)
-            a = ops.gnorm1_apply(x, stats, blk.norm1.weight, blk.norm1.bias, k1, pool=down,
-                                 out=ws.take((B, Ci, Hm, Wm), dev))
-            y = self._conv(blk.conv1, a, pk, load_mode=mode, tile_stats=ys, out=ws.take((B, blk.cout, Ho, Wo), dev))
-            ws.give(a)
+            if not up and self._norm_images_ok(blk.conv1, pk, Ci):
+                # the standalone norm writes the convolution's pre-split fp16 images, staged there by LDS-DMA (see punetg._res)
+                img = ops.gnorm1_apply_images(x, stats, blk.norm1.weight, blk.norm1.bias, k1, pool=down,
+                                              out=ws.take((ops.conv_images_floats(B, Ci, Hm, Wm),), dev))
+                y = ops.conv_img(img, pk[id(blk.conv1)], B, Ci, Hm, Wm, bias=blk.conv1.bias, tile_stats=ys,
+                                 out=ws.take((B, blk.cout, Ho, Wo), dev))
+                ws.give(img)
+            else:
+                a = ops.gnorm1_apply(x, stats, blk.norm1.weight, blk.norm1.bias, k1, pool=down,
+                                     out=ws.take((B, Ci, Hm, Wm), dev))
+                y = self._conv(blk.conv1, a, pk, load_mode=mode, tile_stats=ys, out=ws.take((B, blk.cout, Ho, Wo), dev))
+                ws.give(a)
             ws.give(stats)
             ws.give(scratch)
         # residual_block: convresidual(resample(x))                               (adm.py:345-349)
@@ -546,10 +564,17 @@ class ADM(torch.nn.Module):
             stats = ws.take((B, 2), dev)
             scratch = ws.take((ops.N.lib().ds_gnorm1_workspace_bytes(B) // 4,), dev)
             ops.gnorm1_stats(y, k2, eps=1e-5, stats=stats, workspace=scratch)
-            a2 = ops.gnorm1_apply(y, stats, blk.norm2.weight, blk.norm2.bias, k2, film=film,
-                                  out=ws.take((B, blk.cout, Ho, Wo), dev))
-            out = self._conv(blk.conv2, a2, pk, res1=r, res1_upsampled=r_up, tile_stats=os_, out=y)
-            ws.give(a2)
+            if self._norm_images_ok(blk.conv2, pk, blk.cout):
+                img = ops.gnorm1_apply_images(y, stats, blk.norm2.weight, blk.norm2.bias, k2, film=film,
+                                              out=ws.take((ops.conv_images_floats(B, blk.cout, Ho, Wo),), dev))
+                out = ops.conv_img(img, pk[id(blk.conv2)], B, blk.cout, Ho, Wo, bias=blk.conv2.bias, res1=r,
+                                   res1_upsampled=r_up, tile_stats=os_, out=y)
+                ws.give(img)
+            else:
+                a2 = ops.gnorm1_apply(y, stats, blk.norm2.weight, blk.norm2.bias, k2, film=film,
+                                      out=ws.take((B, blk.cout, Ho, Wo), dev))
+                out = self._conv(blk.conv2, a2, pk, res1=r, res1_upsampled=r_up, tile_stats=os_, out=y)
+                ws.give(a2)
             ws.give(stats)
             ws.give(scratch)
             if ys is not None:

@@ -756,7 +756,8 @@ def inorm_silu_images(x, w, b, kind, eps=1e-5, out=None):
     return out
 
 
-def conv_img(images, pw, B, Cin, H, W, bias=None, shift=None, res1=None, res2=None, tile_stats=None, out=None):
+def conv_img(images, pw, B, Cin, H, W, bias=None, shift=None, res1=None, res2=None, tile_stats=None, out=None,
+             res1_upsampled=False):
     """3x3 'same' zero-padded fp16x3 convolution whose input is given as pre-split fp16 hi / lo images (the layout
     ds_inorm_silu_images writes): patches are staged by LDS-DMA, no split in the kernel.  pw = pack_conv(weight, "fp16x3")."""
     require_device(images, "images")
@@ -774,13 +775,41 @@ def conv_img(images, pw, B, Cin, H, W, bias=None, shift=None, res1=None, res2=No
         if shift.dim() != 2 or shift.shape[1] != Cout or shift.shape[0] not in (1, B):
             raise ValueError(f"shift must be [1 or B, Cout]; got {tuple(shift.shape)}")
         stride = 0 if shift.shape[0] == 1 else Cout
-    for r in (res1, res2):
+    if res1_upsampled and (res1 is None or H % 2 or W % 2 or tuple(res1.shape) != (B, Cout, H // 2, W // 2)):
+        raise ValueError("res1_upsampled: res1 of shape [B, Cout, H/2, W/2]")
+    for r in ((res2,) if res1_upsampled else (res1, res2)):
         if r is not None and tuple(r.shape) != (B, Cout, H, W):
             raise ValueError("residual shape mismatch")
     if tile_stats is not None and tuple(tile_stats.shape) != (B, Cout, conv_tile_count(H, W), 4):
         raise ValueError(f"tile_stats must be {(B, Cout, conv_tile_count(H, W), 4)}")
     N.check(N.lib().ds_conv2d_h3_img(_p(out), _p(images), _p(pw.data), int(pw.wshift), _p(bias), _p(shift), stride, _p(res1),
-                                     _p(res2), B, Cin, Cout, H, W, _p(tile_stats), _stream()), "ds_conv2d_h3_img")
+                                     _p(res2), B, Cin, Cout, H, W, N.DS_RES1_UPSAMPLED if res1_upsampled else 0,
+                                     _p(tile_stats), _stream()), "ds_conv2d_h3_img")
+    return out
+
+
+def gnorm1_apply_images(x, stats, w, b, kind, pool=False, film=None, out=None):
+    """gnorm1_apply (kinds 0 / 1) with the result written as the consuming convolution's pre-split images (conv_img)."""
+    require_device(x, "x")
+    B, C, H, W = x.shape
+    if pool and (H % 2 or W % 2):
+        raise ValueError("pooling needs even H, W")
+    Ho, Wo = (H // 2, W // 2) if pool else (H, W)
+    n = conv_images_floats(B, C, Ho, Wo)
+    if out is None:
+        out = torch.empty(n, dtype=torch.float32, device=x.device)
+    elif out.numel() != n:
+        raise ValueError("images buffer size does not match x")
+    f1 = f2 = None
+    stride = 0
+    if film is not None:
+        if film.dim() != 2 or film.shape[1] != 2 * C or film.shape[0] not in (1, B):
+            raise ValueError("film must be [1 or B, 2C]")
+        require_device(film, "film")
+        stride = 0 if film.shape[0] == 1 else 2 * C
+        f1, f2 = film.data_ptr(), film.data_ptr() + 4 * C
+    N.check(N.lib().ds_gnorm1_apply_images(_p(out), _p(x), _p(stats), _p(w), _p(b), f1, f2, stride, B, C, Ho, Wo, int(kind),
+                                           1 if pool else 0, _stream()), "ds_gnorm1_apply_images")
     return out
 
 

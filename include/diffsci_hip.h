@@ -239,7 +239,11 @@ int ds_inorm_silu_images(void* images, const float* x, const float* w, const flo
 size_t ds_conv_images_bytes(int B, int C, int H, int W);
 int ds_conv2d_h3_img(float* out, const void* images, const void* w_packed, int wshift, const float* bias, const float* shift,
                      int shift_stride, const float* res1, const float* res2, int B, int Cin, int Cout, int H, int W,
-                     float* tile_stats, void* stream);
+                     int flags /* 0 or DS_RES1_UPSAMPLED */, float* tile_stats, void* stream);
+/* ds_gnorm1_apply (ADM's GroupNorm(1,C) / GroupRMSNorm(1,C) [+FiLM] + SiLU [+AvgPool2d(2)], adm.py:306-343) writing those images. */
+int ds_gnorm1_apply_images(void* images, const float* x, const float* stats, const float* w, const float* b,
+                           const float* film_scale, const float* film_shift, int film_stride, int B, int C, int Ho, int Wo,
+                           int kind, int pool, void* stream);
 
 int ds_conv2d_h3_up_supported(int Hl, int Wl);
 size_t ds_conv2d_h3_up_packed_bytes(int Cout, int Cin);

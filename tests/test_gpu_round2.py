@@ -612,3 +612,72 @@ def test_network_with_norm_images_is_bit_identical(M, dev):
     net.fuse_norm, net.norm_images = True, True
     assert all(torch.equal(o, outs[0]) for o in outs)
 
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 16, 16), (1, 64, 24, 40), (3, 96, 8, 12), (2, 40, 16, 16)])
+def test_group_norm_images_and_upsampled_residual(dev, shape):
+    """GroupNorm(1, C) / GroupRMSNorm apply (+ FiLM, + AvgPool(2)) written as pre-split images (ds_gnorm1_apply_images) against
+    ds_gnorm1_apply, and the image-input convolution with the nearest-x2 residual (DS_RES1_UPSAMPLED) against ds_conv2d_h3:
+    bit-identical."""
+    from diffsci_amd import ops
+    B, C, H, W = shape
+    torch.manual_seed(sum(shape) + 1)
+    x = torch.randn(B, C, H, W, device=dev) * 0.8 - 0.1
+    w, b = torch.randn(C, device=dev), torch.randn(C, device=dev)
+    film = torch.randn(B, 2 * C, device=dev) * 0.3
+    for kind in (0, 1):
+        st = ops.gnorm1_stats(x, kind, eps=1e-5)
+        for pool, fl in ((False, None), (True, None), (False, film), (False, film[:1].contiguous())):
+            act = ops.gnorm1_apply(x, st, w, b, kind, pool=pool, film=fl)
+            img = ops.gnorm1_apply_images(x, st, w, b, kind, pool=pool, film=fl)
+            assert torch.equal(img.view(torch.int32), _torch_images(act).view(torch.int32)), (kind, pool, fl is not None)
+    if ((C + 15) // 16) % 2:
+        return
+    wt = torch.randn(C, C, 3, 3, device=dev) / (3 * C ** 0.5)
+    pw = ops.pack_conv(wt, "fp16x3")
+    bias = torch.randn(C, device=dev)
+    low = torch.randn(B, C, H // 2, W // 2, device=dev)
+    ts_a = torch.zeros(B, C, ops.conv_tile_count(H, W), 4, device=dev)
+    ts_b = torch.zeros_like(ts_a)
+    want = ops.conv(act, pw, bias=bias, res1=low, res1_upsampled=True, tile_stats=ts_a)
+    got = ops.conv_img(img, pw, B, C, H, W, bias=bias, res1=low, res1_upsampled=True, tile_stats=ts_b)
+    assert torch.equal(got, want) and torch.equal(ts_a, ts_b)
+    with pytest.raises(ValueError, match="res1_upsampled"):
+        ops.conv_img(img, pw, B, C, H, W, res1=torch.zeros(B, C, H, W, device=dev), res1_upsampled=True)
+
+
+def test_adm_with_norm_images_is_bit_identical(M, dev):
+    """ADM: the standalone-norm blocks on the image route against the fp32 route, eagerly and captured."""
+    from diffsci_amd import ops
+    torch.manual_seed(8)
+    net = M.ADM(M.ADMConfig(model_channels=32, time_embed_dim=16, output_embed_dim=32)).to(dev).eval()
+    for p in net.parameters():
+        if p.dim() == 1:
+            p.data.add_(0.1 * torch.randn_like(p))
+    x, t = torch.randn(2, 1, 32, 32, device=dev), torch.tensor([0.4, -0.7], device=dev)
+    calls = []
+    orig = ops.conv_img
+    ops.conv_img = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    outs = {}
+    try:
+        for fuse in (False, True):
+            net.fuse_norm = fuse
+            for images in (True, False):
+                net.norm_images = images
+                n0 = len(calls)
+                outs[(fuse, images)] = net(x, t).clone()
+                assert (len(calls) > n0) == images
+    finally:
+        ops.conv_img = orig
+    for fuse in (False, True):
+        assert torch.isfinite(outs[(fuse, True)]).all() and torch.equal(outs[(fuse, True)], outs[(fuse, False)])
+    module = M.KarrasModule(net, M.KarrasModuleConfig.from_edm()).to(dev)
+    wn = torch.randn(2, 1, 32, 32, device=dev)
+    res = []
+    for images in (True, False):
+        net.norm_images = images
+        for use_graph in (False, True):
+            module.use_graph = use_graph
+            res.append(module.propagate_white_noise(wn, nsteps=3).clone())
+    net.norm_images = True
+    assert all(torch.equal(r, res[0]) for r in res)
