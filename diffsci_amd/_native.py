@@ -62,6 +62,7 @@ _PROTOS = {
     "ds_inorm_table": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_int, _P]),
     "ds_gnorm1_table": (c_int, [_P, _P, c_int, c_int, _P, c_int, c_int, _P, _P, _P, _P, c_int, c_int, c_longlong,
                                 c_float, c_int, _P]),
+    "ds_gnorm1_stats_tiles": (c_int, [_P, _P, c_int, c_int, _P, c_int, c_int, c_int, c_longlong, c_float, c_int, _P]),
     "ds_conv2d_direct": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "ds_conv3d_direct": (c_int, [_P, _P, _P, _P, _P, c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "ds_volume_to_slices": (c_int, [_P, _P, c_int, c_int, c_int, c_size_t, c_int, c_int, _P]),

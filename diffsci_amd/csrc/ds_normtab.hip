@@ -73,7 +73,8 @@ __global__ __launch_bounds__(G1T) void k_gnorm1_table(float* table, const float*
                                                       const float* __restrict__ sb, int Cb, int ntb,
                                                       const float* __restrict__ w, const float* __restrict__ bias,
                                                       const float* __restrict__ f1, const float* __restrict__ f2,
-                                                      int film_stride, double inv_n, float eps, int kind) {
+                                                      int film_stride, double inv_n, float eps, int kind,
+                                                      float* __restrict__ stats_out) {
   __shared__ double red[2][G1T / 64];
   __shared__ float st[2];
   const int b = blockIdx.x, C = Ca + Cb;
@@ -103,7 +104,12 @@ __global__ __launch_bounds__(G1T) void k_gnorm1_table(float* table, const float*
       st[0] = 0.f;
       st[1] = 1.0f / sqrtf((float)(tq * inv_n) + eps);
     }
+    if (stats_out) {                                       // ds_gnorm1_stats' convention: (mean, rstd) / (0, RMS denominator)
+      stats_out[2 * b + 0] = st[0];
+      stats_out[2 * b + 1] = kind == 0 ? st[1] : sqrtf((float)(tq * inv_n) + eps);
+    }
   }
+  if (!table) return;
   __syncthreads();
   const float M = st[0], rs = st[1];
   const int Cpad = (C + 15) / 16 * 16;
@@ -154,8 +160,26 @@ int ds_gnorm1_table(float* table, const float* stats_a, int Ca, int ntiles_a, co
              DS_ERR_SHAPE, "ds_gnorm1_table: pointers must be 16-byte aligned");
   if (B == 0) return DS_OK;
   hipLaunchKernelGGL(k_gnorm1_table, dim3(B), dim3(G1T), 0, ds::as_stream(stream), table, stats_a, Ca, ntiles_a, stats_b,
-                     Cb, ntiles_b, w, b, film_scale, film_shift, film_stride, 1.0 / (double)count, eps, kind);
+                     Cb, ntiles_b, w, b, film_scale, film_shift, film_stride, 1.0 / (double)count, eps, kind, (float*)nullptr);
   DS_CHECK_LAUNCH("ds_gnorm1_table");
+  return DS_OK;
+}
+
+/* ds_gnorm1_stats without reading the tensor: the (mean, rstd) / (0, RMS denominator) pairs of ds_gnorm1_apply[_images] from the
+ * tile statistics its producer(s) left (one convolution output, or the channel concatenation of two). */
+int ds_gnorm1_stats_tiles(float* stats, const float* stats_a, int Ca, int ntiles_a, const float* stats_b, int Cb, int ntiles_b,
+                          int B, long long count, float eps, int kind, void* stream) {
+  DS_REQUIRE(stats && stats_a, DS_ERR_NULL, "ds_gnorm1_stats_tiles: NULL pointer");
+  DS_REQUIRE(B >= 0 && Ca > 0 && ntiles_a > 0 && Cb >= 0 && count > 0, DS_ERR_SHAPE, "ds_gnorm1_stats_tiles: bad shape");
+  DS_REQUIRE(Cb == 0 || (stats_b && ntiles_b > 0), DS_ERR_NULL, "ds_gnorm1_stats_tiles: second source missing");
+  DS_REQUIRE(kind == 0 || kind == 1, DS_ERR_UNSUPPORTED, "ds_gnorm1_stats_tiles: kind %d", kind);
+  DS_REQUIRE(((reinterpret_cast<uintptr_t>(stats_a) | reinterpret_cast<uintptr_t>(stats_b)) & 15u) == 0, DS_ERR_SHAPE,
+             "ds_gnorm1_stats_tiles: tile statistics must be 16-byte aligned");
+  if (B == 0) return DS_OK;
+  hipLaunchKernelGGL(k_gnorm1_table, dim3(B), dim3(G1T), 0, ds::as_stream(stream), (float*)nullptr, stats_a, Ca, ntiles_a,
+                     stats_b, Cb, ntiles_b, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
+                     (const float*)nullptr, 0, 1.0 / (double)count, eps, kind, stats);
+  DS_CHECK_LAUNCH("ds_gnorm1_stats_tiles");
   return DS_OK;
 }
 

@@ -363,7 +363,7 @@ class KarrasModule(torch.nn.Module, LatentSpaceAutoregressive):
                        float(guidance), condition_signature(y), float(sch.langevin_const), repr(sch.langevin_interval), self.noise_shard,
                        tuple(float(v) for v in table.t.tolist()),
                        tuple((p.data_ptr(), p._version) for p in self.model.parameters()),
-                       tuple(getattr(self.model, a, None) for a in ("conv_precision", "fuse_norm", "fuse_max_cot", "direct_out", "upsample_parity", "norm_images")))
+                       tuple(getattr(self.model, a, None) for a in ("conv_precision", "fuse_norm", "fuse_max_cot", "direct_out", "upsample_parity", "norm_images", "tile_stats_norms")))
                 return self._plans.run(key, make_loop, x, y=y, scale=scale, eps=eps)
             loop = make_loop()
             loop.load(x, scale)

@@ -388,6 +388,9 @@ class ADM(torch.nn.Module):
         self.fuse_norm = True
         self.fuse_max_cot = 4
         self.norm_images = os.environ.get("DIFFSCI_NORM_IMAGES", "1") != "0"      # see PUNetG.norm_images
+        # standalone norms take their statistics from the producer's tile statistics (as the folded ones do) instead of
+        # a pass over the tensor, whenever the producer left them
+        self.tile_stats_norms = os.environ.get("DIFFSCI_TILE_STATS_NORMS", "1") != "0"
         self._packed = None
         self._packed_sig = None
         self._ws = _Workspace()
@@ -519,7 +522,11 @@ class ADM(torch.nn.Module):
             Hm, Wm = (Ho, Wo) if down else (H, W)
             stats = ws.take((B, 2), dev)
             scratch = ws.take((ops.N.lib().ds_gnorm1_workspace_bytes(B) // 4,), dev)
-            ops.gnorm1_stats(x, k1, eps=1e-5, stats=stats, workspace=scratch)
+            if xs is not None and self.tile_stats_norms:   # the producers left tile statistics: no pass over x
+                sa, sb = xs if isinstance(xs, tuple) else (xs, None)
+                ops.gnorm1_stats_tiles(sa, k1, Ci * H * W, stats_b=sb, eps=1e-5, stats=stats)
+            else:
+                ops.gnorm1_stats(x, k1, eps=1e-5, stats=stats, workspace=scratch)
             if not up and self._norm_images_ok(blk.conv1, pk, Ci):
                 # the standalone norm writes the convolution's pre-split fp16 images, staged there by LDS-DMA (see punetg._res)
                 img = ops.gnorm1_apply_images(x, stats, blk.norm1.weight, blk.norm1.bias, k1, pool=down,
@@ -563,7 +570,10 @@ class ADM(torch.nn.Module):
         else:
             stats = ws.take((B, 2), dev)
             scratch = ws.take((ops.N.lib().ds_gnorm1_workspace_bytes(B) // 4,), dev)
-            ops.gnorm1_stats(y, k2, eps=1e-5, stats=stats, workspace=scratch)
+            if ys is not None and self.tile_stats_norms:
+                ops.gnorm1_stats_tiles(ys, k2, blk.cout * Ho * Wo, eps=1e-5, stats=stats)
+            else:
+                ops.gnorm1_stats(y, k2, eps=1e-5, stats=stats, workspace=scratch)
             if self._norm_images_ok(blk.conv2, pk, blk.cout):
                 img = ops.gnorm1_apply_images(y, stats, blk.norm2.weight, blk.norm2.bias, k2, film=film,
                                               out=ws.take((ops.conv_images_floats(B, blk.cout, Ho, Wo),), dev))

@@ -649,6 +649,20 @@ def gnorm1_table(stats_a, w, b, kind, count, stats_b=None, film=None, eps=1e-5, 
     return out
 
 
+def gnorm1_stats_tiles(stats_a, kind, count, stats_b=None, eps=1e-5, stats=None):
+    """gnorm1_stats [B, 2] from the tile statistics of the tensor's producer(s) instead of a pass over the tensor."""
+    require_device(stats_a, "stats_a")
+    B, Ca, nta, _ = stats_a.shape
+    Cb, ntb = (0, 0) if stats_b is None else (stats_b.shape[1], stats_b.shape[2])
+    if stats is None:
+        stats = torch.empty((B, 2), dtype=torch.float32, device=stats_a.device)
+    elif tuple(stats.shape) != (B, 2):
+        raise ValueError(f"stats must be {(B, 2)}")
+    N.check(N.lib().ds_gnorm1_stats_tiles(_p(stats), _p(stats_a), Ca, nta, _p(stats_b), Cb, ntb, B, int(count), float(eps),
+                                          int(kind), _stream()), "ds_gnorm1_stats_tiles")
+    return stats
+
+
 def conv2d(x, w_packed, Cout, ks, bias=None, shift=None, res1=None, res2=None,
            load_mode=N.DS_LOAD_PLAIN, out=None, kind="fp32", wshift=0, prenorm=None, tile_stats=None, circular=False,
            res1_upsampled=False, w_up=None, up_wshift=0, tap_offset=None):

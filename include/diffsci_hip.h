@@ -268,6 +268,10 @@ int ds_inorm_table(float* table, const float* tile_stats, const float* w, const 
 int ds_gnorm1_table(float* table, const float* stats_a, int Ca, int ntiles_a, const float* stats_b, int Cb,
                     int ntiles_b, const float* w, const float* b, const float* film_scale, const float* film_shift,
                     int film_stride, int B, long long count, float eps, int kind, void* stream);
+/* ds_gnorm1_stats without a pass over the tensor: the pairs ds_gnorm1_apply / ds_gnorm1_apply_images take, (mean, rstd)
+ * (kind 0) or (0, RMS denominator) (kind 1), recombined in fp64 from the producers' tile statistics as ds_gnorm1_table does. */
+int ds_gnorm1_stats_tiles(float* stats, const float* stats_a, int Ca, int ntiles_a, const float* stats_b, int Cb,
+                          int ntiles_b, int B, long long count, float eps, int kind, void* stream);
 
 /* 3x3 "same" convolution for Cout <= 4 (the networks' output layers: punetg.py:415, adm.py:193-215) as an
  * exact-fp32 FMA chain, streaming the input once (HBM-bound) instead of padding Cout to a 64-channel MFMA

@@ -681,3 +681,38 @@ def test_adm_with_norm_images_is_bit_identical(M, dev):
             res.append(module.propagate_white_noise(wn, nsteps=3).clone())
     net.norm_images = True
     assert all(torch.equal(r, res[0]) for r in res)
+
+
+def test_group_norm_statistics_from_tile_statistics(M, dev):
+    """ds_gnorm1_stats_tiles: the (mean, rstd) / (0, RMS denominator) pairs from the tile statistics two convolutions left (the
+    channel concatenation of their outputs) against ds_gnorm1_stats over the concatenated tensor; and ADM with its standalone
+    norms fed that way against passes over the tensors."""
+    from diffsci_amd import ops
+    torch.manual_seed(21)
+    B, H, W = 3, 24, 40
+    outs, tss = [], []
+    for C in (32, 48):
+        x = torch.randn(B, 16, H, W, device=dev)
+        pw = ops.pack_conv(torch.randn(C, 16, 3, 3, device=dev) / 12, "fp16x3")
+        ts = torch.zeros(B, C, ops.conv_tile_count(H, W), 4, device=dev)
+        outs.append(ops.conv(x, pw, bias=torch.randn(C, device=dev) * 3, tile_stats=ts))
+        tss.append(ts)
+    cat = torch.cat(outs, dim=1).contiguous()
+    for kind in (0, 1):
+        want = ops.gnorm1_stats(cat, kind, eps=1e-5)
+        got = ops.gnorm1_stats_tiles(tss[0], kind, cat[0].numel(), stats_b=tss[1], eps=1e-5)
+        assert torch.allclose(got, want, rtol=2e-6, atol=1e-7), (kind, got, want)
+        one = ops.gnorm1_stats_tiles(tss[1], kind, outs[1][0].numel(), eps=1e-5)
+        assert torch.allclose(one, ops.gnorm1_stats(outs[1], kind, eps=1e-5), rtol=2e-6, atol=1e-7)
+    net = M.ADM(M.ADMConfig(model_channels=32, time_embed_dim=16, output_embed_dim=32)).to(dev).eval()
+    x, t = torch.randn(2, 1, 32, 32, device=dev), torch.tensor([0.4, -0.7], device=dev)
+    calls = []
+    orig = ops.gnorm1_stats_tiles
+    ops.gnorm1_stats_tiles = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    try:
+        a = net(x, t).clone()
+    finally:
+        ops.gnorm1_stats_tiles = orig
+    net.tile_stats_norms = False
+    b = net(x, t).clone()
+    assert calls and float((a - b).norm() / b.norm()) < 2e-6
