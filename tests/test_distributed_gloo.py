@@ -46,7 +46,10 @@ def test_two_rank_shard_and_gather(nsamples):
     from diffsci_amd.parallel import global_white_noise, shard_rows
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000) + nsamples
+    import socket
+    with socket.socket() as sock:                       # a port the kernel says is free (a pid-derived one collided once)
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
     procs = [ctx.Process(target=_worker, args=(r, 2, port, nsamples, q)) for r in range(2)]
     for p in procs:
         p.start()
