@@ -183,8 +183,11 @@ __device__ __forceinline__ void store_half_rows(int m, const float* tile, float*
   }
 }
 
-template <bool W16, bool PRE, bool CIRC, bool S16>
+// IMGIN: the low-resolution input arrives as pre-split fp16 hi / lo images (ds_gnorm1_apply_images / ds_inorm_silu_images:
+// [b][chunk][piece][h][Hl+2][Wl+2] vectors of 8 channels, zero border); an X buffer is filled by LDS-DMA, no registers, no split.
+template <bool W16, bool PRE, bool CIRC, bool S16, bool IMGIN = false>
 __global__ __launch_bounds__(NT, 2) void k_convup(const UpArgs a) {
+  static_assert(!IMGIN || (S16 && !PRE && !CIRC), "image input: the plain zero-padded 16x16x32 kernel");
   constexpr int TH = Geo<W16>::TH, TW = Geo<W16>::TW, PW = Geo<W16>::PW, NPOS = Geo<W16>::NPOS;
   constexpr int XI = 3;
   static_assert(NPOS > NT && NPOS - NT <= NT / 2, "staging plan assumes 256 < NPOS <= 384");
@@ -317,12 +320,43 @@ __global__ __launch_bounds__(NT, 2) void k_convup(const UpArgs a) {
     }
   };
 
+  // ---- IMGIN: the X buffer [piece][h][HS] is one linear region of XBV = 20 x 64 vectors; DMA instruction k = wv + 4 i fills
+  //      vectors 64 k ..; lane -> (image, position); the 14 pad vectors of an image re-read its last position (never used).
+  //      Tiles divide the input, so every patch position lies inside the bordered image. ----
+  constexpr int NDMA = IMGIN ? XBV / 64 / 4 : 1;
+  static_assert(!IMGIN || XBV == 4 * 64 * NDMA, "whole DMA instructions per wave");
+  int doff[NDMA];
+  const int Wp = a.Wl + 2, Hp = a.Hl + 2;
+  if constexpr (IMGIN) {
+#pragma unroll
+    for (int i = 0; i < NDMA; ++i) {
+      const int L = 64 * (wv + 4 * i) + lane;
+      const int q = L / HS;                                // image 2 * piece + h
+      int pos = L - q * HS;
+      pos = pos < NPOS ? pos : NPOS - 1;
+      const int r = pos / PW, col = pos - r * PW;
+      doff[i] = (q * Hp + (y0 + r + pa)) * Wp + x0 + col;  // bordered coordinates: patch origin (y0 - 1 + pa, x0 - 1) + 1
+    }
+  }
+  const u32x4* img_b = IMGIN ? reinterpret_cast<const u32x4*>(a.in) + (size_t)b * a.n_chunks * 4 * Hp * Wp : nullptr;
+  auto x_dma = [&](int chunk, int buf) __attribute__((always_inline)) {
+    if constexpr (IMGIN) {
+      const u32x4* src = img_b + (size_t)chunk * 4 * Hp * Wp;
+      u32x4* dst = Xs + buf * XBV;
+#pragma unroll
+      for (int i = 0; i < NDMA; ++i)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + doff[i]),
+                                         (__attribute__((address_space(3))) void*)(dst + 64 * (wv + 4 * i)), 16, 0, 0);
+    }
+  };
+
   // ---- prologue: patch 0, weight slabs 0 and 1 ----
+  if constexpr (IMGIN) x_dma(0, 0); else
   x_fetch(0);
   const float bias_shift = ds_epi::fetch_bias_shift(a.bias, a.shift, a.shift_stride, b, cot * COT, a.Cout);
   w_fetch(0, 0);
   w_fetch(1, 1);                                                 // n_steps >= 4 always
-  x_store(0);
+  if constexpr (!IMGIN) x_store(0);
   ds_epi::commit_bias_shift(BS, bias_shift);
   __syncthreads();
 
@@ -358,7 +392,10 @@ __global__ __launch_bounds__(NT, 2) void k_convup(const UpArgs a) {
       const int s = k >> 1, pb = k & 1;
       const int xbuf = chunk & 1;
       if (g + 2 < n_steps) w_fetch(g + 2, slot >= 1 ? slot - 1 : 2);      // (slot + 2) % 3
-      if (k == 0 && chunk + 1 < a.n_chunks) x_fetch(chunk + 1);
+      if (k == 0 && chunk + 1 < a.n_chunks) {
+        // the other buffer's last readers finished before the previous step's barrier; this step's barrier publishes the DMA
+        if constexpr (IMGIN) x_dma(chunk + 1, xbuf ^ 1); else x_fetch(chunk + 1);
+      }
       __builtin_amdgcn_sched_barrier(0);
       const int wofs = slot * WSLAB_VEC + wlane;
       const int xofs = xbuf * XBV + s * PW + pb;
@@ -380,7 +417,8 @@ __global__ __launch_bounds__(NT, 2) void k_convup(const UpArgs a) {
           for (int n = 0; n < 4; ++n)
             acc16[pb][m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[PA[t]][m], fb[PB[t]][n], acc16[pb][m][n], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
-      if (k == 2 && chunk + 1 < a.n_chunks) x_store(xbuf ^ 1);            // published by this step's barrier
+      if constexpr (!IMGIN)
+        if (k == 2 && chunk + 1 < a.n_chunks) x_store(xbuf ^ 1);          // published by this step's barrier
       __syncthreads();
     };
     int chunk = 0;
@@ -530,17 +568,17 @@ bool up_shape16() {
   return v;
 }
 
-template <bool W16, bool PRE, bool CIRC, bool S16>
+template <bool W16, bool PRE, bool CIRC, bool S16, bool IMGIN = false>
 int launch_up_shape(const UpArgs& a, hipStream_t s) {
   constexpr int LDS = S16 ? LDS_BYTES16 : LDS_BYTES;
   {
-    const int rc = ds::ensure_dynamic_lds<&k_convup<W16, PRE, CIRC, S16>>(LDS, "hipFuncSetAttribute(convup)");
+    const int rc = ds::ensure_dynamic_lds<&k_convup<W16, PRE, CIRC, S16, IMGIN>>(LDS, "hipFuncSetAttribute(convup)");
     if (rc != DS_OK) return rc;
   }
   const long long tiles = (long long)a.tiles_y * a.tiles_x;
   DS_REQUIRE(tiles > 0 && tiles < 65536 && a.B < 65536, DS_ERR_SHAPE,
              "ds_conv2d_h3_up: %lld pixel tiles x %d samples exceed the grid limits (65535 each)", tiles, a.B);
-  hipLaunchKernelGGL((k_convup<W16, PRE, CIRC, S16>), dim3((unsigned)a.n_cot * 2u, (unsigned)tiles, (unsigned)a.B), dim3(NT),
+  hipLaunchKernelGGL((k_convup<W16, PRE, CIRC, S16, IMGIN>), dim3((unsigned)a.n_cot * 2u, (unsigned)tiles, (unsigned)a.B), dim3(NT),
                      LDS, s, a);
   DS_CHECK_LAUNCH("ds_conv2d_h3_up");
   return DS_OK;
@@ -620,6 +658,36 @@ int ds_conv2d_h3_up(float* out, const float* in, const void* w_packed, int wshif
                           : (circ ? launch_up<W, false, true>(a, s) : launch_up<W, false, false>(a, s)))
   return w16 ? DS_LU(true) : DS_LU(false);
 #undef DS_LU
+}
+
+int ds_conv2d_h3_up_img(float* out, const void* images, const void* w_packed, int wshift, const float* bias, const float* shift,
+                        int shift_stride, const float* res1, const float* res2, int B, int Cin, int Cout, int Hl, int Wl,
+                        float* tile_stats, void* stream) {
+  DS_REQUIRE(out && images && w_packed, DS_ERR_NULL, "ds_conv2d_h3_up_img: NULL pointer");
+  DS_REQUIRE(B >= 0 && Cin > 0 && Cout > 0 && Hl > 0 && Wl > 0, DS_ERR_SHAPE,
+             "ds_conv2d_h3_up_img: bad shape B=%d Cin=%d Cout=%d Hl=%d Wl=%d", B, Cin, Cout, Hl, Wl);
+  const int geo = up_geometry(Hl, Wl);
+  DS_REQUIRE(geo != 0, DS_ERR_UNSUPPORTED, "ds_conv2d_h3_up_img: %d x %d input is not a whole number of 8x32 or 16x16 tiles", Hl, Wl);
+  DS_REQUIRE(shift == nullptr || shift_stride == 0 || shift_stride >= Cout, DS_ERR_SHAPE,
+             "ds_conv2d_h3_up_img: shift_stride %d < Cout %d", shift_stride, Cout);
+  DS_REQUIRE(((reinterpret_cast<uintptr_t>(w_packed) | reinterpret_cast<uintptr_t>(images)) & 15u) == 0, DS_ERR_SHAPE,
+             "ds_conv2d_h3_up_img: images and w_packed must be 16-byte aligned");
+  DS_REQUIRE(wshift >= -40 && wshift <= 40, DS_ERR_SHAPE, "ds_conv2d_h3_up_img: wshift %d out of range", wshift);
+  DS_REQUIRE((long long)4 * (Hl + 2) * (Wl + 2) < (1ll << 27), DS_ERR_SHAPE, "ds_conv2d_h3_up_img: image planes too large");
+  if (B == 0) return DS_OK;
+  UpArgs a;
+  a.out = out; a.in = reinterpret_cast<const float*>(images); a.wp = reinterpret_cast<const u32x4*>(w_packed); a.bias = bias;
+  a.shift = shift; a.res1 = res1; a.res2 = res2; a.prenorm = nullptr; a.tile_stats = tile_stats;
+  a.unscale = ldexpf(1.0f, -wshift); a.shift_stride = shift_stride; a.res1_up = 0;
+  a.B = B; a.Cin = Cin; a.Cout = Cout; a.Hl = Hl; a.Wl = Wl;
+  const bool w16 = geo == 2;
+  const int TW = w16 ? 16 : 32, TH = w16 ? 16 : 8;
+  a.tiles_x = Wl / TW; a.tiles_y = Hl / TH;
+  a.n_cot = (Cout + COT - 1) / COT;
+  a.n_chunks = (Cin + KC - 1) / KC;
+  a.tiles_x_magic = a.tiles_x == 1 ? 0u : (unsigned)((1ull << 32) / (unsigned)a.tiles_x) + 1u;
+  hipStream_t s = ds::as_stream(stream);
+  return w16 ? launch_up_shape<true, false, false, true, true>(a, s) : launch_up_shape<false, false, false, true, true>(a, s);
 }
 
 }  // extern "C"

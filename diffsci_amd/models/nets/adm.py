@@ -534,6 +534,14 @@ class ADM(torch.nn.Module):
                 y = ops.conv_img(img, pk[id(blk.conv1)], B, Ci, Hm, Wm, bias=blk.conv1.bias, tile_stats=ys,
                                  out=ws.take((B, blk.cout, Ho, Wo), dev))
                 ws.give(img)
+            elif up and self.norm_images and not isinstance(blk.conv1, _CircConv) \
+                    and ops.conv_up_img_supported(pk[id(blk.conv1)], H, W):
+                # the same for the parity kernels of conv1(nearest_x2(.)): images of the low-resolution activation
+                img = ops.gnorm1_apply_images(x, stats, blk.norm1.weight, blk.norm1.bias, k1,
+                                              out=ws.take((ops.conv_images_floats(B, Ci, H, W),), dev))
+                y = ops.conv_up_img(img, pk[id(blk.conv1)], B, Ci, H, W, bias=blk.conv1.bias, tile_stats=ys,
+                                    out=ws.take((B, blk.cout, Ho, Wo), dev))
+                ws.give(img)
             else:
                 a = ops.gnorm1_apply(x, stats, blk.norm1.weight, blk.norm1.bias, k1, pool=down,
                                      out=ws.take((B, Ci, Hm, Wm), dev))

@@ -802,6 +802,40 @@ def conv_img(images, pw, B, Cin, H, W, bias=None, shift=None, res1=None, res2=No
     return out
 
 
+def conv_up_img_supported(pw, Hl, Wl):
+    """conv_up_img takes this packing and low-resolution size."""
+    return (pw.kind == "fp16x3" and pw.ks == 3 and pw.subs is None and pw.up is not None
+            and bool(N.lib().ds_conv2d_h3_up_supported(int(Hl), int(Wl))))
+
+
+def conv_up_img(images, pw, B, Cin, Hl, Wl, bias=None, shift=None, res1=None, res2=None, tile_stats=None, out=None):
+    """conv3x3(nearest_x2(a)) as the four collapsed parity kernels (ds_conv2d_h3_up) with the low-resolution activation a given as
+    pre-split images; output [B, Cout, 2 Hl, 2 Wl].  pw = pack_conv(weight, "fp16x3", upsampled=True)."""
+    require_device(images, "images")
+    if not conv_up_img_supported(pw, Hl, Wl):
+        raise ValueError("conv_up_img: a 3x3 fp16x3 packing with parity kernels and an input of whole 8x32 / 16x16 tiles")
+    Cout, H, W = pw.Cout, 2 * Hl, 2 * Wl
+    if images.numel() != conv_images_floats(B, Cin, Hl, Wl):
+        raise ValueError("images size does not match (B, Cin, Hl, Wl)")
+    if out is None:
+        out = torch.empty((B, Cout, H, W), dtype=torch.float32, device=images.device)
+    elif tuple(out.shape) != (B, Cout, H, W):
+        raise ValueError(f"out has shape {tuple(out.shape)}, expected {(B, Cout, H, W)}")
+    stride = 0
+    if shift is not None:
+        if shift.dim() != 2 or shift.shape[1] != Cout or shift.shape[0] not in (1, B):
+            raise ValueError(f"shift must be [1 or B, Cout]; got {tuple(shift.shape)}")
+        stride = 0 if shift.shape[0] == 1 else Cout
+    for r in (res1, res2):
+        if r is not None and tuple(r.shape) != (B, Cout, H, W):
+            raise ValueError("residual shape mismatch")
+    if tile_stats is not None and tuple(tile_stats.shape) != (B, Cout, conv_tile_count(H, W), 4):
+        raise ValueError(f"tile_stats must be {(B, Cout, conv_tile_count(H, W), 4)}")
+    N.check(N.lib().ds_conv2d_h3_up_img(_p(out), _p(images), _p(pw.up), int(pw.up_wshift), _p(bias), _p(shift), stride, _p(res1),
+                                        _p(res2), B, Cin, Cout, Hl, Wl, _p(tile_stats), _stream()), "ds_conv2d_h3_up_img")
+    return out
+
+
 def gnorm1_apply_images(x, stats, w, b, kind, pool=False, film=None, out=None):
     """gnorm1_apply (kinds 0 / 1) with the result written as the consuming convolution's pre-split images (conv_img)."""
     require_device(x, "x")

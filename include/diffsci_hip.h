@@ -252,6 +252,12 @@ int ds_conv2d_h3_up(float* out, const float* in, const void* w_packed, int wshif
                     const float* shift, int shift_stride, const float* res1, const float* res2,
                     int B, int Cin, int Cout, int Hl, int Wl, int flags, const float* prenorm, float* tile_stats,
                     void* stream);
+/* ds_conv2d_h3_up (zero padding, no fused norm) with the LOW-resolution input given as pre-split images
+ * (ds_gnorm1_apply_images / ds_inorm_silu_images over [B, Cin, Hl, Wl]); w_packed from ds_conv2d_h3_up_pack_weights.
+ * ADM's norm1 -> SiLU -> nearest x2 -> conv1 of an 'up' block (adm.py:312-323). */
+int ds_conv2d_h3_up_img(float* out, const void* images, const void* w_packed, int wshift, const float* bias,
+                        const float* shift, int shift_stride, const float* res1, const float* res2,
+                        int B, int Cin, int Cout, int Hl, int Wl, float* tile_stats, void* stream);
 
 
 /* PUNetG norms from tile statistics: table [B, ceil16(C), 4]; table[b,c] = (mean | 0, rstd*w[c], b[c], 0) for GroupNorm(C,C)

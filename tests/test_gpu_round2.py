@@ -716,3 +716,25 @@ def test_group_norm_statistics_from_tile_statistics(M, dev):
     net.tile_stats_norms = False
     b = net(x, t).clone()
     assert calls and float((a - b).norm() / b.norm()) < 2e-6
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 16, 32, 64), (1, 40, 16, 16, 24), (3, 96, 8, 64, 128), (2, 16, 32, 32, 8)])
+def test_upsampling_convolution_with_image_input(dev, shape):
+    """ds_conv2d_h3_up_img (parity kernels of conv3x3(nearest_x2(a)), a as pre-split images staged by LDS-DMA) against
+    ds_conv2d_h3_up on the fp32 activation: bit-identical outputs and tile statistics."""
+    from diffsci_amd import ops
+    B, C, Hl, Wl, Co = shape
+    torch.manual_seed(sum(shape))
+    a = torch.randn(B, C, Hl, Wl, device=dev)
+    pw = ops.pack_conv(torch.randn(Co, C, 3, 3, device=dev) / (3 * C ** 0.5), "fp16x3", upsampled=True)
+    assert ops.conv_up_img_supported(pw, Hl, Wl)
+    img = _torch_images(a)
+    bias, shift = torch.randn(Co, device=dev), torch.randn(B, Co, device=dev)
+    res = torch.randn(B, Co, 2 * Hl, 2 * Wl, device=dev)
+    ts_a = torch.zeros(B, Co, ops.conv_tile_count(2 * Hl, 2 * Wl), 4, device=dev)
+    ts_b = torch.zeros_like(ts_a)
+    from diffsci_amd._native import DS_LOAD_UPSAMPLE2
+    want = ops.conv(a, pw, bias=bias, shift=shift, res1=res, load_mode=DS_LOAD_UPSAMPLE2, tile_stats=ts_a)
+    got = ops.conv_up_img(img, pw, B, C, Hl, Wl, bias=bias, shift=shift, res1=res, tile_stats=ts_b)
+    assert torch.equal(got, want) and torch.equal(ts_a, ts_b)
+    assert not ops.conv_up_img_supported(pw, 12, 20)
