@@ -46,7 +46,7 @@ def main():
             x = torch.randn(B, cin, D, H, W)
         t = torch.rand(B) * 3 - 1.5
         if family == "punetg":
-            over = dict(model_channels=pick([4, 8, 16]), channel_expansion=exp, input_channels=cin, output_channels=ri(1, 5),
+            over = dict(model_channels=pick([4, 8, 16, 32]), channel_expansion=exp, input_channels=cin, output_channels=ri(1, 5),
                         number_resnet_downward_block=ri(1, 2), number_resnet_upward_block=ri(1, 2),
                         number_resnet_attn_block=ri(1, 3), number_resnet_before_attn_block=ri(0, 2),
                         number_resnet_after_attn_block=ri(0, 2), attn_residual=bool(ri(0, 1)))
@@ -67,7 +67,7 @@ def main():
                 want = punetg_ref.punetg_forward(sd, cfg, x, t)
                 want64 = punetg_ref.punetg_forward({k: w.double() for k, w in sd.items()}, cfg, x.double(), t.double())
         else:
-            over = dict(model_channels=pick([8, 16]), time_embed_dim=8, output_embed_dim=16, channel_expansion=exp,
+            over = dict(model_channels=pick([8, 16, 32]), time_embed_dim=8, output_embed_dim=16, channel_expansion=exp,
                         input_channels=cin, output_channels=ri(1, 5), number_resnet_downward_block=ri(1, 2),
                         number_resnet_upward_block=ri(1, 3), number_resnet_attn_block=ri(1, 2),
                         number_resnet_before_attn_block=ri(0, 1), number_resnet_after_attn_block=ri(0, 1),
