@@ -62,6 +62,54 @@ def fuzz_up(ri, g, dev):
     return max(e, float(((sxx - (want * want).sum(dim=(2, 3))).abs() / (want * want).sum(dim=(2, 3)).clamp_min(1e-30)).max()))
 
 
+def fuzz_images(ri, g, dev):
+    """The image route: ds_gnorm1_apply_images / ds_inorm_silu_images, then ds_conv2d_h3_img or ds_conv2d_h3_up_img -- bit-identical
+    to the fp32 route (norm kernel, then the convolution splitting in its loader) and close to fp64."""
+    B, Cout = ri(1, 3), ri(1, 140)
+    up = ri(0, 2) == 0
+    Cin = ri(1, 70) if up else 32 * ri(1, 3) - ri(0, 15)            # plain kernel: an even number of 16-channel chunks
+    if up:
+        H, W = (8 * ri(1, 3), 32 * ri(1, 2)) if ri(0, 1) else (16 * ri(1, 2), 16 * ri(1, 2))
+    else:
+        H, W = ri(1, 24), ri(1, 40)
+    adm = ri(0, 1) == 1 or (H * W) % 4 != 0 or H * W > 4096          # group-1 norm (any shape) or per-channel norm
+    kind = ri(0, 1)
+    pool = adm and not up and ri(0, 2) == 0
+    Hx, Wx = (2 * H, 2 * W) if pool else (H, W)
+    x = (torch.randn(B, Cin, Hx, Wx, generator=g) * 1.5 + 0.2).to(dev)
+    wn, bn = torch.randn(Cin, generator=g).to(dev), torch.randn(Cin, generator=g).to(dev)
+    film = (torch.randn(B, 2 * Cin, generator=g) * 0.3).to(dev) if adm and ri(0, 1) else None
+    if adm:
+        st = ops.gnorm1_stats(x, kind, eps=1e-5)
+        act = ops.gnorm1_apply(x, st, wn, bn, kind, pool=pool, film=film)
+        img = ops.gnorm1_apply_images(x, st, wn, bn, kind, pool=pool, film=film)
+    else:
+        act = ops.inorm_silu(x, wn, bn, kind=kind)
+        img = ops.inorm_silu_images(x, wn, bn, kind)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)
+    bias, shift = torch.randn(Cout, generator=g).to(dev), torch.randn(B, Cout, generator=g).to(dev)
+    Ho, Wo = (2 * H, 2 * W) if up else (H, W)
+    res_up = not up and Ho % 2 == 0 and Wo % 2 == 0 and ri(0, 2) == 0
+    r1 = torch.randn(B, Cout, *((Ho // 2, Wo // 2) if res_up else (Ho, Wo)), generator=g).to(dev)
+    pw = ops.pack_conv(w.to(dev), "fp16x3", upsampled=up)
+    ts_a = torch.full((B, Cout, ops.conv_tile_count(Ho, Wo), 4), float("nan"), device=dev)
+    ts_b = ts_a.clone()
+    if up:
+        want = ops.conv(act, pw, bias=bias, shift=shift, res1=r1, load_mode=2, tile_stats=ts_a)
+        got = ops.conv_up_img(img, pw, B, Cin, H, W, bias=bias, shift=shift, res1=r1, tile_stats=ts_b)
+    else:
+        want = ops.conv(act, pw, bias=bias, shift=shift, res1=r1, res1_upsampled=res_up, tile_stats=ts_a)
+        got = ops.conv_img(img, pw, B, Cin, H, W, bias=bias, shift=shift, res1=r1, res1_upsampled=res_up, tile_stats=ts_b)
+    exact = adm or H * W <= 1024                                     # larger planes: ds_inorm_silu_images sums its statistics in another order
+    if exact:
+        assert torch.equal(got, want) and torch.equal(ts_a, ts_b), f"image route differs: up={up} adm={adm} Cin={Cin} Cout={Cout} {H}x{W} pool={pool}"
+    a64 = act.double().cpu()
+    src = F.interpolate(a64, scale_factor=2.0, mode="nearest") if up else a64
+    ref = F.conv2d(src, w.double(), bias.double().cpu(), padding=1) + shift.double().cpu()[..., None, None]
+    ref = ref + (F.interpolate(r1.double().cpu(), scale_factor=2.0, mode="nearest") if res_up else r1.double().cpu())
+    return rel(got.cpu(), ref)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=200)
@@ -72,12 +120,12 @@ def main():
     ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))       # noqa: E731
     worst = 0.0
     for it in range(a.n):
-        kind = ["3x3", "3x3", "3x3", "1x1", "direct", "up"][ri(0, 5)]
-        if kind == "up":
-            e = fuzz_up(ri, g, dev)
+        kind = ["3x3", "3x3", "3x3", "1x1", "direct", "up", "images", "images"][ri(0, 7)]
+        if kind in ("up", "images"):
+            e = fuzz_up(ri, g, dev) if kind == "up" else fuzz_images(ri, g, dev)
             worst = max(worst, e)
             if e > 3e-6:
-                print(f"FAIL it={it} kind=up err={e:.3e}")
+                print(f"FAIL it={it} kind={kind} err={e:.3e}")
                 sys.exit(1)
             if it % 25 == 0:
                 print(f"it {it}: ok (worst so far {worst:.2e})", flush=True)
