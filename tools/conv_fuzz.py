@@ -101,7 +101,10 @@ def fuzz_images(ri, g, dev):
         want = ops.conv(act, pw, bias=bias, shift=shift, res1=r1, res1_upsampled=res_up, tile_stats=ts_a)
         got = ops.conv_img(img, pw, B, Cin, H, W, bias=bias, shift=shift, res1=r1, res1_upsampled=res_up, tile_stats=ts_b)
     exact = adm or H * W <= 1024                                     # larger planes: ds_inorm_silu_images sums its statistics in another order
-    if exact:
+    exact = exact and os.environ.get("DS_CONV_SHAPE") != "32"        # the image-input kernels exist in the 16x16x32 form only
+    if not exact:
+        assert rel(got, want) < 2e-6
+    else:
         assert torch.equal(got, want) and torch.equal(ts_a, ts_b), f"image route differs: up={up} adm={adm} Cin={Cin} Cout={Cout} {H}x{W} pool={pool}"
     a64 = act.double().cpu()
     src = F.interpolate(a64, scale_factor=2.0, mode="nearest") if up else a64
