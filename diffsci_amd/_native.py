@@ -58,6 +58,7 @@ _PROTOS = {
     "ds_conv2d_h3_up_packed_bytes": (c_size_t, [c_int, c_int]),
     "ds_conv2d_h3_up_pack_weights": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     "ds_conv2d_h3_up": (c_int, [_P, _P, _P, c_int, _P, _P, c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P]),
+    "ds_table_apply_images": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "ds_conv2d_h3_up_img": (c_int, [_P, _P, _P, c_int, _P, _P, c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "ds_conv_tile_count": (c_int, [c_int, c_int]),
     "ds_inorm_table": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_int, _P]),

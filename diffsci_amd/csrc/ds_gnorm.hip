@@ -226,6 +226,49 @@ __global__ __launch_bounds__(NT) void k_g1_apply_images(g1_u32x4* __restrict__ i
   lo_img[o] = ql;
 }
 
+// The fused loader's activation SiLU((x - M) * A + C) from a norm table [B, ceil16(C), 4] (ds_inorm_table / ds_gnorm1_table),
+// written as pre-split images: any plane size, any norm the tables describe.  Same arithmetic as the loader (hardware exp2 / rcp).
+__global__ __launch_bounds__(NT) void k_table_apply_images(g1_u32x4* __restrict__ img, const float* __restrict__ x,
+                                                           const float4* __restrict__ table, int C, int nchunk, int H, int W,
+                                                           size_t total) {
+  const size_t i = (size_t)blockIdx.x * NT + threadIdx.x;
+  if (i >= total) return;
+  const int Hp = H + 2, Wp = W + 2;
+  const int px = (int)(i % Wp);
+  size_t t = i / Wp;
+  const int py = (int)(t % Hp); t /= Hp;
+  const int h = (int)(t & 1); t >>= 1;
+  const int chunk = (int)(t % nchunk);
+  const int b = (int)(t / nchunk);
+  g1_u32x4* hi_img = img + ((((size_t)b * nchunk + chunk) * 2 + 0) * 2 + h) * Hp * Wp;
+  g1_u32x4* lo_img = img + ((((size_t)b * nchunk + chunk) * 2 + 1) * 2 + h) * Hp * Wp;
+  const size_t o = (size_t)py * Wp + px;
+  g1_u32x4 qh = {0u, 0u, 0u, 0u}, ql = {0u, 0u, 0u, 0u};
+  if (py >= 1 && py <= H && px >= 1 && px <= W) {
+    const float4* trow = table + ((size_t)b * nchunk + chunk) * 16 + 8 * h;
+    float a[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int c = 16 * chunk + 8 * h + k;
+      if (c < C) {
+        const float4 p = trow[k];
+        const float v = (x[(((size_t)b * C + c) * H + (py - 1)) * W + (px - 1)] - p.x) * p.y + p.z;
+        a[k] = v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.44269504088896341f));     // ds_h3::fast_silu
+      } else {
+        a[k] = 0.f;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      unsigned ph, pl;
+      g1_split2(a[2 * j], a[2 * j + 1], ph, pl);
+      qh[j] = ph; ql[j] = pl;
+    }
+  }
+  hi_img[o] = qh;
+  lo_img[o] = ql;
+}
+
 __global__ __launch_bounds__(NT) void k_concat2(float* out, const float* __restrict__ a, const float* __restrict__ b,
                                                 size_t na4, size_t nb4, size_t total4) {
   const size_t i = (size_t)blockIdx.x * NT + threadIdx.x;
@@ -322,6 +365,21 @@ int ds_gnorm1_apply_images(void* images, const float* x, const float* stats, con
   else { if (pool) L(1, 1); else L(1, 0); }
 #undef L
   DS_CHECK_LAUNCH("ds_gnorm1_apply_images");
+  return DS_OK;
+}
+
+int ds_table_apply_images(void* images, const float* x, const float* table, int B, int C, int H, int W, void* stream) {
+  DS_REQUIRE(images && x && table, DS_ERR_NULL, "ds_table_apply_images: NULL pointer");
+  DS_REQUIRE(B >= 0 && C > 0 && H > 0 && W > 0, DS_ERR_SHAPE, "ds_table_apply_images: bad shape");
+  DS_REQUIRE(((reinterpret_cast<uintptr_t>(images) | reinterpret_cast<uintptr_t>(table)) & 15u) == 0, DS_ERR_SHAPE,
+             "ds_table_apply_images: images and table must be 16-byte aligned");
+  if (B == 0) return DS_OK;
+  const int nchunk = (C + 15) / 16;
+  const size_t total = (size_t)B * nchunk * 2 * (H + 2) * (W + 2);
+  DS_REQUIRE((total + NT - 1) / NT < (1ull << 31), DS_ERR_SHAPE, "ds_table_apply_images: too many positions");
+  hipLaunchKernelGGL(k_table_apply_images, dim3((unsigned)((total + NT - 1) / NT)), dim3(NT), 0, ds::as_stream(stream),
+                     reinterpret_cast<g1_u32x4*>(images), x, reinterpret_cast<const float4*>(table), C, nchunk, H, W, total);
+  DS_CHECK_LAUNCH("ds_table_apply_images");
   return DS_OK;
 }
 

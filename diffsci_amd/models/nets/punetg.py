@@ -647,6 +647,23 @@ class PUNetG(torch.nn.Module):
             ws.give(img)
             ws.give(y)
             return out, os_
+        if self._table_images_ok(blk, C, k1, k2) and self._fused() and xs is not None:
+            # planes the image norm kernel does not take (more than 4096 floats): the activation from the fused loader's table
+            # (built from the producer's tile statistics), written as images by an apply pass
+            tab = ws.take((B, ops.table_channels(C), 4), dev)
+            ops.inorm_table(xs, w1, b1, k1, H * W, eps=1e-5, out=tab)
+            img = ops.table_apply_images(x, tab, out=ws.take((ops.conv_images_floats(B, C, H, W),), dev))
+            ys = self._stats_buf(ws, B, C, H, W, dev)
+            y = ops.conv_img(img, pk[id(blk.conv1)], B, C, H, W, bias=blk.conv1.bias, shift=shift, res1=yt, tile_stats=ys,
+                             out=ws.take(x.shape, dev))
+            ops.inorm_table(ys, w2, b2, k2, H * W, eps=1e-5, out=tab)
+            ops.table_apply_images(y, tab, out=img)
+            os_ = self._stats_buf(ws, B, C, H, W, dev) if want_stats else None
+            out = ops.conv_img(img, pk[id(blk.conv2)], B, C, H, W, bias=blk.conv2.bias, res1=x, res2=res2, tile_stats=os_,
+                               out=ws.take(x.shape, dev))
+            for t in (img, y, ys, tab):
+                ws.give(t)
+            return out, os_
         a = ops.inorm_silu(x, w1, b1, kind=k1, eps=1e-5, out=ws.take(x.shape, dev))
         y = self._conv(blk.conv1, a, pk, shift=shift, res1=yt, out=ws.take(x.shape, dev))
         ops.inorm_silu(y, w2, b2, kind=k2, eps=1e-5, out=a)
@@ -654,6 +671,12 @@ class PUNetG(torch.nn.Module):
         self._conv(blk.conv2, a, pk, res1=x, res2=res2, tile_stats=os_, out=y)
         ws.give(a)
         return y, os_
+
+    def _table_images_ok(self, blk, C, k1, k2):
+        """As _norm_images_ok for the table route (any plane size; GroupLN / GroupRMS / no norm)."""
+        return (getattr(self, "norm_images", True) and self.conv_precision == "fp16x3" and not self.circular
+                and self.config.kernel_size == 3 and k1 in (0, 1, 2) and k2 in (0, 1, 2) and ((C + 15) // 16) % 2 == 0
+                and blk.conv1.out_channels == C and blk.conv2.out_channels == C)
 
     def _norm_images_ok(self, blk, C, H, W, k1, k2):
         """The standalone norms of this block can hand their convolutions pre-split images: fp16x3 3x3 convolutions with zero

@@ -802,6 +802,23 @@ def conv_img(images, pw, B, Cin, H, W, bias=None, shift=None, res1=None, res2=No
     return out
 
 
+def table_apply_images(x, table, out=None):
+    """SiLU((x - M) * A + C) from a norm table [B, ceil16(C), 4] (inorm_table / gnorm1_table: the fused loader's arithmetic),
+    written as the convolution's pre-split images (conv_img / conv_up_img).  Any plane size."""
+    require_device(x, "x")
+    require_device(table, "table")
+    B, C, H, W = x.shape
+    if tuple(table.shape) != (B, table_channels(C), 4):
+        raise ValueError(f"table must be {(B, table_channels(C), 4)}; got {tuple(table.shape)}")
+    n = conv_images_floats(B, C, H, W)
+    if out is None:
+        out = torch.empty(n, dtype=torch.float32, device=x.device)
+    elif out.numel() != n:
+        raise ValueError("images buffer size does not match x")
+    N.check(N.lib().ds_table_apply_images(_p(out), _p(x), _p(table), B, C, H, W, _stream()), "ds_table_apply_images")
+    return out
+
+
 def conv_up_img_supported(pw, Hl, Wl):
     """conv_up_img takes this packing and low-resolution size."""
     return (pw.kind == "fp16x3" and pw.ks == 3 and pw.subs is None and pw.up is not None

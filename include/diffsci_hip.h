@@ -245,6 +245,10 @@ int ds_gnorm1_apply_images(void* images, const float* x, const float* stats, con
                            const float* film_scale, const float* film_shift, int film_stride, int B, int C, int Ho, int Wo,
                            int kind, int pool, void* stream);
 
+/* The fused loader's SiLU((x - M)*A + C) from a norm table [B, ceil16(C), 4] (ds_inorm_table / ds_gnorm1_table), written as
+ * those images: any plane size, every norm the tables describe (commonlayers.py:824-829 where ds_inorm_silu_images does not apply). */
+int ds_table_apply_images(void* images, const float* x, const float* table, int B, int C, int H, int W, void* stream);
+
 int ds_conv2d_h3_up_supported(int Hl, int Wl);
 size_t ds_conv2d_h3_up_packed_bytes(int Cout, int Cin);
 int ds_conv2d_h3_up_pack_weights(void* packed, const float* w, int Cout, int Cin, int wshift, void* stream);

@@ -738,3 +738,47 @@ def test_upsampling_convolution_with_image_input(dev, shape):
     got = ops.conv_up_img(img, pw, B, C, Hl, Wl, bias=bias, shift=shift, res1=res, tile_stats=ts_b)
     assert torch.equal(got, want) and torch.equal(ts_a, ts_b)
     assert not ops.conv_up_img_supported(pw, 12, 20)
+
+
+def test_table_images_for_large_planes(M, dev):
+    """Planes beyond the image norm kernel's 4096 floats: the activation comes from the fused loader's table
+    (ds_table_apply_images) -- the kernel against torch on the table's formula, and PUNetG at 96 x 96 against the CPU oracle and
+    against its fp32 route."""
+    from diffsci_amd import ops
+    from oracle import punetg_ref
+    from tests.golden_util import rel_l2
+    torch.manual_seed(31)
+    B, C, H, W = 2, 40, 70, 90
+    x = torch.randn(B, C, H, W, device=dev) * 1.2 + 0.3
+    tab = torch.zeros(B, ops.table_channels(C), 4, device=dev)
+    tab[:, :C, 0], tab[:, :C, 1], tab[:, :C, 2] = torch.randn(B, C, device=dev) * 0.3, torch.rand(B, C, device=dev) + 0.5, torch.randn(B, C, device=dev) * 0.2
+    v = (x - tab[:, :C, 0, None, None]) * tab[:, :C, 1, None, None] + tab[:, :C, 2, None, None]
+    want = _torch_images(torch.nn.functional.silu(v.double()).float())
+    got = ops.table_apply_images(x, tab)
+    nch = (C + 15) // 16
+    dec = lambda im: (lambda t: (t[:, :, 0] + t[:, :, 1]))(im.view(torch.float16).view(B, nch, 2, 2, H + 2, W + 2, 8).float())   # noqa: E731
+    assert float((dec(got) - dec(want)).abs().max()) < 4e-6 * float(dec(want).abs().max())
+    assert float(dec(got)[:, :, :, 0].abs().max()) == 0.0 and float(dec(got)[:, :, :, :, -1].abs().max()) == 0.0      # zero border
+    cfg = punetg_ref.default_config(model_channels=32)
+    sd = punetg_ref.random_state_dict(cfg, seed=9)
+    net = M.PUNetG(M.PUNetGConfig(model_channels=32))
+    net.load_state_dict(sd, strict=True)
+    net = net.to(dev).eval()
+    x, t = torch.randn(1, 1, 96, 96, device=dev), torch.tensor([0.2], device=dev)
+    calls = []
+    orig = ops.table_apply_images
+    ops.table_apply_images = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    try:
+        net.fuse_max_cot = 0                              # every block on standalone norms: level 0 has 9216-float planes
+        with_images = net(x, t).cpu()
+    finally:
+        ops.table_apply_images = orig
+    assert len(calls) >= 4
+    net.norm_images = False
+    plain = net(x, t).cpu()
+    with torch.inference_mode():
+        ref = punetg_ref.punetg_forward(sd, cfg, x.cpu(), t.cpu())
+        ref64 = punetg_ref.punetg_forward({k: w.double() for k, w in sd.items()}, cfg, x.double().cpu(), t.double().cpu())
+    # this deep random-weight network at 96 x 96 amplifies fp32 rounding: the bound is the reference's own fp32-vs-fp64 distance
+    tol = max(1e-5, 4 * rel_l2(ref, ref64))
+    assert rel_l2(with_images, ref64) < tol and rel_l2(plain, ref64) < tol and rel_l2(with_images, plain) < tol
