@@ -75,3 +75,20 @@ def test_product_never_imports_the_oracle():
             if f.endswith(".py"):
                 text = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", text, re.M), os.path.join(dirpath, f)
+
+
+def test_image_layout_helpers_are_host_side(built_lib):
+    """Sizes and shape predicates of the pre-split image route: plain host arithmetic, callable without a GPU."""
+    import ctypes
+    lib = ctypes.CDLL(str(built_lib))
+    lib.ds_conv_images_bytes.restype = ctypes.c_size_t
+    lib.ds_conv_images_bytes.argtypes = [ctypes.c_int] * 4
+    for B, C, H, W in ((1, 1, 1, 1), (2, 16, 8, 8), (3, 40, 17, 33), (64, 256, 32, 32)):
+        chunks = (C + 15) // 16
+        # [b][chunk][piece 2][half 2][H+2][W+2] vectors of 16 bytes
+        assert lib.ds_conv_images_bytes(B, C, H, W) == B * chunks * 4 * (H + 2) * (W + 2) * 16
+    assert lib.ds_conv_images_bytes(0, 16, 8, 8) == 0
+    assert lib.ds_inorm_silu_images_supported(64, 64) == 1 and lib.ds_inorm_silu_images_supported(128, 64) == 0
+    assert lib.ds_inorm_silu_images_supported(3, 3) == 0                      # H*W must be a multiple of 4
+    assert lib.ds_conv2d_h3_up_supported(8, 32) == 1 and lib.ds_conv2d_h3_up_supported(16, 48) == 1
+    assert lib.ds_conv2d_h3_up_supported(12, 20) == 0
