@@ -20,13 +20,18 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # arithmetic; MFMA kernels are unaffected (their FMAs are the matrix instruction's own).
 FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-std=c++17",
          "-Wall", "-Wno-unused-function"]
+# The fp16x3 convolution kernels: no SLP vectorisation.  It packs the epilogue's pairs of 16-lane DPP reductions into v_pk_add_f32,
+# which cannot carry the DPP modifier (two v_mov_b32_dpp + one packed add per step instead of two v_add_f32_dpp), and packed fp32
+# operations issue no faster than their two scalar halves on gfx950.  Same-box A/B: 77.4 -> 78.5 samples/s, launches 223.4 -> 219.3 us
+# (profiles/r02_noslp_ab.log); the attention kernel measured neutral with the flag and keeps the default.
+EXTRA_FLAGS = {f: ["-fno-slp-vectorize"] for f in ("ds_conv3h.hip", "ds_convup.hip", "ds_conv1h.hip")}
 
 
 def _stale():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(ROOT, "include", "diffsci_hip.h")]
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(ROOT, "include", "diffsci_hip.h"), os.path.abspath(__file__)]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
@@ -38,7 +43,7 @@ def build(force=False, verbose=True):
     procs = []
     for src in SOURCES:
         obj = os.path.join(OUTDIR, src.replace(".hip", ".o"))
-        cmd = [HIPCC] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [HIPCC] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd)))
