@@ -123,7 +123,7 @@ __device__ __forceinline__ void store_tile(const f32x16 (&acc)[MT][2], float* ti
       const int co = 32 * m + (q & 3) + 8 * (q >> 2) + 4 * lh;
       const float bsv = bs[co] + bs[64 + co];          // bias + shift, added once per channel (the kernel is vector-issue / power bound)
 #pragma unroll
-      for (int r = 0; r < 2; ++r) tile[(co * 2 + r) * 32 + li] = acc[m][r][q] * e.unscale + bsv;
+      for (int r = 0; r < 2; ++r) tile[(co * 2 + r) * 32 + li] = __builtin_fmaf(acc[m][r][q], e.unscale, bsv);   // unscale is a power of two: the product is exact, one instruction
     }
   store_tile_rows<W16, MT, PF>(tile, e, R);
 }
@@ -146,7 +146,7 @@ __device__ __forceinline__ void store_tile16(const f32x4 (&acc)[2 * MT][4], floa
       const int co = 16 * m + 4 * g + q;
       const float bsv = bs[co] + bs[64 + co];
 #pragma unroll
-      for (int n = 0; n < 4; ++n) tile[(co * 2 + (n >> 1)) * 32 + 16 * (n & 1) + i] = acc[m][n][q] * unscale + bsv;
+      for (int n = 0; n < 4; ++n) tile[(co * 2 + (n >> 1)) * 32 + 16 * (n & 1) + i] = __builtin_fmaf(acc[m][n][q], unscale, bsv);   // exact product (power of two)
     }
   store_tile_rows<W16, MT, PF>(tile, e, R);
 }

@@ -98,8 +98,7 @@ __device__ __forceinline__ void store_half(const f32x16 (&acc0)[2], const f32x16
     const float bv = bs[32 * m + co], sv = bs[64 + 32 * m + co];
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
-      float v0 = acc0[r][q] * e.unscale, v1 = acc1[r][q] * e.unscale;
-      v0 = v0 + bv; v1 = v1 + bv;
+      float v0 = __builtin_fmaf(acc0[r][q], e.unscale, bv), v1 = __builtin_fmaf(acc1[r][q], e.unscale, bv);   // exact product (power of two)
       v0 = v0 + sv; v1 = v1 + sv;
       typedef float f32x2_t __attribute__((ext_vector_type(2)));
       *reinterpret_cast<f32x2_t*>(&tile[((co * 2 + r) * 32 + li) * 2]) = f32x2_t{v0, v1};
@@ -123,8 +122,7 @@ __device__ __forceinline__ void store_half16(const f32x4 (&acc0)[4][4], const f3
       const float bv = bs[32 * m + co], sv = bs[64 + 32 * m + co];
 #pragma unroll
       for (int n = 0; n < 4; ++n) {
-        float v0 = acc0[2 * m + mm][n][q] * e.unscale, v1 = acc1[2 * m + mm][n][q] * e.unscale;
-        v0 = v0 + bv; v1 = v1 + bv;
+        float v0 = __builtin_fmaf(acc0[2 * m + mm][n][q], e.unscale, bv), v1 = __builtin_fmaf(acc1[2 * m + mm][n][q], e.unscale, bv);
         v0 = v0 + sv; v1 = v1 + sv;
         const int li = (16 * (n & 1) + l16) ^ (16 * (g & 1));
         typedef float f32x2_t __attribute__((ext_vector_type(2)));
