@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(ROOT, "diffsci_amd", "csrc")
 OUTDIR = os.path.join(ROOT, "diffsci_amd", "_lib")
 LIB = os.path.join(OUTDIR, "libdiffsci_hip.so")
-SOURCES = ["ds_api.hip", "ds_step.hip", "ds_norm.hip", "ds_gnorm.hip", "ds_normtab.hip", "ds_conv.hip", "ds_conv6.hip", "ds_conv3h.hip", "ds_convup.hip", "ds_conv1h.hip", "ds_convdirect.hip", "ds_conv3d.hip", "ds_attn.hip", "ds_attn3h.hip", "ds_small.hip"]
+SOURCES = ["ds_api.hip", "ds_step.hip", "ds_norm.hip", "ds_gnorm.hip", "ds_normtab.hip", "ds_conv.hip", "ds_conv6.hip", "ds_conv3h.hip", "ds_convup.hip", "ds_conv1h.hip", "ds_convdirect.hip", "ds_conv3d.hip", "ds_attn.hip", "ds_attn3h.hip", "ds_small.hip", "ds_amax.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -ffp-contract=off: the stepper / norm kernels reproduce the reference's one-rounding-per-op
 # arithmetic; MFMA kernels are unaffected (their FMAs are the matrix instruction's own).

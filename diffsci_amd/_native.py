@@ -5,12 +5,12 @@ point of diffsci_amd raises.  Build it with ``python build.py`` (hipcc, gfx950).
 """
 import ctypes
 import os
-from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_longlong, c_size_t, c_uint64, c_void_p
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_longlong, c_size_t, c_uint32, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DIFFSCI_HIP_LIB") or os.path.join(_HERE, "_lib", "libdiffsci_hip.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 DS_IN_NETWORK, DS_IN_SCORE, DS_IN_DRIFT, DS_IN_FLOW = 0, 1, 2, 3
 DS_LOAD_PLAIN, DS_LOAD_MAXPOOL2, DS_LOAD_UPSAMPLE2, DS_LOAD_AVGPOOL2 = 0, 1, 2, 3
 DS_PAD_CIRCULAR = 16
@@ -53,17 +53,21 @@ _PROTOS = {
     "ds_conv2d_x6": (c_int, [_P, _P, _P, _P, _P, c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "ds_conv2d_h3_packed_bytes": (c_size_t, [c_int, c_int]),
     "ds_conv2d_h3_pack_weights": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
-    "ds_conv2d_h3": (c_int, [_P, _P, _P, c_int, _P, _P, c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P]),
+    "ds_conv2d_h3": (c_int, [_P, _P, _P, c_int, _P, _P, c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
+    "ds_absmax_rows": (c_int, [_P, _P, c_int, c_size_t, c_size_t, _P]),
+    "ds_amax_merge": (c_int, [_P, _P, _P, c_int, _P]),
+    "ds_absmax_channels": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_size_t, c_int, _P]),
+    "ds_fill_u32": (c_int, [_P, c_uint32, c_size_t, _P]),
     "ds_conv2d_h3_up_supported": (c_int, [c_int, c_int]),
     "ds_conv2d_h3_up_packed_bytes": (c_size_t, [c_int, c_int]),
     "ds_conv2d_h3_up_pack_weights": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
-    "ds_conv2d_h3_up": (c_int, [_P, _P, _P, c_int, _P, _P, c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P]),
+    "ds_conv2d_h3_up": (c_int, [_P, _P, _P, c_int, _P, _P, c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
     "ds_table_apply_images": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P]),
-    "ds_conv2d_h3_up_img": (c_int, [_P, _P, _P, c_int, _P, _P, c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
+    "ds_conv2d_h3_up_img": (c_int, [_P, _P, _P, c_int, _P, _P, c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P]),
     "ds_conv_tile_count": (c_int, [c_int, c_int]),
-    "ds_inorm_table": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_int, _P]),
+    "ds_inorm_table": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_int, _P, _P]),
     "ds_gnorm1_table": (c_int, [_P, _P, c_int, c_int, _P, c_int, c_int, _P, _P, _P, _P, c_int, c_int, c_longlong,
-                                c_float, c_int, _P]),
+                                c_float, c_int, _P, _P]),
     "ds_gnorm1_stats_tiles": (c_int, [_P, _P, c_int, c_int, _P, c_int, c_int, c_int, c_longlong, c_float, c_int, _P]),
     "ds_conv2d_direct": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "ds_conv3d_direct": (c_int, [_P, _P, _P, _P, _P, c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
@@ -72,7 +76,7 @@ _PROTOS = {
     "ds_conv_images_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "ds_inorm_silu_images_supported": (c_int, [c_int, c_int]),
     "ds_inorm_silu_images": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_int, _P]),
-    "ds_conv2d_h3_img": (c_int, [_P, _P, _P, c_int, _P, _P, c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P]),
+    "ds_conv2d_h3_img": (c_int, [_P, _P, _P, c_int, _P, _P, c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P]),
     "ds_gnorm1_apply_images": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "ds_volume_stat_tiles": (c_int, [c_int, c_size_t]),
     "ds_volume_to_slices_act": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_size_t, _P]),
@@ -82,12 +86,12 @@ _PROTOS = {
     "ds_upsample3d": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "ds_conv1x1_h3_packed_bytes": (c_size_t, [c_int, c_int]),
     "ds_conv1x1_h3_pack_weights": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
-    "ds_conv1x1_h3": (c_int, [_P, _P, _P, c_int, _P, _P, c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P]),
+    "ds_conv1x1_h3": (c_int, [_P, _P, _P, c_int, _P, _P, c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, _P]),
     "ds_attention": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     "ds_attention_generic": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
-    "ds_attention_h3": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
+    "ds_attention_h3": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P]),
     "ds_attention_h3_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
-    "ds_attention_h3_ws": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P]),
+    "ds_attention_h3_ws": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P, _P, _P]),
     "ds_token_l2_normalize": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_float, c_float, _P]),
     "ds_linear": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "ds_fourier_features": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P]),

@@ -3,7 +3,9 @@
 //     S^T = K (Q/sqrt(E))^T          O^T += V^T P^T
 // is split into fp16 hi + lo pieces and lo*hi + hi*lo + hi*hi are accumulated in fp32 by
 // v_mfma_f32_32x32x16_f16.  Softmax statistics, the running maximum / sum and the rescaling of O
-// stay in fp32 on the accumulators.  Domain: |q|, |k|, |v| < 65504.
+// stay in fp32 on the accumulators.  Domain: |q|, |k|, |v| < 65504 and not far below 1 -- or, with in_amax [2][B] (the
+// per-sample max |q, k| and max |v| the in-projection left, ds_conv_epilogue.h), any magnitude: q and k are staged times
+// 2^kqk, v times 2^kv, S is read back times 2^-2kqk inside the softmax's FMA and O times 2^-kv with the final 1 / l.
 //
 // Layout: operands arrive channel-major ([B, 3E, L], what the 1x1 projections write) and the
 // output is channel-major ([B, E, L]).  The regrouping the MFMA wants happens while staging:
@@ -29,6 +31,7 @@
 #include <cstdlib>
 
 #include "ds_common.h"
+#include "ds_conv_epilogue.h"
 
 namespace {
 
@@ -66,7 +69,8 @@ __device__ __forceinline__ f16x8 as_f16x8(u32x4 v) { return __builtin_bit_cast(f
 
 template <int ET, bool IMG>
 __global__ __launch_bounds__(NT) void k_attn3h(float* out, const float* __restrict__ qkv, const u32x4* __restrict__ kimg,
-                                               const u32x4* __restrict__ vimg, int L, float scale, float thr) {
+                                               const u32x4* __restrict__ vimg, int L, float scale, float thr,
+                                               const unsigned* in_amax, unsigned* out_amax) {
   constexpr int E = 32 * ET;
   constexpr int NDG = E / 8;                         // d-groups of 8
   constexpr int NS = E / 16;                         // k-slabs of the S^T product
@@ -103,6 +107,12 @@ __global__ __launch_bounds__(NT) void k_attn3h(float* out, const float* __restri
   const float* Qt = qkv + (size_t)b * 3 * E * L;
   const float* Kt = Qt + (size_t)E * L;
   const float* Vt = Kt + (size_t)E * L;
+  // the sample's activation exponents (0 without in_amax): q, k times 2^ak, v times 2^av; S times 2^-2ak, O times 2^-av -- all exact
+  const int ak = ds_epi::act_exponent_of(ds_epi::act_bits(in_amax, b), -60, 60);
+  const int av = ds_epi::act_exponent_of(ds_epi::act_bits(in_amax, (int)gridDim.y + b), -120, 120);
+  const float a_in = ds_epi::pow2f(ak), v_in = ds_epi::pow2f(av);
+  const float s_log2e = ds_epi::mul_pow2(LOG2E, -2 * ak), s_un = ds_epi::pow2f(-2 * ak), o_un = ds_epi::pow2f(-av);
+  scale = ds_epi::mul_pow2(scale, ak);
 
   // ---- Q fragments: lane (query li, half lh) holds d = 16s + 8lh + 0..7, scaled, split ----
   u32x4 qh[NS], ql[NS];
@@ -161,7 +171,7 @@ __global__ __launch_bounds__(NT) void k_attn3h(float* out, const float* __restri
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           unsigned a, c;
-          split2(sr[i][2 * k], sr[i][2 * k + 1], a, c);
+          split2(sr[i][2 * k] * a_in, sr[i][2 * k + 1] * a_in, a, c);
           h[k] = a; l[k] = c;
         }
         Ks[e] = h;                         // e = dg*32 + key
@@ -190,7 +200,7 @@ __global__ __launch_bounds__(NT) void k_attn3h(float* out, const float* __restri
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           unsigned a, c;
-          split2(sr[i][2 * k], sr[i][2 * k + 1], a, c);
+          split2(sr[i][2 * k] * v_in, sr[i][2 * k + 1] * v_in, a, c);
           h[k] = a; l[k] = c;
         }
         Vs[kg * E + d] = h;
@@ -254,7 +264,7 @@ __global__ __launch_bounds__(NT) void k_attn3h(float* out, const float* __restri
       float mx = S[0];
 #pragma unroll
       for (int r = 1; r < 16; ++r) mx = fmaxf(mx, S[r]);
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * s_un;
       if (__any(mx > m_run + thr)) {
         const float m_new = fmaxf(m_run, mx);
         const float alpha = expf(m_run - m_new);
@@ -269,7 +279,7 @@ __global__ __launch_bounds__(NT) void k_attn3h(float* out, const float* __restri
       const float mneg = -m_run * LOG2E;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        S[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(S[r], LOG2E, mneg));     // e^(S - m): one FMA and the hardware exp2
+        S[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(S[r], s_log2e, mneg));   // e^(S - m): one FMA and the hardware exp2
         rs += S[r];
       }
       rs += __shfl_xor(rs, 32, 64);
@@ -364,7 +374,7 @@ __global__ __launch_bounds__(NT) void k_attn3h(float* out, const float* __restri
       float mx = S[0];
 #pragma unroll
       for (int r = 1; r < 16; ++r) mx = fmaxf(mx, S[r]);
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * s_un;
       // Deferred rescaling: O and l are kept relative to a reference maximum m_run that only moves
       // when some query's block maximum exceeds it by more than RESCALE_T (so P <= e^RESCALE_T,
       // far inside fp16's range for the hi piece).  The O-wide multiply then sits in a rarely
@@ -383,7 +393,7 @@ __global__ __launch_bounds__(NT) void k_attn3h(float* out, const float* __restri
       const float mneg = -m_run * LOG2E;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        S[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(S[r], LOG2E, mneg));     // e^(S - m): one FMA and the hardware exp2
+        S[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(S[r], s_log2e, mneg));   // e^(S - m): one FMA and the hardware exp2
         rs += S[r];
       }
       rs += __shfl_xor(rs, 32, 64);
@@ -425,17 +435,21 @@ __global__ __launch_bounds__(NT) void k_attn3h(float* out, const float* __restri
     __syncthreads();                                            // ... and so have everyone's
   }
   }   // staging form
+  float amax = 0.f;
   if (active) {
-    const float inv = 1.0f / l_run;
+    const float inv = (1.0f / l_run) * o_un;
     float* ob = out + (size_t)b * E * L;
 #pragma unroll
     for (int t = 0; t < ET; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int d = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        ob[(size_t)d * L + q0 + li] = O[t][r] * inv;
+        const float o = O[t][r] * inv;
+        ob[(size_t)d * L + q0 + li] = o;
+        amax = fmaxf(amax, __builtin_fabsf(o));
       }
   }
+  if (out_amax) ds_epi::commit_amax(out_amax + b, amax);
 }
 
 // Pre-pass of the IMG form: one workgroup per (key tile, sample) writes the tile's K and V images
@@ -443,10 +457,12 @@ __global__ __launch_bounds__(NT) void k_attn3h(float* out, const float* __restri
 // with the split every attention workgroup would otherwise redo.  Reads K, V once (8 B/elt), writes as many bytes.
 template <int ET>
 __global__ __launch_bounds__(NT) void k_attn_images(u32x4* __restrict__ kimg, u32x4* __restrict__ vimg,
-                                                   const float* __restrict__ qkv, int L) {
+                                                   const float* __restrict__ qkv, int L, const unsigned* in_amax) {
   constexpr int E = 32 * ET, NDG = E / 8;
   constexpr int KITEMS = NDG * KB, VITEMS = E * 4;
   const int tid = threadIdx.x, kb = blockIdx.x, b = blockIdx.y, nkb = L / KB;
+  const float a_in = ds_epi::pow2f(ds_epi::act_exponent_of(ds_epi::act_bits(in_amax, b), -60, 60));       // the attention kernel's exponents
+  const float v_in = ds_epi::pow2f(ds_epi::act_exponent_of(ds_epi::act_bits(in_amax, (int)gridDim.y + b), -120, 120));
   const float* Kt = qkv + ((size_t)b * 3 + 1) * E * L + (size_t)kb * KB;
   const float* Vt = Kt + (size_t)E * L;
   u32x4* Kd = kimg + ((size_t)b * nkb + kb) * (2 * KITEMS);
@@ -457,7 +473,7 @@ __global__ __launch_bounds__(NT) void k_attn_images(u32x4* __restrict__ kimg, u3
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       unsigned a, c;
-      split2(Kt[(size_t)(8 * dg + 2 * k) * L + key], Kt[(size_t)(8 * dg + 2 * k + 1) * L + key], a, c);
+      split2(Kt[(size_t)(8 * dg + 2 * k) * L + key] * a_in, Kt[(size_t)(8 * dg + 2 * k + 1) * L + key] * a_in, a, c);
       h[k] = a; l[k] = c;
     }
     Kd[e] = h;
@@ -466,7 +482,7 @@ __global__ __launch_bounds__(NT) void k_attn_images(u32x4* __restrict__ kimg, u3
   for (int e = tid; e < VITEMS; e += NT) {
     const int d = e >> 2, kg = e & 3;
     const float* p = Vt + (size_t)d * L + 8 * kg;
-    const f32x4 v0 = *reinterpret_cast<const f32x4*>(p), v1 = *reinterpret_cast<const f32x4*>(p + 4);
+    const f32x4 v0 = *reinterpret_cast<const f32x4*>(p) * v_in, v1 = *reinterpret_cast<const f32x4*>(p + 4) * v_in;
     u32x4 h, l;
     unsigned a, c;
     split2(v0[0], v0[1], a, c); h[0] = a; l[0] = c;
@@ -479,7 +495,8 @@ __global__ __launch_bounds__(NT) void k_attn_images(u32x4* __restrict__ kimg, u3
 }
 
 template <int ET, bool IMG>
-int launch_attn3h(float* out, const float* qkv, void* workspace, int B, int L, float scale, hipStream_t s) {
+int launch_attn3h(float* out, const float* qkv, void* workspace, int B, int L, float scale, const unsigned* in_amax,
+                  unsigned* out_amax, hipStream_t s) {
   constexpr int E = 32 * ET;
   const size_t lds = (size_t)2 * (2 * (E / 8) * KB + 2 * 4 * E) * 16;    // K and V, double-buffered
   if (lds > 48 * 1024) {
@@ -491,18 +508,19 @@ int launch_attn3h(float* out, const float* qkv, void* workspace, int B, int L, f
   if (IMG) {
     kimg = reinterpret_cast<u32x4*>(workspace);
     vimg = kimg + (size_t)B * L * (E / 4);                                // K images: B * (L/32) tiles * 8E vectors
-    hipLaunchKernelGGL((k_attn_images<ET>), dim3(L / KB, B), dim3(NT), 0, s, kimg, vimg, qkv, L);
+    hipLaunchKernelGGL((k_attn_images<ET>), dim3(L / KB, B), dim3(NT), 0, s, kimg, vimg, qkv, L, in_amax);
     DS_CHECK_LAUNCH("ds_attention_h3 (images)");
   }
   dim3 g((L + 127) / 128, B);
   static const float thr = [] { const char* e = getenv("DS_ATTN_T"); return e ? (float)atof(e) : RESCALE_T; }();   // diagnostic knob
-  hipLaunchKernelGGL((k_attn3h<ET, IMG>), g, dim3(NT), lds, s, out, qkv, kimg, vimg, L, scale, thr);
+  hipLaunchKernelGGL((k_attn3h<ET, IMG>), g, dim3(NT), lds, s, out, qkv, kimg, vimg, L, scale, thr, in_amax, out_amax);
   DS_CHECK_LAUNCH("ds_attention_h3");
   return DS_OK;
 }
 
 template <bool IMG>
-int attention_h3(float* out, const float* qkv, void* workspace, int B, int E, int L, void* stream) {
+int attention_h3(float* out, const float* qkv, void* workspace, int B, int E, int L, const unsigned* in_amax, unsigned* out_amax,
+                 void* stream) {
   DS_REQUIRE(out && qkv, DS_ERR_NULL, "ds_attention_h3: NULL pointer");
   DS_REQUIRE(B >= 0 && E > 0 && L > 0, DS_ERR_SHAPE, "ds_attention_h3: bad shape B=%d E=%d L=%d", B, E, L);
   DS_REQUIRE(L % 32 == 0, DS_ERR_UNSUPPORTED, "ds_attention_h3: L=%d must be a multiple of 32", L);
@@ -514,10 +532,10 @@ int attention_h3(float* out, const float* qkv, void* workspace, int B, int E, in
   const float scale = (float)sqrt(1.0 / (double)E);
   hipStream_t s = ds::as_stream(stream);
   switch (E) {
-    case 32: return launch_attn3h<1, IMG>(out, qkv, workspace, B, L, scale, s);
-    case 64: return launch_attn3h<2, IMG>(out, qkv, workspace, B, L, scale, s);
-    case 128: return launch_attn3h<4, IMG>(out, qkv, workspace, B, L, scale, s);
-    case 256: return launch_attn3h<8, IMG>(out, qkv, workspace, B, L, scale, s);
+    case 32: return launch_attn3h<1, IMG>(out, qkv, workspace, B, L, scale, in_amax, out_amax, s);
+    case 64: return launch_attn3h<2, IMG>(out, qkv, workspace, B, L, scale, in_amax, out_amax, s);
+    case 128: return launch_attn3h<4, IMG>(out, qkv, workspace, B, L, scale, in_amax, out_amax, s);
+    case 256: return launch_attn3h<8, IMG>(out, qkv, workspace, B, L, scale, in_amax, out_amax, s);
     default:
       ds::set_error("ds_attention_h3: E=%d unsupported (32, 64, 128, 256)", E);
       return DS_ERR_UNSUPPORTED;
@@ -526,8 +544,9 @@ int attention_h3(float* out, const float* qkv, void* workspace, int B, int E, in
 
 }  // namespace
 
-extern "C" int ds_attention_h3(float* out, const float* qkv, int B, int E, int L, void* stream) {
-  return attention_h3<false>(out, qkv, nullptr, B, E, L, stream);
+extern "C" int ds_attention_h3(float* out, const float* qkv, int B, int E, int L, const unsigned* in_amax, unsigned* out_amax,
+                               void* stream) {
+  return attention_h3<false>(out, qkv, nullptr, B, E, L, in_amax, out_amax, stream);
 }
 
 extern "C" size_t ds_attention_h3_workspace_bytes(int B, int E, int L) {
@@ -535,6 +554,7 @@ extern "C" size_t ds_attention_h3_workspace_bytes(int B, int E, int L) {
   return (size_t)B * L * E * 8;                      // K and V images: 2 pieces x 2 bytes per element, each
 }
 
-extern "C" int ds_attention_h3_ws(float* out, const float* qkv, void* workspace, int B, int E, int L, void* stream) {
-  return attention_h3<true>(out, qkv, workspace, B, E, L, stream);
+extern "C" int ds_attention_h3_ws(float* out, const float* qkv, void* workspace, int B, int E, int L, const unsigned* in_amax,
+                                  unsigned* out_amax, void* stream) {
+  return attention_h3<true>(out, qkv, workspace, B, E, L, in_amax, out_amax, stream);
 }

@@ -47,7 +47,10 @@ struct Conv1hArgs {
   const float* res2;
   float* tile_stats;      // see ds_conv_epilogue.h, or NULL
   int res1_up;
-  float unscale;
+  const unsigned* in_amax;   // per-sample max |input| (float bits) -> activation exponent (ds_conv_epilogue.h), or NULL
+  unsigned* out_amax;        // per-sample max |output| slots, or NULL
+  int wshift;
+  int amax_split;            // channels >= amax_split (> 0) report to out_amax[B + b]
   int shift_stride;
   int B, Cin, Cout, H, W, Hin, Win;
   int tiles_x, tiles_y, n_cot, n_chunks;
@@ -113,6 +116,7 @@ __global__ __launch_bounds__(NT, 2) void k_conv1h(const Conv1hArgs a) {
   const unsigned offb = off * 4u, rowb = (unsigned)a.Win * 4u;        // BYTE offsets: a plane is < 2^29 floats (host check)
   const float* in_b = a.in + (size_t)b * a.Cin * HWin;                // uniform: loads are s[base] + v offset
   const u32x4* wp = a.wp + (size_t)cot * n * WSLAB_VEC;
+  ds_epi::ActScale ascale;
 
   auto x_fetch = [&](float (&R)[KC], int chunk) {
     const int cbase = chunk * KC;
@@ -142,7 +146,7 @@ __global__ __launch_bounds__(NT, 2) void k_conv1h(const Conv1hArgs a) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         unsigned ph, pl;
-        split2(R[8 * h + 2 * k], R[8 * h + 2 * k + 1], ph, pl);
+        split2(R[8 * h + 2 * k] * ascale.in_scale, R[8 * h + 2 * k + 1] * ascale.in_scale, ph, pl);   // exact (power of two)
         qh[k] = ph; ql[k] = pl;
       }
       xb[h * NPOS + tid] = qh;
@@ -188,10 +192,14 @@ __global__ __launch_bounds__(NT, 2) void k_conv1h(const Conv1hArgs a) {
   float R0[KC], R1[KC];
   u32x4 W0, W1;
   const float bias_shift = ds_epi::fetch_bias_shift(a.bias, a.shift, a.shift_stride, b, cot * COT, a.Cout);
+  __builtin_amdgcn_sched_barrier(0);
+  const unsigned amax_bits = ds_epi::act_bits(a.in_amax, b);   // every input of this kernel is a raw tensor; consumed behind the first loads
   w_fetch(W0, 0);
   x_fetch(R0, 0);
   w_fetch(W1, n > 1 ? 1 : 0);
   x_fetch(R1, n > 1 ? 1 : 0);
+  __builtin_amdgcn_sched_barrier(0);
+  ascale = ds_epi::act_scale_of(amax_bits, a.wshift);
   w_store(W0, 0);
   x_store(R0, 0);
   ds_epi::commit_bias_shift(BS, bias_shift);
@@ -223,7 +231,8 @@ __global__ __launch_bounds__(NT, 2) void k_conv1h(const Conv1hArgs a) {
   {
     ds_epi::Args e;
     e.out = a.out; e.bias = a.bias; e.shift = a.shift; e.res1 = a.res1; e.res2 = a.res2; e.res1_up = a.res1_up;
-    e.unscale = a.unscale; e.shift_stride = a.shift_stride;
+    e.unscale = ds_epi::unscale_from_in(ascale.in_scale, a.wshift); e.shift_stride = a.shift_stride;
+    e.out_amax = a.out_amax ? a.out_amax + b + ((a.amax_split > 0 && cot * COT >= a.amax_split) ? a.B : 0) : nullptr;
     e.b = b; e.co_base = cot * COT; e.y0 = y0 + (W16 ? 4 : 2) * wv; e.x0 = x0;
     e.Cout = a.Cout; e.H = a.H; e.W = a.W;
     e.tile_stats = a.tile_stats; e.tile = ty * a.tiles_x + tx; e.ntiles = a.tiles_x * a.tiles_y;
@@ -291,7 +300,7 @@ int ds_conv1x1_h3_pack_weights(void* packed, const float* w, int Cout, int Cin, 
 
 int ds_conv1x1_h3(float* out, const float* in, const void* w_packed, int wshift, const float* bias, const float* shift,
                   int shift_stride, const float* res1, const float* res2, int B, int Cin, int Cout, int H, int W,
-                  int load_mode, float* tile_stats, void* stream) {
+                  int load_mode, float* tile_stats, const unsigned* in_amax, unsigned* out_amax, int amax_split, void* stream) {
   DS_REQUIRE(out && in && w_packed, DS_ERR_NULL, "ds_conv1x1_h3: NULL pointer");
   DS_REQUIRE(B >= 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, DS_ERR_SHAPE,
              "ds_conv1x1_h3: bad shape B=%d Cin=%d Cout=%d H=%d W=%d", B, Cin, Cout, H, W);
@@ -305,11 +314,12 @@ int ds_conv1x1_h3(float* out, const float* in, const void* w_packed, int wshift,
   DS_REQUIRE(load_mode != DS_LOAD_AVGPOOL2 || (reinterpret_cast<uintptr_t>(in) & 7u) == 0, DS_ERR_SHAPE,
              "ds_conv1x1_h3: AVGPOOL2 input must be 8-byte aligned");
   DS_REQUIRE(wshift >= -40 && wshift <= 40, DS_ERR_SHAPE, "ds_conv1x1_h3: wshift %d out of range", wshift);
+  DS_REQUIRE(amax_split >= 0 && amax_split % COT == 0, DS_ERR_SHAPE, "ds_conv1x1_h3: amax_split %d must be a multiple of 64", amax_split);
   if (B == 0) return DS_OK;
   Conv1hArgs a;
   a.out = out; a.in = in; a.wp = reinterpret_cast<const u32x4*>(w_packed); a.bias = bias; a.shift = shift;
   a.res1 = res1; a.res2 = res2; a.shift_stride = shift_stride; a.tile_stats = tile_stats; a.res1_up = 0;
-  a.unscale = ldexpf(1.0f, -wshift);
+  a.wshift = wshift; a.in_amax = in_amax; a.out_amax = out_amax; a.amax_split = amax_split;
   a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W;
   a.Hin = load_mode == DS_LOAD_AVGPOOL2 ? 2 * H : (load_mode == DS_LOAD_UPSAMPLE2 ? H / 2 : H);
   a.Win = load_mode == DS_LOAD_AVGPOOL2 ? 2 * W : (load_mode == DS_LOAD_UPSAMPLE2 ? W / 2 : W);

@@ -86,7 +86,9 @@ struct Conv3hArgs {
   const float* res2;
   const float* prenorm;   // [B][ceil16(Cin)][4] = (M, A, C, -), zero rows past Cin, or NULL: the loader applies SiLU((x - M)*A + C)
   float* tile_stats;      // see ds_conv_epilogue.h, or NULL
-  float unscale;        // 2^-wshift
+  const unsigned* in_amax;   // per-sample max |input| (float bits) -> the loader's activation exponent (ds_conv_epilogue.h), or NULL
+  unsigned* out_amax;        // per-sample max |output| slots, merged with atomicMax, or NULL
+  int wshift;                // the packed weights carry 2^wshift
   int shift_stride;
   int res1_up;            // res1 is at half resolution (see ds_conv_epilogue.h)
   int circular;           // periodic padding in both dimensions (CircularConv2d, commonlayers.py:918-971)
@@ -225,6 +227,9 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_conv3h(const Conv3hArgs a) 
   }
   const float* in_b = a.in + (size_t)b * a.Cin * HWin;
   const u32x4* wp = a.wp + (size_t)cot * n_steps * WSLAB_VEC;
+  // the sample's power-of-two activation scale, undone in the epilogue: a raw input is multiplied by it, the fused
+  // norm + SiLU loader produces its activation times it.  The load is issued here and consumed behind the first patch's loads.
+  ds_epi::ActScale ascale;
 
   float xr[XI][8];
   int xnch = KC;
@@ -269,7 +274,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_conv3h(const Conv3hArgs a) 
 #pragma unroll
     for (int k = 0; k < 8; ++k) p[k] = pp[8 * h + k];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) xr[i][k] = fast_silu((xr[i][k] - p[k][0]) * p[k][1] + p[k][2]);
+    for (int k = 0; k < 8; ++k) xr[i][k] = ds_h3::fast_silu_scaled((xr[i][k] - p[k][0]) * p[k][1] + p[k][2], ascale.inv_scale);
   };
   auto x_store = [&](int buf) __attribute__((always_inline)) {                       // [normalise + SiLU,] split to fp16 pieces, write the LDS image
     u32x4* xb = Xs + buf * XBV;
@@ -285,8 +290,9 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_conv3h(const Conv3hArgs a) 
         u32x4 qh, ql;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          const float v0 = (item_ok && 8 * h + 2 * k < xnch) ? xr[i][2 * k] : 0.f;
-          const float v1 = (item_ok && 8 * h + 2 * k + 1 < xnch) ? xr[i][2 * k + 1] : 0.f;
+          float v0 = (item_ok && 8 * h + 2 * k < xnch) ? xr[i][2 * k] : 0.f;
+          float v1 = (item_ok && 8 * h + 2 * k + 1 < xnch) ? xr[i][2 * k + 1] : 0.f;
+          if constexpr (!PRE) { v0 *= ascale.in_scale; v1 *= ascale.in_scale; }   // exact (power of two)
           unsigned ph, pl;
           split2(v0, v1, ph, pl);
           qh[k] = ph; ql[k] = pl;
@@ -395,12 +401,17 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_conv3h(const Conv3hArgs a) 
   };
 
   // ---- prologue: patch 0, weight slabs 0 and 1 ----
+  // (scalar loads share one counter: issued any earlier, the first wait for a kernel argument would wait for this load too)
+  __builtin_amdgcn_sched_barrier(0);
+  const unsigned amax_bits = ds_epi::act_bits(IMGIN ? nullptr : a.in_amax, b);
   if constexpr (IMGIN) x_dma(0, 0); else
   x_fetch(0);
   const float bias_shift = ds_epi::fetch_bias_shift(a.bias, a.shift, a.shift_stride, b, cot * COT, a.Cout);
   w_fetch(0, 0);
   if (n_steps > 1) w_fetch(1, 1);
   STAMP(1);
+  __builtin_amdgcn_sched_barrier(0);
+  ascale = ds_epi::act_scale_of(amax_bits, a.wshift);
   if constexpr (!IMGIN) x_store(0);
   ds_epi::commit_bias_shift(BS, bias_shift);
   __syncthreads();
@@ -541,7 +552,9 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_conv3h(const Conv3hArgs a) 
   {
     ds_epi::Args e;
     e.out = a.out; e.bias = a.bias; e.shift = a.shift; e.res1 = a.res1; e.res2 = a.res2; e.res1_up = a.res1_up;
-    e.unscale = a.unscale; e.shift_stride = a.shift_stride;
+    e.unscale = PRE ? ds_epi::unscale_from_inv(ascale.inv_scale, a.wshift) : ds_epi::unscale_from_in(ascale.in_scale, a.wshift);
+    e.shift_stride = a.shift_stride;
+    e.out_amax = a.out_amax ? a.out_amax + b : nullptr;
     e.b = b; e.co_base = cot * COT + 32 * mh; e.y0 = y0 + wave_row; e.x0 = x0;
     e.Cout = a.Cout; e.H = a.H; e.W = a.W;
     e.tile_stats = a.tile_stats; e.tile = ty * a.tiles_x + tx; e.ntiles = a.tiles_x * a.tiles_y;
@@ -635,7 +648,9 @@ int launch_conv3h_c(const Conv3hArgs& a, hipStream_t s) {
     }
     return launch_conv3h_w<MODE, W16, PRE, CIRC, 4, true>(a, s);
   }
-  return conv3h_waves(PRE) == 8 ? launch_conv3h_w<MODE, W16, PRE, CIRC, 8>(a, s) : launch_conv3h_w<MODE, W16, PRE, CIRC, 4>(a, s);
+  // the eight-wave max-pool loader would spill (180 B/lane of scratch at 128 VGPRs: four loads per element in flight): four waves
+  if constexpr (MODE == DS_LOAD_MAXPOOL2) return launch_conv3h_w<MODE, W16, PRE, CIRC, 4>(a, s);
+  else return conv3h_waves(PRE) == 8 ? launch_conv3h_w<MODE, W16, PRE, CIRC, 8>(a, s) : launch_conv3h_w<MODE, W16, PRE, CIRC, 4>(a, s);
 }
 
 template <int MODE, bool W16, bool PRE>
@@ -667,7 +682,8 @@ int ds_conv2d_h3_pack_weights(void* packed, const float* w, int Cout, int Cin, i
 
 int ds_conv2d_h3(float* out, const float* in, const void* w_packed, int wshift, const float* bias, const float* shift,
                  int shift_stride, const float* res1, const float* res2, int B, int Cin, int Cout, int H, int W,
-                 int load_mode, const float* prenorm, float* tile_stats, void* stream) {
+                 int load_mode, const float* prenorm, float* tile_stats, const unsigned* in_amax, unsigned* out_amax,
+                 void* stream) {
   DS_REQUIRE(out && in && w_packed, DS_ERR_NULL, "ds_conv2d_h3: NULL pointer");
   DS_REQUIRE(B >= 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, DS_ERR_SHAPE,
              "ds_conv2d_h3: bad shape B=%d Cin=%d Cout=%d H=%d W=%d", B, Cin, Cout, H, W);
@@ -696,7 +712,7 @@ int ds_conv2d_h3(float* out, const float* in, const void* w_packed, int wshift, 
   a.prenorm = prenorm; a.tile_stats = tile_stats; a.circular = circular; a.res1_up = res1_up; a.oy = oy; a.ox = ox;
   a.out = out; a.in = in; a.wp = reinterpret_cast<const u32x4*>(w_packed); a.bias = bias; a.shift = shift;
   a.res1 = res1; a.res2 = res2; a.shift_stride = shift_stride;
-  a.unscale = ldexpf(1.0f, -wshift);
+  a.wshift = wshift; a.in_amax = in_amax; a.out_amax = out_amax;
   a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W;
   a.Hin = load_mode == DS_LOAD_MAXPOOL2 ? 2 * H : (load_mode == DS_LOAD_UPSAMPLE2 ? H / 2 : H);
   a.Win = load_mode == DS_LOAD_MAXPOOL2 ? 2 * W : (load_mode == DS_LOAD_UPSAMPLE2 ? W / 2 : W);
@@ -744,7 +760,7 @@ size_t ds_conv_images_bytes(int B, int C, int H, int W) {
 
 int ds_conv2d_h3_img(float* out, const void* images, const void* w_packed, int wshift, const float* bias, const float* shift,
                      int shift_stride, const float* res1, const float* res2, int B, int Cin, int Cout, int H, int W,
-                     int flags, float* tile_stats, void* stream) {
+                     int flags, float* tile_stats, unsigned* out_amax, void* stream) {
   DS_REQUIRE(out && images && w_packed, DS_ERR_NULL, "ds_conv2d_h3_img: NULL pointer");
   DS_REQUIRE((flags & ~DS_RES1_UPSAMPLED) == 0, DS_ERR_UNSUPPORTED, "ds_conv2d_h3_img: flags %d (DS_RES1_UPSAMPLED only)", flags);
   DS_REQUIRE(!(flags & DS_RES1_UPSAMPLED) || (res1 && H % 2 == 0 && W % 2 == 0 && (reinterpret_cast<uintptr_t>(res1) & 7u) == 0),
@@ -765,7 +781,7 @@ int ds_conv2d_h3_img(float* out, const void* images, const void* w_packed, int w
   a.out = out; a.in = reinterpret_cast<const float*>(images); a.wp = reinterpret_cast<const u32x4*>(w_packed);
   a.bias = bias; a.shift = shift; a.res1 = res1; a.res2 = res2; a.shift_stride = shift_stride; a.tile_stats = tile_stats;
   a.res1_up = (flags & DS_RES1_UPSAMPLED) ? 1 : 0;
-  a.unscale = ldexpf(1.0f, -wshift);
+  a.wshift = wshift; a.out_amax = out_amax;
   a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.Hin = H; a.Win = W;
   const long long pad32 = (long long)((W + 31) / 32 * 32) * ((H + 7) / 8 * 8);
   const long long pad16 = (long long)((W + 15) / 16 * 16) * ((H + 15) / 16 * 16);

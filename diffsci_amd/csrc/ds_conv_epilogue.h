@@ -6,6 +6,10 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#ifndef DS_AMAX_EPILOGUE
+#define DS_AMAX_EPILOGUE 1      // 0: measurement builds only (tools/ab_bench.sh): what does the out_amax code cost the launches that do not use it?
+#endif
+
 namespace ds_epi {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -32,7 +36,78 @@ struct Args {
   // ds_convup.hip only: the tile is in LOW-resolution coordinates (y0, x0; H, W are the output's) and covers output
   // rows 2y + pa
   int pa, pb;
+  // Optional: max |stored value| of sample b, as float bits, merged with atomicMax into *out_amax (the slot of THIS
+  // sample; zeroed by the host before the launch).  The fp16x3 kernel that consumes the tensor takes its per-sample
+  // activation exponent from it (act_scale below) instead of a reduction pass over the tensor.
+  unsigned* out_amax;
 };
+
+// ---- per-sample activation exponent of the fp16x3 kernels --------------------------------------------------------
+// x = hi + lo in fp16 keeps 22 significand bits only while lo is a normal fp16 number, i.e. for |x| in [2^-3, 2^16):
+// fp16 has 5 exponent bits where the reference's fp32 convolution (punetg.py:719-735 feeds raw user fields,
+// preconditioners.py:139-161 c_in = 1) has 8.  A launch whose input is not normalised by construction therefore
+// multiplies its input by 2^k in the loader, k chosen per SAMPLE so that the sample's max |x| lands in [2^13, 2^14),
+// and undoes it exactly in the epilogue next to the weight scale: 2^-(wshift + k).  A block floating point with the
+// sample's exponent: elements down to 2^-19 of the sample's maximum keep >= 20 bits, the absolute floor is 2^-39 of
+// the maximum, the whole fp32 range of magnitudes is accepted (no overflow either).  Per sample, so a sample's result
+// does not depend on what else is in the batch.
+struct ActScale {
+  float in_scale;     // 2^k
+  float unscale;      // 2^-(wshift + k)
+  float inv_scale;    // 2^-k: the fused norm + SiLU loader forms SiLU(v) * 2^k = v * rcp(2^-k (1 + exp2(-v log2 e))) (ds_h3_common.h)
+};
+// amax: per-sample max |x| as float bits (written by an earlier kernel), or NULL = no scaling (normalised input).
+// Two stages, so that the load's round trip hides behind the kernel's first global loads: act_bits() ISSUES it right in front
+// of them, act_scale_of() / act_exponent_of() consume it behind them.  A VECTOR load on purpose (the lane offset below is zero,
+// but opaque to the compiler): scalar loads share one counter with the kernel-argument loads and return out of order, so the first
+// wait for any kernel argument also waited for this L2 round trip in front of every workgroup's first loads (+2.4 % on the
+// level-0 launches); vector loads return in order and are waited for one by one -- this one has landed when the first patch
+// element has.
+__device__ __forceinline__ unsigned act_bits(const unsigned* amax, int b) {
+  if (!amax) return 0u;
+  int z = 0;
+  asm volatile("" : "+v"(z));
+  return amax[b + z];
+}
+// The exponent k with max * 2^k in [2^13, 2^14), clamped to [lo, hi]; 0 for a zero / subnormal / non-finite maximum.
+__device__ __forceinline__ int act_exponent_of(unsigned bits, int lo, int hi) {
+  bits = __builtin_amdgcn_readfirstlane(bits);
+  const int e = (int)((bits >> 23) & 0xffu);
+  const int k = (e == 0 || e == 255) ? 0 : 140 - e;
+  return k > hi ? hi : (k < lo ? lo : k);
+}
+__device__ __forceinline__ float pow2f(int k) { return __builtin_bit_cast(float, (unsigned)(127 + k) << 23); }   // -126 <= k <= 127
+// x * 2^k by exponent arithmetic (x and the product normal floats): integer instructions, so a wave-uniform x stays in a
+// scalar register (gfx950 has no scalar float multiply)
+__device__ __forceinline__ float mul_pow2(float x, int k) { return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, x) + ((unsigned)k << 23)); }
+// 2^-(wshift + k) from in_scale = 2^k or inv_scale = 2^-k (exponent arithmetic): lets the kernels carry ONE scalar through their
+// main loop and rebuild the epilogue's factor from it
+__device__ __forceinline__ float unscale_from_in(float in_scale, int wshift) {
+  return __builtin_bit_cast(float, ((unsigned)(254 - wshift) << 23) - __builtin_bit_cast(unsigned, in_scale));
+}
+__device__ __forceinline__ float unscale_from_inv(float inv_scale, int wshift) {
+  return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, inv_scale) - ((unsigned)wshift << 23));
+}
+__device__ __forceinline__ ActScale act_scale_of(unsigned bits, int wshift) {
+  // 2^k and 2^-(wshift + k) both stay normal floats
+  const int hi = 126 - wshift < 126 ? 126 - wshift : 126, lo = -126 - wshift > -126 ? -126 - wshift : -126;
+  const int k = act_exponent_of(bits, lo, hi);
+  ActScale s;
+  s.in_scale = __builtin_bit_cast(float, (unsigned)(127 + k) << 23);
+  s.unscale = __builtin_bit_cast(float, (unsigned)(127 - wshift - k) << 23);
+  s.inv_scale = __builtin_bit_cast(float, (unsigned)(127 - k) << 23);
+  return s;
+}
+
+// wave-wide maximum of non-negative values, merged into the sample's slot
+__device__ __forceinline__ void commit_amax(unsigned* slot, float m) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0) atomicMax(slot, __builtin_bit_cast(unsigned, m));
+}
+__device__ __forceinline__ float abs_max4(f32x4 v) {
+  return fmaxf(fmaxf(__builtin_fabsf(v.x), __builtin_fabsf(v.y)), fmaxf(__builtin_fabsf(v.z), __builtin_fabsf(v.w)));
+}
 
 // sum over the 8 lanes of an aligned lane octet, then over the pair of octets of a 16-lane row
 __device__ __forceinline__ float row16_sum(float v) {
@@ -163,6 +238,8 @@ __device__ __forceinline__ void store_tile_rows(float* tile, const Args& e, cons
     const bool pix_ok = rp.pix_ok;
     const size_t idx_lane = rp.idx_lane, idx_step = rp.idx_step;
     const float cnt_row = stats ? row16_sum(pix_ok ? 4.f : 0.f) : 0.f;     // valid pixels of a channel in this wave: the same for every channel
+    const bool want_amax = DS_AMAX_EPILOGUE && e.out_amax != nullptr;
+    float amax = 0.f;
     float sK[8 * MT], ssum[8 * MT], ssq[8 * MT], scnt[8 * MT];   // per (half, k): channel 4*(4*half+k) + lane/16, valid in every lane of the row
 #pragma unroll
     for (int half = 0; half < 2 * MT; ++half) {       // batches of 4 wave-instructions
@@ -226,6 +303,10 @@ __device__ __forceinline__ void store_tile_rows(float* tile, const Args& e, cons
 #pragma unroll
       for (int k = 0; k < 4; ++k)
         if (ok[k]) *reinterpret_cast<f32x4*>(e.out + idx[k]) = v[k];
+      if (want_amax) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) amax = ok[k] ? fmaxf(amax, abs_max4(v[k])) : amax;
+      }
       if (stats) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -242,6 +323,7 @@ __device__ __forceinline__ void store_tile_rows(float* tile, const Args& e, cons
         }
       }
     }
+    if (want_amax) commit_amax(e.out_amax, amax);
     if (stats) {                                      // all reads of the wave's tile are done: reuse its head as [32*MT co][4]
       if ((lane & 15) == 0) {
 #pragma unroll
@@ -253,6 +335,7 @@ __device__ __forceinline__ void store_tile_rows(float* tile, const Args& e, cons
     }
   } else {
     // ragged width: element-wise, compact loop (correctness path for odd shapes); one channel per iteration
+    float amax = 0.f;
     for (int i = lane; i < 32 * MT * 2 * 32; i += 64) {
       const int co = i >> 6, r = (i >> 5) & 1, x = i & 31;
       const int gy = e.y0 + (W16 ? 2 * r + (x >> 4) : r), gxx = e.x0 + (W16 ? (x & 15) : x);
@@ -265,6 +348,7 @@ __device__ __forceinline__ void store_tile_rows(float* tile, const Args& e, cons
                                        : e.res1[idx]);
         if (e.res2) v = v + e.res2[idx];
         e.out[idx] = v;
+        amax = fmaxf(amax, __builtin_fabsf(v));
       }
       if (stats) {
         const float K = __shfl(v, 0, 64);                              // the wave's first pixel of the channel
@@ -277,6 +361,7 @@ __device__ __forceinline__ void store_tile_rows(float* tile, const Args& e, cons
         if (lane == 0) { tile[4 * co] = K; tile[4 * co + 1] = sv; tile[4 * co + 2] = qv; tile[4 * co + 3] = nv; }
       }
     }
+    if (DS_AMAX_EPILOGUE && e.out_amax) commit_amax(e.out_amax, amax);
   }
 }
 

@@ -67,7 +67,9 @@ struct UpArgs {
   const float* res2;
   const float* prenorm;   // as ds_conv2d_h3, over the LOW-resolution input
   float* tile_stats;
-  float unscale;
+  const unsigned* in_amax;   // per-sample max |input| (float bits) -> activation exponent (ds_conv_epilogue.h), or NULL
+  unsigned* out_amax;        // per-sample max |output| slots, or NULL
+  int wshift;
   int shift_stride;
   int res1_up;
   int B, Cin, Cout, Hl, Wl;
@@ -142,6 +144,7 @@ __device__ __forceinline__ void store_half_rows(int m, const float* tile, float*
   const int yq = W16 ? (p4 >> 5) : 0;
   const size_t plane = (size_t)e.H * e.W;
   const bool stats = e.tile_stats != nullptr;
+  float amax = 0.f;
 #pragma unroll
   for (int it = 0; it < 16; ++it) {
     const int seg = it * 4 + (lane >> 4);
@@ -163,6 +166,7 @@ __device__ __forceinline__ void store_half_rows(int m, const float* tile, float*
     }
     if (e.res2) v = v + *reinterpret_cast<const f32x4*>(e.res2 + idx);
     if (ok) *reinterpret_cast<f32x4*>(e.out + idx) = v;
+    if (e.out_amax) amax = ok ? fmaxf(amax, ds_epi::abs_max4(v)) : amax;
     if (stats) {
       // lanes 0-15 / 16-31 of a 32-lane half hold rows r = 0 / 1 of one channel; the shift K is the channel's first value
       const float K = __shfl(ok ? v.x : 0.f, lane & 32, 64);
@@ -179,6 +183,7 @@ __device__ __forceinline__ void store_half_rows(int m, const float* tile, float*
       }
     }
   }
+  if (e.out_amax) ds_epi::commit_amax(e.out_amax, amax);
 }
 
 // IMGIN: the low-resolution input arrives as pre-split fp16 hi / lo images (ds_gnorm1_apply_images / ds_inorm_silu_images:
@@ -253,6 +258,7 @@ __global__ __launch_bounds__(NT, 2) void k_convup(const UpArgs a) {
   }
   const float* in_b = a.in + (size_t)b * a.Cin * HW;
   const u32x4* wp = a.wp + (size_t)(cot * 2 + pa) * n_steps * WSLAB_VEC;
+  ds_epi::ActScale ascale;
 
   float xr[XI][8];
   int xnch = KC;
@@ -282,7 +288,7 @@ __global__ __launch_bounds__(NT, 2) void k_convup(const UpArgs a) {
 #pragma unroll
     for (int k = 0; k < 8; ++k) p[k] = pp[8 * h + k];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) xr[i][k] = fast_silu((xr[i][k] - p[k][0]) * p[k][1] + p[k][2]);
+    for (int k = 0; k < 8; ++k) xr[i][k] = ds_h3::fast_silu_scaled((xr[i][k] - p[k][0]) * p[k][1] + p[k][2], ascale.inv_scale);
   };
   auto x_store = [&](int buf) __attribute__((always_inline)) {
     u32x4* xb = Xs + buf * XBV;
@@ -295,8 +301,9 @@ __global__ __launch_bounds__(NT, 2) void k_convup(const UpArgs a) {
         u32x4 qh, ql;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          const float v0 = (item_ok && 8 * h + 2 * k < xnch) ? xr[i][2 * k] : 0.f;
-          const float v1 = (item_ok && 8 * h + 2 * k + 1 < xnch) ? xr[i][2 * k + 1] : 0.f;
+          float v0 = (item_ok && 8 * h + 2 * k < xnch) ? xr[i][2 * k] : 0.f;
+          float v1 = (item_ok && 8 * h + 2 * k + 1 < xnch) ? xr[i][2 * k + 1] : 0.f;
+          if constexpr (!PRE) { v0 *= ascale.in_scale; v1 *= ascale.in_scale; }   // exact (power of two)
           unsigned ph, pl;
           split2(v0, v1, ph, pl);
           qh[k] = ph; ql[k] = pl;
@@ -349,18 +356,24 @@ __global__ __launch_bounds__(NT, 2) void k_convup(const UpArgs a) {
   };
 
   // ---- prologue: patch 0, weight slabs 0 and 1 ----
+  __builtin_amdgcn_sched_barrier(0);
+  const unsigned amax_bits = ds_epi::act_bits(IMGIN ? nullptr : a.in_amax, b);   // see ds_conv3h.hip: issued here, consumed behind the first loads
   if constexpr (IMGIN) x_dma(0, 0); else
   x_fetch(0);
   const float bias_shift = ds_epi::fetch_bias_shift(a.bias, a.shift, a.shift_stride, b, cot * COT, a.Cout);
   w_fetch(0, 0);
   w_fetch(1, 1);                                                 // n_steps >= 4 always
+  __builtin_amdgcn_sched_barrier(0);
+  ascale = ds_epi::act_scale_of(amax_bits, a.wshift);
   if constexpr (!IMGIN) x_store(0);
   ds_epi::commit_bias_shift(BS, bias_shift);
   __syncthreads();
 
   ds_epi::Args e;
   e.out = a.out; e.bias = a.bias; e.shift = a.shift; e.res1 = a.res1; e.res2 = a.res2; e.res1_up = a.res1_up;
-  e.unscale = a.unscale; e.shift_stride = a.shift_stride;
+  e.unscale = PRE ? ds_epi::unscale_from_inv(ascale.inv_scale, a.wshift) : ds_epi::unscale_from_in(ascale.in_scale, a.wshift);
+    e.shift_stride = a.shift_stride;
+  e.out_amax = nullptr;                                             // set behind the main loop (live range)
   e.b = b; e.co_base = cot * COT; e.y0 = y0 + wave_row; e.x0 = x0;
   e.Cout = a.Cout; e.H = 2 * a.Hl; e.W = 2 * a.Wl;
   e.pa = pa; e.pb = 0;
@@ -427,6 +440,8 @@ __global__ __launch_bounds__(NT, 2) void k_convup(const UpArgs a) {
     }
     if (chunk < a.n_chunks) { step16(chunk, 0, 0); step16(chunk, 1, 1); step16(chunk, 2, 2); step16(chunk, 3, 0); ++chunk; }
     if (chunk < a.n_chunks) { step16(chunk, 0, 1); step16(chunk, 1, 2); step16(chunk, 2, 0); step16(chunk, 3, 1); }
+    e.out_amax = a.out_amax ? a.out_amax + b : nullptr;
+    e.unscale = PRE ? ds_epi::unscale_from_inv(ascale.inv_scale, a.wshift) : ds_epi::unscale_from_in(ascale.in_scale, a.wshift);
     store_half16<W16>(acc16[0], acc16[1], 0, tile, BS, stat, e);
     store_half16<W16>(acc16[0], acc16[1], 1, tile, BS, stat, e);
   } else {
@@ -512,6 +527,8 @@ __global__ __launch_bounds__(NT, 2) void k_convup(const UpArgs a) {
   if (chunk < a.n_chunks) { step(chunk, 0, 0); step(chunk, 1, 1); step(chunk, 2, 2); step(chunk, 3, 0); ++chunk; }
   if (chunk < a.n_chunks) { step(chunk, 0, 1); step(chunk, 1, 2); step(chunk, 2, 0); step(chunk, 3, 1); }
 
+    e.out_amax = a.out_amax ? a.out_amax + b : nullptr;
+    e.unscale = PRE ? ds_epi::unscale_from_inv(ascale.inv_scale, a.wshift) : ds_epi::unscale_from_in(ascale.in_scale, a.wshift);
     store_half<W16>(acc[0][0], acc[1][0], 0, tile, BS, stat, e);
     store_half<W16>(acc[0][1], acc[1][1], 1, tile, BS, stat, e);
   }
@@ -620,7 +637,7 @@ int ds_conv2d_h3_up_pack_weights(void* packed, const float* w, int Cout, int Cin
 
 int ds_conv2d_h3_up(float* out, const float* in, const void* w_packed, int wshift, const float* bias, const float* shift,
                     int shift_stride, const float* res1, const float* res2, int B, int Cin, int Cout, int Hl, int Wl,
-                    int flags, const float* prenorm, float* tile_stats, void* stream) {
+                    int flags, const float* prenorm, float* tile_stats, const unsigned* in_amax, unsigned* out_amax, void* stream) {
   DS_REQUIRE(out && in && w_packed, DS_ERR_NULL, "ds_conv2d_h3_up: NULL pointer");
   DS_REQUIRE(B >= 0 && Cin > 0 && Cout > 0 && Hl > 0 && Wl > 0, DS_ERR_SHAPE,
              "ds_conv2d_h3_up: bad shape B=%d Cin=%d Cout=%d Hl=%d Wl=%d", B, Cin, Cout, Hl, Wl);
@@ -642,7 +659,7 @@ int ds_conv2d_h3_up(float* out, const float* in, const void* w_packed, int wshif
   UpArgs a;
   a.out = out; a.in = in; a.wp = reinterpret_cast<const u32x4*>(w_packed); a.bias = bias; a.shift = shift;
   a.res1 = res1; a.res2 = res2; a.prenorm = prenorm; a.tile_stats = tile_stats;
-  a.unscale = ldexpf(1.0f, -wshift); a.shift_stride = shift_stride; a.res1_up = res1_up;
+  a.wshift = wshift; a.in_amax = in_amax; a.out_amax = out_amax; a.shift_stride = shift_stride; a.res1_up = res1_up;
   a.B = B; a.Cin = Cin; a.Cout = Cout; a.Hl = Hl; a.Wl = Wl;
   const bool w16 = geo == 2;
   const int TW = w16 ? 16 : 32, TH = w16 ? 16 : 8;
@@ -660,7 +677,7 @@ int ds_conv2d_h3_up(float* out, const float* in, const void* w_packed, int wshif
 
 int ds_conv2d_h3_up_img(float* out, const void* images, const void* w_packed, int wshift, const float* bias, const float* shift,
                         int shift_stride, const float* res1, const float* res2, int B, int Cin, int Cout, int Hl, int Wl,
-                        float* tile_stats, void* stream) {
+                        float* tile_stats, unsigned* out_amax, void* stream) {
   DS_REQUIRE(out && images && w_packed, DS_ERR_NULL, "ds_conv2d_h3_up_img: NULL pointer");
   DS_REQUIRE(B >= 0 && Cin > 0 && Cout > 0 && Hl > 0 && Wl > 0, DS_ERR_SHAPE,
              "ds_conv2d_h3_up_img: bad shape B=%d Cin=%d Cout=%d Hl=%d Wl=%d", B, Cin, Cout, Hl, Wl);
@@ -676,7 +693,7 @@ int ds_conv2d_h3_up_img(float* out, const void* images, const void* w_packed, in
   UpArgs a;
   a.out = out; a.in = reinterpret_cast<const float*>(images); a.wp = reinterpret_cast<const u32x4*>(w_packed); a.bias = bias;
   a.shift = shift; a.res1 = res1; a.res2 = res2; a.prenorm = nullptr; a.tile_stats = tile_stats;
-  a.unscale = ldexpf(1.0f, -wshift); a.shift_stride = shift_stride; a.res1_up = 0;
+  a.wshift = wshift; a.in_amax = nullptr; a.out_amax = out_amax; a.shift_stride = shift_stride; a.res1_up = 0;
   a.B = B; a.Cin = Cin; a.Cout = Cout; a.Hl = Hl; a.Wl = Wl;
   const bool w16 = geo == 2;
   const int TW = w16 ? 16 : 32, TH = w16 ? 16 : 8;

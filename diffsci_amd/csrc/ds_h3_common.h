@@ -30,4 +30,13 @@ __device__ __forceinline__ float fast_silu(float v) {
   return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.44269504088896341f));
 }
 
+// The same times 2^k, exactly (inv_scale = 2^-k): SiLU(v) * 2^k = v * rcp(2^-k * (1 + exp2(-v log2 e))), the bracket formed by ONE
+// fma(e, 2^-k, 2^-k) -- a power-of-two multiple of (1 + e), so the result is the unscaled form's times 2^k bit for bit, in the
+// same five instructions (mul with a literal, exp2, fma with one scalar operand, rcp, mul).  [An fma(v, -log2 e, -k) in front of
+// the exp2 needs two scalar operands: one more than a gfx9 VOP3 instruction takes, i.e. an extra move per element.]
+__device__ __forceinline__ float fast_silu_scaled(float v, float inv_scale) {
+  const float e = __builtin_amdgcn_exp2f(v * -1.44269504088896341f);
+  return v * __builtin_amdgcn_rcpf(__builtin_fmaf(e, inv_scale, inv_scale));
+}
+
 }  // namespace ds_h3

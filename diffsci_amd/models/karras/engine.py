@@ -52,6 +52,17 @@ def condition_signature(y):
     return repr(type(y))
 
 
+MODEL_SWITCHES = ("conv_precision", "fuse_norm", "fuse_max_cot", "direct_out", "upsample_parity", "norm_images", "tile_stats_norms",
+                  "exact_input_layer", "capturable")
+
+
+def model_signature(model):
+    """What a captured plan bakes in of the network: the parameters' addresses and versions and every attribute that selects
+    kernels (the documented A/B switches, the precision the guards may have moved it to).  Shared by KarrasModule and SIModule."""
+    return (tuple((p.data_ptr(), p._version) for p in model.parameters()),
+            tuple(getattr(model, a, None) for a in MODEL_SWITCHES))
+
+
 class ModuleSource:
     """model(c_in*x, c_noise[, y]) of KarrasModule.get_denoiser (karrasmodule.py:702-716)."""
     input_kind = DS_IN_NETWORK
@@ -162,11 +173,13 @@ class ModuleSource:
                 fu = self.model.forward_with_shifts(xin, self.shifts_u, row=index, out=self._buf(slot, "u"))
             return f, fu
         cn = self.cnoise[index]
+        # our networks' domain guards (nets/precision.py) cost a host read: the run checks once at its end, not per evaluation
+        net = getattr(self.model, "forward_unguarded", self.model)
         if self.conditional:
-            f = self.model(xin, cn, self.y)
-            fu = self.model(xin, cn) if self.cfg else None
+            f = net(xin, cn, self.y)
+            fu = net(xin, cn) if self.cfg else None
         else:
-            f, fu = self.model(xin, cn), None
+            f, fu = net(xin, cn), None
         ops.require_device(f, "model output")
         return f.contiguous(), (None if fu is None else fu.contiguous())
 

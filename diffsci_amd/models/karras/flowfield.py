@@ -20,7 +20,7 @@ import torch
 from ... import ops
 from ..nets import precision
 from ..._native import DS_IN_FLOW, DS_IN_NETWORK
-from .engine import Loop, ModuleSource, PlanCache, condition_signature
+from .engine import Loop, ModuleSource, PlanCache, condition_signature, model_signature
 from . import edmbatchnorm
 from .karrasmodule import dict_to, dict_unsqueeze
 from .steptable import EvalRow, StepRow, StepTable
@@ -384,9 +384,7 @@ class SIModule(torch.nn.Module):
         """Capture the whole run once per (shape, schedule, guidance, condition structure) and replay it; what depends
         on the condition's values is refreshed in plan-owned buffers before every replay (engine.PlanCache)."""
         key = (tuple(x.shape), tuple(float(v) for v in table.t), float(guidance), condition_signature(y), bool(return_history),
-               bool(integrate_on_sigma), getattr(self.model, "conv_precision", None), getattr(self.model, "fuse_norm", None),
-               getattr(self.model, "fuse_max_cot", None))
-        key = key + (str(x.device), tuple((p.data_ptr(), p._version) for p in self.model.parameters()))
+               bool(integrate_on_sigma), str(x.device), model_signature(self.model))
         return self._plans.run(key, lambda: Loop(table, src, x, return_history), x, y=y, scale=scale)
 
     def _integrate_generic(self, x, time_schedule, y, guidance, return_history, integrate_on_sigma, scale):

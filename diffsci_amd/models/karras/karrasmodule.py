@@ -20,7 +20,7 @@ from ..nets import precision
 from ..._native import DS_IN_NETWORK
 from . import edmbatchnorm, noisesamplers, preconditioners, schedulers
 from .autoregressivesample import LatentSpaceAutoregressive
-from .engine import Loop, ModuleSource, PlanCache, condition_signature
+from .engine import Loop, ModuleSource, PlanCache, condition_signature, model_signature
 from .steptable import build_step_table
 
 
@@ -361,9 +361,7 @@ class KarrasModule(torch.nn.Module, LatentSpaceAutoregressive):
                 key = (tuple(x.shape), str(x.device), nsteps, i0, i1, record_history, table.kind, injected,
                        (integ.s_schurn, integ.s_tmin, integ.s_tmax, integ.s_noise) if table.kind == "karras" else None,
                        float(guidance), condition_signature(y), float(sch.langevin_const), repr(sch.langevin_interval), self.noise_shard,
-                       tuple(float(v) for v in table.t.tolist()),
-                       tuple((p.data_ptr(), p._version) for p in self.model.parameters()),
-                       tuple(getattr(self.model, a, None) for a in ("conv_precision", "fuse_norm", "fuse_max_cot", "direct_out", "upsample_parity", "norm_images", "tile_stats_norms")))
+                       tuple(float(v) for v in table.t.tolist()), model_signature(self.model))
                 return self._plans.run(key, make_loop, x, y=y, scale=scale, eps=eps)
             loop = make_loop()
             loop.load(x, scale)

@@ -25,7 +25,7 @@ import yaml
 from ... import ops
 from ..._native import DS_LOAD_AVGPOOL2, DS_LOAD_PLAIN, DS_LOAD_UPSAMPLE2
 from . import precision
-from .punetg import _AffineHolder, _Attn, _CircConv, _Fourier, _Workspace, make_conv, require_eval
+from .punetg import _AffineHolder, _AmaxArena, _Attn, _CircConv, _Fourier, _Workspace, make_conv, require_eval
 
 _FIELDS = dict(
     input_channels=1, output_channels=1, dimension=2, model_channels=64, time_embed_dim=64,
@@ -394,6 +394,9 @@ class ADM(torch.nn.Module):
         self._packed = None
         self._packed_sig = None
         self._ws = _Workspace()
+        self._am = None              # the amax arena of the forward pass in flight (see PUNetG.forward_with_shifts)
+        self._window_cache = {}
+        self.exact_input_layer = False   # see PUNetG.exact_input_layer
 
     # ------------------------------------------------------------------ reference surface
     def export_description(self) -> dict[str, Any]:
@@ -407,15 +410,19 @@ class ADM(torch.nn.Module):
 
     @ops.device_guard
     def forward(self, x, t, y=None):
-        """adm.py:199-216."""
+        """adm.py:199-216.  Top-level call: guarded (see PUNetG.forward)."""
+        out = self.forward_unguarded(x, t, y)
+        if precision.needs_escalation(self, out, x):
+            precision.escalate(self)
+            out = self.forward_unguarded(x, t, y)
+        return out
+
+    @ops.device_guard
+    def forward_unguarded(self, x, t, y=None):
         ops.require_device(x, "x")
         te = self.embed_time(t.reshape(-1).to(x), self.embed_condition(y))
         shifts = self.time_shifts(te)
-        out = self.forward_with_shifts(x.contiguous(), shifts, row=None)
-        if precision.needs_escalation(self, out, x, te):
-            precision.escalate(self)
-            out = self.forward_with_shifts(x.contiguous(), shifts, row=None)
-        return out
+        return self.forward_with_shifts(x.contiguous(), shifts, row=None)
 
     # ------------------------------------------------------------------ conditioning
     def embed_condition(self, y):
@@ -458,7 +465,7 @@ class ADM(torch.nn.Module):
         for b in blocks:
             convs += [b.conv1, b.conv2, b.convresidual]
         attns = [b.attn for b in blocks if hasattr(b, "attn")]
-        sig = (self.conv_precision, getattr(self, "upsample_parity", True)) + tuple((m.weight.data_ptr(), m.weight._version) for m in convs) + tuple(
+        sig = (self.conv_precision, getattr(self, "upsample_parity", True), self.exact_input_layer) + tuple((m.weight.data_ptr(), m.weight._version) for m in convs) + tuple(
             (a.mhattn.in_proj_weight.data_ptr(), a.mhattn.in_proj_weight._version) for a in attns)
         if self._packed is not None and sig == self._packed_sig:
             return self._packed
@@ -467,6 +474,10 @@ class ADM(torch.nn.Module):
             ups = {id(b.conv1) for b in blocks if b.sample == "up"} if getattr(self, "upsample_parity", True) else set()
             for m in convs:
                 pk[id(m)] = ops.pack_conv(m.weight.detach(), self.conv_precision, upsampled=id(m) in ups)
+            if self.conv_precision == "fp16x3":
+                pk[(id(self.input_layer), "wmax")] = self.input_layer.weight.detach().abs().amax(dim=(0, 2, 3)).contiguous()
+                if self.exact_input_layer:
+                    pk[(id(self.input_layer), "exact")] = ops.pack_conv(self.input_layer.weight.detach(), "fp32")
             for a in attns:
                 E = a.mhattn.embed_dim
                 prec = "fp16x3" if self.conv_precision == "fp16x3" else "fp32"
@@ -476,8 +487,26 @@ class ADM(torch.nn.Module):
         return pk
 
     # ------------------------------------------------------------------ the network
-    def _conv(self, m, x, pk, **kw):
-        return ops.conv(x, pk[id(m)], bias=m.bias, circular=isinstance(m, _CircConv), **kw)
+    def _amax_kw(self, m_or_pack, pk=None, **kw):
+        """in_amax / out_amax are arguments of the fp16x3 kernels only."""
+        p = m_or_pack if pk is None else pk[id(m_or_pack)]
+        return kw if p.kind == "fp16x3" else {}
+
+    def _conv(self, m, x, pk, in_amax=None, out_amax=None, **kw):
+        return ops.conv(x, pk[id(m)], bias=m.bias, circular=isinstance(m, _CircConv),
+                        **self._amax_kw(m, pk, in_amax=in_amax, out_amax=out_amax), **kw)
+
+    def _raw_amax(self, x, xa):
+        """in_amax of a launch that reads the raw tensor x: the row its producer left, else a reduction into a row."""
+        if self._am is None:
+            return None
+        return xa if xa is not None else self._am.of(x)
+
+    def _normed_amax(self, blk, a):
+        """in_amax of a standalone norm (+ FiLM) + SiLU output: inside the fp16x3 window for affine parameters of ordinary size."""
+        if self._am is None or precision.norms_in_window(self._window_cache, id(blk), (blk.norm1, blk.norm2)):
+            return ops.NORMALISED
+        return self._am.of(a)
 
     def _fused(self):
         return self.fuse_norm and self.conv_precision == "fp16x3"
@@ -494,10 +523,11 @@ class ADM(torch.nn.Module):
         return (self.norm_images and not isinstance(conv, _CircConv) and p.kind == "fp16x3" and p.ks == 3 and p.subs is None
                 and ((Cin + 15) // 16) % 2 == 0)
 
-    def _block(self, blk, x, film, pk, ws, xs=None, want_stats=True):
+    def _block(self, blk, x, film, pk, ws, xs=None, want_stats=True, xa=None, out_amax=None):
         """ADMBaseBlock.forward (adm.py:292-349); returns (fresh buffer, its tile statistics); x untouched.
         xs: tile statistics of x -- one buffer, or a pair when x is the channel concatenation of two
-        convolution outputs -- or None (then norm1 runs as standalone kernels)."""
+        convolution outputs -- or None (then norm1 runs as standalone kernels).  xa: the amax row of x (convresidual reads
+        the raw x), out_amax: a zeroed row for the result's (see PUNetG.forward_with_shifts)."""
         B, Ci, H, W = x.shape
         dev = x.device
         down, up = blk.sample == "down", blk.sample == "up"
@@ -514,9 +544,10 @@ class ADM(torch.nn.Module):
         if fuse1 and xs is not None and not down and not up:
             sa, sb = xs if isinstance(xs, tuple) else (xs, None)
             tab = ws.take((B, ops.table_channels(Ci), 4), dev)
-            ops.gnorm1_table(sa, blk.norm1.weight, blk.norm1.bias, k1, Ci * H * W, stats_b=sb, eps=1e-5, out=tab)
+            ta = self._am.row() if self._am is not None else None              # the activation's exponent: see PUNetG._res
+            ops.gnorm1_table(sa, blk.norm1.weight, blk.norm1.bias, k1, Ci * H * W, stats_b=sb, eps=1e-5, out=tab, act_amax=ta)
             y = self._conv(blk.conv1, x, pk, load_mode=mode, prenorm=tab, tile_stats=ys,
-                           out=ws.take((B, blk.cout, Ho, Wo), dev))
+                           out=ws.take((B, blk.cout, Ho, Wo), dev), in_amax=ta)
             ws.give(tab)
         else:                                                                     # pooling follows the activation
             Hm, Wm = (Ho, Wo) if down else (H, W)
@@ -545,14 +576,16 @@ class ADM(torch.nn.Module):
             else:
                 a = ops.gnorm1_apply(x, stats, blk.norm1.weight, blk.norm1.bias, k1, pool=down,
                                      out=ws.take((B, Ci, Hm, Wm), dev))
-                y = self._conv(blk.conv1, a, pk, load_mode=mode, tile_stats=ys, out=ws.take((B, blk.cout, Ho, Wo), dev))
+                y = self._conv(blk.conv1, a, pk, load_mode=mode, tile_stats=ys, out=ws.take((B, blk.cout, Ho, Wo), dev),
+                               in_amax=self._normed_amax(blk, a))
                 ws.give(a)
             ws.give(stats)
             ws.give(scratch)
         # residual_block: convresidual(resample(x))                               (adm.py:345-349)
         r_up = False
+        raw = self._raw_amax(x, xa) if pk[id(blk.convresidual)].kind == "fp16x3" else None       # pooling / upsampling keep max |x| a bound
         if down and pk[id(blk.convresidual)].kind == "fp16x3":
-            r = self._conv(blk.convresidual, x, pk, load_mode=DS_LOAD_AVGPOOL2, out=ws.take((B, blk.cout, Ho, Wo), dev))
+            r = self._conv(blk.convresidual, x, pk, load_mode=DS_LOAD_AVGPOOL2, out=ws.take((B, blk.cout, Ho, Wo), dev), in_amax=raw)
         elif down:
             a = ops.gnorm1_apply(x, None, None, None, 2, pool=True, out=ws.take((B, Ci, Ho, Wo), dev))
             r = self._conv(blk.convresidual, a, pk, out=ws.take((B, blk.cout, Ho, Wo), dev))
@@ -560,18 +593,21 @@ class ADM(torch.nn.Module):
         elif up and pk[id(blk.convresidual)].kind == "fp16x3" and pk[id(blk.conv2)].kind == "fp16x3":
             # a 1x1 convolution commutes with nearest upsampling: project at low resolution (a quarter of the
             # pixels) and let conv2's epilogue add the result upsampled
-            r = self._conv(blk.convresidual, x, pk, out=ws.take((B, blk.cout, H, W), dev))
+            r = self._conv(blk.convresidual, x, pk, out=ws.take((B, blk.cout, H, W), dev), in_amax=raw)
             r_up = True
         else:
-            r = self._conv(blk.convresidual, x, pk, load_mode=mode, out=ws.take((B, blk.cout, Ho, Wo), dev))
+            r = self._conv(blk.convresidual, x, pk, load_mode=mode, out=ws.take((B, blk.cout, Ho, Wo), dev), in_amax=raw)
         # norm2 -> FiLM -> act -> conv2, + residual                               (adm.py:325-337)
         has_attn = hasattr(blk, "attn")
         os_ = self._stats_buf(ws, B, blk.cout, Ho, Wo, dev) if (want_stats and not has_attn) else None
+        h3 = self._am is not None
+        oa = (self._am.row() if has_attn else out_amax) if h3 else None            # conv2's result feeds the attention, or is the block's
         if fuse2:
             tab = ws.take((B, ops.table_channels(blk.cout), 4), dev)
-            ops.gnorm1_table(ys, blk.norm2.weight, blk.norm2.bias, k2, blk.cout * Ho * Wo, film=film, eps=1e-5, out=tab)
+            ta = self._am.row() if h3 else None
+            ops.gnorm1_table(ys, blk.norm2.weight, blk.norm2.bias, k2, blk.cout * Ho * Wo, film=film, eps=1e-5, out=tab, act_amax=ta)
             out = self._conv(blk.conv2, y, pk, res1=r, res1_upsampled=r_up, prenorm=tab, tile_stats=os_,
-                             out=ws.take((B, blk.cout, Ho, Wo), dev))
+                             out=ws.take((B, blk.cout, Ho, Wo), dev), in_amax=ta, out_amax=oa)
             ws.give(tab)
             ws.give(ys)
             ws.give(y)
@@ -586,12 +622,13 @@ class ADM(torch.nn.Module):
                 img = ops.gnorm1_apply_images(y, stats, blk.norm2.weight, blk.norm2.bias, k2, film=film,
                                               out=ws.take((ops.conv_images_floats(B, blk.cout, Ho, Wo),), dev))
                 out = ops.conv_img(img, pk[id(blk.conv2)], B, blk.cout, Ho, Wo, bias=blk.conv2.bias, res1=r,
-                                   res1_upsampled=r_up, tile_stats=os_, out=y)
+                                   res1_upsampled=r_up, tile_stats=os_, out=y, out_amax=oa)
                 ws.give(img)
             else:
                 a2 = ops.gnorm1_apply(y, stats, blk.norm2.weight, blk.norm2.bias, k2, film=film,
                                       out=ws.take((B, blk.cout, Ho, Wo), dev))
-                out = self._conv(blk.conv2, a2, pk, res1=r, res1_upsampled=r_up, tile_stats=os_, out=y)
+                out = self._conv(blk.conv2, a2, pk, res1=r, res1_upsampled=r_up, tile_stats=os_, out=y,
+                                 in_amax=self._normed_amax(blk, a2), out_amax=oa)
                 ws.give(a2)
             ws.give(stats)
             ws.give(scratch)
@@ -600,26 +637,35 @@ class ADM(torch.nn.Module):
         ws.give(r)
         if has_attn:
             os_ = self._stats_buf(ws, B, blk.cout, Ho, Wo, dev) if want_stats else None
-            out2 = self._attention(blk.attn, out, pk, ws, tile_stats=os_)
+            out2 = self._attention(blk.attn, out, pk, ws, tile_stats=os_, in_amax=oa, out_amax=out_amax)
             ws.give(out)
             out = out2
         return out, os_
 
-    def _attention(self, att, x, pk, ws, tile_stats=None):
-        """TwoDimensionalAttention.forward (attention.py:67-72,82-90), channel-major."""
+    def _attention(self, att, x, pk, ws, tile_stats=None, in_amax=None, out_amax=None):
+        """TwoDimensionalAttention.forward (attention.py:67-72,82-90), channel-major; amax rows as PUNetG._attention."""
         B, E, Hh, Ww = x.shape
         L = Hh * Ww
         m = att.mhattn
-        qkv = ops.conv(x, pk[(id(att), "in")], bias=m.in_proj_bias, out=ws.take((B, 3 * E, Hh, Ww), x.device))
+        am = self._am
+        h3 = am is not None and pk[(id(att), "in")].kind == "fp16x3"
+        a_qkv, a_o = (am.rows(2), am.row()) if h3 else (None, None)
+        akw = (lambda **kw: kw) if h3 else (lambda **kw: {})
+        split = 2 * E if E % 32 == 0 else 0                           # one exponent for q and k, one for v
+        qkv = ops.conv(x, pk[(id(att), "in")], bias=m.in_proj_bias, out=ws.take((B, 3 * E, Hh, Ww), x.device),
+                       **akw(in_amax=self._raw_amax(x, in_amax) if h3 else None, out_amax=a_qkv if split else None, amax_split=split))
+        if h3 and not split:
+            ops.absmax_rows(qkv[:, :2 * E], out=a_qkv[:B])
+            ops.absmax_rows(qkv[:, 2 * E:], out=a_qkv[B:])
         nws = ops.attention_workspace_floats(B, E, L, self.conv_precision)
         aws = ws.take((nws,), x.device) if nws else None
         o = ops.attention(qkv.view(B, 3 * E, L), E, out=ws.take((B, E, L), x.device),
-                          precision=self.conv_precision, workspace=aws)
+                          precision=self.conv_precision, workspace=aws, **akw(in_amax=a_qkv, out_amax=a_o))
         if aws is not None:
             ws.give(aws)
         y = ops.conv(o.view(B, E, Hh, Ww), pk[(id(att), "out")], bias=m.out_proj.bias,
                      res1=x if self.config.attn_residual else None, tile_stats=tile_stats,
-                     out=ws.take(x.shape, x.device))
+                     out=ws.take(x.shape, x.device), **akw(in_amax=a_o, out_amax=out_amax))
         ws.give(qkv)
         ws.give(o)
         return y
@@ -652,63 +698,91 @@ class ADM(torch.nn.Module):
                 if q is not None:
                     ws.give(q)
 
-        hs = self._stats_buf(ws, B, cfg.model_channels, H, W, dev)
-        h = self._conv(self.input_layer, x, pk, tile_stats=hs, out=ws.take((B, cfg.model_channels, H, W), dev))
-        skips = [(h, hs)]                                                       # adm.py:667-675
-        for lay in self.encoder.layers:
-            for blk in lay.input_blocks:
-                h2, hs2 = self._block(blk, h, film(), pk, ws, xs=hs)
-                if not any(h is s for s, _ in skips):
-                    give(h, hs)
-                h, hs = h2, hs2
-            skips.append((h, hs))
-        for blk in self.middle_block.middle_blocks:
-            h2, hs2 = self._block(blk, h, film(), pk, ws, xs=hs)
-            if not any(h is s for s, _ in skips):
-                give(h, hs)
-            h, hs = h2, hs2
-        nl = len(self.decoder.layers)
+        # activation exponents of the raw-input launches (input layer, every block's convresidual, the attention, a wide
+        # output layer): rows of one arena per forward, filled by the producers' epilogues -- see PUNetG.forward_with_shifts
+        h3 = self.conv_precision == "fp16x3"
+        am = self._am = _AmaxArena(ws, B, dev) if h3 else None
 
-        def join(h, hs, skip, sks):                                              # adm.py:297-304
-            if cfg.skip_integration_type == "concat":
-                hc = ops.concat2(h, skip, out=ws.take((B, h.shape[1] + skip.shape[1]) + tuple(h.shape[2:]), dev))
-                return hc, ((hs, sks) if (hs is not None and sks is not None) else None)   # statistics of a concat are additive
-            return ops.add(h, skip, out=ws.take(h.shape, dev)), None
+        def slot():
+            return am.row() if h3 else None
 
-        for li, lay in enumerate(self.decoder.layers):                          # adm.py:764-774, 927-934
-            skip, sks = skips.pop()
-            nblk = len(lay.input_blocks)
-            if cfg.decoder_type == 1:
-                hc, hcs = join(h, hs, skip, sks)
-                pending = [(h, hs)] + ([(skip, sks)] if skip is not h else [])     # statistics are read by block 0's table
-                for j, blk in enumerate(lay.input_blocks):
-                    final = li == nl - 1 and j == nblk - 1                        # feeds the output layer: no norm follows
-                    h2, hs2 = self._block(blk, hc, film(), pk, ws, xs=hcs, want_stats=not final)
-                    if j == 0:
-                        ws.give(hc)
-                        for t, ts in pending:
-                            give(t, ts)
-                    else:
-                        give(hc, hcs)
-                    hc, hcs = h2, hs2
-                h, hs = hc, hcs
-            else:                                                               # every block joins the skip (adm.py:848-851)
-                for j, blk in enumerate(lay.input_blocks):
-                    final = li == nl - 1 and j == nblk - 1
-                    hc, hcs = join(h, hs, skip, sks)
-                    h2, hs2 = self._block(blk, hc, film(), pk, ws, xs=hcs, want_stats=not final)
-                    ws.give(hc)
-                    if h is not skip:
+        try:
+            ha = slot()
+            if h3 and self.exact_input_layer:                                       # see PUNetG.forward_with_shifts
+                hs = None
+                h = ops.conv(x, pk[(id(self.input_layer), "exact")], bias=self.input_layer.bias,
+                             out=ws.take((B, cfg.model_channels, H, W), dev))
+                ops.absmax_rows(h, out=ha)
+            else:
+                hs = self._stats_buf(ws, B, cfg.model_channels, H, W, dev)
+                h = self._conv(self.input_layer, x, pk, tile_stats=hs, out=ws.take((B, cfg.model_channels, H, W), dev),
+                               in_amax=am.of_input(x, precision.input_layer_flag(self, dev), pk[(id(self.input_layer), "wmax")]) if h3 else None,
+                               out_amax=ha)
+            skips = [(h, hs, ha)]                                                   # adm.py:667-675
+            for lay in self.encoder.layers:
+                for blk in lay.input_blocks:
+                    ha2 = slot()
+                    h2, hs2 = self._block(blk, h, film(), pk, ws, xs=hs, xa=ha, out_amax=ha2)
+                    if not any(h is s for s, _, _ in skips):
                         give(h, hs)
-                    h, hs = h2, hs2
-                give(skip, sks)
-        for s_, ss in skips:                                                     # the stem copy is never consumed
-            if s_ is not h:
-                give(s_, ss)
-        m = self.output_layer
-        if m.out_channels <= 4:                              # see PUNetG._out_conv
-            y = ops.conv_direct(h, m.weight, m.bias, out=out)
-        else:
-            y = self._conv(m, h, pk, out=out)
-        give(h, hs)
-        return y
+                    h, hs, ha = h2, hs2, ha2
+                skips.append((h, hs, ha))
+            for blk in self.middle_block.middle_blocks:
+                ha2 = slot()
+                h2, hs2 = self._block(blk, h, film(), pk, ws, xs=hs, xa=ha, out_amax=ha2)
+                if not any(h is s for s, _, _ in skips):
+                    give(h, hs)
+                h, hs, ha = h2, hs2, ha2
+            nl = len(self.decoder.layers)
+
+            def join(h, hs, ha, skip, sks, ska):                                     # adm.py:297-304
+                if cfg.skip_integration_type == "concat":
+                    hc = ops.concat2(h, skip, out=ws.take((B, h.shape[1] + skip.shape[1]) + tuple(h.shape[2:]), dev))
+                    hca = ops.amax_merge(slot(), ha, ska) if h3 else None           # max over the two halves
+                    return hc, ((hs, sks) if (hs is not None and sks is not None) else None), hca   # statistics of a concat are additive
+                hc = ops.add(h, skip, out=ws.take(h.shape, dev))
+                return hc, None, (am.of(hc) if h3 else None)
+
+            for li, lay in enumerate(self.decoder.layers):                          # adm.py:764-774, 927-934
+                skip, sks, ska = skips.pop()
+                nblk = len(lay.input_blocks)
+                if cfg.decoder_type == 1:
+                    hc, hcs, hca = join(h, hs, ha, skip, sks, ska)
+                    pending = [(h, hs)] + ([(skip, sks)] if skip is not h else [])     # statistics are read by block 0's table
+                    for j, blk in enumerate(lay.input_blocks):
+                        final = li == nl - 1 and j == nblk - 1                        # feeds the output layer: no norm follows
+                        ha2 = slot()
+                        h2, hs2 = self._block(blk, hc, film(), pk, ws, xs=hcs, want_stats=not final, xa=hca, out_amax=ha2)
+                        if j == 0:
+                            ws.give(hc)
+                            for t, ts in pending:
+                                give(t, ts)
+                        else:
+                            give(hc, hcs)
+                        hc, hcs, hca = h2, hs2, ha2
+                    h, hs, ha = hc, hcs, hca
+                else:                                                               # every block joins the skip (adm.py:848-851)
+                    for j, blk in enumerate(lay.input_blocks):
+                        final = li == nl - 1 and j == nblk - 1
+                        hc, hcs, hca = join(h, hs, ha, skip, sks, ska)
+                        ha2 = slot()
+                        h2, hs2 = self._block(blk, hc, film(), pk, ws, xs=hcs, want_stats=not final, xa=hca, out_amax=ha2)
+                        ws.give(hc)
+                        if h is not skip:
+                            give(h, hs)
+                        h, hs, ha = h2, hs2, ha2
+                    give(skip, sks)
+            for s_, ss, _ in skips:                                                  # the stem copy is never consumed
+                if s_ is not h:
+                    give(s_, ss)
+            m = self.output_layer
+            if m.out_channels <= 4:                              # see PUNetG._out_conv
+                y = ops.conv_direct(h, m.weight, m.bias, out=out)
+            else:
+                y = self._conv(m, h, pk, out=out, in_amax=ha)
+            give(h, hs)
+            return y
+        finally:
+            if am is not None:
+                am.release()
+            self._am = None

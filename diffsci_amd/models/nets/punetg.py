@@ -234,6 +234,49 @@ class _Workspace:
         self.free.setdefault((tuple(t.shape), str(t.device)), []).append(t)
 
 
+class _AmaxArena:
+    """Per-forward rows of "amax" slots (ops.py: per-sample max |x| as float bits, the activation exponents of the fp16x3
+    kernels' raw-input launches), taken from the workspace and zeroed by ONE fill launch; producers' epilogues merge into a
+    row (out_amax), the raw-input consumer reads it (in_amax)."""
+    ROWS = 256
+
+    def __init__(self, ws, B, dev):
+        self.ws, self.buf = ws, ws.take((self.ROWS, max(B, 1)), dev)
+        self.i32 = ops.amax_zero(self.buf.view(torch.int32))
+        self.n = 0
+
+    def row(self):
+        if self.n >= self.ROWS:
+            raise RuntimeError("amax arena exhausted")
+        self.n += 1
+        return self.i32[self.n - 1]
+
+    def rows(self, n):
+        """n consecutive rows as one [n * B] tensor."""
+        if self.n + n > self.ROWS:
+            raise RuntimeError("amax arena exhausted")
+        self.n += n
+        return self.i32[self.n - n:self.n].view(-1)
+
+    def of(self, x, rows=None):
+        """Slots filled by a reduction over x (a tensor no epilogue of ours produced)."""
+        return ops.absmax_rows(x, rows, out=self.row())
+
+    def of_input(self, x, flag, wmax):
+        """The same for a network input x [B, C, ...] (c_in * x next to raw user fields): per-channel maxima first, `flag` raised
+        when one exponent per sample cannot serve the input layer given its weights (ops.absmax_channels; precision.input_layer_flag)."""
+        C = x.shape[1]
+        if self.n + C + 1 > self.ROWS:
+            return self.of(x)
+        out = self.row()
+        scratch = self.i32[self.n:self.n + C].view(-1)
+        self.n += C
+        return ops.absmax_channels(x, out, scratch, flag, wmax)
+
+    def release(self):
+        self.ws.give(self.buf)
+
+
 class PUNetG(torch.nn.Module):
     def __init__(self,
                  config: PUNetGConfig,
@@ -315,6 +358,10 @@ class PUNetG(torch.nn.Module):
         self._packed = None
         self._packed_sig = None
         self._ws = _Workspace()
+        self._am = None              # the amax arena of the forward pass in flight
+        self._window_cache = {}
+        # set by precision.escalate_input when the input's channels differ by more than 2^14 in magnitude within a sample
+        self.exact_input_layer = False
 
     # ------------------------------------------------------------------ reference surface
     def export_description(self) -> dict[str, Any]:
@@ -329,7 +376,17 @@ class PUNetG(torch.nn.Module):
 
     @ops.device_guard
     def forward(self, x, t=None, y=None):
-        """punetg.py:389-416.  x [B, Cin, H, W]; t [B] noise conditioning; y optional condition."""
+        """punetg.py:389-416.  x [B, Cin, H, W]; t [B] noise conditioning; y optional condition.  A top-level call: the result
+        is checked by the domain guards (nets/precision.py: one device reduction and a host read) and recomputed if one fires;
+        the sampler's eager path calls forward_unguarded and checks once per run."""
+        out = self.forward_unguarded(x, t, y)
+        if precision.needs_escalation(self, out, x):
+            precision.escalate(self)
+            out = self.forward_unguarded(x, t, y)
+        return out
+
+    @ops.device_guard
+    def forward_unguarded(self, x, t=None, y=None):
         ops.require_device(x, "x")
         B = x.shape[0]
         ye = self.embed_condition(y)
@@ -344,11 +401,7 @@ class PUNetG(torch.nn.Module):
             else:
                 te = self.embed_time(t.reshape(-1).to(x), ye)
             shifts = self.time_shifts(te)
-        out = self.forward_with_shifts(x.contiguous(), shifts, row=None)
-        if precision.needs_escalation(self, out, x, te):
-            precision.escalate(self)
-            out = self.forward_with_shifts(x.contiguous(), shifts, row=None)
-        return out
+        return self.forward_with_shifts(x.contiguous(), shifts, row=None)
 
     # ------------------------------------------------------------------ conditioning
     def embed_condition(self, y):
@@ -546,7 +599,7 @@ class PUNetG(torch.nn.Module):
                         if self.inhouse_attn else [a.mhattn.in_proj_weight, a.mhattn.out_proj.weight])
         if self.mp:
             tracked += [lin.weight for lin in self._timeblock_linears()]
-        sig = (self.conv_precision, getattr(self, "upsample_parity", True)) + tuple((t.data_ptr(), t._version) for t in tracked)
+        sig = (self.conv_precision, getattr(self, "upsample_parity", True), self.exact_input_layer) + tuple((t.data_ptr(), t._version) for t in tracked)
         if self._packed is not None and sig == self._packed_sig:
             return self._packed
         pk = {}
@@ -559,6 +612,10 @@ class PUNetG(torch.nn.Module):
                     pk[(id(m), "eff")] = w                         # the direct output-layer kernel takes the raw layout
                 if self.dim == 2:
                     pk[id(m)] = ops.pack_conv(w, self.conv_precision, upsampled=id(m) in ups)
+                    if m is self.convin and self.conv_precision == "fp16x3":
+                        pk[(id(m), "wmax")] = w.abs().amax(dim=(0, 2, 3)).contiguous()   # the input layer's channel guard
+                        if self.exact_input_layer:
+                            pk[(id(m), "exact")] = ops.pack_conv(w, "fp32")
                 elif self.conv_precision == "fp16x3":              # volumes on the matrix cores: one packing per depth tap
                     pk[(id(m), "3d")] = ops.pack_conv3d(w, upsampled=id(m) in ups)
                 # other precisions: ds_conv3d_direct reads the torch layout
@@ -578,15 +635,22 @@ class PUNetG(torch.nn.Module):
         return pk
 
     # ------------------------------------------------------------------ the network
-    def _conv(self, m, x, pk, **kw):
-        return ops.conv(x, pk[id(m)], bias=m.bias, circular=self.circular, **kw)
+    def _amax_kw(self, **kw):
+        """in_amax / out_amax are arguments of the fp16x3 kernels only."""
+        return kw if self.conv_precision == "fp16x3" else {}
 
-    def _out_conv(self, m, h, pk, out, circular):
+    def _conv(self, m, x, pk, in_amax=None, out_amax=None, **kw):
+        return ops.conv(x, pk[id(m)], bias=m.bias, circular=self.circular, **self._amax_kw(in_amax=in_amax, out_amax=out_amax), **kw)
+
+    def _out_is_direct(self, m):
+        return m.out_channels <= 4 and getattr(self, "direct_out", True) and self.config.in_out_kernel_size == 3
+
+    def _out_conv(self, m, h, pk, out, circular, in_amax=None):
         """The output layer: Cout <= 4 streams the input once through the direct fp32 kernel instead of
         padding Cout to a 64-channel MFMA tile."""
-        if m.out_channels <= 4 and getattr(self, "direct_out", True) and self.config.in_out_kernel_size == 3:
+        if self._out_is_direct(m):
             return ops.conv_direct(h, pk.get((id(m), "eff"), m.weight), m.bias, circular=circular, out=out)
-        return ops.conv(h, pk[id(m)], bias=m.bias, circular=circular, out=out)
+        return ops.conv(h, pk[id(m)], bias=m.bias, circular=circular, out=out, **self._amax_kw(in_amax=in_amax))
 
     def _fused(self):
         return self.fuse_norm and self.conv_precision == "fp16x3"
@@ -597,9 +661,10 @@ class PUNetG(torch.nn.Module):
             return None
         return ws.take((B, C, ops.conv_tile_count(H, W), 4), dev)
 
-    def _res(self, blk, x, shift, pk, ws, res2=None, xs=None, want_stats=True):
+    def _res(self, blk, x, shift, pk, ws, res2=None, xs=None, want_stats=True, out_amax=None):
         """ResnetBlockC.forward (commonlayers.py:824-833); returns (fresh buffer, its tile statistics);
-        x untouched.  xs = tile statistics of x (from the convolution that produced it) or None."""
+        x untouched.  xs = tile statistics of x (from the convolution that produced it) or None.  out_amax: a zeroed amax row
+        that receives the per-sample max |result| (the result feeds a raw-input launch: Down/UpSampler, attention)."""
         B, C, H, W = x.shape
         dev = x.device
         if self.extra_residual is not None:
@@ -615,6 +680,8 @@ class PUNetG(torch.nn.Module):
             ops.add(y, er.contiguous(), out=y)                      # (conv2 + x) + extra_residual(x)
             if res2 is not None:
                 ops.add(y, res2, out=y)                             # x + xa of bottom_forward, after the block as in the reference
+            if out_amax is not None:
+                ops.absmax_rows(y, out=out_amax)
             return y, None                                          # no tile statistics of the sum: the consumer normalises standalone
         yt = None
         if shift is not None and shift.dim() == 4:         # a field of time shifts: conv1's epilogue adds it as a residual
@@ -622,20 +689,28 @@ class PUNetG(torch.nn.Module):
         k1, k2 = self.norm_kinds                           # 0 GroupLN, 1 GroupRMS, 2 none, 3 GroupPix (not a table)
         w1, b1 = getattr(blk.gnorm1, "weight", None), getattr(blk.gnorm1, "bias", None)
         w2, b2 = getattr(blk.gnorm2, "weight", None), getattr(blk.gnorm2, "bias", None)
+        # The folded route: the table call also leaves a bound on the activation's argument per sample (act_amax), and the loader
+        # produces SiLU(norm(x)) times the power of two taken from it -- inside the fp16x3 window whatever the affine parameters or
+        # an eps-dominated variance do.  The image / standalone routes below rely on the norm to put its output in the window:
+        # real norms with affine parameters of ordinary size (windowed); otherwise the activation's exponent is measured.
         if (self._fused() and xs is not None and (C + 63) // 64 <= self.fuse_max_cot and k1 != 3 and k2 != 3
                 and self.config.kernel_size == 3):                                  # the norm+SiLU loader is the 3x3 kernel's
+            am = self._am
+            t1, t2 = (am.row(), am.row()) if am is not None else (ops.amax_new(B, dev), ops.amax_new(B, dev))
             tab = ws.take((B, ops.table_channels(C), 4), dev)
-            ops.inorm_table(xs, w1, b1, k1, H * W, eps=1e-5, out=tab)
+            ops.inorm_table(xs, w1, b1, k1, H * W, eps=1e-5, out=tab, act_amax=t1)
             ys = self._stats_buf(ws, B, C, H, W, dev)
-            y = self._conv(blk.conv1, x, pk, shift=shift, res1=yt, prenorm=tab, tile_stats=ys, out=ws.take(x.shape, dev))
-            ops.inorm_table(ys, w2, b2, k2, H * W, eps=1e-5, out=tab)
+            y = self._conv(blk.conv1, x, pk, shift=shift, res1=yt, prenorm=tab, tile_stats=ys, out=ws.take(x.shape, dev), in_amax=t1)
+            ops.inorm_table(ys, w2, b2, k2, H * W, eps=1e-5, out=tab, act_amax=t2)
             os_ = self._stats_buf(ws, B, C, H, W, dev) if want_stats else None
-            out = self._conv(blk.conv2, y, pk, res1=x, res2=res2, prenorm=tab, tile_stats=os_, out=ws.take(x.shape, dev))
+            out = self._conv(blk.conv2, y, pk, res1=x, res2=res2, prenorm=tab, tile_stats=os_, out=ws.take(x.shape, dev),
+                             in_amax=t2, out_amax=out_amax)
             ws.give(y)
             ws.give(ys)
             ws.give(tab)
             return out, os_
-        if self._norm_images_ok(blk, C, H, W, k1, k2):
+        windowed = k1 in (0, 1) and k2 in (0, 1) and self._norms_in_window(blk)
+        if windowed and self._norm_images_ok(blk, C, H, W, k1, k2):
             # standalone norms (the 256-channel level): written as the convolution's pre-split fp16 images, which it stages by
             # LDS-DMA -- same bytes as the fp32 result, bit-identical values, no split in the convolution (ops.conv_img)
             img = ops.inorm_silu_images(x, w1, b1, k1, eps=1e-5, out=ws.take((ops.conv_images_floats(B, C, H, W),), dev))
@@ -643,11 +718,11 @@ class PUNetG(torch.nn.Module):
             ops.inorm_silu_images(y, w2, b2, k2, eps=1e-5, out=img)
             os_ = self._stats_buf(ws, B, C, H, W, dev) if want_stats else None
             out = ops.conv_img(img, pk[id(blk.conv2)], B, C, H, W, bias=blk.conv2.bias, res1=x, res2=res2, tile_stats=os_,
-                               out=ws.take(x.shape, dev))
+                               out=ws.take(x.shape, dev), out_amax=out_amax)
             ws.give(img)
             ws.give(y)
             return out, os_
-        if self._table_images_ok(blk, C, k1, k2) and self._fused() and xs is not None:
+        if windowed and self._table_images_ok(blk, C, k1, k2) and self._fused() and xs is not None:
             # planes the image norm kernel does not take (more than 4096 floats): the activation from the fused loader's table
             # (built from the producer's tile statistics), written as images by an apply pass
             tab = ws.take((B, ops.table_channels(C), 4), dev)
@@ -660,17 +735,31 @@ class PUNetG(torch.nn.Module):
             ops.table_apply_images(y, tab, out=img)
             os_ = self._stats_buf(ws, B, C, H, W, dev) if want_stats else None
             out = ops.conv_img(img, pk[id(blk.conv2)], B, C, H, W, bias=blk.conv2.bias, res1=x, res2=res2, tile_stats=os_,
-                               out=ws.take(x.shape, dev))
+                               out=ws.take(x.shape, dev), out_amax=out_amax)
             for t in (img, y, ys, tab):
                 ws.give(t)
             return out, os_
+        # standalone norms; the activation's exponent is measured (one reduction pass) unless the norm puts it in the window
         a = ops.inorm_silu(x, w1, b1, kind=k1, eps=1e-5, out=ws.take(x.shape, dev))
-        y = self._conv(blk.conv1, a, pk, shift=shift, res1=yt, out=ws.take(x.shape, dev))
+        y = self._conv(blk.conv1, a, pk, shift=shift, res1=yt, out=ws.take(x.shape, dev), in_amax=self._act_amax(a, windowed))
         ops.inorm_silu(y, w2, b2, kind=k2, eps=1e-5, out=a)
         os_ = self._stats_buf(ws, B, C, H, W, dev) if want_stats else None
-        self._conv(blk.conv2, a, pk, res1=x, res2=res2, tile_stats=os_, out=y)
+        self._conv(blk.conv2, a, pk, res1=x, res2=res2, tile_stats=os_, out=y, in_amax=self._act_amax(a, windowed), out_amax=out_amax)
         ws.give(a)
         return y, os_
+
+    def _act_amax(self, a, windowed):
+        """in_amax of a standalone norm + SiLU output: none needed inside the fp16x3 window, else a reduction into an arena row
+        (a row of the current forward's arena; outside a forward -- never -- ops reduces into a fresh tensor)."""
+        if windowed or self.conv_precision != "fp16x3":
+            return ops.NORMALISED
+        return self._am.of(a) if self._am is not None else None
+
+    def _norms_in_window(self, blk):
+        """Both norms of the block are affine-free or carry affine parameters of ordinary size (|w|, |b| largest entries within
+        [2^-6, 2^6] / below 2^6): SiLU(norm(x) * w + b) then sits inside the fp16x3 window (|x| in [2^-3, 2^16) at 22 bits,
+        degrading gracefully to 2^-25 absolute) for any input magnitude.  Checked on the host once per parameter version."""
+        return precision.norms_in_window(self._window_cache, id(blk), (blk.gnorm1, blk.gnorm2))
 
     def _table_images_ok(self, blk, C, k1, k2):
         """As _norm_images_ok for the table route (any plane size; GroupLN / GroupRMS / no norm)."""
@@ -735,81 +824,120 @@ class PUNetG(torch.nn.Module):
             if ts is not None:
                 ws.give(ts)
 
-        H, W = x.shape[2:]
-        xe = None
-        if not cfg.bias:                                                         # punetg.py:390-394
-            ones = ws.take((B, 1, H, W), dev)
-            ones.fill_(1.0)
-            xe = ops.concat2(x, ones, out=ws.take((B, x.shape[1] + 1, H, W), dev))
-            ws.give(ones)
-            x = xe
-        if isinstance(self.convin, _FourierInput):
-            hs = None                                                            # no producer statistics: standalone first norm
-            h = ops.fourier_channels(x, self.convin.W, out=ws.take((B, cfg.model_channels, H, W), dev))
-        else:
-            hs = self._stats_buf(ws, B, cfg.model_channels, H, W, dev)
-            h = self._conv(self.convin, x, pk, tile_stats=hs, out=ws.take((B, cfg.model_channels, H, W), dev))
-        if xe is not None:
-            ws.give(xe)
-        skips = []
-        for lv, blocks in enumerate(self.downward_blocks):                      # punetg.py:356-365
-            for blk in blocks:
-                h2, hs2 = self._res(blk, h, sh(), pk, ws, xs=hs)
+        # Activation exponents (ops.py): every launch that reads a tensor which no norm has put into the fp16x3 window --
+        # convin, the Down / UpSamplers, the attention and its projections, a k x k output layer -- takes the per-sample max |x|
+        # its producer's epilogue left in a row of this arena (ha travels with h like the tile statistics hs), or a reduction
+        # over the tensor where the producer is not one of our epilogues (the network input).
+        h3 = self.conv_precision == "fp16x3"
+        am = self._am = _AmaxArena(ws, B, dev) if h3 else None
+
+        def slot(needed=True):
+            return am.row() if (h3 and needed) else None
+
+        def amax_of(t, ta):                                                      # the row that travels with t, else a reduction
+            if not h3:
+                return None
+            return ta if ta is not None else am.of(t)
+
+        try:
+            H, W = x.shape[2:]
+            xe = None
+            if not cfg.bias:                                                         # punetg.py:390-394
+                ones = ws.take((B, 1, H, W), dev)
+                ones.fill_(1.0)
+                xe = ops.concat2(x, ones, out=ws.take((B, x.shape[1] + 1, H, W), dev))
+                ws.give(ones)
+                x = xe
+            ndown = len(self.downward_blocks)
+            if isinstance(self.convin, _FourierInput):
+                hs = None                                                            # no producer statistics: standalone first norm
+                h = ops.fourier_channels(x, self.convin.W, out=ws.take((B, cfg.model_channels, H, W), dev))
+            elif h3 and self.exact_input_layer:
+                # the input's channels are too far apart in magnitude for one exponent per sample (precision.escalate_input):
+                # exact-fp32 kernel, no tile statistics (the first block normalises standalone)
+                hs = None
+                h = ops.conv(x, pk[(id(self.convin), "exact")], bias=self.convin.bias, out=ws.take((B, cfg.model_channels, H, W), dev))
+            else:
+                hs = self._stats_buf(ws, B, cfg.model_channels, H, W, dev)
+                h = self._conv(self.convin, x, pk, tile_stats=hs, out=ws.take((B, cfg.model_channels, H, W), dev),
+                               in_amax=am.of_input(x, precision.input_layer_flag(self, dev), pk[(id(self.convin), "wmax")]) if h3 else None)
+            ha = None
+            if xe is not None:
+                ws.give(xe)
+            skips = []
+            for lv, blocks in enumerate(self.downward_blocks):                      # punetg.py:356-365
+                for j, blk in enumerate(blocks):
+                    ha2 = slot(j == len(blocks) - 1)                                 # the level's last block feeds the DownSampler
+                    h2, hs2 = self._res(blk, h, sh(), pk, ws, xs=hs, out_amax=ha2)
+                    give(h, hs)
+                    h, hs, ha = h2, hs2, ha2
+                skips.append(h)
+                if hs is not None:
+                    ws.give(hs)                                                      # the skip is only added, never normalised
+                ds = self.downsamplers[lv].conv
+                Ho, Wo = h.shape[2] // 2, h.shape[3] // 2
+                hs = self._stats_buf(ws, B, ds.out_channels, Ho, Wo, dev)
+                h = self._conv(ds, h, pk, load_mode=DS_LOAD_MAXPOOL2, tile_stats=hs,
+                               out=ws.take((B, ds.out_channels, Ho, Wo), dev), in_amax=amax_of(h, ha))
+                ha = None
+            nattn, nafter = len(self.attn_resnet_block), len(self.after_block)
+            for j, blk in enumerate(self.before_block):                               # punetg.py:378-387
+                ha2 = slot(j == len(self.before_block) - 1 and nattn == 0 and nafter == 0 and ndown > 0)
+                h2, hs2 = self._res(blk, h, sh(), pk, ws, xs=hs, out_amax=ha2)
                 give(h, hs)
-                h, hs = h2, hs2
-            skips.append(h)
-            if hs is not None:
-                ws.give(hs)                                                      # the skip is only added, never normalised
-            ds = self.downsamplers[lv].conv
-            Ho, Wo = h.shape[2] // 2, h.shape[3] // 2
-            hs = self._stats_buf(ws, B, ds.out_channels, Ho, Wo, dev)
-            h = self._conv(ds, h, pk, load_mode=DS_LOAD_MAXPOOL2, tile_stats=hs,
-                           out=ws.take((B, ds.out_channels, Ho, Wo), dev))
-        for blk in self.before_block:                                             # punetg.py:378-387
-            h2, hs2 = self._res(blk, h, sh(), pk, ws, xs=hs)
-            give(h, hs)
-            h, hs = h2, hs2
-        xa, xas = h, hs
-        nattn = len(self.attn_resnet_block)
-        for i, blk in enumerate(self.attn_resnet_block):
-            last = i == nattn - 1
-            # x + xa is folded into the last residual block's epilogue when no attention follows it
-            xa2, xas2 = self._res(blk, xa, sh(), pk, ws, xs=xas,
-                                  res2=h if (last and i >= len(self.attn_block)) else None)
-            if xa is not h:
-                give(xa, xas)
-            xa, xas = xa2, xas2
-            if i < len(self.attn_block):
-                xas2 = self._stats_buf(ws, B, xa.shape[1], xa.shape[2], xa.shape[3], dev)
-                xa2 = self._attention(self.attn_block[i], xa, pk, ws, res2=h if last else None, tile_stats=xas2)
-                give(xa, xas)
-                xa, xas = xa2, xas2
-        if nattn == 0:
-            xa, xas = ops.add(h, h, out=ws.take(h.shape, dev)), None
-        give(h, hs if xas is not hs else None)
-        h, hs = xa, xas
-        for blk in self.after_block:
-            h2, hs2 = self._res(blk, h, sh(), pk, ws, xs=hs)
-            give(h, hs)
-            h, hs = h2, hs2
-        nup = len(self.upward_blocks)
-        for lv, blocks in enumerate(self.upward_blocks):                         # punetg.py:367-376
-            us = self.upsamplers[lv].conv
-            skip = skips.pop()
-            hs2 = self._stats_buf(ws, B, skip.shape[1], skip.shape[2], skip.shape[3], dev)
-            h2 = self._conv(us, h, pk, load_mode=DS_LOAD_UPSAMPLE2, res1=skip, tile_stats=hs2,
-                            out=ws.take(skip.shape, dev))
-            give(h, hs)
-            ws.give(skip)
-            h, hs = h2, hs2
-            for j, blk in enumerate(blocks):
-                final = lv == nup - 1 and j == len(blocks) - 1                   # feeds convout: no norm follows
-                h2, hs2 = self._res(blk, h, sh(), pk, ws, xs=hs, want_stats=not final)
+                h, hs, ha = h2, hs2, ha2
+            xa, xas, xaa = h, hs, ha
+            for i, blk in enumerate(self.attn_resnet_block):
+                last = i == nattn - 1
+                attn_next = i < len(self.attn_block)
+                # x + xa is folded into the last residual block's epilogue when no attention follows it
+                xaa2 = slot(attn_next or (last and nafter == 0 and ndown > 0))
+                xa2, xas2 = self._res(blk, xa, sh(), pk, ws, xs=xas,
+                                      res2=h if (last and not attn_next) else None, out_amax=xaa2)
+                if xa is not h:
+                    give(xa, xas)
+                xa, xas, xaa = xa2, xas2, xaa2
+                if attn_next:
+                    xas2 = self._stats_buf(ws, B, xa.shape[1], xa.shape[2], xa.shape[3], dev)
+                    xaa2 = slot(last and nafter == 0 and ndown > 0)
+                    xa2 = self._attention(self.attn_block[i], xa, pk, ws, res2=h if last else None, tile_stats=xas2,
+                                          in_amax=amax_of(xa, xaa), out_amax=xaa2)
+                    give(xa, xas)
+                    xa, xas, xaa = xa2, xas2, xaa2
+            if nattn == 0:
+                xa, xas, xaa = ops.add(h, h, out=ws.take(h.shape, dev)), None, None
+            give(h, hs if xas is not hs else None)
+            h, hs, ha = xa, xas, xaa
+            for j, blk in enumerate(self.after_block):
+                ha2 = slot(j == nafter - 1 and ndown > 0)                            # feeds the first UpSampler
+                h2, hs2 = self._res(blk, h, sh(), pk, ws, xs=hs, out_amax=ha2)
                 give(h, hs)
-                h, hs = h2, hs2
-        y = self._out_conv(self.convout, h, pk, out, self.circular)
-        give(h, hs)
-        return y
+                h, hs, ha = h2, hs2, ha2
+            nup = len(self.upward_blocks)
+            direct_out = self._out_is_direct(self.convout)
+            for lv, blocks in enumerate(self.upward_blocks):                         # punetg.py:367-376
+                us = self.upsamplers[lv].conv
+                skip = skips.pop()
+                hs2 = self._stats_buf(ws, B, skip.shape[1], skip.shape[2], skip.shape[3], dev)
+                h2 = self._conv(us, h, pk, load_mode=DS_LOAD_UPSAMPLE2, res1=skip, tile_stats=hs2,
+                                out=ws.take(skip.shape, dev), in_amax=amax_of(h, ha))
+                give(h, hs)
+                ws.give(skip)
+                h, hs, ha = h2, hs2, None
+                for j, blk in enumerate(blocks):
+                    lastb = j == len(blocks) - 1
+                    final = lv == nup - 1 and lastb                                  # feeds convout: no norm follows
+                    ha2 = slot(lastb and (not final or not direct_out))              # the next UpSampler, or a matrix-core output layer
+                    h2, hs2 = self._res(blk, h, sh(), pk, ws, xs=hs, want_stats=not final, out_amax=ha2)
+                    give(h, hs)
+                    h, hs, ha = h2, hs2, ha2
+            y = self._out_conv(self.convout, h, pk, out, self.circular, in_amax=None if direct_out else amax_of(h, ha))
+            give(h, hs)
+            return y
+        finally:
+            if am is not None:
+                am.release()
+            self._am = None
 
     # ------------------------------------------------------------------ volumes (dimension = 3)
     def _forward3d(self, x, shifts, row=None, out=None):
@@ -853,9 +981,10 @@ class PUNetG(torch.nn.Module):
             Bc, C, D, H, W = shape
             return ws.take((Bc, C, ops.volume_stat_tiles(D, H * W), 4), dev)
 
-        def conv(m, h, load_mode=0, dst=None, fresh=False, want_stats=False, **kw):
+        def conv(m, h, load_mode=0, dst=None, fresh=False, want_stats=False, normalised=False, **kw):
             """-> (tensor, statistics or None).  Every buffer comes from the workspace (a captured loop must not allocate);
-            fresh: the caller's result."""
+            fresh: the caller's result.  normalised: h is a norm + SiLU output inside the fp16x3 window; otherwise the
+            matrix-core route measures per-slice activation exponents on its slice copy (ops.conv3d_mfma)."""
             f = {0: (1, 1), DS_LOAD_MAXPOOL2: (1, 2), DS_LOAD_UPSAMPLE2: (2, 1)}[load_mode]
             shape = (h.shape[0], m.out_channels) + tuple(v * f[0] // f[1] for v in h.shape[2:])
             if dst is None and not fresh:
@@ -866,7 +995,7 @@ class PUNetG(torch.nn.Module):
             if packs is not None and m.out_channels > 4 and m.in_channels > 4:
                 st = stats_buf(shape) if (fold and want_stats) else None
                 return ops.conv3d_mfma(h, packs, bias=m.bias, circular=self.circular, load_mode=load_mode, out=dst, ws=ws,
-                                       out_stats=st, **kw), st
+                                       out_stats=st, in_amax=ops.NORMALISED if normalised else None, **kw), st
             return ops.conv3d(h, pk.get((id(m), "eff"), m.weight), bias=m.bias, circular=self.circular, load_mode=load_mode,
                               out=dst, **kw), None
 
@@ -880,7 +1009,9 @@ class PUNetG(torch.nn.Module):
             w2, b2 = getattr(blk.gnorm2, "weight", None), getattr(blk.gnorm2, "bias", None)
             C = h.shape[1]
             p1, p2 = pk.get((id(blk.conv1), "3d")), pk.get((id(blk.conv2), "3d"))
-            if fold and hs is not None and p1 is not None and p2 is not None and C > 4 and (C + 63) // 64 <= self.fuse_max_cot:
+            windowed = k1 in (0, 1) and k2 in (0, 1) and self._norms_in_window(blk)
+            if (fold and windowed and hs is not None and p1 is not None and p2 is not None and C > 4
+                    and (C + 63) // 64 <= self.fuse_max_cot):
                 tab = ops.inorm_table(hs, w1, b1, k1, h[0, 0].numel(), eps=1e-5, out=ws.take((B, ops.table_channels(C), 4), dev))
                 os_ = stats_buf(h.shape) if want_stats else None
                 y = ops.resblock3d_fused(h, tab, p1, blk.conv1.bias, sh(), p2, blk.conv2.bias, w2, b2, k2, res2=res2,
@@ -888,12 +1019,12 @@ class PUNetG(torch.nn.Module):
                 ws.give(tab)
                 return y, os_
             a = ops.inorm_silu(h, w1, b1, kind=k1, eps=1e-5, out=ws.take(h.shape, dev))
-            y, _ = conv(blk.conv1, a, shift=sh())
+            y, _ = conv(blk.conv1, a, shift=sh(), normalised=windowed)
             ops.inorm_silu(y, w2, b2, kind=k2, eps=1e-5, out=a)
             if self.extra_residual is None:
-                _, os_ = conv(blk.conv2, a, res1=h, res2=res2, dst=y, want_stats=want_stats)
+                _, os_ = conv(blk.conv2, a, res1=h, res2=res2, dst=y, want_stats=want_stats, normalised=windowed)
             else:
-                conv(blk.conv2, a, res1=h, dst=y)
+                conv(blk.conv2, a, res1=h, dst=y, normalised=windowed)
                 ops.add(y, self.extra_residual(h).contiguous(), out=y)
                 if res2 is not None:
                     ops.add(y, res2, out=y)
@@ -975,30 +1106,49 @@ class PUNetG(torch.nn.Module):
         give(h, hs)
         return y
 
-    def _attention(self, att, x, pk, ws, res2=None, tile_stats=None):
-        """TwoDimensionalAttention.forward (attention.py:67-72,82-90), channel-major throughout."""
+    def _attention(self, att, x, pk, ws, res2=None, tile_stats=None, in_amax=None, out_amax=None):
+        """TwoDimensionalAttention.forward (attention.py:67-72,82-90), channel-major throughout.  The block's three launches
+        read raw tensors: x (in_amax: its producer's row, or None = reduced here), qkv and the attention output, whose
+        exponents travel from epilogue to loader through rows of the forward's arena."""
         B, E, Hh, Ww = x.shape
         L = Hh * Ww
         m = att.mhattn
         in_bias = None if self.inhouse_attn else m.in_proj_bias    # the in-house attention has no biases
         out_bias = None if self.inhouse_attn else m.out_proj.bias
-        qkv = ops.conv(x, pk[(id(att), "in")], bias=in_bias, out=ws.take((B, 3 * E, Hh, Ww), x.device))
+        am = self._am if self.conv_precision == "fp16x3" else None
+        own = None
+        if am is None and self.conv_precision == "fp16x3":           # called outside forward_with_shifts (the 3-D path sets its own)
+            own = am = _AmaxArena(ws, B, x.device)
+        split = 2 * E if E % 32 == 0 else 0                           # one exponent for q and k, one for v (E % 32: the fp16x3 attention)
+        a_qkv = am.rows(2) if am is not None else None
+        a_o = am.row() if am is not None else None
+        if am is not None and in_amax is None:
+            in_amax = am.of(x)
+        direct = not self.cosine_attn and split > 0
+        qkv = ops.conv(x, pk[(id(att), "in")], bias=in_bias, out=ws.take((B, 3 * E, Hh, Ww), x.device),
+                       **self._amax_kw(in_amax=in_amax, out_amax=a_qkv if direct else None, amax_split=split if direct else 0))
         if self.cosine_attn:
             # cosine_similarity (attention.py:362-372): unit queries and keys, logits without 1/sqrt(E) -- the
             # attention kernels scale by 1/sqrt(E), which the queries' gain cancels
             ops.token_l2_normalize(qkv.view(B, 3 * E, L), 0, E, eps=1e-8, gain=math.sqrt(E))
             ops.token_l2_normalize(qkv.view(B, 3 * E, L), E, E, eps=1e-8, gain=1.0)
+        if am is not None and not direct:                             # q and k were rewritten, or a head width the epilogue cannot split: measure
+            ops.absmax_rows(qkv[:, :2 * E], out=a_qkv[:B])
+            ops.absmax_rows(qkv[:, 2 * E:], out=a_qkv[B:])
         nws = ops.attention_workspace_floats(B, E, L, self.conv_precision)
         aws = ws.take((nws,), x.device) if nws else None
         o = ops.attention(qkv.view(B, 3 * E, L), E, out=ws.take((B, E, L), x.device),
-                          precision=self.conv_precision, workspace=aws)
+                          precision=self.conv_precision, workspace=aws, **self._amax_kw(in_amax=a_qkv, out_amax=a_o))
         if aws is not None:
             ws.give(aws)
         res1 = x if self.config.attn_residual else None
         y = ops.conv(o.view(B, E, Hh, Ww), pk[(id(att), "out")], bias=out_bias,
-                     res1=res1, res2=res2, tile_stats=tile_stats, out=ws.take(x.shape, x.device))
+                     res1=res1, res2=res2, tile_stats=tile_stats, out=ws.take(x.shape, x.device),
+                     **self._amax_kw(in_amax=a_o, out_amax=out_amax))
         ws.give(qkv)
         ws.give(o)
+        if own is not None:
+            own.release()
         return y
 
 
@@ -1064,15 +1214,19 @@ class PUNetGCond(PUNetG):
 
     @ops.device_guard
     def forward(self, x, t, y=None):
+        out = self.forward_unguarded(x, t, y)
+        if precision.needs_escalation(self, out, x, self._ycat):
+            precision.escalate(self)
+            out = self.forward_unguarded(x, t, y)
+        return out
+
+    @ops.device_guard
+    def forward_unguarded(self, x, t, y=None):
         ops.require_device(x, "x")
         rest, self._ycat = self._split_condition(y)
         te = self.embed_time(t.reshape(-1).to(x), PUNetG.embed_condition(self, rest))
         shifts = self.time_shifts(te)
-        out = self.forward_with_shifts(x.contiguous(), shifts, row=None)
-        if precision.needs_escalation(self, out, x, te, self._ycat):
-            precision.escalate(self)
-            out = self.forward_with_shifts(x.contiguous(), shifts, row=None)
-        return out
+        return self.forward_with_shifts(x.contiguous(), shifts, row=None)
 
     def embed_condition(self, y):
         """Planned sampler entry: remember the channel fields, embed what is left of y."""

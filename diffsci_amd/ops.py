@@ -61,6 +61,95 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+# ---------------------------------------------------------------- per-sample activation exponents of the fp16x3 kernels
+# fp16 has 5 exponent bits; the reference's fp32 convolutions take raw user fields (punetg.py:719-735) and c_in = 1
+# parameterisations (preconditioners.py:139-161) at any magnitude.  A launch whose input is not normalised by construction
+# scales sample b by a power of two taken from max |x_b| (include/diffsci_hip.h: in_amax / out_amax).  "amax" tensors are
+# int32 [rows] holding float bits; they are MERGED into (atomicMax), so they start from zero.
+class _Normalised:
+    """in_amax=NORMALISED: the input is normalised by construction (a norm + SiLU output): no scaling, no reduction."""
+
+    def __repr__(self):
+        return "ops.NORMALISED"
+
+
+NORMALISED = _Normalised()
+
+
+def _pi(t, n, what="amax"):
+    if t is None:
+        return None
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.int32 and t.is_contiguous() and t.numel() == n):
+        raise TypeError(f"{what} must be a contiguous int32 device tensor of {n} entries (float bits of per-sample max |x|)")
+    if t.device.index != torch.cuda.current_device():
+        raise RuntimeError(f"{what} lives on another device than the current one")
+    return t.data_ptr()
+
+
+def amax_zero(t):
+    """Zero amax slots (a one-line kernel: hipGraph memset nodes replay unreliably on this ROCm, see ds_amax.hip)."""
+    N.check(N.lib().ds_fill_u32(_pi(t, t.numel()), 0, t.numel(), _stream()), "ds_fill_u32")
+    return t
+
+
+def amax_new(rows, device):
+    return torch.zeros(int(rows), dtype=torch.int32, device=device)
+
+
+def absmax_rows(x, rows=None, out=None):
+    """out[r] = max(out[r], float bits of max |x[r]|) over the rows of x viewed as [rows, -1] (default: the batch dimension).
+    x: contiguous, or a channel slice x_full[:, c0:c1] of a contiguous tensor (rows = samples, dense inside a row).
+    out=None: a fresh zeroed tensor (an allocation: captured code passes its own, zeroed, slots)."""
+    require_device(x, "x")
+    if x.is_contiguous():
+        rows = x.shape[0] if rows is None else int(rows)
+        n = x.numel() // max(rows, 1)
+        stride = n
+    else:
+        if rows not in (None, x.shape[0]) or x.dim() < 2 or not x[0].is_contiguous():
+            raise ValueError("absmax_rows: x must be contiguous or a channel slice of a contiguous tensor")
+        rows, n, stride = x.shape[0], x[0].numel(), x.stride(0)
+    if out is None:
+        out = amax_new(rows, x.device)
+    N.check(N.lib().ds_absmax_rows(_pi(out, rows), x.data_ptr(), rows, n, stride, _stream()), "ds_absmax_rows")
+    return out
+
+
+CHANNEL_GAP = 14     # binades: see ds_absmax_channels
+
+
+def absmax_channels(x, out, scratch, flag=None, wmax=None, gap=CHANNEL_GAP):
+    """absmax_rows for an input layer's x [B, C, *spatial]: out [B] (zeroed slots) <- per-sample maxima; scratch: zeroed int32
+    [B*C]; flag (int32 [1] or None) is OR-ed with 1 when one exponent per sample cannot serve the layer given its weights (wmax
+    [C]: largest |weight| per input channel) -- the caller's signal to run that layer on the exact-fp32 kernel (nets/precision.py)."""
+    require_device(x, "x")
+    if not x.is_contiguous():
+        raise ValueError("absmax_channels: x must be contiguous")
+    B, C = x.shape[0], x.shape[1]
+    if wmax is not None and wmax.numel() != C:
+        raise ValueError("absmax_channels: wmax must hold one entry per input channel")
+    N.check(N.lib().ds_absmax_channels(_pi(out, B), _pi(flag, 1, "flag"), _pi(scratch, B * C, "scratch"), x.data_ptr(), _p(wmax, "wmax"),
+                                       B, C, x.numel() // max(B * C, 1), int(gap), _stream()), "ds_absmax_channels")
+    return out
+
+
+def amax_merge(out, a, b=None):
+    """out[i] = max(out[i], a[i], b[i]): the amax of a channel concatenation from those of its parts."""
+    n = out.numel()
+    N.check(N.lib().ds_amax_merge(_pi(out, n), _pi(a, n), _pi(b, n), n, _stream()), "ds_amax_merge")
+    return out
+
+
+def _in_amax(x, in_amax, rows, raw):
+    """Pointer for a kernel's in_amax argument.  raw: the launch reads x without a normalising loader (with one, only an
+    explicit row -- the table call's act_amax -- means anything)."""
+    if in_amax is NORMALISED or (in_amax is None and not raw):
+        return None
+    if in_amax is None:
+        in_amax = absmax_rows(x, rows)
+    return _pi(in_amax, rows, "in_amax")
+
+
 def _same_numel(*ts):
     n = None
     for t in ts:
@@ -297,16 +386,23 @@ def _slice_rows(shift, B, D, Cout, ws=None):
     return buf.view(ns, Cout)[1:ns - 1], buf
 
 
-def _depth_taps(s_in, s_out, packs, bias, rows, load_mode, circular, prenorm=None, tile_stats=None):
+def _depth_taps(s_in, s_out, packs, bias, rows, load_mode, circular, prenorm=None, tile_stats=None, in_amax=None):
     """The three depth-tap launches of a 3x3x3 convolution over slice-major volumes: the centre tap initialises the
     accumulator (all slices of s_out but the outermost two), the others add to it; prenorm: per-SLICE table
-    [B*(D+2), ceil16(Cin), 4] (ds_slice_tables) for the fused norm + SiLU loader; tile_stats: filled by the last launch."""
+    [B*(D+2), ceil16(Cin), 4] (ds_slice_tables) for the fused norm + SiLU loader; tile_stats: filled by the last launch.
+    in_amax: per-SLICE max |s_in| [B*(D+2)] (every slice is a 2-D sample with its own exponent), NORMALISED, or None = computed
+    here."""
     ns = s_in.shape[0]
     acc = s_out[1:ns - 1]
+    if prenorm is not None:
+        in_amax = NORMALISED
+    elif in_amax is None:
+        in_amax = absmax_rows(s_in)
     for n, dz in enumerate((0, -1, 1)):
         conv(s_in[1 + dz:ns - 1 + dz], packs[dz + 1], bias=bias if n == 0 else None, shift=rows if n == 0 else None,
              res1=None if n == 0 else acc, load_mode=load_mode, circular=circular, out=acc,
-             prenorm=None if prenorm is None else prenorm[1 + dz:ns - 1 + dz], tile_stats=tile_stats if n == 2 else None)
+             prenorm=None if prenorm is None else prenorm[1 + dz:ns - 1 + dz], tile_stats=tile_stats if n == 2 else None,
+             in_amax=in_amax if in_amax is NORMALISED else in_amax[1 + dz:ns - 1 + dz])
     return acc
 
 
@@ -348,7 +444,7 @@ def resblock3d_fused(h, tab1, packs1, bias1, shift, packs2, bias2, w2, b2, kind2
     s2[ns - 1].zero_()
     ts = take((ns - 2, C, conv_tile_count(H, W), 4))
     rows, rows_buf = _slice_rows(shift, B, D, C, ws)
-    _depth_taps(s1, s2, packs1, bias1, rows, N.DS_LOAD_PLAIN, False, tile_stats=ts)
+    _depth_taps(s1, s2, packs1, bias1, rows, N.DS_LOAD_PLAIN, False, tile_stats=ts, in_amax=NORMALISED)   # S1 = SiLU(norm1(h))
     tab2 = take((ns, table_channels(C), 4))
     N.check(N.lib().ds_slice_tables(_p(tab2), _p(ts), _p(w2), _p(b2), B, C, D, ts.shape[2], D * H * W, float(eps), int(kind2),
                                     _stream()), "ds_slice_tables")
@@ -362,12 +458,14 @@ def resblock3d_fused(h, tab1, packs1, bias1, shift, packs2, bias2, w2, b2, kind2
 
 
 def conv3d_mfma(x, packs, bias=None, shift=None, res1=None, res2=None, load_mode=N.DS_LOAD_PLAIN, circular=False, out=None,
-                ws=None, out_stats=None):
+                ws=None, out_stats=None, in_amax=None):
     """3x3x3 'same' convolution of a volume on the matrix cores: three 2-D fp16x3 convolutions (one per depth tap) over
     a slice-major, depth-padded copy of the volume (ds_volume_to_slices / ds_slices_to_volume).  Same arguments and
     fusions as conv3d; packs = pack_conv3d(weight).  ws: an optional buffer pool (take(shape, device) / give(tensor)) for
     the two slice copies, so that a captured loop allocates nothing.  out_stats: [B, Cout, volume_stat_tiles(D, H*W), 4],
-    filled with the result's shifted partial sums (the consumer's norm table, ds_inorm_table with count D*H*W)."""
+    filled with the result's shifted partial sums (the consumer's norm table, ds_inorm_table with count D*H*W).
+    in_amax: NORMALISED for a norm + SiLU output; otherwise the per-slice activation exponents are taken from a reduction over the
+    slice copy (in a pool buffer when ws is given)."""
     require_device(x, "x")
     B, Cin, Din, Hi, Wi = x.shape
     Cout = packs[0].Cout
@@ -395,10 +493,19 @@ def conv3d_mfma(x, packs, bias=None, shift=None, res1=None, res2=None, load_mode
                                         _stream()), "ds_volume_to_slices")
     s_out = take((ns, Cout, H, W))
     rows, rows_buf = _slice_rows(shift, B, D, Cout, ws)
-    _depth_taps(s_in, s_out, packs, bias, rows, load_mode, circular)
+    am_buf = None
+    if in_amax is not NORMALISED:
+        if ws is None:
+            in_amax = absmax_rows(s_in)
+        else:
+            am_buf = ws.take((ns,), x.device)
+            in_amax = absmax_rows(s_in, out=amax_zero(am_buf.view(torch.int32)))
+    _depth_taps(s_in, s_out, packs, bias, rows, load_mode, circular, in_amax=in_amax)
     _from_slices(out, s_out, res1, res2, B, Cout, D, H * W, out_stats)
     if rows_buf is not None:
         ws.give(rows_buf)
+    if am_buf is not None:
+        ws.give(am_buf)
     if ws is not None:
         ws.give(s_in)
         ws.give(s_out)
@@ -580,13 +687,15 @@ def conv(x, pw, **kw):
         raise NotImplementedError("periodic padding with kernels larger than 3x3")
     if kw.get("res1_upsampled", False):
         raise NotImplementedError("res1_upsampled with kernels larger than 3x3")
-    stats, out = kw.pop("tile_stats", None), kw.pop("out", None)
+    stats, out, out_amax = kw.pop("tile_stats", None), kw.pop("out", None), kw.pop("out_amax", None)
     first = dict(bias=kw.pop("bias", None), shift=kw.pop("shift", None), res1=kw.pop("res1", None), res2=kw.pop("res2", None))
+    if kw.get("in_amax", None) is None and kw.get("prenorm", None) is None:
+        kw["in_amax"] = absmax_rows(x)                                # one reduction for all the blocks
     n = len(pw.subs)
     for i, (oy, ox, sub) in enumerate(pw.subs):
         extra = first if i == 0 else dict(res1=out)
         out = conv2d(x, sub.data, sub.Cout, 3, kind="fp16x3", wshift=sub.wshift, tap_offset=(oy, ox), out=out,
-                     tile_stats=stats if i == n - 1 else None, **extra, **kw)
+                     tile_stats=stats if i == n - 1 else None, out_amax=out_amax if i == n - 1 else None, **extra, **kw)
     return out
 
 
@@ -615,20 +724,22 @@ def table_channels(C):
     return (C + 15) // 16 * 16
 
 
-def inorm_table(tile_stats, w, b, kind, count, eps=1e-5, out=None):
-    """PUNetG norm table [B, ceil16(C), 4] from a convolution's tile statistics [B, C, ntiles, 4]."""
+def inorm_table(tile_stats, w, b, kind, count, eps=1e-5, out=None, act_amax=None):
+    """PUNetG norm table [B, ceil16(C), 4] from a convolution's tile statistics [B, C, ntiles, 4].  act_amax: zeroed int32 [B]
+    that receives a bound on the activation's argument -- pass it as in_amax next to prenorm=table."""
     B, C, nt, _ = tile_stats.shape
     if out is None:
         out = torch.empty((B, table_channels(C), 4), dtype=torch.float32, device=tile_stats.device)
     elif tuple(out.shape) != (B, table_channels(C), 4):
         raise ValueError(f"table must be {(B, table_channels(C), 4)}")
     N.check(N.lib().ds_inorm_table(_p(out), _p(tile_stats), _p(w), _p(b), B, C, nt, int(count), float(eps), int(kind),
-                                   _stream()), "ds_inorm_table")
+                                   _pi(act_amax, B, "act_amax"), _stream()), "ds_inorm_table")
     return out
 
 
-def gnorm1_table(stats_a, w, b, kind, count, stats_b=None, film=None, eps=1e-5, out=None):
-    """ADM norm table [B, ceil16(Ca+Cb), 4] from tile statistics of one tensor or of the two halves of a concat."""
+def gnorm1_table(stats_a, w, b, kind, count, stats_b=None, film=None, eps=1e-5, out=None, act_amax=None):
+    """ADM norm table [B, ceil16(Ca+Cb), 4] from tile statistics of one tensor or of the two halves of a concat.
+    act_amax: as inorm_table."""
     B, Ca, nta, _ = stats_a.shape
     Cb, ntb = (0, 0) if stats_b is None else (stats_b.shape[1], stats_b.shape[2])
     C = Ca + Cb
@@ -645,7 +756,7 @@ def gnorm1_table(stats_a, w, b, kind, count, stats_b=None, film=None, eps=1e-5, 
         stride = 0 if film.shape[0] == 1 else 2 * C
         f1, f2 = film.data_ptr(), film.data_ptr() + 4 * C
     N.check(N.lib().ds_gnorm1_table(_p(out), _p(stats_a), Ca, nta, _p(stats_b), Cb, ntb, _p(w), _p(b), f1, f2, stride,
-                                    B, int(count), float(eps), int(kind), _stream()), "ds_gnorm1_table")
+                                    B, int(count), float(eps), int(kind), _pi(act_amax, B, "act_amax"), _stream()), "ds_gnorm1_table")
     return out
 
 
@@ -665,10 +776,14 @@ def gnorm1_stats_tiles(stats_a, kind, count, stats_b=None, eps=1e-5, stats=None)
 
 def conv2d(x, w_packed, Cout, ks, bias=None, shift=None, res1=None, res2=None,
            load_mode=N.DS_LOAD_PLAIN, out=None, kind="fp32", wshift=0, prenorm=None, tile_stats=None, circular=False,
-           res1_upsampled=False, w_up=None, up_wshift=0, tap_offset=None):
+           res1_upsampled=False, w_up=None, up_wshift=0, tap_offset=None, in_amax=None, out_amax=None, amax_split=0):
     """'same' zero-padded conv; x [B, Cin, Hin, Win]; shift [1 or B, Cout] or None.
     fp16x3 kernels only: prenorm [B, ceil16(Cin), 4] (3x3) applies SiLU((x-M)*A+C) in the loader; tile_stats
-    [B, Cout, conv_tile_count(H, W), 4] receives per-tile (K, sum(x-K), sum((x-K)^2), n) of the output."""
+    [B, Cout, conv_tile_count(H, W), 4] receives per-tile (K, sum(x-K), sum((x-K)^2), n) of the output;
+    in_amax: int32 [B] per-sample max |x| (float bits) left by x's producer, NORMALISED for a norm + SiLU output, None = reduce
+    x here (one extra read pass and an allocation: captured code passes slots); out_amax: zeroed int32 [B] slots that receive the
+    per-sample max |out| for the next raw-input launch; amax_split (fp16x3 1x1 only): out_amax is [2, B] and channels >=
+    amax_split report to its second row (the attention in-projection: q, k | v)."""
     B, Cin, Hin, Win = x.shape
     if load_mode in (N.DS_LOAD_MAXPOOL2, N.DS_LOAD_AVGPOOL2):
         if Hin % 2 or Win % 2:
@@ -705,6 +820,14 @@ def conv2d(x, w_packed, Cout, ks, bias=None, shift=None, res1=None, res2=None,
         raise ValueError("bias must have Cout entries")
     if (prenorm is not None or tile_stats is not None) and kind != "fp16x3":
         raise ValueError("prenorm / tile_stats are features of the fp16x3 kernels")
+    pin = pout = None
+    if kind == "fp16x3":
+        pin = _in_amax(x, in_amax, B, raw=prenorm is None)
+        if amax_split and (ks != 1 or amax_split % 64):
+            raise ValueError("amax_split: the fp16x3 1x1 convolution, a multiple of 64")
+        pout = _pi(out_amax, 2 * B if amax_split else B, "out_amax")
+    elif out_amax is not None:
+        raise ValueError("out_amax is a feature of the fp16x3 kernels (use absmax_rows on the result)")
     if circular and ks == 3 and kind != "fp16x3":
         raise NotImplementedError("periodic padding is implemented in the fp16x3 convolution only")
     if prenorm is not None and (ks != 3 or tuple(prenorm.shape) != (B, table_channels(Cin), 4)):
@@ -720,8 +843,8 @@ def conv2d(x, w_packed, Cout, ks, bias=None, shift=None, res1=None, res2=None,
         w_up = None                                                      # the parity kernel has no offset form
     if kind == "fp16x3" and ks == 1:
         N.check(N.lib().ds_conv1x1_h3(_p(out), _p(x), _p(w_packed), int(wshift), _p(bias), _p(shift), stride,
-                                      _p(res1), _p(res2), B, Cin, Cout, H, W, load_mode, _p(tile_stats), _stream()),
-                "ds_conv1x1_h3")
+                                      _p(res1), _p(res2), B, Cin, Cout, H, W, load_mode, _p(tile_stats), pin, pout,
+                                      int(amax_split), _stream()), "ds_conv1x1_h3")
     elif kind == "fp16x3" and load_mode == N.DS_LOAD_UPSAMPLE2 and w_up is not None \
             and N.lib().ds_conv2d_h3_up_supported(Hin, Win):
         if w_up.numel() != N.lib().ds_conv2d_h3_up_packed_bytes(Cout, Cin) // 4:
@@ -729,12 +852,12 @@ def conv2d(x, w_packed, Cout, ks, bias=None, shift=None, res1=None, res2=None,
         N.check(N.lib().ds_conv2d_h3_up(_p(out), _p(x), _p(w_up), int(up_wshift), _p(bias), _p(shift), stride,
                                         _p(res1), _p(res2), B, Cin, Cout, Hin, Win,
                                         (N.DS_PAD_CIRCULAR if circular else 0) | (N.DS_RES1_UPSAMPLED if res1_upsampled else 0),
-                                        _p(prenorm), _p(tile_stats), _stream()), "ds_conv2d_h3_up")
+                                        _p(prenorm), _p(tile_stats), pin, pout, _stream()), "ds_conv2d_h3_up")
     elif kind == "fp16x3":
         N.check(N.lib().ds_conv2d_h3(_p(out), _p(x), _p(w_packed), int(wshift), _p(bias), _p(shift), stride,
                                      _p(res1), _p(res2), B, Cin, Cout, H, W,
                                      load_mode | tap | (N.DS_PAD_CIRCULAR if circular else 0) | (N.DS_RES1_UPSAMPLED if res1_upsampled else 0),
-                                     _p(prenorm), _p(tile_stats),
+                                     _p(prenorm), _p(tile_stats), pin, pout,
                                      _stream()), "ds_conv2d_h3")
     elif kind == "bf16x6":
         N.check(N.lib().ds_conv2d_x6(_p(out), _p(x), _p(w_packed), _p(bias), _p(shift), stride, _p(res1),
@@ -771,7 +894,7 @@ def inorm_silu_images(x, w, b, kind, eps=1e-5, out=None):
 
 
 def conv_img(images, pw, B, Cin, H, W, bias=None, shift=None, res1=None, res2=None, tile_stats=None, out=None,
-             res1_upsampled=False):
+             res1_upsampled=False, out_amax=None):
     """3x3 'same' zero-padded fp16x3 convolution whose input is given as pre-split fp16 hi / lo images (the layout
     ds_inorm_silu_images writes): patches are staged by LDS-DMA, no split in the kernel.  pw = pack_conv(weight, "fp16x3")."""
     require_device(images, "images")
@@ -798,7 +921,7 @@ def conv_img(images, pw, B, Cin, H, W, bias=None, shift=None, res1=None, res2=No
         raise ValueError(f"tile_stats must be {(B, Cout, conv_tile_count(H, W), 4)}")
     N.check(N.lib().ds_conv2d_h3_img(_p(out), _p(images), _p(pw.data), int(pw.wshift), _p(bias), _p(shift), stride, _p(res1),
                                      _p(res2), B, Cin, Cout, H, W, N.DS_RES1_UPSAMPLED if res1_upsampled else 0,
-                                     _p(tile_stats), _stream()), "ds_conv2d_h3_img")
+                                     _p(tile_stats), _pi(out_amax, B, "out_amax"), _stream()), "ds_conv2d_h3_img")
     return out
 
 
@@ -825,7 +948,8 @@ def conv_up_img_supported(pw, Hl, Wl):
             and bool(N.lib().ds_conv2d_h3_up_supported(int(Hl), int(Wl))))
 
 
-def conv_up_img(images, pw, B, Cin, Hl, Wl, bias=None, shift=None, res1=None, res2=None, tile_stats=None, out=None):
+def conv_up_img(images, pw, B, Cin, Hl, Wl, bias=None, shift=None, res1=None, res2=None, tile_stats=None, out=None,
+                out_amax=None):
     """conv3x3(nearest_x2(a)) as the four collapsed parity kernels (ds_conv2d_h3_up) with the low-resolution activation a given as
     pre-split images; output [B, Cout, 2 Hl, 2 Wl].  pw = pack_conv(weight, "fp16x3", upsampled=True)."""
     require_device(images, "images")
@@ -849,7 +973,8 @@ def conv_up_img(images, pw, B, Cin, Hl, Wl, bias=None, shift=None, res1=None, re
     if tile_stats is not None and tuple(tile_stats.shape) != (B, Cout, conv_tile_count(H, W), 4):
         raise ValueError(f"tile_stats must be {(B, Cout, conv_tile_count(H, W), 4)}")
     N.check(N.lib().ds_conv2d_h3_up_img(_p(out), _p(images), _p(pw.up), int(pw.up_wshift), _p(bias), _p(shift), stride, _p(res1),
-                                        _p(res2), B, Cin, Cout, Hl, Wl, _p(tile_stats), _stream()), "ds_conv2d_h3_up_img")
+                                        _p(res2), B, Cin, Cout, Hl, Wl, _p(tile_stats), _pi(out_amax, B, "out_amax"), _stream()),
+            "ds_conv2d_h3_up_img")
     return out
 
 
@@ -907,28 +1032,42 @@ def attention_workspace_floats(B, E, L, precision="fp16x3"):
     return 0
 
 
-def attention(qkv, E, out=None, precision="fp32", workspace=None):
+def attention(qkv, E, out=None, precision="fp32", workspace=None, in_amax=None, out_amax=None):
     """qkv [B, 3E, L] channel-major -> out [B, E, L].  precision "fp16x3": split-fp16 MFMA
-    (fp32-level accuracy, |operands| < 65504, E <= 256); anything else, or wider heads: exact-fp32 MFMA.
-    workspace: float tensor of attention_workspace_floats(...) elements; allocated here when needed and not given."""
+    (fp32-level accuracy, E <= 256); anything else, or wider heads: exact-fp32 MFMA.
+    workspace: float tensor of attention_workspace_floats(...) elements; allocated here when needed and not given.
+    in_amax: int32 [2, B] -- per-sample max |q, k| and max |v| (conv2d(..., amax_split=2E) leaves them), None = reduced here;
+    out_amax [B]: as conv2d.  The fp16x3 kernels stage q, k and v times the sample's powers of two; the exact-fp32 kernels need
+    none, and an out_amax request is served by a reduction over their result."""
     B, E3, L = qkv.shape
     if E3 != 3 * E:
         raise ValueError("qkv must be [B, 3E, L]")
     if out is None:
         out = torch.empty((B, E, L), dtype=torch.float32, device=qkv.device)
-    if L % 32 != 0 or E not in (32, 64, 128, 256, 384, 512):
-        N.check(N.lib().ds_attention_generic(_p(out), _p(qkv), B, E, L, _stream()), "ds_attention_generic")
-    elif _attention_uses_images(E, L, precision):
+    h3 = precision == "fp16x3" and L % 32 == 0 and E in (32, 64, 128, 256)
+    if h3:
+        if in_amax is None:
+            in_amax = amax_new(2 * B, qkv.device)
+            absmax_rows(qkv[:, :2 * E], out=in_amax[:B])
+            absmax_rows(qkv[:, 2 * E:], out=in_amax[B:])
+        pin, pout = (None if in_amax is NORMALISED else _pi(in_amax, 2 * B, "in_amax")), _pi(out_amax, B, "out_amax")
+    if h3 and _attention_uses_images(E, L, precision):
         need = attention_workspace_floats(B, E, L)
         if workspace is None:
             workspace = torch.empty(need, dtype=torch.float32, device=qkv.device)
         elif workspace.numel() < need:
             raise ValueError("attention workspace too small")
-        N.check(N.lib().ds_attention_h3_ws(_p(out), _p(qkv), _p(workspace, "workspace"), B, E, L, _stream()), "ds_attention_h3_ws")
-    elif precision == "fp16x3" and E <= 256:
-        N.check(N.lib().ds_attention_h3(_p(out), _p(qkv), B, E, L, _stream()), "ds_attention_h3")
+        N.check(N.lib().ds_attention_h3_ws(_p(out), _p(qkv), _p(workspace, "workspace"), B, E, L, pin, pout, _stream()),
+                "ds_attention_h3_ws")
+    elif h3:
+        N.check(N.lib().ds_attention_h3(_p(out), _p(qkv), B, E, L, pin, pout, _stream()), "ds_attention_h3")
     else:
-        N.check(N.lib().ds_attention(_p(out), _p(qkv), B, E, L, _stream()), "ds_attention")
+        if L % 32 != 0 or E not in (32, 64, 128, 256, 384, 512):
+            N.check(N.lib().ds_attention_generic(_p(out), _p(qkv), B, E, L, _stream()), "ds_attention_generic")
+        else:
+            N.check(N.lib().ds_attention(_p(out), _p(qkv), B, E, L, _stream()), "ds_attention")
+        if out_amax is not None:
+            absmax_rows(out, B, out=out_amax)
     return out
 
 

@@ -50,7 +50,7 @@ typedef enum ds_status {
 } ds_status;
 
 /* Library / device introspection. */
-int ds_version(void);                       /* ABI version, currently 2 */
+int ds_version(void);                       /* ABI version, currently 3 */
 const char* ds_last_error(void);            /* thread-local, never NULL */
 int ds_device_info(int* cu_count, int* lds_bytes_per_cu, char* arch_name, int arch_name_len);
 
@@ -198,19 +198,44 @@ int ds_conv2d_x6(float* out, const float* in, const void* w_packed, const float*
  * pieces (22-23 significand bits kept), three piece products accumulated in fp32; weights are
  * pre-scaled by 2^wshift at pack time (undone exactly in the epilogue) so that their low pieces
  * stay normal; gfx950's fp16 MFMA honours subnormal inputs.  Representation error ~1e-7 relative,
- * i.e. below the accumulation-order noise of an fp32 convolution.  Domain: |in| < 65504 (larger
- * magnitudes give inf/nan).  Twice the rate of ds_conv2d_x6. */
+ * i.e. below the accumulation-order noise of an fp32 convolution.  Twice the rate of ds_conv2d_x6.
+ * Domain.  fp16 has 5 exponent bits: x = hi + lo keeps its 22 bits for |x| in [2^-3, 2^16), degrades below (absolute
+ * floor 2^-25) and overflows above.  Inputs that are normalised by construction (the prenorm loader, the *_img entry
+ * points) sit inside that window.  Any other input -- the reference's fp32 convolutions take raw user fields
+ * (punetg.py:719-735) and c_in = 1 parameterisations (preconditioners.py:139-161) at any magnitude -- is given with
+ *   in_amax  [B] per-sample max |in| as float bits (NULL: no scaling): the loader multiplies sample b by 2^k, k chosen
+ *            so that its maximum lands in [2^13, 2^14), and the epilogue undoes it exactly (2^-(wshift + k)): a block
+ *            floating point with the sample's exponent, the whole fp32 range of magnitudes, results of a sample
+ *            independent of the rest of the batch.  Produced by
+ *   out_amax [B] (NULL: off): the epilogue merges max |out[b]| into slot b with atomicMax -- zero the slots first
+ *            (ds_fill_u32) -- or by ds_absmax_rows for tensors that come from elsewhere. */
 size_t ds_conv2d_h3_packed_bytes(int Cout, int Cin);
 int ds_conv2d_h3_pack_weights(void* packed, const float* w, int Cout, int Cin, int wshift, void* stream);
 int ds_conv2d_h3(float* out, const float* in, const void* w_packed, int wshift, const float* bias,
                  const float* shift, int shift_stride, const float* res1, const float* res2,
                  int B, int Cin, int Cout, int H, int W, int load_mode,
-                 const float* prenorm, float* tile_stats, void* stream);
+                 const float* prenorm, float* tile_stats, const unsigned* in_amax, unsigned* out_amax, void* stream);
+/* out[r] = max(out[r], bits(max |x[r*row_stride .. +n_per_row)|)): the in_amax of a tensor no epilogue produced (one read pass,
+ * HBM-bound).  Merging semantics: zero the slots first; several calls accumulate (channel concatenations). */
+int ds_absmax_rows(unsigned* out, const float* x, int rows, size_t n_per_row, size_t row_stride, void* stream);
+int ds_amax_merge(unsigned* out, const unsigned* a, const unsigned* b /* or NULL */, int n, void* stream);   /* out[i] = max(out[i], a[i], b[i]):
+                                                                       the amax of a channel concatenation (adm.py:299) from those of its parts */
+int ds_fill_u32(unsigned* p, unsigned value, size_t n, void* stream);          /* zeroing amax slots: a kernel, not a memset node (ds_amax.hip) */
+/* The same reduction for an INPUT layer, x [B, C, HW] (user data: c_in * x next to raw condition fields, punetg.py:719-735):
+ * scratch [B*C] (zeroed) receives the per-(sample, channel) maxima, out[b] their maximum m, and *flag (may be NULL) is OR-ed
+ * with 1 when one exponent per sample cannot serve the layer: with wmax [C] (the layer's largest |weight| per input channel)
+ * when m * wmax[c] > 2^gap * max_c'(max|x[b,c']| * wmax[c']) for a channel c that carries data -- the common exponent's
+ * rounding error, seen through that channel's weights, would exceed fp32's own accumulation noise (a field of 1e-8 whose
+ * weights are 1e8 times the others'); without wmax when a non-zero channel lies more than `gap` binades below m.  The host then
+ * re-runs the input layer on the exact-fp32 kernel (nets/precision.py). */
+int ds_absmax_channels(unsigned* out, unsigned* flag, unsigned* scratch, const float* x, const float* wmax, int B, int C,
+                       size_t HW, int gap, void* stream);
 /* Two optional fusions of the normalisation around the convolution (NULL = off):
  *   prenorm    [B, ceil16(Cin), 4] = (M, A, C, -), rows past Cin zero: the loader applies SiLU((x - M)*A + C) to every input element
  *              before the convolution (zero padding stays zero) -- the norm -> act of ResnetBlockC /
  *              ADMBaseBlock (commonlayers.py:824-829, adm.py:312-337) without materialising its output.
- *              Not with MAXPOOL2.  Tables come from ds_inorm_table / ds_gnorm1_table.
+ *              Not with MAXPOOL2.  Tables come from ds_inorm_table / ds_gnorm1_table.  With prenorm, in_amax is the
+ *              table call's act_amax row (a bound on the activation's argument): the loader produces SiLU(.) * 2^k.
  *   tile_stats [B, Cout, ntiles, 4]: per output channel and pixel tile of the stored values, (K, S, Q, n):
  *              n valid pixels, K one of them, S = sum(x-K), Q = sum((x-K)^2) (shifted sums: no mean^2
  *              cancellation in fp32); ntiles = ds_conv_tile_count(H, W); consumed by the *_table calls,
@@ -239,7 +264,7 @@ int ds_inorm_silu_images(void* images, const float* x, const float* w, const flo
 size_t ds_conv_images_bytes(int B, int C, int H, int W);
 int ds_conv2d_h3_img(float* out, const void* images, const void* w_packed, int wshift, const float* bias, const float* shift,
                      int shift_stride, const float* res1, const float* res2, int B, int Cin, int Cout, int H, int W,
-                     int flags /* 0 or DS_RES1_UPSAMPLED */, float* tile_stats, void* stream);
+                     int flags /* 0 or DS_RES1_UPSAMPLED */, float* tile_stats, unsigned* out_amax, void* stream);
 /* ds_gnorm1_apply (ADM's GroupNorm(1,C) / GroupRMSNorm(1,C) [+FiLM] + SiLU [+AvgPool2d(2)], adm.py:306-343) writing those images. */
 int ds_gnorm1_apply_images(void* images, const float* x, const float* stats, const float* w, const float* b,
                            const float* film_scale, const float* film_shift, int film_stride, int B, int C, int Ho, int Wo,
@@ -255,20 +280,25 @@ int ds_conv2d_h3_up_pack_weights(void* packed, const float* w, int Cout, int Cin
 int ds_conv2d_h3_up(float* out, const float* in, const void* w_packed, int wshift, const float* bias,
                     const float* shift, int shift_stride, const float* res1, const float* res2,
                     int B, int Cin, int Cout, int Hl, int Wl, int flags, const float* prenorm, float* tile_stats,
-                    void* stream);
+                    const unsigned* in_amax, unsigned* out_amax, void* stream);
 /* ds_conv2d_h3_up (zero padding, no fused norm) with the LOW-resolution input given as pre-split images
  * (ds_gnorm1_apply_images / ds_inorm_silu_images over [B, Cin, Hl, Wl]); w_packed from ds_conv2d_h3_up_pack_weights.
  * ADM's norm1 -> SiLU -> nearest x2 -> conv1 of an 'up' block (adm.py:312-323). */
 int ds_conv2d_h3_up_img(float* out, const void* images, const void* w_packed, int wshift, const float* bias,
                         const float* shift, int shift_stride, const float* res1, const float* res2,
-                        int B, int Cin, int Cout, int Hl, int Wl, float* tile_stats, void* stream);
+                        int B, int Cin, int Cout, int Hl, int Wl, float* tile_stats, unsigned* out_amax, void* stream);
 
 
 /* PUNetG norms from tile statistics: table [B, ceil16(C), 4]; table[b,c] = (mean | 0, rstd*w[c], b[c], 0) for GroupNorm(C,C)
  * (kind 0) / GroupRMSNorm(C,C) (kind 1), (0, 1, 0, 0) for no normalisation (kind 2); count = H*W.
  * commonlayers.py:766-770, 372-384, 891-899. */
 int ds_inorm_table(float* table, const float* tile_stats, const float* w, const float* b, int B, int C, int ntiles,
-                   int count, float eps, int kind, void* stream);
+                   int count, float eps, int kind, unsigned* act_amax, void* stream);
+/* act_amax (both table calls; optional, [B], zeroed): a bound on the sample's max |(x - M)*A + C| as float bits -- from
+ * |x - mean| <= sqrt(n var), |x| <= sqrt(sum x^2) -- merged with atomicMax.  Given to the consuming convolution as in_amax next to
+ * prenorm, the loader scales its activation by the sample's power of two (at no cost: the factor rides in the SiLU's own exp2 and
+ * reciprocal), so SiLU(norm(x)) stays inside the fp16x3 window whatever the affine parameters, FiLM rows or eps-dominated
+ * variances do (commonlayers.py:766-770: (x - mean)/sqrt(var + 1e-5) of a tensor of rms 1e-7 is 3e-5, not 1). */
 
 /* ADM norms from tile statistics, per sample over (C, H, W), optionally over the channel concatenation
  * of two tensors (Cb = 0: one source): kind 0 GroupNorm(1,C): (mean_b, rstd_b*w[c], b[c]); kind 1
@@ -277,7 +307,7 @@ int ds_inorm_table(float* table, const float* tile_stats, const float* w, const 
  * adm.py:306-343, 385-406, 764-766. */
 int ds_gnorm1_table(float* table, const float* stats_a, int Ca, int ntiles_a, const float* stats_b, int Cb,
                     int ntiles_b, const float* w, const float* b, const float* film_scale, const float* film_shift,
-                    int film_stride, int B, long long count, float eps, int kind, void* stream);
+                    int film_stride, int B, long long count, float eps, int kind, unsigned* act_amax, void* stream);
 /* ds_gnorm1_stats without a pass over the tensor: the pairs ds_gnorm1_apply / ds_gnorm1_apply_images take, (mean, rstd)
  * (kind 0) or (0, RMS denominator) (kind 1), recombined in fp64 from the producers' tile statistics as ds_gnorm1_table does. */
 int ds_gnorm1_stats_tiles(float* stats, const float* stats_a, int Ca, int ntiles_a, const float* stats_b, int Cb,
@@ -335,8 +365,9 @@ int ds_slice_tables(float* table, const float* tile_stats, const float* w, const
 int ds_avgpool3d(float* out, const float* x, int planes, int Do, int Ho, int Wo, void* stream);
 int ds_upsample3d(float* out, const float* x, int planes, int Di, int Hi, int Wi, void* stream);
 
-/* 1x1 convolution in the fp16x3 scheme of ds_conv2d_h3 (same epilogue terms, same domain
- * |in| < 65504).  ADM's residual projection convresidual(resample(x)) (adm.py:345-349) with the
+/* 1x1 convolution in the fp16x3 scheme of ds_conv2d_h3 (same epilogue terms, same domain and
+ * in_amax / out_amax; amax_split > 0 (a multiple of 64): channels >= amax_split report to out_amax[B + b] instead of
+ * out_amax[b] -- the attention in-projection keeps one exponent for q and k and one for v).  ADM's residual projection convresidual(resample(x)) (adm.py:345-349) with the
  * resampling folded into the load: load_mode PLAIN, UPSAMPLE2 (nearest x2, in is [B,Cin,H/2,W/2])
  * or AVGPOOL2 (AvgPool2d(2) in torch's summation order, in is [B,Cin,2H,2W]); also the attention
  * in/out projections.  Packed weights: [ceil(Cout/64)][ceil(Cin/16)][piece 2][h 2][64 co][8 ci] fp16. */
@@ -344,7 +375,8 @@ size_t ds_conv1x1_h3_packed_bytes(int Cout, int Cin);
 int ds_conv1x1_h3_pack_weights(void* packed, const float* w, int Cout, int Cin, int wshift, void* stream);
 int ds_conv1x1_h3(float* out, const float* in, const void* w_packed, int wshift, const float* bias,
                   const float* shift, int shift_stride, const float* res1, const float* res2,
-                  int B, int Cin, int Cout, int H, int W, int load_mode, float* tile_stats, void* stream);
+                  int B, int Cin, int Cout, int H, int W, int load_mode, float* tile_stats,
+                  const unsigned* in_amax, unsigned* out_amax, int amax_split, void* stream);
 
 /* Single-head self-attention over L = H*W positions, channel-major operands:
  *   qkv [B, 3E, L] (rows 0..E-1 = Q^T, E..2E-1 = K^T, 2E..3E-1 = V^T), out [B, E, L] = (softmax(Q K^T / sqrt(E)) V)^T.
@@ -363,14 +395,18 @@ int ds_token_l2_normalize(float* x, int B, int Ctot, int c0, int C, int L, float
 
 /* The same attention with both matrix products on the fp16 matrix cores in the fp16x3 scheme of
  * ds_conv2d_h3 (operands split into fp16 hi + lo, three products, fp32 accumulation and fp32
- * softmax statistics): fp32-level accuracy for |q|, |k|, |v| < 65504. Same layouts; E <= 256. */
-int ds_attention_h3(float* out, const float* qkv, int B, int E, int L, void* stream);
+ * softmax statistics): fp32-level accuracy for |q|, |k|, |v| < 65504 and not far below 1, or -- with in_amax [2][B], the
+ * per-sample max |q, k| and max |v| the in-projection left (ds_conv1x1_h3 with amax_split = 2E) -- for any magnitude: q and k
+ * are staged times 2^kqk, v times 2^kv, the logits read back times 2^-2kqk, the output times 2^-kv.  out_amax [B]: max |out[b]|,
+ * merged.  Same layouts; E <= 256. */
+int ds_attention_h3(float* out, const float* qkv, int B, int E, int L, const unsigned* in_amax, unsigned* out_amax, void* stream);
 /* The same with a caller-provided workspace of ds_attention_h3_workspace_bytes(B, E, L) bytes (16-byte aligned): a
  * pre-pass splits K and V once per sample into images that have the kernel's LDS layout, and the attention kernel
  * stages its key tiles by LDS-DMA instead of re-splitting them in every 128-query workgroup -- the form for long
  * sequences (L = 4096 tokens at a 64 x 64 bottleneck: every tile is otherwise split 32 times).  Same results bit for bit. */
 size_t ds_attention_h3_workspace_bytes(int B, int E, int L);
-int ds_attention_h3_ws(float* out, const float* qkv, void* workspace, int B, int E, int L, void* stream);
+int ds_attention_h3_ws(float* out, const float* qkv, void* workspace, int B, int E, int L, const unsigned* in_amax,
+                       unsigned* out_amax, void* stream);
 
 /* y[m, n] = act(sum_k x[m,k]*w[n,k] + b[n]); act 0 none, 1 SiLU, 2 ReLU.  torch Linear layout.
  * ResnetTimeBlock (commonlayers.py:516-522) and MLPUncond (mlp.py:30-37). b may be NULL. */

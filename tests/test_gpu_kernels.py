@@ -586,7 +586,7 @@ def test_conv_upsample_parity_fallback_and_errors(dev):
     assert rel_l2(got, want) < 3e-7
     out = torch.empty(1, 8, 24, 40, device=dev)
     rc = ops.N.lib().ds_conv2d_h3_up(out.data_ptr(), x.to(dev).data_ptr(), pw.up.data_ptr(), 0, None, None, 0, None, None,
-                                     1, 16, 8, 12, 20, 0, None, None, None)
+                                     1, 16, 8, 12, 20, 0, None, None, None, None, None)
     assert rc != 0 and b"whole number" in ops.N.lib().ds_last_error()
 
 

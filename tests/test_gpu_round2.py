@@ -559,7 +559,7 @@ def test_norm_images_and_image_input_convolution(dev, shape):
         return
     ts_a = torch.zeros(B, C, ops.conv_tile_count(H, W), 4, device=dev)
     ts_b = torch.zeros_like(ts_a)
-    want = ops.conv(act, pw, bias=bias, shift=shift, res1=res, tile_stats=ts_a)
+    want = ops.conv(act, pw, bias=bias, shift=shift, res1=res, tile_stats=ts_a, in_amax=ops.NORMALISED)   # as the networks call it
     got = ops.conv_img(img, pw, B, C, H, W, bias=bias, shift=shift, res1=res, tile_stats=ts_b)
     if exact:
         assert torch.equal(got, want) and torch.equal(ts_a, ts_b)
@@ -639,7 +639,7 @@ def test_group_norm_images_and_upsampled_residual(dev, shape):
     low = torch.randn(B, C, H // 2, W // 2, device=dev)
     ts_a = torch.zeros(B, C, ops.conv_tile_count(H, W), 4, device=dev)
     ts_b = torch.zeros_like(ts_a)
-    want = ops.conv(act, pw, bias=bias, res1=low, res1_upsampled=True, tile_stats=ts_a)
+    want = ops.conv(act, pw, bias=bias, res1=low, res1_upsampled=True, tile_stats=ts_a, in_amax=ops.NORMALISED)
     got = ops.conv_img(img, pw, B, C, H, W, bias=bias, res1=low, res1_upsampled=True, tile_stats=ts_b)
     assert torch.equal(got, want) and torch.equal(ts_a, ts_b)
     with pytest.raises(ValueError, match="res1_upsampled"):
@@ -734,7 +734,7 @@ def test_upsampling_convolution_with_image_input(dev, shape):
     ts_a = torch.zeros(B, Co, ops.conv_tile_count(2 * Hl, 2 * Wl), 4, device=dev)
     ts_b = torch.zeros_like(ts_a)
     from diffsci_amd._native import DS_LOAD_UPSAMPLE2
-    want = ops.conv(a, pw, bias=bias, shift=shift, res1=res, load_mode=DS_LOAD_UPSAMPLE2, tile_stats=ts_a)
+    want = ops.conv(a, pw, bias=bias, shift=shift, res1=res, load_mode=DS_LOAD_UPSAMPLE2, tile_stats=ts_a, in_amax=ops.NORMALISED)
     got = ops.conv_up_img(img, pw, B, C, Hl, Wl, bias=bias, shift=shift, res1=res, tile_stats=ts_b)
     assert torch.equal(got, want) and torch.equal(ts_a, ts_b)
     assert not ops.conv_up_img_supported(pw, 12, 20)

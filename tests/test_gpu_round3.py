@@ -1,0 +1,265 @@
+"""Round 3 on a real MI355X: the fp16x3 kernels over the whole fp32 range of magnitudes.
+
+fp16 has five exponent bits; the reference's fp32 convolutions take raw user fields (punetg.py:719-735) and c_in = 1
+parameterisations (preconditioners.py:139-161) at any magnitude.  Every launch whose input is not normalised by construction
+takes a per-sample activation exponent (include/diffsci_hip.h: in_amax / out_amax); these tests scale WHOLE inputs by 2^-k
+(no O(1) bias, shift or residual to hide behind) and hold the results to the same fp64 bounds as unit-scale data."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import punetg_ref  # noqa: E402
+from tests.golden_util import rel_l2  # noqa: E402
+
+REL = 1e-5
+SHIFTS = [0, 8, 16, 24, 40, -20, -60]          # the whole input times 2^-k: 4e-3 .. 9e-13, and 1e6, 1e18
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from diffsci_amd import ops
+    return ops
+
+
+@pytest.fixture(scope="module")
+def M():
+    import diffsci_amd.models as M
+    return M
+
+
+def _bits_of_max(t):
+    """float bits of the per-sample max |t| (what an out_amax row must hold)."""
+    return t.reshape(t.shape[0], -1).abs().amax(dim=1).contiguous().view(torch.int32)
+
+
+CONV_CASES = [
+    # B, Cin, Cout, H, W, ks, mode (0 plain, 1 max-pool, 2 nearest-up, 3 avg-pool [1x1])
+    (2, 32, 64, 16, 32, 3, 0),
+    (1, 64, 64, 16, 16, 3, 1),       # DownSampler
+    (2, 64, 32, 16, 64, 3, 2),       # UpSampler on the parity kernels (whole 8 x 32 tiles at low resolution)
+    (1, 40, 24, 18, 26, 3, 2),       # UpSampler on the gather loader (ragged)
+    (1, 1, 8, 16, 32, 3, 0),         # input layer
+    (2, 19, 70, 9, 13, 3, 0),        # nothing divides anything
+    (2, 32, 96, 8, 8, 1, 0),         # attention in-projection
+    (2, 40, 72, 12, 20, 1, 3),       # ADM convresidual(AvgPool2d(2)(x))
+    (2, 48, 64, 16, 32, 1, 2),       # ADM convresidual(nearest x2 (x))
+]
+
+
+@pytest.mark.parametrize("k", SHIFTS)
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_fp16x3_convolutions_on_scaled_inputs(dev, ops, case, k):
+    B, Cin, Cout, H, W, ks, mode = case
+    g = torch.Generator().manual_seed(hash(case) % 1000 + 7)
+    Hin, Win = (2 * H, 2 * W) if mode in (1, 3) else ((H // 2, W // 2) if mode == 2 else (H, W))
+    x = torch.randn(B, Cin, Hin, Win, generator=g) * 2.0 ** -k
+    w = torch.randn(Cout, Cin, ks, ks, generator=g) / math.sqrt(Cin * ks * ks)
+    pool = {1: lambda t: F.max_pool2d(t, 2), 3: lambda t: F.avg_pool2d(t, 2), 2: lambda t: F.interpolate(t, scale_factor=2.0, mode="nearest")}
+    src = pool[mode](x) if mode else x
+    want = F.conv2d(src.double(), w.double(), padding="same")
+    ref32 = F.conv2d(src, w, padding="same")
+    pw = ops.pack_conv(w.to(dev), "fp16x3", upsampled=(mode == 2 and ks == 3))
+    slots = ops.amax_new(B, dev)
+    got = ops.conv(x.to(dev), pw, load_mode=mode, out_amax=slots)          # in_amax=None: reduced by ops
+    rel, rel32 = rel_l2(got.cpu(), want), rel_l2(ref32, want)
+    assert rel <= max(3 * rel32, 3e-7), (rel, rel32)
+    err, err32 = (got.cpu().double() - want).abs().max().item(), (ref32.double() - want).abs().max().item()
+    assert err <= max(4 * err32, 1e-6 * want.abs().max().item()), (err, err32)
+    # the epilogue's record of its own output, for the next raw-input launch
+    assert torch.equal(slots, _bits_of_max(got))
+    # the producer's row gives the same result as the reduction, bit for bit
+    row = ops.absmax_rows(x.to(dev))
+    assert torch.equal(row, _bits_of_max(x.to(dev)))
+    again = ops.conv(x.to(dev), pw, load_mode=mode, in_amax=row)
+    assert torch.equal(again, got)
+    if k >= 24:
+        # what the exponent is for: without it the same launch is far outside the tolerance
+        bare = ops.conv(x.to(dev), pw, load_mode=mode, in_amax=ops.NORMALISED)
+        assert rel_l2(bare.cpu(), want) > 1e-3
+
+
+def test_activation_exponents_are_per_sample(dev, ops):
+    """Samples of very different magnitudes in one batch: each result equals the sample run alone, bit for bit."""
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(4, 32, 16, 32, generator=g)
+    x[1] *= 2.0 ** -30
+    x[2] *= 2.0 ** 25
+    x[3] = 0
+    w = torch.randn(64, 32, 3, 3, generator=g) / 17
+    bias = torch.randn(64, generator=g)
+    pw = ops.pack_conv(w.to(dev), "fp16x3")
+    full = ops.conv(x.to(dev), pw, bias=bias.to(dev))
+    for b in range(4):
+        one = ops.conv(x[b:b + 1].to(dev), pw, bias=bias.to(dev))
+        assert torch.equal(full[b:b + 1], one), b
+    want = F.conv2d(x.double(), w.double(), bias.double(), padding="same")
+    for b in range(3):
+        assert rel_l2(full[b].cpu(), want[b]) < 3e-7, b
+    assert torch.equal(full[3].cpu(), bias[:, None, None].expand(64, 16, 32))
+
+
+@pytest.mark.parametrize("k", [0, 8, 16, 24, 40])
+@pytest.mark.parametrize("shape", [(2, 32, 32, 32), (1, 64, 16, 64)])
+def test_image_input_routes_on_scaled_inputs(dev, ops, shape, k):
+    """The norm-fed launches: the norm resets the scale, so the image-input convolution and the parity kernels see the same
+    activation whatever the magnitude of x (up to eps inside the variance, which the fp64 reference shares)."""
+    B, C, H, W = shape
+    g = torch.Generator().manual_seed(5 + k)
+    x = (torch.randn(B, C, H, W, generator=g) + 0.3) * 2.0 ** -k
+    gw, gb = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.1
+    w = torch.randn(C, C, 3, 3, generator=g) / math.sqrt(9 * C)
+    a64 = F.silu(F.group_norm(x.double(), C, gw.double(), gb.double(), eps=1e-5))
+    a32 = F.silu(F.group_norm(x, C, gw, gb, eps=1e-5))
+    img = ops.inorm_silu_images(x.to(dev), gw.to(dev), gb.to(dev), 0, eps=1e-5)
+    pw = ops.pack_conv(w.to(dev), "fp16x3", upsampled=True)
+    got = ops.conv_img(img, pw, B, C, H, W).cpu()
+    want, ref32 = F.conv2d(a64, w.double(), padding="same"), F.conv2d(a32, w, padding="same")
+    assert rel_l2(got, want) <= max(3 * rel_l2(ref32, want), 1e-6)
+    if ops.conv_up_img_supported(pw, H, W):
+        up = lambda t: F.interpolate(t, scale_factor=2.0, mode="nearest")          # noqa: E731
+        got = ops.conv_up_img(img, pw, B, C, H, W).cpu()
+        want, ref32 = F.conv2d(up(a64), w.double(), padding="same"), F.conv2d(up(a32), w, padding="same")
+        assert rel_l2(got, want) <= max(3 * rel_l2(ref32, want), 1e-6)
+
+
+@pytest.mark.parametrize("k", [0, 10, 24, 40, -12, -30])
+@pytest.mark.parametrize("E,L,B", [(64, 256, 2), (256, 1024, 1), (128, 2048, 1), (32, 96, 3)])
+def test_attention_on_scaled_operands(dev, ops, E, L, B, k):
+    """softmax(q k^T / sqrt(E)) v with q, k, v times 2^-k: the logits shrink (a near-uniform softmax) or blow up (a one-hot one);
+    the output carries v's scale either way."""
+    g = torch.Generator().manual_seed(3)
+    qkv = torch.randn(B, 3 * E, L, generator=g) * 2.0 ** -k
+    if k < 0:
+        qkv[:, :2 * E] *= 2.0 ** k                        # keep the logits where they are: only v carries the factor
+    q, kk, v = (qkv[:, i * E:(i + 1) * E].double().transpose(1, 2) for i in range(3))
+    want = (torch.softmax(q @ kk.transpose(1, 2) / math.sqrt(E), dim=-1) @ v).transpose(1, 2)
+    q, kk, v = (t.float() for t in (q, kk, v))
+    ref32 = (torch.softmax(q @ kk.transpose(1, 2) / math.sqrt(E), dim=-1) @ v).transpose(1, 2)
+    slots = ops.amax_new(B, dev)
+    got = ops.attention(qkv.to(dev), E, precision="fp16x3", out_amax=slots)
+    assert rel_l2(got.cpu(), want) <= max(4 * rel_l2(ref32, want), 1e-6)
+    assert torch.equal(slots, _bits_of_max(got))
+
+
+def _zero_bias_sd(cfg, seed):
+    """Reference-initialised weights with the convolution biases removed: the magnitude of the input is then the magnitude of
+    the first activations (with biases a tiny input drowns in them and any arithmetic passes)."""
+    sd = punetg_ref.random_state_dict(cfg, seed=seed)
+    for k in sd:
+        if k.endswith(".bias") and (k.startswith("convin") or "conv1.bias" in k or "conv2.bias" in k or "samplers" in k):
+            sd[k] = torch.zeros_like(sd[k])
+    return sd
+
+
+@pytest.mark.parametrize("k", [0, 14, 27, -14])
+def test_network_on_small_and_large_inputs(M, dev, k):
+    """PUNetG on inputs of magnitude 2^-k (6e-5, 7e-9; 1.6e4), biases zeroed: against the CPU oracle in fp32 and in fp64."""
+    cfg = punetg_ref.default_config(model_channels=32)
+    sd = _zero_bias_sd(cfg, 3)
+    net = M.PUNetG(M.PUNetGConfig(model_channels=32))
+    net.load_state_dict(sd, strict=True)
+    net = net.to(dev).eval()
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(2, 1, 32, 32, generator=g) * 2.0 ** -k
+    t = torch.tensor([0.4, -1.1])
+    got = net(x.to(dev), t.to(dev)).cpu()
+    with torch.inference_mode():
+        ref = punetg_ref.punetg_forward(sd, cfg, x, t)
+        ref64 = punetg_ref.punetg_forward({n: w.double() for n, w in sd.items()}, cfg, x.double(), t.double())
+    assert rel_l2(got, ref) < REL
+    assert rel_l2(got, ref64) <= max(4 * rel_l2(ref, ref64), 2e-6)
+
+
+def test_conditional_network_with_a_tiny_field(M, dev):
+    """PUNetGCond (punetg.py:719-735) with x at unit scale and a channel field of magnitude 1e-8.
+    (a) reference-initialised weights: the field's contribution is 1e-8 of the output; one exponent per sample serves.
+    (b) the adversarial checkpoint: the field's input weights are 1e8 times larger, so the field matters as much as x.  One
+        exponent per sample cannot serve both channels: the input layer's channel reduction raises the flag, the guard moves that
+        layer to the exact-fp32 kernel (a warning, once) and the result matches the oracle."""
+    import warnings
+    cfg = punetg_ref.default_config(model_channels=16, input_channels=2)
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(2, 1, 32, 32, generator=g)
+    field = torch.randn(2, 1, 32, 32, generator=g) * 1e-8
+    t = torch.tensor([0.2, 0.9])
+    for adversarial in (False, True):
+        sd = punetg_ref.random_state_dict(cfg, seed=4)
+        if adversarial:
+            sd["convin.weight"][:, 1] *= 1e8
+        net = M.nets.PUNetGCond(M.PUNetGConfig(model_channels=16, input_channels=2, output_channels=1), channel_conditional_items=["f"])
+        net.load_state_dict(sd, strict=True)
+        net = net.to(dev).eval()
+        with torch.inference_mode():
+            want = punetg_ref.punetg_forward(sd, cfg, torch.cat([x, field], dim=1), t)
+            base = punetg_ref.punetg_forward(sd, cfg, torch.cat([x, torch.zeros_like(field)], dim=1), t)
+        with warnings.catch_warnings(record=True) as rec:
+            warnings.simplefilter("always")
+            got = net(x.to(dev), t.to(dev), {"f": field.to(dev)}).cpu()
+        assert rel_l2(got, want) < REL
+        if adversarial:
+            assert rel_l2(want, base) > 0.05                                  # the field matters ...
+            assert net.exact_input_layer and any("exact-fp32" in str(r.message) for r in rec)
+            module = M.KarrasModule(net, M.KarrasModuleConfig.from_edm(), conditional=True)
+            wn = torch.randn(2, 1, 32, 32, generator=g)
+            eager_or_graph = []
+            for use_graph in (False, True):
+                module.use_graph = use_graph
+                eager_or_graph.append(module.propagate_white_noise(wn.to(dev), y={"f": field.to(dev)}, nsteps=3).cpu())
+            assert torch.equal(*eager_or_graph)
+        else:
+            assert not net.exact_input_layer and not rec
+
+
+def test_sampler_raises_the_input_flag_inside_a_captured_run(M, dev):
+    """The same disparity met first inside a captured sampling run: the run is repeated once with the exact input layer."""
+    import warnings
+    from oracle import karras_ref as K
+    cfg = punetg_ref.default_config(model_channels=8, input_channels=2)
+    sd = punetg_ref.random_state_dict(cfg, seed=6)
+    sd["convin.weight"][:, 1] *= 1e8
+    net = M.nets.PUNetGCond(M.PUNetGConfig(model_channels=8, input_channels=2, output_channels=1), channel_conditional_items=["f"])
+    net.load_state_dict(sd, strict=True)
+    module = M.KarrasModule(net.to(dev).eval(), M.KarrasModuleConfig.from_edm(), conditional=True)
+    g = torch.Generator().manual_seed(2)
+    wn = torch.randn(2, 1, 16, 16, generator=g)
+    field = torch.randn(1, 1, 16, 16, generator=g) * 1e-8
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        got = module.propagate_white_noise(wn.to(dev), y={"f": field.to(dev)}, nsteps=4).cpu()
+    assert net.exact_input_layer and sum("exact-fp32" in str(r.message) for r in rec) == 1
+    ref = punetg_ref.make_net(sd, cfg)
+    want = K.propagate_white_noise(lambda xx, tt, y=None: ref(torch.cat([xx, field.expand(xx.shape[0], -1, -1, -1)], dim=1), tt),
+                                   wn, 4)
+    assert rel_l2(got, want) < 5e-5
+
+
+@pytest.mark.parametrize("std", [1e-4, 1e-8])
+def test_null_preconditioner_with_small_data(M, dev, std):
+    """c_in = 1 (NullPreconditioner, preconditioners.py:139-161): the network sees the state itself, here of std 1e-4 / 1e-8
+    -- the denoiser of the reference's own toy test protocol, on a UNet with its biases removed."""
+    from oracle import karras_ref as K
+    cfg = punetg_ref.default_config(model_channels=16)
+    sd = _zero_bias_sd(cfg, 9)
+    net = M.PUNetG(M.PUNetGConfig(model_channels=16))
+    net.load_state_dict(sd, strict=True)
+    conf = M.KarrasModuleConfig.from_edm()
+    conf.preconditioner = M.karras.NullPreconditioner()
+    module = M.KarrasModule(net.to(dev).eval(), conf)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2, 1, 32, 32, generator=g) * std
+    sigma = torch.tensor([0.5, 2.0])
+    got = module.get_denoiser(x.to(dev), sigma.to(dev))[0].cpu()
+    ref = punetg_ref.make_net(sd, cfg)
+    with torch.inference_mode():
+        want = K.denoiser(ref, x, sigma, precond=K.null_precond)
+    assert rel_l2(got, want) < REL

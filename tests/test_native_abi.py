@@ -37,7 +37,7 @@ def test_ctypes_binding_matches_header(built_lib):
     from diffsci_amd import _native
     assert _native.exported_symbols() == header_functions()
     L = _native.lib()
-    assert L.ds_version() == 2
+    assert L.ds_version() == _native.ABI_VERSION == 3
     assert L.ds_last_error() is not None
 
 
