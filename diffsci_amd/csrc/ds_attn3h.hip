@@ -111,7 +111,7 @@ __global__ __launch_bounds__(NT) void k_attn3h(float* out, const float* __restri
   const int ak = ds_epi::act_exponent_of(ds_epi::act_bits(in_amax, b), -60, 60);
   const int av = ds_epi::act_exponent_of(ds_epi::act_bits(in_amax, (int)gridDim.y + b), -120, 120);
   const float a_in = ds_epi::pow2f(ak), v_in = ds_epi::pow2f(av);
-  const float s_log2e = ds_epi::mul_pow2(LOG2E, -2 * ak), s_un = ds_epi::pow2f(-2 * ak), o_un = ds_epi::pow2f(-av);
+  const float s_un = ds_epi::pow2f(-2 * ak), o_un = ds_epi::pow2f(-av);
   scale = ds_epi::mul_pow2(scale, ak);
 
   // ---- Q fragments: lane (query li, half lh) holds d = 16s + 8lh + 0..7, scaled, split ----
@@ -276,10 +276,14 @@ __global__ __launch_bounds__(NT) void k_attn3h(float* out, const float* __restri
           for (int r = 0; r < 16; ++r) O[t][r] *= alpha;
       }
       float rs = 0.f;
-      const float mneg = -m_run * LOG2E;
+      const float mneg = -m_run;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        S[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(S[r], s_log2e, mneg));   // e^(S - m): one FMA and the hardware exp2
+        // e^(S - m): the difference FIRST (one fma with the logits' power of two: exact for nearby values), then log2(e) and the
+        // hardware exp2.  [fma(S, log2 e, -m log2 e) saves an instruction but rounds m log2 e on its own: at logits of 1e12 -- an
+        // untrained network's -- that is off by 1e5, the exponent overflows and the sample turns into NaN where the reference's
+        // softmax is a finite one-hot.]
+        S[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(S[r], s_un, mneg) * LOG2E);
         rs += S[r];
       }
       rs += __shfl_xor(rs, 32, 64);
@@ -390,10 +394,14 @@ __global__ __launch_bounds__(NT) void k_attn3h(float* out, const float* __restri
           for (int r = 0; r < 16; ++r) O[t][r] *= alpha;
       }
       float rs = 0.f;
-      const float mneg = -m_run * LOG2E;
+      const float mneg = -m_run;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        S[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(S[r], s_log2e, mneg));   // e^(S - m): one FMA and the hardware exp2
+        // e^(S - m): the difference FIRST (one fma with the logits' power of two: exact for nearby values), then log2(e) and the
+        // hardware exp2.  [fma(S, log2 e, -m log2 e) saves an instruction but rounds m log2 e on its own: at logits of 1e12 -- an
+        // untrained network's -- that is off by 1e5, the exponent overflows and the sample turns into NaN where the reference's
+        // softmax is a finite one-hot.]
+        S[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(S[r], s_un, mneg) * LOG2E);
         rs += S[r];
       }
       rs += __shfl_xor(rs, 32, 64);

@@ -151,6 +151,27 @@ def test_attention_on_scaled_operands(dev, ops, E, L, B, k):
     assert torch.equal(slots, _bits_of_max(got))
 
 
+@pytest.mark.parametrize("mag", [3e2, 5e5])
+def test_attention_with_huge_logits(dev, ops, mag):
+    """q, k of magnitude 5e5 (an untrained network's residual stream): logits ~1e12 with an fp32 ulp of 65536.  The reference's
+    softmax subtracts the row maximum first and stays finite (a one-hot, up to ties inside an ulp); so must the kernel."""
+    E, L, B = 32, 64, 2
+    g = torch.Generator().manual_seed(17)
+    qkv = torch.randn(B, 3 * E, L, generator=g)
+    qkv[:, :2 * E] *= mag
+    got = ops.attention(qkv.to(dev), E, precision="fp16x3").cpu()
+    assert torch.isfinite(got).all()
+    q, kk, v = (qkv[:, i * E:(i + 1) * E].double().transpose(1, 2) for i in range(3))
+    want = (torch.softmax(q @ kk.transpose(1, 2) / math.sqrt(E), dim=-1) @ v).transpose(1, 2)
+    # rows whose two largest logits are closer than fp32 can tell apart may pick either key: compare the others
+    S = q @ kk.transpose(1, 2) / math.sqrt(E)
+    top2 = S.topk(2, dim=-1).values
+    clear = (top2[..., 0] - top2[..., 1]) > 1e-5 * top2[..., 0].abs() + 20.0
+    assert clear.float().mean() > 0.9
+    err = (got.double() - want).abs().transpose(1, 2)[clear]
+    assert err.max() < 1e-4
+
+
 def _zero_bias_sd(cfg, seed):
     """Reference-initialised weights with the convolution biases removed: the magnitude of the input is then the magnitude of
     the first activations (with biases a tiny input drowns in them and any arithmetic passes)."""
