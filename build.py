@@ -19,7 +19,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -ffp-contract=off: the stepper / norm kernels reproduce the reference's one-rounding-per-op
 # arithmetic; MFMA kernels are unaffected (their FMAs are the matrix instruction's own).
 FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-std=c++17",
-         "-Wall", "-Wno-unused-function"]
+         "-Wall", "-Wno-unused-function"] + os.environ.get("DS_EXTRA_HIPCC_FLAGS", "").split()     # measurement builds (-DDS_...=1)
 # The fp16x3 convolution kernels: no SLP vectorisation.  It packs the epilogue's pairs of 16-lane DPP reductions into v_pk_add_f32,
 # which cannot carry the DPP modifier (two v_mov_b32_dpp + one packed add per step instead of two v_add_f32_dpp), and packed fp32
 # operations issue no faster than their two scalar halves on gfx950.  Same-box A/B: 77.4 -> 78.5 samples/s, launches 223.4 -> 219.3 us
