@@ -59,6 +59,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-other-precisions", action="store_true", help="skip the bf16x6 / exact-fp32 legs of the line")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the config-3 (ADM-128) and config-5-share legs of the line")
     ap.add_argument("--fuse-max-cot", type=int, default=None, help="fuse norms only in layers with Cout/64 <= this")
     ap.add_argument("--no-up-parity", action="store_true", help="UpSampler convolutions through the generic gather loader")
     ap.add_argument("--no-direct-out", action="store_true", help="output layer on the MFMA kernel (Cout padded to 64)")
@@ -343,6 +344,125 @@ def other_precisions(args, dev, wn):
     return out
 
 
+class _FlopCounter:
+    """Algorithmic FLOPs of one network evaluation: hooks on the convolution / attention entry points of diffsci_amd.ops during
+    ONE eager forward (true channel counts, no padding; the parity kernels are counted as the 3x3 convolution they replace)."""
+
+    def __init__(self, ops):
+        self.ops, self.flops, self.by = ops, 0.0, {}
+        self.saved = {}
+
+    def _add(self, kind, f):
+        self.flops += f
+        self.by[kind] = self.by.get(kind, 0.0) + f
+
+    def __enter__(self):
+        ops, me = self.ops, self
+
+        def conv2d(x, w_packed, Cout, ks, *a, **k):
+            out = me.saved["conv2d"](x, w_packed, Cout, ks, *a, **k)
+            me._add("conv3x3" if ks == 3 else "conv1x1", 2.0 * out.shape[0] * Cout * x.shape[1] * ks * ks * out.shape[2] * out.shape[3])
+            return out
+
+        def conv_img(images, pw, B, Cin, H, W, *a, **k):
+            me._add("conv3x3", 2.0 * B * pw.Cout * Cin * 9 * H * W)
+            return me.saved["conv_img"](images, pw, B, Cin, H, W, *a, **k)
+
+        def conv_up_img(images, pw, B, Cin, Hl, Wl, *a, **k):
+            me._add("conv3x3", 2.0 * B * pw.Cout * Cin * 9 * 4 * Hl * Wl)
+            return me.saved["conv_up_img"](images, pw, B, Cin, Hl, Wl, *a, **k)
+
+        def conv_direct(x, w, *a, **k):
+            me._add("conv3x3", 2.0 * x.shape[0] * w.shape[0] * x.shape[1] * 9 * x.shape[2] * x.shape[3])
+            return me.saved["conv_direct"](x, w, *a, **k)
+
+        def attention(qkv, E, *a, **k):
+            me._add("attention", 4.0 * qkv.shape[0] * qkv.shape[2] * qkv.shape[2] * E)
+            return me.saved["attention"](qkv, E, *a, **k)
+
+        for name, fn in (("conv2d", conv2d), ("conv_img", conv_img), ("conv_up_img", conv_up_img), ("conv_direct", conv_direct),
+                         ("attention", attention)):
+            self.saved[name] = getattr(ops, name)
+            setattr(ops, name, fn)
+        return self
+
+    def __exit__(self, *exc):
+        for name, fn in self.saved.items():
+            setattr(self.ops, name, fn)
+        return False
+
+
+def other_configs(dev):
+    """BASELINE.json configs[2] and configs[4] (one GPU's share) on this box, after the timed region: one capture run and ONE
+    timed run each (the driver sees them next to the headline; tools/bench_adm.py / bench_cfg5.py are the stand-alone forms).
+    `eval_equiv` prices the WHOLE evaluation -- norms, attention, resampling, step kernels included -- against the fp16x3
+    convolution peak with the network's algorithmic FLOPs: a lower bound on its dominant kernel's own fraction."""
+    import diffsci_amd.models as M
+    from diffsci_amd import ops
+    out = {}
+
+    def timed(module, wn, evals, **kw):
+        t0 = time.perf_counter()
+        o = module.propagate_white_noise(wn, **kw)                  # eager pass + capture + first replay
+        torch.cuda.synchronize()
+        first = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        o = module.propagate_white_noise(wn, **kw)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        assert bool(torch.isfinite(o).all())
+        return dt, first
+
+    def price(net, x, t, y, dt, evals, per_eval_batch):
+        with torch.inference_mode(), _FlopCounter(ops) as fc:
+            net(x, t, y) if y is not None else net(x, t)
+        tf = fc.flops * (per_eval_batch / x.shape[0]) / 1e12          # TFLOP per evaluation of the sampler's batch
+        ach = tf / (dt / evals)
+        return {"algorithmic_TFLOP_per_eval": round(tf, 3), "achieved_TFLOPs_equiv": round(ach, 1), "peak": round(BF16_PEAK_TFLOPS / 3.0, 1),
+                "frac": round(ach / (BF16_PEAK_TFLOPS / 3.0), 4), "flop_share": {k: round(v / fc.flops, 3) for k, v in fc.by.items()}}
+
+    try:
+        torch.manual_seed(0)
+        c, B, S, N = 128, 32, 256, 50
+        net = M.ADM(M.ADMConfig(input_channels=3, output_channels=3, model_channels=c, time_embed_dim=c, output_embed_dim=4 * c,
+                                channel_expansion=[1, 2, 4, 4], skip_integration_type="concat"))
+        module = M.KarrasModule(net, M.KarrasModuleConfig.from_edm()).to(dev).eval()
+        wn = torch.randn(B, 3, S, S, device=dev)
+        evals = 2 * N - 1
+        dt, first = timed(module, wn, evals, nsteps=N, integrator="karras")
+        out["config3_adm128"] = {
+            "workload": f"ADM-{c} (concat skips, attention at 16^2), [{B},3,{S},{S}], {N}-step sigma-churn (KarrasIntegrator, noise generated in the kernels)",
+            "samples/s": round(B / dt, 3), "ms_per_eval": round(1e3 * dt / evals, 2), "first_call_s": round(first, 2),
+            "dominant_kernel": "k_conv3h / k_convup (fp16x3 3x3 convolutions: folded norm loader, image input, parity upsampling)",
+            "eval_equiv": price(net, wn[:2], torch.tensor([0.5, 1.0], device=dev), None, dt, evals, B)}
+        del module, net, wn
+        torch.cuda.empty_cache()
+    except Exception as e:                                   # reporting only: never fail the bench line on it
+        out["config3_adm128"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+    try:
+        torch.manual_seed(0)
+        B, S, N, g = 16, 256, 100, 2.0
+        net = M.PUNetG(M.PUNetGConfig(input_channels=4, output_channels=4), conditional_embedding=M.nets.PorosityEmbedder(dembed=64))
+        module = M.KarrasModule(net, M.KarrasModuleConfig.from_edm(), conditional=True).to(dev).eval()
+        wn = torch.randn(B, 4, S, S, device=dev)
+        y = {"porosity": torch.tensor([0.2], device=dev)}
+        evals = 2 * N - 1                                                # guided evaluations: each is one launch set on batch 2B
+        dt, first = timed(module, wn, evals, y=y, guidance=g, nsteps=N)
+        out["config5_share_cond_punetg64"] = {
+            "workload": f"conditional PUNetG-64 (PorosityEmbedder), [{B},4,{S},{S}] per GPU, classifier-free guidance {g} "
+                        f"(conditional + unconditional evaluation as one of batch {2 * B}), {N}-step Heun",
+            "samples/s": round(B / dt, 3), "ms_per_eval": round(1e3 * dt / evals, 2), "network_calls": 2 * evals,
+            "first_call_s": round(first, 2),
+            "dominant_kernel": "k_conv3h (fp16x3 3x3 convolutions) -- attention at L = 4096 (k_attn3h) is ~10 %",
+            "eval_equiv": price(net, wn[:2], torch.tensor([0.5, 1.0], device=dev), {"porosity": torch.tensor([0.2], device=dev)},
+                                dt, evals, 2 * B)}
+        del module, net, wn
+        torch.cuda.empty_cache()
+    except Exception as e:
+        out["config5_share_cond_punetg64"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+    return out
+
+
 def cpu_baseline(sd, cfg, args):
     """The CPU oracle (a port: the reference itself cannot travel) on this host's cores, on a
     bounded sample of the same workload."""
@@ -468,6 +588,11 @@ def main():
         if world == 1 and not args.no_other_precisions and args.precision == "fp16x3":
             line["other_precisions"] = other_precisions(args, dev, noise[0])
             print(f"[bench] other precisions {line['other_precisions']}", file=sys.stderr, flush=True)
+        if world == 1 and not args.no_other_configs and args.precision == "fp16x3":
+            del module
+            torch.cuda.empty_cache()
+            line["other_configs"] = other_configs(dev)
+            print(f"[bench] other configs {line['other_configs']}", file=sys.stderr, flush=True)
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(sd, cfg, args)
         print(json.dumps(line), flush=True)
