@@ -57,6 +57,9 @@ def parse():
     ap.add_argument("--size", type=int, default=128)
     ap.add_argument("--channels", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="go through the multi-rank code (RCCL process group, gather, barriers, all-reduce of the time) even with one rank "
+                         "(also DIFFSCI_BENCH_FORCE_DIST=1): what one GPU can exercise of the N > 1 path")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-other-precisions", action="store_true", help="skip the bf16x6 / exact-fp32 legs of the line")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the config-3 (ADM-128) and config-5-share legs of the line")
@@ -488,15 +491,15 @@ def cpu_baseline(sd, cfg, args):
                       f"scaled by {full}/{evals} evaluations to the {args.nsteps}-step workload"}
 
 
-def launcher_command(argv, n, port):
+def launcher_command(argv, n, port, script=None):
     """The command `python bench.py --gpus N` runs for itself when no launcher started it: one rank per GPU through
     torch.distributed.run on this node (the reference's multi-GPU sampler spawns its own workers too,
     stochasticity_paper/scripts/test-diffusion-cifar10karras-colormap-parallel.py:191-291)."""
     return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
-            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+            "--master-addr", "127.0.0.1", "--master-port", str(port), script or os.path.abspath(__file__)] + list(argv)
 
 
-def self_launch(args):
+def self_launch(args, argv=None, script=None):
     """Parent of a multi-rank run started without a launcher.  Runs BEFORE anything touches the GPU in this process
     (a process that has initialised HIP must not be replaced or forked into ranks); relays the children's output
     (rank 0 prints the JSON line) and exits with their status."""
@@ -508,7 +511,7 @@ def self_launch(args):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL across processes needs it on this driver
     env.setdefault("OMP_NUM_THREADS", str(max(1, host_cores() // max(1, args.gpus))))
-    cmd = launcher_command(sys.argv[1:], args.gpus, port)
+    cmd = launcher_command(sys.argv[1:] if argv is None else argv, args.gpus, port, script)
     print(f"[bench] starting {args.gpus} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
     return subprocess.call(cmd, env=env)
 
@@ -525,9 +528,16 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    force = args.force_dist or os.environ.get("DIFFSCI_BENCH_FORCE_DIST") == "1"
+    if world > 1 or force:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "WORLD_SIZE" not in os.environ:                 # one rank, no launcher: a rendezvous of our own
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ.setdefault("MASTER_PORT", str(sk.getsockname()[1]))
+            os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK=str(local_rank))
         dist.init_process_group("nccl", device_id=dev)
     from diffsci_amd.parallel import gather_samples, global_white_noise, shard_rows
     module, sd, cfg = build_module(args, dev)
@@ -543,7 +553,7 @@ def main():
 
     def one_step(i):
         out = module.propagate_white_noise(noise[i], nsteps=args.nsteps)
-        return gather_samples(out) if world > 1 else out
+        return gather_samples(out) if dist is not None else out
 
     for i in range(args.warmup):
         one_step(args.steps + i)

@@ -18,6 +18,34 @@ def shard_rows(total, world, rank):
 
 
 _CHUNK_FLOATS = 1 << 24        # 64 MiB of throw-away noise at a time while skipping other ranks' rows
+_SKIP_AHEAD_OK = None          # once per process: does this torch's CPU normal fill skip ahead the way the chunked draw assumes?
+
+
+def skip_ahead_matches_full_draw():
+    """The chunked draw below leans on an implementation detail of the installed torch (CPU normal_fill: one uniform per
+    element, Box-Muller in aligned blocks of 16); a torch upgrade that changes it would hand every rank VALID but DIFFERENT
+    noise than the unsharded draw, silently.  So the first use in a process draws a small case both ways (rows of 16, 32 and
+    48 floats, skipped in one and in several chunks) and the chunked path is used only if they agree bit for bit."""
+    global _SKIP_AHEAD_OK
+    if _SKIP_AHEAD_OK is None:
+        ok = True
+        for per_row, total, lo, hi, chunk in ((16, 5, 2, 4, 1), (32, 7, 3, 7, 2), (48, 4, 1, 2, 8)):
+            g = torch.Generator()
+            g.manual_seed(12345 + per_row)
+            full = torch.randn(total, per_row, generator=g)[lo:hi]
+            g.manual_seed(12345 + per_row)
+            r = 0
+            while r < lo:
+                n = min(chunk, lo - r)
+                torch.randn(n, per_row, generator=g)
+                r += n
+            ok = ok and torch.equal(torch.randn(hi - lo, per_row, generator=g), full)
+        _SKIP_AHEAD_OK = bool(ok)
+        if not ok:
+            import warnings
+            warnings.warn("diffsci_amd.parallel: this torch's CPU normal fill does not skip ahead row by row; every rank draws the "
+                          "full global noise tensor and keeps its rows (same values, more host memory)", RuntimeWarning)
+    return _SKIP_AHEAD_OK
 
 
 def global_white_noise(total, shape, seed, rows=None):
@@ -37,7 +65,7 @@ def global_white_noise(total, shape, seed, rows=None):
     per_row = 1
     for d in shape:
         per_row *= int(d)
-    if per_row % 16 or per_row == 0 or total * per_row < 16:
+    if per_row % 16 or per_row == 0 or total * per_row < 16 or not skip_ahead_matches_full_draw():
         return torch.randn(total, *shape, generator=g)[lo:hi].contiguous()
     chunk_rows = max(1, _CHUNK_FLOATS // per_row)
     r = 0

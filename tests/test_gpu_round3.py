@@ -284,3 +284,33 @@ def test_null_preconditioner_with_small_data(M, dev, std):
     with torch.inference_mode():
         want = K.denoiser(ref, x, sigma, precond=K.null_precond)
     assert rel_l2(got, want) < REL
+
+
+@pytest.mark.parametrize("launcher", [True, False])
+def test_bench_multi_rank_code_on_one_rank(launcher):
+    """What one GPU can exercise of bench.py's N > 1 path: init_process_group("nccl") (RCCL), the row shard of the global
+    noise, gather_samples (an all_gather_into_tensor on the GPU), the barriers and the all_reduce(MAX) of the time -- once
+    under the driver's launcher line (torch.distributed.run, one rank) and once with the in-process rendezvous of --force-dist."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tail = ["--gpus", "1", "--force-dist", "--steps", "1", "--warmup", "0", "--nsteps", "4", "--batch", "8", "--size", "64",
+            "--no-cpu-baseline", "--no-other-precisions", "--no-other-configs"]
+    if launcher:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.join(root, "bench.py")] + tail
+    else:
+        cmd = [sys.executable, os.path.join(root, "bench.py")] + tail
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["config"]["rccl_world_size"] == 1 and line["n_gpus"] == 1 and line["value"] > 0
+    assert "dp1" in line["config"]["parallelism"] and line["config"]["global_batch"] == 8

@@ -1,6 +1,7 @@
 """Host-side logic of the drop-in surface (no GPU): sigma grid, per-step tables, configuration
 objects, state_dict compatibility, batching / sharding helpers, error behaviour."""
 import math
+import os
 
 import pytest
 import torch
@@ -10,6 +11,8 @@ from diffsci_amd.models.karras.steptable import build_step_table
 from diffsci_amd.parallel import global_white_noise, shard_rows
 from oracle import karras_ref as K
 from tests.golden_util import load
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _exact_on_same_isa(got, want):
@@ -286,3 +289,53 @@ def test_bench_self_launch_command():
     assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29555"
     assert cmd[-4:] == ["--gpus", "4", "--steps", "2"] and cmd[-5].endswith("bench.py")
+
+
+def test_bench_self_launch_relays_the_rank_zero_line_and_the_exit_code(tmp_path, capfd):
+    """bench.py --gpus N without a launcher starts its own N ranks (torch.distributed.run as a child process, before anything
+    touches the GPU) and relays rank 0's JSON line and the ranks' exit status -- driven here end to end with a stub script in
+    place of bench.py (two CPU ranks)."""
+    import argparse
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    stub = tmp_path / "stub.py"
+    stub.write_text(
+        "import json, os, sys\n"
+        "rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])\n"
+        "assert os.environ['MASTER_ADDR'] == '127.0.0.1' and os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY') == '0'\n"
+        "if rank == 0:\n"
+        "    print(json.dumps({'metric': 'stub', 'n_gpus': world, 'argv': sys.argv[1:]}), flush=True)\n"
+        "sys.exit(int(sys.argv[sys.argv.index('--exit') + 1]) if (rank == 1 and '--exit' in sys.argv) else 0)\n")
+    args = argparse.Namespace(gpus=2)
+    rc = bench.self_launch(args, argv=["--gpus", "2", "--steps", "1"], script=str(stub))
+    out = capfd.readouterr().out
+    line = [ln for ln in out.splitlines() if ln.startswith("{")]
+    assert rc == 0 and len(line) == 1
+    d = json.loads(line[0])
+    assert d["n_gpus"] == 2 and d["argv"] == ["--gpus", "2", "--steps", "1"]
+    rc = bench.self_launch(args, argv=["--gpus", "2", "--exit", "3"], script=str(stub))
+    assert rc != 0                                             # a failing rank fails the run
+    cmd = bench.launcher_command(["--gpus", "4"], 4, 1234)
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and cmd[-3].endswith("bench.py")
+
+
+def test_global_noise_skip_ahead_is_self_checked(monkeypatch):
+    """The chunked per-rank draw leans on a detail of torch's CPU normal fill; the first use in a process checks it on a small
+    case, and a torch that fails the check gets the full draw (same values) instead of silently different noise."""
+    from diffsci_amd import parallel
+    monkeypatch.setattr(parallel, "_SKIP_AHEAD_OK", None)
+    assert parallel.skip_ahead_matches_full_draw() is True and parallel._SKIP_AHEAD_OK is True     # this torch passes
+    full = parallel.global_white_noise(6, [2, 4, 4], seed=3)
+    assert torch.equal(parallel.global_white_noise(6, [2, 4, 4], seed=3, rows=(2, 5)), full[2:5])
+    calls = []
+    real = torch.randn
+    monkeypatch.setattr(torch, "randn", lambda *a, **k: (calls.append(a), real(*a, **k))[1])
+    parallel.global_white_noise(6, [2, 4, 4], seed=3, rows=(2, 5))
+    assert all(a[0] < 6 for a in calls)                        # chunked: never the whole tensor
+    monkeypatch.setattr(parallel, "_SKIP_AHEAD_OK", False)     # a torch whose generator does not skip ahead like that
+    calls.clear()
+    assert torch.equal(parallel.global_white_noise(6, [2, 4, 4], seed=3, rows=(2, 5)), full[2:5])
+    assert calls[0][0] == 6                                     # the full draw
