@@ -29,10 +29,22 @@ __device__ __forceinline__ float drift(float x, float f, float fu, bool has_u, c
     if (has_u) F = k.one_minus_guidance * fu + k.guidance * f;
     return k.neg_mult * (F / k.sigma_sq);
   }
+  if (k.scaled) {                                // non-constant scaling (VP), schedulers.py:275-293
+    const float xs = x / k.scale;                // score_fn(x / s, sigma)
+    const float score = (k.input_kind == DS_IN_SCORE) ? f : score_of(xs, f, fu, has_u, k);
+    float d = k.scale_mult * x + k.neg_mult * score;          // scale_multiplier*x - multiplier*score
+    if (k.stochastic) d = d + k.neg_lang * score;             // -(langevin * 1/s * score)
+    return d;
+  }
   float score = (k.input_kind == DS_IN_SCORE) ? f : score_of(x, f, fu, has_u, k);
   float d = k.neg_mult * score;
   if (k.stochastic) d = d + k.neg_lang * score;
   return d;
+}
+
+// the next evaluation's network input: c_in * x, or c_in * (x / s) under a non-constant scaling
+__device__ __forceinline__ float next_input(float r, float c_in_next, float next_scale) {
+  return (next_scale == 1.0f || next_scale == 0.0f) ? c_in_next * r : c_in_next * (r / next_scale);   // 0: a zero-initialised struct
 }
 
 inline int grid_for(size_t n4) {
@@ -117,7 +129,7 @@ __device__ __forceinline__ void euler_one(float x, float f, float fu, float e, c
   float r = x + dt * d;
   if (HAS_EPS) r = r + (noise_coef * e) * sq;
   xo = r;
-  xi = c_in_next * r;
+  xi = next_input(r, c_in_next, k.next_scale);
 }
 
 template <bool HAS_U, int NOISE>        // NOISE: 0 none, 1 injected eps, 2 in-kernel Philox
@@ -161,7 +173,7 @@ __device__ __forceinline__ void heun_one(float x, float f1, float f1u, float f2,
   float d2 = drift(xe, f2, f2u, HAS_U, k2);
   float r = x + (0.5f * (d1 + d2)) * dt;
   xo = r;
-  xi = c_in_next * r;
+  xi = next_input(r, c_in_next, k2.next_scale);
 }
 
 template <bool HAS_U>
@@ -212,23 +224,24 @@ __global__ __launch_bounds__(kThreads) void k_drift(float* out, const float* x, 
 template <bool PHILOX>
 __global__ __launch_bounds__(kThreads) void k_churn(float* xhat, float* xin_out, const float* x,
                                                     const float* __restrict__ eps, const unsigned long long* rng,
-                                                    unsigned long long rng_offset, float coef, float c_in, size_t n4,
-                                                    size_t n) {
+                                                    unsigned long long rng_offset, float coef, float c_in, float ratio,
+                                                    float scale, size_t n4, size_t n) {
   size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x;
   size_t stride = (size_t)gridDim.x * kThreads;
   for (; i < n4; i += stride) {
     float4 vx = reinterpret_cast<const float4*>(x)[i];
     float4 ve = PHILOX ? philox_normal4(rng, rng_offset, i) : reinterpret_cast<const float4*>(eps)[i];
     float4 o, q;
+    if (ratio != 1.0f) { vx.x = ratio * vx.x; vx.y = ratio * vx.y; vx.z = ratio * vx.z; vx.w = ratio * vx.w; }   // (s_hat/s)*x
     o.x = vx.x + coef * ve.x; o.y = vx.y + coef * ve.y; o.z = vx.z + coef * ve.z; o.w = vx.w + coef * ve.w;
-    q.x = c_in * o.x; q.y = c_in * o.y; q.z = c_in * o.z; q.w = c_in * o.w;
+    q.x = next_input(o.x, c_in, scale); q.y = next_input(o.y, c_in, scale); q.z = next_input(o.z, c_in, scale); q.w = next_input(o.w, c_in, scale);
     reinterpret_cast<float4*>(xhat)[i] = o;
     if (xin_out) reinterpret_cast<float4*>(xin_out)[i] = q;
   }
   for (size_t t = n4 * 4 + (size_t)blockIdx.x * kThreads + threadIdx.x; t < n; t += stride) {
-    float o = x[t] + coef * (PHILOX ? philox_normal1(rng, rng_offset, t) : eps[t]);
+    float o = (ratio != 1.0f ? ratio * x[t] : x[t]) + coef * (PHILOX ? philox_normal1(rng, rng_offset, t) : eps[t]);
     xhat[t] = o;
-    if (xin_out) xin_out[t] = c_in * o;
+    if (xin_out) xin_out[t] = next_input(o, c_in, scale);
   }
 }
 
@@ -446,7 +459,7 @@ int ds_karras_score(float* s_out, const float* x, const float* f, const float* f
 }
 
 int ds_karras_churn(float* xhat_out, float* xin_out, const float* x, const float* eps, const uint64_t* philox_state,
-                    uint64_t philox_offset, float coef, float c_in, size_t n, void* stream) {
+                    uint64_t philox_offset, float coef, float c_in, float ratio, float scale, size_t n, void* stream) {
   DS_REQUIRE(xhat_out && x, DS_ERR_NULL, "ds_karras_churn: NULL pointer");
   DS_REQUIRE((eps != nullptr) != (philox_state != nullptr), DS_ERR_NULL,
              "ds_karras_churn: exactly one of eps (injected noise) and philox_state (in-kernel noise) must be given");
@@ -456,11 +469,11 @@ int ds_karras_churn(float* xhat_out, float* xin_out, const float* x, const float
   dim3 g(grid_elems(n4, n)), b(kThreads);
   hipStream_t s = ds::as_stream(stream);
   if (eps)
-    hipLaunchKernelGGL((k_churn<false>), g, b, 0, s, xhat_out, xin_out, x, eps, nullptr, 0ull, coef, c_in, n4, n);
+    hipLaunchKernelGGL((k_churn<false>), g, b, 0, s, xhat_out, xin_out, x, eps, nullptr, 0ull, coef, c_in, ratio, scale, n4, n);
   else
     hipLaunchKernelGGL((k_churn<true>), g, b, 0, s, xhat_out, xin_out, x, eps,
                        reinterpret_cast<const unsigned long long*>(philox_state), (unsigned long long)philox_offset, coef,
-                       c_in, n4, n);
+                       c_in, ratio, scale, n4, n);
   DS_CHECK_LAUNCH("ds_karras_churn");
   return DS_OK;
 }

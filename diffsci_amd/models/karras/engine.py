@@ -33,6 +33,8 @@ class ScoreFnSource:
 
     def evaluate(self, state, xin, row, index, slot):
         sigma = self._ones * row.sigma            # t*ones(B): schedulers.py:254
+        if row.scaled:                            # score_fn(x / s, sigma), schedulers.py:287
+            state = ops.div_scalar(state.contiguous(), row.scale)
         s = self.score_fn(state, sigma)
         ops.require_device(s, "score_fn output")
         return s.contiguous(), None
@@ -288,20 +290,26 @@ class Loop:
         cur = self.x
         e = 0
         if source.wants_xin and n > 0 and not karras:
-            ops.scale(cur, table.rows[0].first.c_in, out=xin)       # c_in*x, karrasmodule.py:702
+            r0 = table.rows[0].first
+            if r0.scaled:                                            # c_in * (x / s): schedulers.py:287, karrasmodule.py:702
+                ops.scale(ops.div_scalar(cur, r0.scale, out=xin), r0.c_in, out=xin)
+            else:
+                ops.scale(cur, r0.c_in, out=xin)                     # c_in*x, karrasmodule.py:702
         for i, row in enumerate(table.rows):
             nxt = self.history[i + 1] if self.record_history else cur
             nxt_row = table.rows[i + 1] if i + 1 < n else None
             chain = source.wants_xin and nxt_row is not None and not karras
             c_in_next = nxt_row.first.c_in if chain else 1.0
+            s_next = nxt_row.first.scale if chain else 1.0
             xin_next = xin if chain else None
             base = cur
             eps_i = eps[i] if eps is not None else None
             philox_i = (self.rng, i * self.counters_per_step + self.noise_base) if (self.rng is not None) else None
             if karras:
                 base = tmp                                           # x_hat, integrators.py:104-105
-                ops.churn(cur, eps_i, row.churn_coef, xhat_out=base, xin_out=xin, c_in=row.first.c_in, philox=philox_i)
-            k1 = row.first.coef(kind, g)
+                ops.churn(cur, eps_i, row.churn_coef, xhat_out=base, xin_out=xin, c_in=row.first.c_in, philox=philox_i,
+                          ratio=row.churn_ratio, scale=row.first.scale)
+            k1 = row.first.coef(kind, g, next_scale=s_next if row.second is None else row.second.scale)
             f1, f1u = source.evaluate(base, xin, row.first, e, 0)
             e += 1
             if row.second is None:
@@ -309,7 +317,7 @@ class Loop:
                           eps=eps_i if em else None, philox=philox_i if em else None,
                           noise_coef=row.noise_coef, sqrt_abs_dt=row.sqrt_abs_dt)
             else:
-                k2 = row.second.coef(kind, g)
+                k2 = row.second.coef(kind, g, next_scale=s_next)
                 xe = None
                 if not source.wants_xin:
                     xe = self.tmp2 if karras else tmp

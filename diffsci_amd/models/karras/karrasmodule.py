@@ -339,7 +339,7 @@ class KarrasModule(torch.nn.Module, LatentSpaceAutoregressive):
             sch.set_temporary_integrator(integrator)
         try:
             integ = sch.integrator
-            if not schedulers._is_builtin(integ) or not sch.scheduler_fns.constant_scaling_fn:
+            if not schedulers._is_builtin(integ):      # user Integrator subclasses: the reference's own loop, step by step
                 def rhs(xx, sigma):
                     return self.get_score(xx, sigma, y, guidance)
                 xs = x if scale is None else ops.scale(x.contiguous(), scale)

@@ -46,7 +46,7 @@ class Scheduler(torch.nn.Module):
         """schedulers.py:48-89.  ``eps`` (extension): [nsteps, *x.shape] injected noise for the
         stochastic integrators instead of device-generator draws."""
         integrator = self.integrator if not stochastic else self.stochastic_integrator
-        if _is_builtin(integrator) and self.scheduler_fns.constant_scaling_fn:
+        if _is_builtin(integrator):                    # both branches of rhs (constant scaling; s(t): VP) are tabulated
             table = build_step_table(self, integrator, nsteps, backward=backward)
             src = ScoreFnSource(score_fn, x.shape[0], x)
             out = run_table(table, src, x, record_history=record_history, eps=eps)
@@ -67,7 +67,7 @@ class Scheduler(torch.nn.Module):
         integrator = self.integrator if not stochastic else self.stochastic_integrator
         if not backward:
             raise NotImplementedError
-        if _is_builtin(integrator) and self.scheduler_fns.constant_scaling_fn:
+        if _is_builtin(integrator):                    # both branches of rhs (constant scaling; s(t): VP) are tabulated
             table = build_step_table(self, integrator, nsteps, backward=True,
                                      initial_step=initial_step, final_step=final_step)
             src = ScoreFnSource(score_fn, x.shape[0], x)

@@ -7,7 +7,9 @@ on the CPU, in fp32, with the reference's own torch operation sequence (same ops
 0-dim tensors), so the numbers handed to the kernels are bit-identical to the ones the
 reference's CPU path computes.  Nothing here touches the GPU.
 
-Only the constant-scaling (EDM) branch of Scheduler.rhs (schedulers.py:259-274) is tabulated.
+Both branches of Scheduler.rhs are tabulated: constant scaling (EDM / VE, schedulers.py:259-274) and a scaling function
+s(t) (VP, schedulers.py:275-293: rows carry s, s'/s and the multiplier s*sigma'*sigma, and the kernels divide the state by s
+on the way into the network).
 """
 import math
 from dataclasses import dataclass, field
@@ -32,12 +34,18 @@ class EvalRow:
     c_out: float = 1.0
     c_in: float = 1.0
     c_noise: float = 0.0
+    # non-constant scaling (VP): x~ = x / scale goes into the score, d = scale_mult*x + neg_mult*score
+    scaled: bool = False
+    scale: float = 1.0
+    scale_mult: float = 0.0
 
-    def coef(self, input_kind=DS_IN_NETWORK, guidance=1.0):
+    def coef(self, input_kind=DS_IN_NETWORK, guidance=1.0, next_scale=1.0):
+        """next_scale: s at the evaluation the emitted network input feeds (xin = c_in * (x / s))."""
         return EvalCoef(c_out=self.c_out, c_skip=self.c_skip, sigma_sq=self.sigma_sq,
                         neg_mult=self.neg_mult, neg_lang=self.neg_lang, guidance=float(guidance),
                         one_minus_guidance=float(1 - guidance), input_kind=int(input_kind),
-                        stochastic=int(self.stochastic))
+                        stochastic=int(self.stochastic), scaled=int(self.scaled), scale=self.scale,
+                        scale_mult=self.scale_mult, next_scale=float(next_scale))
 
 
 @dataclass
@@ -47,6 +55,7 @@ class StepRow:
     second: Optional[EvalRow]
     dt: float                      # step used by the update (dt, or dt_hat for the churn sampler)
     churn_coef: Optional[float] = None   # std*s_noise (KarrasIntegrator) -- None for other integrators
+    churn_ratio: float = 1.0       # s(t_hat)/s(t) (integrators.py:103): 1 under constant scaling
     noise_coef: float = 0.0        # sqrt(2*langevin) (Euler-Maruyama)
     sqrt_abs_dt: float = 0.0
 
@@ -79,19 +88,31 @@ def make_eval_row(t, scheduler, stochastic=False, backward=True, preconditioner=
     """Scalars of Scheduler.rhs at time t (schedulers.py:254-274) and of the preconditioner
     (karrasmodule.py:690-704) -- all as fp32 0-dim tensor arithmetic in the reference's order."""
     fns = scheduler.scheduler_fns
-    if not fns.constant_scaling_fn:
-        raise NotImplementedError("only constant-scaling (EDM) scheduling functions are on the HIP path")
     sigma = fns.noise_fn(t)
-    sigma_deriv = fns.noise_fn_deriv(t)
-    if getattr(fns, "has_pf_score_multiplier", False):
-        multiplier = fns.pf_score_multiplier(t)
-    else:
-        multiplier = sigma * sigma_deriv
-    row = EvalRow(t=t, sigma=_f(sigma), sigma_sq=_f(sigma ** 2), neg_mult=_f(-multiplier))
-    if stochastic:
-        lang = scheduler.langevin_factor(t)
-        row.stochastic = True
-        row.neg_lang = _f(-lang) if backward else _f(lang)     # schedulers.py:269-274
+    if fns.constant_scaling_fn:
+        sigma_deriv = fns.noise_fn_deriv(t)
+        if getattr(fns, "has_pf_score_multiplier", False):
+            multiplier = fns.pf_score_multiplier(t)
+        else:
+            multiplier = sigma * sigma_deriv
+        row = EvalRow(t=t, sigma=_f(sigma), sigma_sq=_f(sigma ** 2), neg_mult=_f(-multiplier))
+        if stochastic:
+            lang = scheduler.langevin_factor(t)
+            row.stochastic = True
+            row.neg_lang = _f(-lang) if backward else _f(lang)     # schedulers.py:269-274
+    else:                                                          # schedulers.py:275-293, the same scalar operations in order
+        s = fns.scaling_fn(t)
+        scale_multiplier = fns.scaling_fn_deriv(t) / s
+        if getattr(fns, "has_pf_score_multiplier", False):
+            multiplier = fns.pf_score_multiplier(t)
+        else:
+            multiplier = s * (fns.noise_fn_deriv(t) * fns.noise_fn(t))
+        row = EvalRow(t=t, sigma=_f(sigma), sigma_sq=_f(sigma ** 2), neg_mult=_f(-multiplier), scaled=True, scale=_f(s),
+                      scale_mult=_f(scale_multiplier))
+        if stochastic:
+            k = scheduler.langevin_factor(t) * 1 / s               # -(langevin * 1/s * score); sign flipped forward
+            row.stochastic = True
+            row.neg_lang = _f(-k) if backward else _f(k)
     if preconditioner is not None:
         row.c_skip = _f(preconditioner.skip_scaling(sigma))
         row.c_out = _f(preconditioner.output_scaling(sigma))
@@ -156,11 +177,9 @@ def build_step_table(scheduler, integrator, nsteps, backward=True, initial_step=
             t_hat = fns.inverse_noise_fn(sigma_hat)
             scale = fns.scaling_fn(ti)
             scale_hat = fns.scaling_fn(t_hat)
-            if _f(scale_hat / scale) != 1.0:
-                raise NotImplementedError("churn with a non-constant scaling function")
             std = scale_hat * torch.sqrt(sigma_hat ** 2 - sigma ** 2)
             t2 = ti + dti
             dt_hat = t2 - t_hat
             table.rows.append(StepRow(ev(t_hat), ev(t2) if t2 > 0 else None, _f(dt_hat),
-                                      churn_coef=_f(std * integrator.s_noise)))
+                                      churn_coef=_f(std * integrator.s_noise), churn_ratio=_f(scale_hat / scale)))
     return table

@@ -286,13 +286,13 @@ def heun(x, f1, k1, f2, k2, dt, f1u=None, f2u=None, x_out=None, xin_out=None, c_
     return x_out
 
 
-def churn(x, eps, coef, xhat_out, xin_out=None, c_in=1.0, philox=None):
-    """x_hat = x + coef*eps, with eps injected (a tensor) or, eps=None, generated in the kernel from
-    philox = (state, offset)."""
+def churn(x, eps, coef, xhat_out, xin_out=None, c_in=1.0, philox=None, ratio=1.0, scale=1.0):
+    """x_hat = ratio*x + coef*eps, with eps injected (a tensor) or, eps=None, generated in the kernel from
+    philox = (state, offset); xin_out = c_in * (x_hat / scale)."""
     n = _same_numel(x, eps, xhat_out, xin_out)
     ps, po = _philox(philox)
-    N.check(N.lib().ds_karras_churn(_p(xhat_out), _p(xin_out), _p(x), _p(eps), ps, po, float(coef), float(c_in), n,
-                                    _stream()), "ds_karras_churn")
+    N.check(N.lib().ds_karras_churn(_p(xhat_out), _p(xin_out), _p(x), _p(eps), ps, po, float(coef), float(c_in), float(ratio),
+                                    float(scale), n, _stream()), "ds_karras_churn")
     return xhat_out
 
 

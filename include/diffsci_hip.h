@@ -71,6 +71,15 @@ typedef struct ds_eval_coef {
   int   input_kind; /* what `f` holds: 0 network output F (apply the preconditioner),
                        1 score (generic score_fn path of Scheduler.rhs), 2 drift (already rhs) */
   int   stochastic; /* 1: add neg_lang*score to the drift                                 */
+  /* Non-constant scaling s(t) (VP; Scheduler.rhs, schedulers.py:275-293).  scaled = 0: the three fields are ignored and the
+   * arithmetic is the constant-scaling branch's, bit for bit.  scaled = 1:
+   *   x~ = x / scale;  score = score(x~)  [D = c_out*F + c_skip*x~, F = net(c_in*x~, c_noise)];
+   *   d = scale_mult*x + neg_mult*score [+ neg_lang*score]   with neg_mult = -(s sigma' sigma), neg_lang = -(lambda*1/s)  */
+  int   scaled;
+  float scale;      /* s(t)                                                                */
+  float scale_mult; /* s'(t) / s(t)                                                        */
+  float next_scale; /* s at the evaluation the emitted network input (xin_out) feeds: xin_out = c_in_next * (x_out / next_scale)
+                       when != 1 and != 0 (the reference calls score_fn(x / s, sigma), schedulers.py:287)                     */
 } ds_eval_coef;
 
 enum { DS_IN_NETWORK = 0, DS_IN_SCORE = 1, DS_IN_DRIFT = 2,
@@ -123,13 +132,13 @@ int ds_karras_heun(float* x_out, float* xin_out, const float* x,
                    const float* f2, const float* f2u, const ds_eval_coef* k2,
                    float dt, float c_in_next, size_t n, void* stream);
 
-/* Noise injection x_hat = x + coef*eps; xin_out (optional) = c_in * x_hat.
- * KarrasIntegrator.step sigma-churn (integrators.py:98-105, coef = std*s_noise, scale ratio = 1)
- * and Scheduler.renoise (schedulers.py:166-176).  Exactly one of eps (injected, [n]) and philox_state
- * (generated in the kernel: 12 B per element instead of 16, no eps buffer) is given. */
+/* Noise injection x_hat = ratio*x + coef*eps (ratio == 1: x + coef*eps); xin_out (optional) = c_in * x_hat, or
+ * c_in * (x_hat / scale) when scale != 1.  KarrasIntegrator.step sigma-churn (integrators.py:98-105: ratio = s(t_hat)/s(t),
+ * coef = std*s_noise, scale = s(t_hat)) and Scheduler.renoise (schedulers.py:166-176).  Exactly one of eps (injected, [n]) and
+ * philox_state (generated in the kernel: 12 B per element instead of 16, no eps buffer) is given. */
 int ds_karras_churn(float* xhat_out, float* xin_out, const float* x, const float* eps,
                     const uint64_t* philox_state, uint64_t philox_offset,
-                    float coef, float c_in, size_t n, void* stream);
+                    float coef, float c_in, float ratio, float scale, size_t n, void* stream);
 
 /* Denoiser with per-sample coefficients (sigma differs across the batch):
  * out = c_out[b]*F + c_skip[b]*x, F as above.  karrasmodule.py:717-718.  Coefficient arrays are

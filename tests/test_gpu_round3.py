@@ -314,3 +314,37 @@ def test_bench_multi_rank_code_on_one_rank(launcher):
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["config"]["rccl_world_size"] == 1 and line["n_gpus"] == 1 and line["value"] > 0
     assert "dp1" in line["config"]["parallelism"] and line["config"]["global_batch"] == 8
+
+
+def test_vp_runs_the_tabulated_captured_loop(M, dev):
+    """VP (non-constant scaling s(t), Scheduler.rhs schedulers.py:275-293) on the fused stepper: the step rows carry s, s'/s and the
+    multiplier, the kernels divide the state by s on the way into the network, and the run is captured like an EDM one -- same
+    launches per step -- against the reference's goldens (Heun, Euler, sigma-churn with the s(t_hat)/s(t) rescaling)."""
+    from tests.golden_util import load
+    v, _ = load("vpve8")
+    _, sd = load("punetg8_forward")
+    net = M.PUNetG(M.PUNetGConfig(model_channels=8))
+    net.load_state_dict(sd)
+    net = net.to(dev).eval()
+    nodes = {}
+    for tag in ("vp", "ve"):
+        cfg = M.KarrasModuleConfig.from_vp(M=2) if tag == "vp" else M.KarrasModuleConfig.from_ve()
+        sch = cfg.noisescheduler
+        orig = sch.create_steps
+        sch.create_steps = (lambda n, tag=tag, orig=orig: v[f"{tag}_steps_{n - 1}"].clone() if f"{tag}_steps_{n - 1}" in v else orig(n))
+        module = M.KarrasModule(net, cfg)
+        wn = v["white_noise"].to(dev)
+        ref_err = rel_l2(v[f"{tag}_punetg_heun_N6"], v[f"{tag}_punetg_heun_N6_f64"])
+        tol = max(REL, 4 * ref_err)
+        outs = []
+        for use_graph in (False, True, True):
+            module.use_graph = use_graph
+            h = module.propagate_white_noise(wn, nsteps=6, record_history=True).cpu()
+            assert rel_l2(h[:2], v[f"{tag}_punetg_heun_N6"][:2]) < REL and rel_l2(h, v[f"{tag}_punetg_heun_N6"]) < tol
+            outs.append(h)
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
+        assert len(module._plans.plans) == 1                               # planned and captured, not the step-by-step loop
+        nodes[tag] = next(iter(module._plans.plans.values()))[1].nodes
+        o = module.propagate_white_noise(wn, nsteps=6, integrator="euler").cpu()
+        assert rel_l2(o, v[f"{tag}_punetg_euler_N6"]) < tol
+    assert nodes["vp"] <= nodes["ve"] + 1                                   # one extra launch: x / s in front of the first c_in * x

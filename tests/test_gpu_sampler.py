@@ -633,14 +633,15 @@ def test_vp_ve_parameterisations(M, net8, dev, tag):
 
 def test_vp_sigma_churn(M, dev, monkeypatch):
     """KarrasIntegrator on the VP parameterisation (non-constant scaling: the churn rescales x by s(t_hat)/s(t),
-    integrators.py:103), with the reference's recorded draws replayed through torch.randn_like."""
+    integrators.py:103), with the reference's recorded draws injected (round 3: the tabulated stepper runs this too --
+    x_hat = (s_hat/s)*x + coef*eps in the churn kernel, x / s on the way into the score)."""
     v, _ = load("vp_karras")
     sch = M.KarrasModuleConfig.from_vp(M=2).noisescheduler
     sch.create_steps = lambda n: v["steps_6"].clone()
-    draws = iter(v["eps"])
-    monkeypatch.setattr(torch, "randn_like", lambda t, *a, **k: next(draws).to(t))
+    eps = torch.stack([e for e in v["eps"]])[:6].to(dev)
     sch.set_temporary_integrator("karras")
-    h = sch.propagate_backward((v["x"] * sch.maximum_scale).to(dev), K.gaussian_target_score(0.7), 6, record_history=True).cpu()
+    h = sch.propagate_backward((v["x"] * sch.maximum_scale).to(dev), K.gaussian_target_score(0.7), 6, record_history=True,
+                               eps=eps).cpu()
     sch.unset_temporary_integrator()
     torch.testing.assert_close(h, v["hist_N6"], rtol=1e-5, atol=1e-5 * sch.maximum_scale)
 
