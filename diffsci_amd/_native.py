@@ -22,7 +22,7 @@ class EvalCoef(Structure):
     _fields_ = [("c_out", c_float), ("c_skip", c_float), ("sigma_sq", c_float),
                 ("neg_mult", c_float), ("neg_lang", c_float), ("guidance", c_float),
                 ("one_minus_guidance", c_float), ("input_kind", c_int), ("stochastic", c_int),
-                ("scaled", c_int), ("scale", c_float), ("scale_mult", c_float), ("next_scale", c_float)]
+                ("scaled", c_int), ("scale", c_float), ("scale_mult", c_float), ("next_scale", c_float), ("xin_copies", c_int)]
 
 
 class NativeLibraryError(RuntimeError):
@@ -42,7 +42,7 @@ _PROTOS = {
                                 _P, _P, c_uint64, c_float, c_float, c_size_t, _P]),
     "ds_karras_heun": (c_int, [_P, _P, _P, _P, _P, POINTER(EvalCoef), _P, _P, POINTER(EvalCoef),
                                c_float, c_float, c_size_t, _P]),
-    "ds_karras_churn": (c_int, [_P, _P, _P, _P, _P, c_uint64, c_float, c_float, c_float, c_float, c_size_t, _P]),
+    "ds_karras_churn": (c_int, [_P, _P, _P, _P, _P, c_uint64, c_float, c_float, c_float, c_float, c_int, c_size_t, _P]),
     "ds_karras_denoiser": (c_int, [_P, _P, _P, _P, c_float, c_float, _P, _P, c_int, c_size_t, _P]),
     "ds_inorm_silu": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_float, c_int, _P]),
     "ds_conv2d_packed_floats": (c_size_t, [c_int, c_int, c_int]),

@@ -154,14 +154,20 @@ __global__ __launch_bounds__(kThreads) void k_euler(float* x_out, float* xin_out
     euler_one<HAS_U, HAS_EPS>(vx.z, vf.z, vu.z, ve.z, k, dt, noise_coef, sq, c_in_next, o.z, q.z);
     euler_one<HAS_U, HAS_EPS>(vx.w, vf.w, vu.w, ve.w, k, dt, noise_coef, sq, c_in_next, o.w, q.w);
     if (x_out) reinterpret_cast<float4*>(x_out)[i] = o;
-    if (xin_out) reinterpret_cast<float4*>(xin_out)[i] = q;
+    if (xin_out) {
+      reinterpret_cast<float4*>(xin_out)[i] = q;
+      if (k.xin_copies == 2) reinterpret_cast<float4*>(xin_out + n)[i] = q;       // the batched-guidance evaluation reads [2B, ...]
+    }
   }
   for (size_t t = n4 * 4 + (size_t)blockIdx.x * kThreads + threadIdx.x; t < n; t += stride) {
     float o, q;
     const float e = NOISE == 1 ? eps[t] : NOISE == 2 ? philox_normal1(rng, rng_offset, t) : 0.f;
     euler_one<HAS_U, HAS_EPS>(x[t], f[t], HAS_U ? fu[t] : 0.f, e, k, dt, noise_coef, sq, c_in_next, o, q);
     if (x_out) x_out[t] = o;
-    if (xin_out) xin_out[t] = q;
+    if (xin_out) {
+      xin_out[t] = q;
+      if (k.xin_copies == 2) xin_out[n + t] = q;
+    }
   }
 }
 
@@ -199,13 +205,19 @@ __global__ __launch_bounds__(kThreads) void k_heun(float* x_out, float* xin_out,
     heun_one<HAS_U>(vx.z, a.z, au.z, b.z, bu.z, k1, k2, dt, c_in_next, o.z, q.z);
     heun_one<HAS_U>(vx.w, a.w, au.w, b.w, bu.w, k1, k2, dt, c_in_next, o.w, q.w);
     reinterpret_cast<float4*>(x_out)[i] = o;
-    if (xin_out) reinterpret_cast<float4*>(xin_out)[i] = q;
+    if (xin_out) {
+      reinterpret_cast<float4*>(xin_out)[i] = q;
+      if (k2.xin_copies == 2) reinterpret_cast<float4*>(xin_out + n)[i] = q;
+    }
   }
   for (size_t t = n4 * 4 + (size_t)blockIdx.x * kThreads + threadIdx.x; t < n; t += stride) {
     float o, q;
     heun_one<HAS_U>(x[t], f1[t], HAS_U ? f1u[t] : 0.f, f2[t], HAS_U ? f2u[t] : 0.f, k1, k2, dt, c_in_next, o, q);
     x_out[t] = o;
-    if (xin_out) xin_out[t] = q;
+    if (xin_out) {
+      xin_out[t] = q;
+      if (k2.xin_copies == 2) xin_out[n + t] = q;
+    }
   }
 }
 
@@ -225,7 +237,7 @@ template <bool PHILOX>
 __global__ __launch_bounds__(kThreads) void k_churn(float* xhat, float* xin_out, const float* x,
                                                     const float* __restrict__ eps, const unsigned long long* rng,
                                                     unsigned long long rng_offset, float coef, float c_in, float ratio,
-                                                    float scale, size_t n4, size_t n) {
+                                                    float scale, int xin_copies, size_t n4, size_t n) {
   size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x;
   size_t stride = (size_t)gridDim.x * kThreads;
   for (; i < n4; i += stride) {
@@ -236,12 +248,18 @@ __global__ __launch_bounds__(kThreads) void k_churn(float* xhat, float* xin_out,
     o.x = vx.x + coef * ve.x; o.y = vx.y + coef * ve.y; o.z = vx.z + coef * ve.z; o.w = vx.w + coef * ve.w;
     q.x = next_input(o.x, c_in, scale); q.y = next_input(o.y, c_in, scale); q.z = next_input(o.z, c_in, scale); q.w = next_input(o.w, c_in, scale);
     reinterpret_cast<float4*>(xhat)[i] = o;
-    if (xin_out) reinterpret_cast<float4*>(xin_out)[i] = q;
+    if (xin_out) {
+      reinterpret_cast<float4*>(xin_out)[i] = q;
+      if (xin_copies == 2) reinterpret_cast<float4*>(xin_out + n)[i] = q;
+    }
   }
   for (size_t t = n4 * 4 + (size_t)blockIdx.x * kThreads + threadIdx.x; t < n; t += stride) {
     float o = (ratio != 1.0f ? ratio * x[t] : x[t]) + coef * (PHILOX ? philox_normal1(rng, rng_offset, t) : eps[t]);
     xhat[t] = o;
-    if (xin_out) xin_out[t] = next_input(o, c_in, scale);
+    if (xin_out) {
+      xin_out[t] = next_input(o, c_in, scale);
+      if (xin_copies == 2) xin_out[n + t] = xin_out[t];
+    }
   }
 }
 
@@ -393,7 +411,8 @@ int ds_karras_euler(float* x_out, float* xin_out, const float* x, const float* f
   DS_REQUIRE((reinterpret_cast<uintptr_t>(philox_state) & 7u) == 0, DS_ERR_SHAPE, "ds_karras_euler: state must be 8-byte aligned");
   DS_REQUIRE(!(!blends(k->input_kind) && fu), DS_ERR_SHAPE, "ds_karras_euler: guidance blend needs network outputs or flow fields");
   if (n == 0) return DS_OK;
-  const size_t n4 = vec4_count(n, {x_out, xin_out, x, f, fu, eps});
+  DS_REQUIRE(k->xin_copies >= 0 && k->xin_copies <= 2, DS_ERR_SHAPE, "ds_karras_euler: xin_copies %d", k->xin_copies);
+  const size_t n4 = (k->xin_copies == 2 && (n & 3)) ? 0 : vec4_count(n, {x_out, xin_out, x, f, fu, eps});   // the second copy starts n floats in
   dim3 g(grid_elems(n4, n)), b(kThreads);
   hipStream_t s = ds::as_stream(stream);
   const unsigned long long* rng = reinterpret_cast<const unsigned long long*>(philox_state);
@@ -417,7 +436,8 @@ int ds_karras_heun(float* x_out, float* xin_out, const float* x, const float* f1
   DS_REQUIRE(!((!blends(k1->input_kind) || !blends(k2->input_kind)) && f1u), DS_ERR_SHAPE,
              "ds_karras_heun: guidance blend needs network outputs or flow fields");
   if (n == 0) return DS_OK;
-  const size_t n4 = vec4_count(n, {x_out, xin_out, x, f1, f2, f1u, f2u});
+  DS_REQUIRE(k2->xin_copies >= 0 && k2->xin_copies <= 2, DS_ERR_SHAPE, "ds_karras_heun: xin_copies %d", k2->xin_copies);
+  const size_t n4 = (k2->xin_copies == 2 && (n & 3)) ? 0 : vec4_count(n, {x_out, xin_out, x, f1, f2, f1u, f2u});
   dim3 g(grid_elems(n4, n)), b(kThreads);
   hipStream_t s = ds::as_stream(stream);
   if (f1u)
@@ -459,21 +479,23 @@ int ds_karras_score(float* s_out, const float* x, const float* f, const float* f
 }
 
 int ds_karras_churn(float* xhat_out, float* xin_out, const float* x, const float* eps, const uint64_t* philox_state,
-                    uint64_t philox_offset, float coef, float c_in, float ratio, float scale, size_t n, void* stream) {
+                    uint64_t philox_offset, float coef, float c_in, float ratio, float scale, int xin_copies, size_t n,
+                    void* stream) {
   DS_REQUIRE(xhat_out && x, DS_ERR_NULL, "ds_karras_churn: NULL pointer");
   DS_REQUIRE((eps != nullptr) != (philox_state != nullptr), DS_ERR_NULL,
              "ds_karras_churn: exactly one of eps (injected noise) and philox_state (in-kernel noise) must be given");
   DS_REQUIRE((reinterpret_cast<uintptr_t>(philox_state) & 7u) == 0, DS_ERR_SHAPE, "ds_karras_churn: state must be 8-byte aligned");
   if (n == 0) return DS_OK;
-  const size_t n4 = vec4_count(n, {xhat_out, xin_out, x, eps});
+  DS_REQUIRE(xin_copies >= 0 && xin_copies <= 2, DS_ERR_SHAPE, "ds_karras_churn: xin_copies %d", xin_copies);
+  const size_t n4 = (xin_copies == 2 && (n & 3)) ? 0 : vec4_count(n, {xhat_out, xin_out, x, eps});
   dim3 g(grid_elems(n4, n)), b(kThreads);
   hipStream_t s = ds::as_stream(stream);
   if (eps)
-    hipLaunchKernelGGL((k_churn<false>), g, b, 0, s, xhat_out, xin_out, x, eps, nullptr, 0ull, coef, c_in, ratio, scale, n4, n);
+    hipLaunchKernelGGL((k_churn<false>), g, b, 0, s, xhat_out, xin_out, x, eps, nullptr, 0ull, coef, c_in, ratio, scale, xin_copies, n4, n);
   else
     hipLaunchKernelGGL((k_churn<true>), g, b, 0, s, xhat_out, xin_out, x, eps,
                        reinterpret_cast<const unsigned long long*>(philox_state), (unsigned long long)philox_offset, coef,
-                       c_in, ratio, scale, n4, n);
+                       c_in, ratio, scale, xin_copies, n4, n);
   DS_CHECK_LAUNCH("ds_karras_churn");
   return DS_OK;
 }

@@ -20,6 +20,7 @@ from .steptable import StepTable
 class ScoreFnSource:
     input_kind = DS_IN_SCORE
     wants_xin = False
+    xin_copies = 1
     guidance = 1.0
 
     def __init__(self, score_fn, batch, like):
@@ -90,6 +91,8 @@ class ModuleSource:
         # whose channel condition cannot be dropped (the reference's cannot run the unconditional branch either).
         self.batched_cfg = (self.planned and self.cfg and getattr(module, "batch_cfg", True)
                             and not hasattr(self.model, "_split_condition"))
+        # ... and the step kernels write the network input into both halves of the [2B, ...] buffer themselves (ds_eval_coef.xin_copies)
+        self.xin_copies = 2 if self.batched_cfg else 1
         self._out = {}
         self.shifts_c = self.shifts_u = self.shifts_cu = None
 
@@ -126,7 +129,6 @@ class ModuleSource:
                 for cu, u in zip(self.shifts_cu, self.shifts_u):
                     cu[:, B:].copy_(u[:, None, :].expand(-1, B, -1))
                 self._fill_conditional_half()
-                self._x2 = torch.empty((2 * B,) + tuple(self.like.shape[1:]), dtype=torch.float32, device=dev)
         else:
             self.cnoise = cn[:, None].expand(len(evals), self.batch).contiguous().to(dev)
 
@@ -160,13 +162,11 @@ class ModuleSource:
 
     def evaluate(self, state, xin, row, index, slot):
         if self.planned and self.batched_cfg:
-            B = self.batch
-            self._x2[:B].copy_(xin)
-            self._x2[B:].copy_(xin)
+            B = self.batch                      # xin is [2B, ...]: both halves written by the step kernel that produced it
             key = (slot, "cu")
             if key not in self._out:
-                self._out[key] = torch.empty_like(self._x2)
-            f2 = self.model.forward_with_shifts(self._x2, self.shifts_cu, row=index, out=self._out[key])
+                self._out[key] = torch.empty_like(xin)
+            f2 = self.model.forward_with_shifts(xin, self.shifts_cu, row=index, out=self._out[key])
             return f2[:B], f2[B:]
         if self.planned:
             f = self.model.forward_with_shifts(xin, self.shifts_c, row=index, out=self._buf(slot, "c"))
@@ -221,7 +221,9 @@ class Loop:
         else:
             self.history = None
             self.x = new()
-        self.xin = new() if source.wants_xin else None
+        copies = getattr(source, "xin_copies", 1)
+        self.xin = (new() if copies == 1 else torch.empty((copies * shape[0],) + shape[1:], dtype=torch.float32, device=dev)) \
+            if source.wants_xin else None
         self.tmp = new() if (not source.wants_xin or table.kind == "karras") else None
         self.tmp2 = new() if (not source.wants_xin and table.kind == "karras") else None
         self.eps = self.rng = None
@@ -289,12 +291,14 @@ class Loop:
         em = table.kind == "euler-maruyama"
         cur = self.x
         e = 0
+        copies = getattr(source, "xin_copies", 1)
         if source.wants_xin and n > 0 and not karras:
             r0 = table.rows[0].first
-            if r0.scaled:                                            # c_in * (x / s): schedulers.py:287, karrasmodule.py:702
-                ops.scale(ops.div_scalar(cur, r0.scale, out=xin), r0.c_in, out=xin)
-            else:
-                ops.scale(cur, r0.c_in, out=xin)                     # c_in*x, karrasmodule.py:702
+            for half in (xin.view((copies,) + tuple(cur.shape)) if copies > 1 else (xin,)):
+                if r0.scaled:                                        # c_in * (x / s): schedulers.py:287, karrasmodule.py:702
+                    ops.scale(ops.div_scalar(cur, r0.scale, out=half), r0.c_in, out=half)
+                else:
+                    ops.scale(cur, r0.c_in, out=half)                # c_in*x, karrasmodule.py:702
         for i, row in enumerate(table.rows):
             nxt = self.history[i + 1] if self.record_history else cur
             nxt_row = table.rows[i + 1] if i + 1 < n else None
@@ -308,8 +312,8 @@ class Loop:
             if karras:
                 base = tmp                                           # x_hat, integrators.py:104-105
                 ops.churn(cur, eps_i, row.churn_coef, xhat_out=base, xin_out=xin, c_in=row.first.c_in, philox=philox_i,
-                          ratio=row.churn_ratio, scale=row.first.scale)
-            k1 = row.first.coef(kind, g, next_scale=s_next if row.second is None else row.second.scale)
+                          ratio=row.churn_ratio, scale=row.first.scale, xin_copies=copies)
+            k1 = row.first.coef(kind, g, next_scale=s_next if row.second is None else row.second.scale, xin_copies=copies)
             f1, f1u = source.evaluate(base, xin, row.first, e, 0)
             e += 1
             if row.second is None:
@@ -317,7 +321,7 @@ class Loop:
                           eps=eps_i if em else None, philox=philox_i if em else None,
                           noise_coef=row.noise_coef, sqrt_abs_dt=row.sqrt_abs_dt)
             else:
-                k2 = row.second.coef(kind, g, next_scale=s_next)
+                k2 = row.second.coef(kind, g, next_scale=s_next, xin_copies=copies)
                 xe = None
                 if not source.wants_xin:
                     xe = self.tmp2 if karras else tmp

@@ -150,6 +150,12 @@ def _in_amax(x, in_amax, rows, raw):
     return _pi(in_amax, rows, "in_amax")
 
 
+def _xin_numel(x, xin_out, copies):
+    """xin_out of the step kernels: numel of x, or twice that when the kernel writes two copies (batched guidance)."""
+    if xin_out is not None and xin_out.numel() != x.numel() * (2 if copies == 2 else 1):
+        raise ValueError(f"xin_out holds {xin_out.numel()} elements; expected {x.numel() * (2 if copies == 2 else 1)}")
+
+
 def _same_numel(*ts):
     n = None
     for t in ts:
@@ -270,7 +276,8 @@ def philox_normal(state, offset, shape, out=None):
 
 def euler(x, f, k, dt, fu=None, x_out=None, xin_out=None, c_in_next=1.0, eps=None, noise_coef=0.0,
           sqrt_abs_dt=0.0, philox=None):
-    n = _same_numel(x, f, fu, x_out, xin_out, eps)
+    n = _same_numel(x, f, fu, x_out, eps)
+    _xin_numel(x, xin_out, k.xin_copies)
     ps, po = _philox(philox)
     N.check(N.lib().ds_karras_euler(_p(x_out), _p(xin_out), _p(x), _p(f), _p(fu), ctypes.byref(k),
                                     float(dt), float(c_in_next), _p(eps), ps, po, float(noise_coef),
@@ -279,20 +286,22 @@ def euler(x, f, k, dt, fu=None, x_out=None, xin_out=None, c_in_next=1.0, eps=Non
 
 
 def heun(x, f1, k1, f2, k2, dt, f1u=None, f2u=None, x_out=None, xin_out=None, c_in_next=1.0):
-    n = _same_numel(x, f1, f2, f1u, f2u, x_out, xin_out)
+    n = _same_numel(x, f1, f2, f1u, f2u, x_out)
+    _xin_numel(x, xin_out, k2.xin_copies)
     N.check(N.lib().ds_karras_heun(_p(x_out), _p(xin_out), _p(x), _p(f1), _p(f1u), ctypes.byref(k1),
                                    _p(f2), _p(f2u), ctypes.byref(k2), float(dt), float(c_in_next), n,
                                    _stream()), "ds_karras_heun")
     return x_out
 
 
-def churn(x, eps, coef, xhat_out, xin_out=None, c_in=1.0, philox=None, ratio=1.0, scale=1.0):
+def churn(x, eps, coef, xhat_out, xin_out=None, c_in=1.0, philox=None, ratio=1.0, scale=1.0, xin_copies=1):
     """x_hat = ratio*x + coef*eps, with eps injected (a tensor) or, eps=None, generated in the kernel from
-    philox = (state, offset); xin_out = c_in * (x_hat / scale)."""
-    n = _same_numel(x, eps, xhat_out, xin_out)
+    philox = (state, offset); xin_out = c_in * (x_hat / scale), written xin_copies (1 or 2) times back to back."""
+    n = _same_numel(x, eps, xhat_out)
+    _xin_numel(x, xin_out, xin_copies)
     ps, po = _philox(philox)
     N.check(N.lib().ds_karras_churn(_p(xhat_out), _p(xin_out), _p(x), _p(eps), ps, po, float(coef), float(c_in), float(ratio),
-                                    float(scale), n, _stream()), "ds_karras_churn")
+                                    float(scale), int(xin_copies), n, _stream()), "ds_karras_churn")
     return xhat_out
 
 

@@ -80,6 +80,9 @@ typedef struct ds_eval_coef {
   float scale_mult; /* s'(t) / s(t)                                                        */
   float next_scale; /* s at the evaluation the emitted network input (xin_out) feeds: xin_out = c_in_next * (x_out / next_scale)
                        when != 1 and != 0 (the reference calls score_fn(x / s, sigma), schedulers.py:287)                     */
+  int   xin_copies; /* 2: xin_out holds TWO copies back to back ([2n] floats): classifier-free guidance evaluates the
+                       conditional and the unconditional branch as one evaluation of batch 2B on the same input
+                       (karrasmodule.py:706-713); 0 / 1: one copy                                                         */
 } ds_eval_coef;
 
 enum { DS_IN_NETWORK = 0, DS_IN_SCORE = 1, DS_IN_DRIFT = 2,
@@ -138,7 +141,8 @@ int ds_karras_heun(float* x_out, float* xin_out, const float* x,
  * philox_state (generated in the kernel: 12 B per element instead of 16, no eps buffer) is given. */
 int ds_karras_churn(float* xhat_out, float* xin_out, const float* x, const float* eps,
                     const uint64_t* philox_state, uint64_t philox_offset,
-                    float coef, float c_in, float ratio, float scale, size_t n, void* stream);
+                    float coef, float c_in, float ratio, float scale, int xin_copies /* as ds_eval_coef.xin_copies */,
+                    size_t n, void* stream);
 
 /* Denoiser with per-sample coefficients (sigma differs across the batch):
  * out = c_out[b]*F + c_skip[b]*x, F as above.  karrasmodule.py:717-718.  Coefficient arrays are
