@@ -66,9 +66,9 @@ _PROTOS = {
     "ds_table_apply_images": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "ds_conv2d_h3_up_img": (c_int, [_P, _P, _P, c_int, _P, _P, c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P]),
     "ds_conv_tile_count": (c_int, [c_int, c_int]),
-    "ds_inorm_table": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_int, _P, _P]),
+    "ds_inorm_table": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_int, _P]),
     "ds_gnorm1_table": (c_int, [_P, _P, c_int, c_int, _P, c_int, c_int, _P, _P, _P, _P, c_int, c_int, c_longlong,
-                                c_float, c_int, _P, _P]),
+                                c_float, c_int, _P]),
     "ds_gnorm1_stats_tiles": (c_int, [_P, _P, c_int, c_int, _P, c_int, c_int, c_int, c_longlong, c_float, c_int, _P]),
     "ds_conv2d_direct": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "ds_conv3d_direct": (c_int, [_P, _P, _P, _P, _P, c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),

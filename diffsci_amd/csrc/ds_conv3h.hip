@@ -273,8 +273,11 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_conv3h(const Conv3hArgs a) 
     f32x4 p[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) p[k] = pp[8 * h + k];
+    // the sample's activation exponent rides in the table's fourth column (2^-k, the same in every row; 0 = none): scalar select
+    const float inv = p[0][3] == 0.f ? 1.0f : p[0][3];
+    ascale.inv_scale = inv;                                          // the epilogue undoes it (unscale_from_inv)
 #pragma unroll
-    for (int k = 0; k < 8; ++k) xr[i][k] = ds_h3::fast_silu_scaled((xr[i][k] - p[k][0]) * p[k][1] + p[k][2], ascale.inv_scale);
+    for (int k = 0; k < 8; ++k) xr[i][k] = ds_h3::fast_silu_scaled((xr[i][k] - p[k][0]) * p[k][1] + p[k][2], inv);
   };
   auto x_store = [&](int buf) __attribute__((always_inline)) {                       // [normalise + SiLU,] split to fp16 pieces, write the LDS image
     u32x4* xb = Xs + buf * XBV;
@@ -403,7 +406,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_conv3h(const Conv3hArgs a) 
   // ---- prologue: patch 0, weight slabs 0 and 1 ----
   // (scalar loads share one counter: issued any earlier, the first wait for a kernel argument would wait for this load too)
   __builtin_amdgcn_sched_barrier(0);
-  const unsigned amax_bits = ds_epi::act_bits(IMGIN ? nullptr : a.in_amax, b);
+  const unsigned amax_bits = ds_epi::act_bits((IMGIN || PRE) ? nullptr : a.in_amax, b);
   if constexpr (IMGIN) x_dma(0, 0); else
   x_fetch(0);
   const float bias_shift = ds_epi::fetch_bias_shift(a.bias, a.shift, a.shift_stride, b, cot * COT, a.Cout);
@@ -411,7 +414,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_conv3h(const Conv3hArgs a) 
   if (n_steps > 1) w_fetch(1, 1);
   STAMP(1);
   __builtin_amdgcn_sched_barrier(0);
-  ascale = ds_epi::act_scale_of(amax_bits, a.wshift);
+  ascale = ds_epi::act_scale_of(PRE ? 0u : amax_bits, a.wshift);   // PRE: the table carries the exponent (x_activate)
   if constexpr (!IMGIN) x_store(0);
   ds_epi::commit_bias_shift(BS, bias_shift);
   __syncthreads();
@@ -685,6 +688,7 @@ int ds_conv2d_h3(float* out, const float* in, const void* w_packed, int wshift, 
                  int load_mode, const float* prenorm, float* tile_stats, const unsigned* in_amax, unsigned* out_amax,
                  void* stream) {
   DS_REQUIRE(out && in && w_packed, DS_ERR_NULL, "ds_conv2d_h3: NULL pointer");
+  DS_REQUIRE(!(prenorm && in_amax), DS_ERR_UNSUPPORTED, "ds_conv2d_h3: in_amax is for raw inputs (with prenorm the table's fourth column carries the exponent)");
   DS_REQUIRE(B >= 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, DS_ERR_SHAPE,
              "ds_conv2d_h3: bad shape B=%d Cin=%d Cout=%d H=%d W=%d", B, Cin, Cout, H, W);
   const int circular = (load_mode & DS_PAD_CIRCULAR) ? 1 : 0;

@@ -287,8 +287,11 @@ __global__ __launch_bounds__(NT, 2) void k_convup(const UpArgs a) {
     f32x4 p[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) p[k] = pp[8 * h + k];
+    // the sample's activation exponent rides in the table's fourth column (2^-k, the same in every row; 0 = none): scalar select
+    const float inv = p[0][3] == 0.f ? 1.0f : p[0][3];
+    ascale.inv_scale = inv;                                          // the epilogue undoes it (unscale_from_inv)
 #pragma unroll
-    for (int k = 0; k < 8; ++k) xr[i][k] = ds_h3::fast_silu_scaled((xr[i][k] - p[k][0]) * p[k][1] + p[k][2], ascale.inv_scale);
+    for (int k = 0; k < 8; ++k) xr[i][k] = ds_h3::fast_silu_scaled((xr[i][k] - p[k][0]) * p[k][1] + p[k][2], inv);
   };
   auto x_store = [&](int buf) __attribute__((always_inline)) {
     u32x4* xb = Xs + buf * XBV;
@@ -357,14 +360,14 @@ __global__ __launch_bounds__(NT, 2) void k_convup(const UpArgs a) {
 
   // ---- prologue: patch 0, weight slabs 0 and 1 ----
   __builtin_amdgcn_sched_barrier(0);
-  const unsigned amax_bits = ds_epi::act_bits(IMGIN ? nullptr : a.in_amax, b);   // see ds_conv3h.hip: issued here, consumed behind the first loads
+  const unsigned amax_bits = ds_epi::act_bits((IMGIN || PRE) ? nullptr : a.in_amax, b);   // see ds_conv3h.hip: issued here, consumed behind the first loads
   if constexpr (IMGIN) x_dma(0, 0); else
   x_fetch(0);
   const float bias_shift = ds_epi::fetch_bias_shift(a.bias, a.shift, a.shift_stride, b, cot * COT, a.Cout);
   w_fetch(0, 0);
   w_fetch(1, 1);                                                 // n_steps >= 4 always
   __builtin_amdgcn_sched_barrier(0);
-  ascale = ds_epi::act_scale_of(amax_bits, a.wshift);
+  ascale = ds_epi::act_scale_of(PRE ? 0u : amax_bits, a.wshift);   // PRE: the table carries the exponent (x_activate)
   if constexpr (!IMGIN) x_store(0);
   ds_epi::commit_bias_shift(BS, bias_shift);
   __syncthreads();
@@ -639,6 +642,7 @@ int ds_conv2d_h3_up(float* out, const float* in, const void* w_packed, int wshif
                     int shift_stride, const float* res1, const float* res2, int B, int Cin, int Cout, int Hl, int Wl,
                     int flags, const float* prenorm, float* tile_stats, const unsigned* in_amax, unsigned* out_amax, void* stream) {
   DS_REQUIRE(out && in && w_packed, DS_ERR_NULL, "ds_conv2d_h3_up: NULL pointer");
+  DS_REQUIRE(!(prenorm && in_amax), DS_ERR_UNSUPPORTED, "ds_conv2d_h3_up: in_amax is for raw inputs (with prenorm the table's fourth column carries the exponent)");
   DS_REQUIRE(B >= 0 && Cin > 0 && Cout > 0 && Hl > 0 && Wl > 0, DS_ERR_SHAPE,
              "ds_conv2d_h3_up: bad shape B=%d Cin=%d Cout=%d Hl=%d Wl=%d", B, Cin, Cout, Hl, Wl);
   DS_REQUIRE((flags & ~(DS_PAD_CIRCULAR | DS_RES1_UPSAMPLED)) == 0, DS_ERR_UNSUPPORTED, "ds_conv2d_h3_up: flags %d", flags);

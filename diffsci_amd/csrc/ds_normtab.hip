@@ -12,10 +12,12 @@
 //                    over the channel concatenation of two tensors (adm.py:306-343, 385-406, 764-766):
 //                    kind 0: M = mean_b, A = rstd_b*w[c], C = b[c];  kind 1: M = 0, A = w[c]/d_b, C = b[c];
 //                    with FiLM rows (the block's second norm): A *= te1[b,c], C = C*te1[b,c] + te2[b,c]
-// act_amax (optional, [B], zeroed): a bound on max |(x - M)*A + C| over the sample, merged with atomicMax as float bits --
-// |x - mean| <= sqrt(n var) and |x| <= sqrt(sum x^2) hold for every element, so U = |A| sqrt(n m2) + |C| can never be exceeded.
-// The consuming loader scales its activation by the sample's power of two taken from it (ds_conv_epilogue.h: act_scale), which
-// keeps SiLU(norm(x)) inside the fp16x3 window whatever the norm's affine parameters, FiLM rows or eps-dominated variances do.
+// Fourth column: 2^-k, the sample's activation exponent for the consuming loader (0 = none).  U = max_c |A_c| sqrt(n m2_c) + |C_c|
+// bounds every |(x - M)*A + C| of the sample (|x - mean| <= sqrt(n var), |x| <= sqrt(sum x^2)); k puts U at 2^13 and the loader
+// produces SiLU(.) * 2^k at no cost (ds_h3_common.h: fast_silu_scaled), undone in the convolution's epilogue: SiLU(norm(x)) stays
+// inside the fp16x3 window whatever the norm's affine parameters, FiLM rows or eps-dominated variances do
+// (commonlayers.py:766-770: (x - mean)/sqrt(var + 1e-5) of a tensor of rms 1e-7 is 3e-5, not 1).  The value rides in the rows
+// the loader reads anyway: no extra load, no atomics.
 #include "ds_common.h"
 
 namespace {
@@ -31,59 +33,65 @@ __device__ __forceinline__ void acc_tile(const float4 v, double& s, double& q) {
   q += Q + 2.0 * K * S + n * K * K;
 }
 
-// 16 lanes per (b, c) plane
-__global__ __launch_bounds__(256) void k_inorm_table(float* table, const float* __restrict__ ts, const float* __restrict__ w,
-                                                     const float* __restrict__ bias, int planes, int C, int Cpad, int ntiles,
-                                                     double inv_n, float eps, int kind, unsigned* __restrict__ act_amax) {
-  // planes = B * Cpad table rows; rows with c >= C are the zero padding of the last 16-channel chunk
-  // act_amax: the block's 16 rows belong to at most two samples (Cpad >= 16); their bounds meet in LDS first, so a sample's slot
-  // sees Cpad/16 global atomics instead of C (64 same-address atomics arriving together cost this 5 us kernel 29 us more)
-  __shared__ unsigned smax[2];
-  if (threadIdx.x < 2) smax[threadIdx.x] = 0u;
-  if (act_amax) __syncthreads();
-  const int bb0 = (blockIdx.x * 16) / Cpad;
-  const int row = blockIdx.x * 16 + (threadIdx.x >> 4);
-  const int l = threadIdx.x & 15;
-  const int bb = row / Cpad, c = row - bb * Cpad;
-  const bool real = row < planes && c < C;
-  const int plane = bb * C + c;
-  double s = 0.0, q = 0.0;
-  if (real) {
-    const float4* p = reinterpret_cast<const float4*>(ts) + (size_t)plane * ntiles;
-    for (int t = l; t < ntiles; t += 16) acc_tile(p[t], s, q);
-  }
-  s = group_sum_d(s, 16);
-  q = group_sum_d(q, 16);
-  if (row < planes && !real && l == 0) reinterpret_cast<float4*>(table)[row] = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (real && l == 0) {
-    float M, rs;
-    double dev2 = q;                            // sum of squared deviations from M: bounds every |x - M|^2
-    if (kind == 0) {
-      const double mean = s * inv_n;
-      double var = q * inv_n - mean * mean;
-      if (var < 0.0) var = 0.0;
-      M = (float)mean;
-      rs = 1.0f / sqrtf((float)var + eps);
-      dev2 = var / inv_n;
-    } else if (kind == 1) {
-      M = 0.f;
-      rs = 1.0f / sqrtf((float)(q * inv_n) + eps);
-    } else {                                   // kind 2: no normalisation, the loader applies SiLU alone
-      M = 0.f;
-      rs = 1.0f;
+// 2^-k for a bound U on the activation's argument: U * 2^k in [2^13, 2^14); |k| <= 80 keeps 2^-(wshift + k) a normal float for
+// every weight shift (|wshift| <= 40)
+__device__ __forceinline__ float inv_scale_of(float U) {
+  const unsigned bits = __builtin_bit_cast(unsigned, U);
+  const int e = (int)((bits >> 23) & 0xffu);
+  int k = (e == 0 || e == 255) ? 0 : 140 - e;
+  k = k > 80 ? 80 : (k < -80 ? -80 : k);
+  return __builtin_bit_cast(float, (unsigned)(127 - k) << 23);
+}
+
+// one workgroup per sample, 16 lanes per (b, c) plane, 64 planes at a time
+constexpr int ITT = 1024;
+__global__ __launch_bounds__(ITT) void k_inorm_table(float* table, const float* __restrict__ ts, const float* __restrict__ w,
+                                                     const float* __restrict__ bias, int C, int Cpad, int ntiles,
+                                                     double inv_n, float eps, int kind) {
+  __shared__ unsigned smax;
+  const int bb = blockIdx.x;
+  const int l = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  if (threadIdx.x == 0) smax = 0u;
+  __syncthreads();
+  float4* rows = reinterpret_cast<float4*>(table) + (size_t)bb * Cpad;
+  float U = 0.f;
+  for (int c = grp; c < Cpad; c += ITT / 16) {
+    const bool real = c < C;
+    double s = 0.0, q = 0.0;
+    if (real) {
+      const float4* p = reinterpret_cast<const float4*>(ts) + ((size_t)bb * C + c) * ntiles;
+      for (int t = l; t < ntiles; t += 16) acc_tile(p[t], s, q);
     }
-    float4 o;
-    o.x = M; o.y = rs * ((w && kind != 2) ? w[c] : 1.f); o.z = (bias && kind != 2) ? bias[c] : 0.f; o.w = 0.f;
-    reinterpret_cast<float4*>(table)[row] = o;
-    if (act_amax) {
-      const float U = fabsf(o.y) * (float)sqrt(dev2 > 0.0 ? dev2 : 0.0) * 1.0000005f + fabsf(o.z);
-      atomicMax(&smax[bb - bb0], __builtin_bit_cast(unsigned, U));
+    s = group_sum_d(s, 16);
+    q = group_sum_d(q, 16);
+    if (l != 0) continue;
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);                  // rows with c >= C: the zero padding of the last 16-channel chunk
+    if (real) {
+      float M, rs;
+      double dev2 = q;                          // sum of squared deviations from M: bounds every |x - M|^2
+      if (kind == 0) {
+        const double mean = s * inv_n;
+        double var = q * inv_n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        M = (float)mean;
+        rs = 1.0f / sqrtf((float)var + eps);
+        dev2 = var / inv_n;
+      } else if (kind == 1) {
+        M = 0.f;
+        rs = 1.0f / sqrtf((float)(q * inv_n) + eps);
+      } else {                                   // kind 2: no normalisation, the loader applies SiLU alone
+        M = 0.f;
+        rs = 1.0f;
+      }
+      o.x = M; o.y = rs * ((w && kind != 2) ? w[c] : 1.f); o.z = (bias && kind != 2) ? bias[c] : 0.f;
+      U = fmaxf(U, fabsf(o.y) * (float)sqrt(dev2 > 0.0 ? dev2 : 0.0) * 1.0000005f + fabsf(o.z));
     }
+    rows[c] = o;
   }
-  if (act_amax) {
-    __syncthreads();
-    if (threadIdx.x < 2 && smax[threadIdx.x] != 0u) atomicMax(act_amax + bb0 + threadIdx.x, smax[threadIdx.x]);
-  }
+  if (l == 0 && U > 0.f) atomicMax(&smax, __builtin_bit_cast(unsigned, U));       // LDS
+  __syncthreads();
+  const float inv = inv_scale_of(__builtin_bit_cast(float, smax));
+  for (int c = threadIdx.x; c < Cpad; c += ITT) reinterpret_cast<float*>(rows + c)[3] = inv;    // padded rows too: the loader reads any row's
 }
 
 // one workgroup of 1024 threads per sample: the tile statistics of one sample are up to 1 MiB (256 channels x 256
@@ -94,9 +102,11 @@ __global__ __launch_bounds__(G1T) void k_gnorm1_table(float* table, const float*
                                                       const float* __restrict__ w, const float* __restrict__ bias,
                                                       const float* __restrict__ f1, const float* __restrict__ f2,
                                                       int film_stride, double inv_n, float eps, int kind,
-                                                      float* __restrict__ stats_out, unsigned* __restrict__ act_amax) {
+                                                      float* __restrict__ stats_out) {
   __shared__ double red[2][G1T / 64];
   __shared__ float st[3];
+  __shared__ unsigned smax;
+  if (threadIdx.x == 0) smax = 0u;
   const int b = blockIdx.x, C = Ca + Cb;
   double s = 0.0, q = 0.0;
   {
@@ -149,10 +159,11 @@ __global__ __launch_bounds__(G1T) void k_gnorm1_table(float* table, const float*
     reinterpret_cast<float4*>(table)[(size_t)b * Cpad + c] = o;
     U = fmaxf(U, fabsf(o.y) * dev + fabsf(o.z));
   }
-  if (act_amax) {
-    for (int o = 32; o > 0; o >>= 1) U = fmaxf(U, __shfl_xor(U, o, 64));
-    if ((threadIdx.x & 63) == 0) atomicMax(act_amax + b, __builtin_bit_cast(unsigned, U));
-  }
+  for (int o = 32; o > 0; o >>= 1) U = fmaxf(U, __shfl_xor(U, o, 64));
+  if ((threadIdx.x & 63) == 0 && U > 0.f) atomicMax(&smax, __builtin_bit_cast(unsigned, U));    // LDS
+  __syncthreads();
+  const float inv = inv_scale_of(__builtin_bit_cast(float, smax));
+  for (int c = threadIdx.x; c < Cpad; c += G1T) reinterpret_cast<float*>(reinterpret_cast<float4*>(table) + (size_t)b * Cpad + c)[3] = inv;
 }
 
 }  // namespace
@@ -160,7 +171,7 @@ __global__ __launch_bounds__(G1T) void k_gnorm1_table(float* table, const float*
 extern "C" {
 
 int ds_inorm_table(float* table, const float* tile_stats, const float* w, const float* b, int B, int C, int ntiles,
-                   int count, float eps, int kind, unsigned* act_amax, void* stream) {
+                   int count, float eps, int kind, void* stream) {
   DS_REQUIRE(table && tile_stats, DS_ERR_NULL, "ds_inorm_table: NULL pointer");
   DS_REQUIRE(B >= 0 && C > 0 && ntiles > 0 && count > 0, DS_ERR_SHAPE, "ds_inorm_table: bad shape");
   DS_REQUIRE(kind >= 0 && kind <= 2, DS_ERR_UNSUPPORTED, "ds_inorm_table: kind %d (0 GroupLN, 1 GroupRMS, 2 none)", kind);
@@ -169,16 +180,16 @@ int ds_inorm_table(float* table, const float* tile_stats, const float* w, const 
              DS_ERR_SHAPE, "ds_inorm_table: misaligned pointer");
   if (B == 0) return DS_OK;
   const int Cpad = (C + 15) / 16 * 16;
-  const int planes = B * Cpad;
-  hipLaunchKernelGGL(k_inorm_table, dim3((planes + 15) / 16), dim3(256), 0, ds::as_stream(stream), table, tile_stats, w,
-                     b, planes, C, Cpad, ntiles, 1.0 / (double)count, eps, kind, act_amax);
+  DS_REQUIRE(B < 65536 * 32, DS_ERR_SHAPE, "ds_inorm_table: B=%d", B);
+  hipLaunchKernelGGL(k_inorm_table, dim3((unsigned)B), dim3(ITT), 0, ds::as_stream(stream), table, tile_stats, w,
+                     b, C, Cpad, ntiles, 1.0 / (double)count, eps, kind);
   DS_CHECK_LAUNCH("ds_inorm_table");
   return DS_OK;
 }
 
 int ds_gnorm1_table(float* table, const float* stats_a, int Ca, int ntiles_a, const float* stats_b, int Cb,
                     int ntiles_b, const float* w, const float* b, const float* film_scale, const float* film_shift,
-                    int film_stride, int B, long long count, float eps, int kind, unsigned* act_amax, void* stream) {
+                    int film_stride, int B, long long count, float eps, int kind, void* stream) {
   DS_REQUIRE(table && stats_a, DS_ERR_NULL, "ds_gnorm1_table: NULL pointer");
   DS_REQUIRE(B >= 0 && Ca > 0 && ntiles_a > 0 && Cb >= 0 && count > 0, DS_ERR_SHAPE, "ds_gnorm1_table: bad shape");
   DS_REQUIRE(Cb == 0 || (stats_b && ntiles_b > 0), DS_ERR_NULL, "ds_gnorm1_table: second source missing");
@@ -188,7 +199,7 @@ int ds_gnorm1_table(float* table, const float* stats_a, int Ca, int ntiles_a, co
              DS_ERR_SHAPE, "ds_gnorm1_table: pointers must be 16-byte aligned");
   if (B == 0) return DS_OK;
   hipLaunchKernelGGL(k_gnorm1_table, dim3(B), dim3(G1T), 0, ds::as_stream(stream), table, stats_a, Ca, ntiles_a, stats_b,
-                     Cb, ntiles_b, w, b, film_scale, film_shift, film_stride, 1.0 / (double)count, eps, kind, (float*)nullptr, act_amax);
+                     Cb, ntiles_b, w, b, film_scale, film_shift, film_stride, 1.0 / (double)count, eps, kind, (float*)nullptr);
   DS_CHECK_LAUNCH("ds_gnorm1_table");
   return DS_OK;
 }
@@ -206,7 +217,7 @@ int ds_gnorm1_stats_tiles(float* stats, const float* stats_a, int Ca, int ntiles
   if (B == 0) return DS_OK;
   hipLaunchKernelGGL(k_gnorm1_table, dim3(B), dim3(G1T), 0, ds::as_stream(stream), (float*)nullptr, stats_a, Ca, ntiles_a,
                      stats_b, Cb, ntiles_b, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
-                     (const float*)nullptr, 0, 1.0 / (double)count, eps, kind, stats, (unsigned*)nullptr);
+                     (const float*)nullptr, 0, 1.0 / (double)count, eps, kind, stats);
   DS_CHECK_LAUNCH("ds_gnorm1_stats_tiles");
   return DS_OK;
 }

@@ -544,10 +544,9 @@ class ADM(torch.nn.Module):
         if fuse1 and xs is not None and not down and not up:
             sa, sb = xs if isinstance(xs, tuple) else (xs, None)
             tab = ws.take((B, ops.table_channels(Ci), 4), dev)
-            ta = self._am.row() if self._am is not None else None              # the activation's exponent: see PUNetG._res
-            ops.gnorm1_table(sa, blk.norm1.weight, blk.norm1.bias, k1, Ci * H * W, stats_b=sb, eps=1e-5, out=tab, act_amax=ta)
+            ops.gnorm1_table(sa, blk.norm1.weight, blk.norm1.bias, k1, Ci * H * W, stats_b=sb, eps=1e-5, out=tab)   # + the activation's exponent
             y = self._conv(blk.conv1, x, pk, load_mode=mode, prenorm=tab, tile_stats=ys,
-                           out=ws.take((B, blk.cout, Ho, Wo), dev), in_amax=ta)
+                           out=ws.take((B, blk.cout, Ho, Wo), dev))
             ws.give(tab)
         else:                                                                     # pooling follows the activation
             Hm, Wm = (Ho, Wo) if down else (H, W)
@@ -604,10 +603,9 @@ class ADM(torch.nn.Module):
         oa = (self._am.row() if has_attn else out_amax) if h3 else None            # conv2's result feeds the attention, or is the block's
         if fuse2:
             tab = ws.take((B, ops.table_channels(blk.cout), 4), dev)
-            ta = self._am.row() if h3 else None
-            ops.gnorm1_table(ys, blk.norm2.weight, blk.norm2.bias, k2, blk.cout * Ho * Wo, film=film, eps=1e-5, out=tab, act_amax=ta)
+            ops.gnorm1_table(ys, blk.norm2.weight, blk.norm2.bias, k2, blk.cout * Ho * Wo, film=film, eps=1e-5, out=tab)
             out = self._conv(blk.conv2, y, pk, res1=r, res1_upsampled=r_up, prenorm=tab, tile_stats=os_,
-                             out=ws.take((B, blk.cout, Ho, Wo), dev), in_amax=ta, out_amax=oa)
+                             out=ws.take((B, blk.cout, Ho, Wo), dev), out_amax=oa)
             ws.give(tab)
             ws.give(ys)
             ws.give(y)

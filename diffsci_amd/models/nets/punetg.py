@@ -689,22 +689,20 @@ class PUNetG(torch.nn.Module):
         k1, k2 = self.norm_kinds                           # 0 GroupLN, 1 GroupRMS, 2 none, 3 GroupPix (not a table)
         w1, b1 = getattr(blk.gnorm1, "weight", None), getattr(blk.gnorm1, "bias", None)
         w2, b2 = getattr(blk.gnorm2, "weight", None), getattr(blk.gnorm2, "bias", None)
-        # The folded route: the table call also leaves a bound on the activation's argument per sample (act_amax), and the loader
-        # produces SiLU(norm(x)) times the power of two taken from it -- inside the fp16x3 window whatever the affine parameters or
-        # an eps-dominated variance do.  The image / standalone routes below rely on the norm to put its output in the window:
+        # The folded route: the table carries the sample's activation exponent in its fourth column (a bound on the activation's
+        # argument from the statistics), and the loader produces SiLU(norm(x)) times that power of two -- inside the fp16x3 window
+        # whatever the affine parameters or an eps-dominated variance do.  The image / standalone routes below rely on the norm to put its output in the window:
         # real norms with affine parameters of ordinary size (windowed); otherwise the activation's exponent is measured.
         if (self._fused() and xs is not None and (C + 63) // 64 <= self.fuse_max_cot and k1 != 3 and k2 != 3
                 and self.config.kernel_size == 3):                                  # the norm+SiLU loader is the 3x3 kernel's
-            am = self._am
-            t1, t2 = (am.row(), am.row()) if am is not None else (ops.amax_new(B, dev), ops.amax_new(B, dev))
             tab = ws.take((B, ops.table_channels(C), 4), dev)
-            ops.inorm_table(xs, w1, b1, k1, H * W, eps=1e-5, out=tab, act_amax=t1)
+            ops.inorm_table(xs, w1, b1, k1, H * W, eps=1e-5, out=tab)
             ys = self._stats_buf(ws, B, C, H, W, dev)
-            y = self._conv(blk.conv1, x, pk, shift=shift, res1=yt, prenorm=tab, tile_stats=ys, out=ws.take(x.shape, dev), in_amax=t1)
-            ops.inorm_table(ys, w2, b2, k2, H * W, eps=1e-5, out=tab, act_amax=t2)
+            y = self._conv(blk.conv1, x, pk, shift=shift, res1=yt, prenorm=tab, tile_stats=ys, out=ws.take(x.shape, dev))
+            ops.inorm_table(ys, w2, b2, k2, H * W, eps=1e-5, out=tab)
             os_ = self._stats_buf(ws, B, C, H, W, dev) if want_stats else None
             out = self._conv(blk.conv2, y, pk, res1=x, res2=res2, prenorm=tab, tile_stats=os_, out=ws.take(x.shape, dev),
-                             in_amax=t2, out_amax=out_amax)
+                             out_amax=out_amax)
             ws.give(y)
             ws.give(ys)
             ws.give(tab)

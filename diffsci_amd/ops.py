@@ -141,9 +141,9 @@ def amax_merge(out, a, b=None):
 
 
 def _in_amax(x, in_amax, rows, raw):
-    """Pointer for a kernel's in_amax argument.  raw: the launch reads x without a normalising loader (with one, only an
-    explicit row -- the table call's act_amax -- means anything)."""
-    if in_amax is NORMALISED or (in_amax is None and not raw):
+    """Pointer for a kernel's in_amax argument.  raw: the launch reads x without a normalising loader (with one, the table's
+    fourth column carries the exponent)."""
+    if in_amax is NORMALISED or not raw:
         return None
     if in_amax is None:
         in_amax = absmax_rows(x, rows)
@@ -733,22 +733,22 @@ def table_channels(C):
     return (C + 15) // 16 * 16
 
 
-def inorm_table(tile_stats, w, b, kind, count, eps=1e-5, out=None, act_amax=None):
-    """PUNetG norm table [B, ceil16(C), 4] from a convolution's tile statistics [B, C, ntiles, 4].  act_amax: zeroed int32 [B]
-    that receives a bound on the activation's argument -- pass it as in_amax next to prenorm=table."""
+def inorm_table(tile_stats, w, b, kind, count, eps=1e-5, out=None):
+    """PUNetG norm table [B, ceil16(C), 4] from a convolution's tile statistics [B, C, ntiles, 4]: rows (M, A, C, 2^-k), k the
+    sample's activation exponent for the consuming loader."""
     B, C, nt, _ = tile_stats.shape
     if out is None:
         out = torch.empty((B, table_channels(C), 4), dtype=torch.float32, device=tile_stats.device)
     elif tuple(out.shape) != (B, table_channels(C), 4):
         raise ValueError(f"table must be {(B, table_channels(C), 4)}")
     N.check(N.lib().ds_inorm_table(_p(out), _p(tile_stats), _p(w), _p(b), B, C, nt, int(count), float(eps), int(kind),
-                                   _pi(act_amax, B, "act_amax"), _stream()), "ds_inorm_table")
+                                   _stream()), "ds_inorm_table")
     return out
 
 
-def gnorm1_table(stats_a, w, b, kind, count, stats_b=None, film=None, eps=1e-5, out=None, act_amax=None):
-    """ADM norm table [B, ceil16(Ca+Cb), 4] from tile statistics of one tensor or of the two halves of a concat.
-    act_amax: as inorm_table."""
+def gnorm1_table(stats_a, w, b, kind, count, stats_b=None, film=None, eps=1e-5, out=None):
+    """ADM norm table [B, ceil16(Ca+Cb), 4] from tile statistics of one tensor or of the two halves of a concat (rows as
+    inorm_table)."""
     B, Ca, nta, _ = stats_a.shape
     Cb, ntb = (0, 0) if stats_b is None else (stats_b.shape[1], stats_b.shape[2])
     C = Ca + Cb
@@ -765,7 +765,7 @@ def gnorm1_table(stats_a, w, b, kind, count, stats_b=None, film=None, eps=1e-5, 
         stride = 0 if film.shape[0] == 1 else 2 * C
         f1, f2 = film.data_ptr(), film.data_ptr() + 4 * C
     N.check(N.lib().ds_gnorm1_table(_p(out), _p(stats_a), Ca, nta, _p(stats_b), Cb, ntb, _p(w), _p(b), f1, f2, stride,
-                                    B, int(count), float(eps), int(kind), _pi(act_amax, B, "act_amax"), _stream()), "ds_gnorm1_table")
+                                    B, int(count), float(eps), int(kind), _stream()), "ds_gnorm1_table")
     return out
 
 

@@ -247,8 +247,8 @@ int ds_absmax_channels(unsigned* out, unsigned* flag, unsigned* scratch, const f
  *   prenorm    [B, ceil16(Cin), 4] = (M, A, C, -), rows past Cin zero: the loader applies SiLU((x - M)*A + C) to every input element
  *              before the convolution (zero padding stays zero) -- the norm -> act of ResnetBlockC /
  *              ADMBaseBlock (commonlayers.py:824-829, adm.py:312-337) without materialising its output.
- *              Not with MAXPOOL2.  Tables come from ds_inorm_table / ds_gnorm1_table.  With prenorm, in_amax is the
- *              table call's act_amax row (a bound on the activation's argument): the loader produces SiLU(.) * 2^k.
+ *              Not with MAXPOOL2.  Tables come from ds_inorm_table / ds_gnorm1_table; their fourth column carries the sample's
+ *              activation exponent (the loader produces SiLU(.) * 2^k), so in_amax is not used with prenorm.
  *   tile_stats [B, Cout, ntiles, 4]: per output channel and pixel tile of the stored values, (K, S, Q, n):
  *              n valid pixels, K one of them, S = sum(x-K), Q = sum((x-K)^2) (shifted sums: no mean^2
  *              cancellation in fp32); ntiles = ds_conv_tile_count(H, W); consumed by the *_table calls,
@@ -302,16 +302,17 @@ int ds_conv2d_h3_up_img(float* out, const void* images, const void* w_packed, in
                         int B, int Cin, int Cout, int Hl, int Wl, float* tile_stats, unsigned* out_amax, void* stream);
 
 
-/* PUNetG norms from tile statistics: table [B, ceil16(C), 4]; table[b,c] = (mean | 0, rstd*w[c], b[c], 0) for GroupNorm(C,C)
- * (kind 0) / GroupRMSNorm(C,C) (kind 1), (0, 1, 0, 0) for no normalisation (kind 2); count = H*W.
+/* PUNetG norms from tile statistics: table [B, ceil16(C), 4]; table[b,c] = (mean | 0, rstd*w[c], b[c], 2^-k) for GroupNorm(C,C)
+ * (kind 0) / GroupRMSNorm(C,C) (kind 1), (0, 1, 0, 2^-k) for no normalisation (kind 2); count = H*W.
  * commonlayers.py:766-770, 372-384, 891-899. */
 int ds_inorm_table(float* table, const float* tile_stats, const float* w, const float* b, int B, int C, int ntiles,
-                   int count, float eps, int kind, unsigned* act_amax, void* stream);
-/* act_amax (both table calls; optional, [B], zeroed): a bound on the sample's max |(x - M)*A + C| as float bits -- from
- * |x - mean| <= sqrt(n var), |x| <= sqrt(sum x^2) -- merged with atomicMax.  Given to the consuming convolution as in_amax next to
- * prenorm, the loader scales its activation by the sample's power of two (at no cost: the factor rides in the SiLU's own exp2 and
- * reciprocal), so SiLU(norm(x)) stays inside the fp16x3 window whatever the affine parameters, FiLM rows or eps-dominated
- * variances do (commonlayers.py:766-770: (x - mean)/sqrt(var + 1e-5) of a tensor of rms 1e-7 is 3e-5, not 1). */
+                   int count, float eps, int kind, void* stream);
+/* The fourth column (both table calls): 2^-k, the sample's activation exponent, the same in every row of the sample (padding
+ * rows included); 0 in a hand-made table means none.  U = max_c |A_c| sqrt(n m2_c) + |C_c| bounds every |(x - M)*A + C| of the sample
+ * (|x - mean| <= sqrt(n var), |x| <= sqrt(sum x^2)), k puts U at 2^13, the consuming loader produces SiLU(.) * 2^k at no cost (the
+ * factor rides in the SiLU's own fma and reciprocal) and the convolution's epilogue undoes it: SiLU(norm(x)) stays inside the
+ * fp16x3 window whatever the affine parameters, FiLM rows or eps-dominated variances do (commonlayers.py:766-770:
+ * (x - mean)/sqrt(var + 1e-5) of a tensor of rms 1e-7 is 3e-5, not 1). */
 
 /* ADM norms from tile statistics, per sample over (C, H, W), optionally over the channel concatenation
  * of two tensors (Cb = 0: one source): kind 0 GroupNorm(1,C): (mean_b, rstd_b*w[c], b[c]); kind 1
@@ -320,7 +321,7 @@ int ds_inorm_table(float* table, const float* tile_stats, const float* w, const 
  * adm.py:306-343, 385-406, 764-766. */
 int ds_gnorm1_table(float* table, const float* stats_a, int Ca, int ntiles_a, const float* stats_b, int Cb,
                     int ntiles_b, const float* w, const float* b, const float* film_scale, const float* film_shift,
-                    int film_stride, int B, long long count, float eps, int kind, unsigned* act_amax, void* stream);
+                    int film_stride, int B, long long count, float eps, int kind, void* stream);
 /* ds_gnorm1_stats without a pass over the tensor: the pairs ds_gnorm1_apply / ds_gnorm1_apply_images take, (mean, rstd)
  * (kind 0) or (0, RMS denominator) (kind 1), recombined in fp64 from the producers' tile statistics as ds_gnorm1_table does. */
 int ds_gnorm1_stats_tiles(float* stats, const float* stats_a, int Ca, int ntiles_a, const float* stats_b, int Cb,

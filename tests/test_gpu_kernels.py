@@ -388,8 +388,14 @@ def test_conv_tile_stats_and_fused_prenorm(dev, case):
     for kind in (0, 1):
         # PUNetG: per-(b, c) norms
         tab_full = ops.inorm_table(ts, wn.to(dev), bn.to(dev), kind, Hin * Win).cpu().double()
-        assert tab_full.shape[1] == ops.table_channels(Cin) and not tab_full[:, Cin:].any()   # zero rows pad the last chunk
+        assert tab_full.shape[1] == ops.table_channels(Cin) and not tab_full[:, Cin:, :3].any()   # zero rows pad the last chunk
+        # fourth column: 2^-k, the sample's activation exponent -- one power of two per sample (padding rows included) that puts
+        # a bound on |(x - M)*A + C| at 2^13
+        inv = tab_full[..., 3]
+        assert (inv == inv[:, :1]).all() and (torch.log2(inv[:, 0]) % 1 == 0).all()
         tab = tab_full[:, :Cin]
+        arg = ((yc - tab[..., 0, None, None]) * tab[..., 1, None, None] + tab[..., 2, None, None]).abs().amax(dim=(1, 2, 3))
+        assert (arg / inv[:, 0] < 2.0 ** 14).all() and (arg / inv[:, 0] > 2.0 ** 5).all()
         mean = yc.mean(dim=(2, 3)) if kind == 0 else torch.zeros(B, Cin, dtype=torch.float64)
         den = (yc.var(dim=(2, 3), unbiased=False) + 1e-5).sqrt() if kind == 0 else ((yc * yc).mean(dim=(2, 3)) + 1e-5).sqrt()
         torch.testing.assert_close(tab[..., 0], mean, rtol=1e-5, atol=1e-6)
@@ -414,8 +420,8 @@ def test_conv_tile_stats_and_fused_prenorm(dev, case):
     tab2 = ops.gnorm1_table(ts, torch.cat([wn, wn]).to(dev), torch.cat([bn, bn]).to(dev), 0, 2 * Cin * Hin * Win,
                             stats_b=ts).cpu()
     tab1 = ops.gnorm1_table(ts, wn.to(dev), bn.to(dev), 0, Cin * Hin * Win).cpu()
-    torch.testing.assert_close(tab2[:, :Cin], tab1[:, :Cin], rtol=1e-6, atol=1e-7)
-    torch.testing.assert_close(tab2[:, Cin:2 * Cin], tab1[:, :Cin], rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(tab2[:, :Cin, :3], tab1[:, :Cin, :3], rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(tab2[:, Cin:2 * Cin, :3], tab1[:, :Cin, :3], rtol=1e-6, atol=1e-7)
 
 
 @pytest.mark.parametrize("case", [(2, 16, 24, 32, 32, 0), (1, 40, 8, 20, 36, 0), (2, 8, 16, 16, 16, 0), (1, 8, 8, 9, 13, 0),

@@ -45,6 +45,8 @@ def fuzz_up(ri, g, dev):
         M, A, C = torch.randn(B, Cin, generator=g) * 0.3, torch.rand(B, Cin, generator=g) + 0.5, torch.randn(B, Cin, generator=g) * 0.3
         tab = torch.zeros(B, ops.table_channels(Cin), 4)
         tab[:, :Cin, 0], tab[:, :Cin, 1], tab[:, :Cin, 2] = M, A, C
+        if ri(0, 1):
+            tab[:, :, 3] = 2.0 ** -ri(-4, 11)                                     # an activation exponent: exact, the result does not change
         xin = F.silu((xin - M.double()[..., None, None]) * A.double()[..., None, None] + C.double()[..., None, None])
     up = F.interpolate(xin, scale_factor=2.0, mode="nearest")
     if circ:
@@ -196,6 +198,8 @@ def main():
                 M, A, C = torch.randn(B, Cin, generator=g) * 0.3, torch.rand(B, Cin, generator=g) + 0.5, torch.randn(B, Cin, generator=g) * 0.3
                 tab = torch.zeros(B, ops.table_channels(Cin), 4)
                 tab[:, :Cin, 0], tab[:, :Cin, 1], tab[:, :Cin, 2] = M, A, C
+                if ri(0, 1):
+                    tab[:, :, 3] = 2.0 ** -ri(-4, 11)
                 xin = x.double()
                 act = F.silu((xin - M.double()[..., None, None]) * A.double()[..., None, None] + C.double()[..., None, None])
                 s64 = F.interpolate(act, scale_factor=2.0, mode="nearest") if mode == 2 else act
