@@ -75,6 +75,12 @@ constexpr int LDS_BYTES = STAGE_BYTES + 128 * 4;              // + bias / shift 
 constexpr int STAGE_BYTES16 = (2 * XBUF_VEC16 + 3 * WSLAB_VEC) * 16;   // 81,152
 constexpr int LDS_BYTES16 = STAGE_BYTES16 + 128 * 4;                   // 81,664: two workgroups still fit 160 KiB
 static_assert(2 * LDS_BYTES16 <= 160 * 1024, "two workgroups per CU");
+// TWO: staging = two X buffers + a 3-slot ring of two slabs (118,016 B); the epilogue's eight 16 KiB wave tiles (131,072 B) reach
+// beyond it, so the bias / shift rows sit behind THEM
+constexpr int TWO_STAGE_BYTES = (2 * XBUF_VEC16 + 3 * 2 * WSLAB_VEC) * 16;
+constexpr int TWO_EPI_BYTES = 8 * 64 * 2 * 32 * 4;
+static_assert(TWO_EPI_BYTES >= TWO_STAGE_BYTES, "bias / shift rows behind the larger of the two");
+constexpr int LDS_BYTES_TWO = TWO_EPI_BYTES + 2 * 128 * 4;          // 132,096: one workgroup per CU
 
 struct Conv3hArgs {
   float* out;
@@ -122,26 +128,35 @@ template <int MT> struct Frags { f16x8 a[2][MT]; f16x8 b[2][2]; };   // [piece][
 // vectors of 8 channels, zero border) and is staged by LDS-DMA -- no staging registers, no split in this kernel.  Staging the
 // patches from fp32 costs 16-29 % of the kernel (profiles/r02_stamps_nostage.log), and at four channel tiles every element is
 // split 5.3 times; the producer splits it once.  16x16x32 variant, four waves, plain load, zero padding, no fused norm.
-template <int MODE, bool W16, bool PRE, bool CIRC, int NW, bool S16 = false, bool IMGIN = false>
-__global__ __launch_bounds__(64 * NW, NW / 2) void k_conv3h(const Conv3hArgs a) {
-  constexpr int M16 = 16 / NW;                                       // S16: 16-channel tiles per wave (4, or 2 with eight waves)
+// TWO (round 3; S16, eight waves): the workgroup owns TWO 64-channel tiles of the same pixel tile -- waves 0-3 the first, 4-7 the
+//         second, each wave a whole 64 x 64 tile as with NW = 4 -- and stages (fetches, activates, splits) the input patch ONCE for
+//         both: at 128 output channels every element is otherwise loaded, normalised and split twice.  One
+//         workgroup per CU (X buffers shared, weight ring doubled, eight 16 KiB epilogue tiles: 132 KB of LDS), 2 waves per SIMD
+//         as with two four-wave workgroups.
+template <int MODE, bool W16, bool PRE, bool CIRC, int NW, bool S16 = false, bool IMGIN = false, bool TWO = false>
+__global__ __launch_bounds__(64 * NW, TWO ? 2 : NW / 2) void k_conv3h(const Conv3hArgs a) {
+  static_assert(!TWO || (S16 && NW == 8 && !IMGIN), "two channel tiles per workgroup: the eight-wave 16x16x32 kernel");
+  constexpr int COTS = TWO ? 2 : 1;
+  constexpr int M16 = TWO ? 4 : 16 / NW;                             // S16: 16-channel tiles per wave (4, or 2 with eight waves on one tile)
   static_assert(!IMGIN || (S16 && NW == 4 && MODE == DS_LOAD_PLAIN && !PRE && !CIRC), "image input: plain 16x16x32 four-wave kernel");
   constexpr int TH = Geo<W16>::TH, TW = Geo<W16>::TW, PW = Geo<W16>::PW, NPOS = Geo<W16>::NPOS;
   constexpr int NTH = 64 * NW;                                       // threads
-  constexpr int MT = 8 / NW;                                         // 32-channel tiles per wave: 2 or 1
+  constexpr int MT = TWO ? 2 : 8 / NW;                               // 32-channel tiles per wave: 2 or 1
   constexpr int XI = (Geo<W16>::XITEMS + NTH - 1) / NTH;             // staging items per thread: 3 or 2
   constexpr int HS = S16 ? NPOS + HPAD16 : NPOS;                     // vectors between the h = 0 and h = 1 images of a piece
   constexpr int PS = S16 ? 2 * NPOS + HPAD16 : 2 * NPOS;             // ... between the two pieces
   constexpr int XBV = S16 ? XBUF_VEC16 : XBUF_VEC;                   // ... between the two X buffers
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   u32x4* Xs = reinterpret_cast<u32x4*>(smem);                        // [buf][piece][h][pos]
-  u32x4* Ws = Xs + 2 * XBV;                                          // [slot][piece][kx][h][co]
-  float* BS = reinterpret_cast<float*>(smem + (S16 ? STAGE_BYTES16 : STAGE_BYTES));   // [2][64] bias, shift
+  u32x4* Ws = Xs + 2 * XBV;                                          // [slot][channel tile][piece][kx][h][co]
+  constexpr int WSV = COTS * WSLAB_VEC;                              // vectors per ring slot
+  float* BS = reinterpret_cast<float*>(smem + (TWO ? TWO_EPI_BYTES : (S16 ? STAGE_BYTES16 : STAGE_BYTES)));   // [channel tile][2][64] bias, shift
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int rw = wv & 3;                               // row group of the wave
-  const int mh = NW == 8 ? (wv >> 2) : 0;              // its 32-channel half (NW = 8)
+  const int mh = (NW == 8 && !TWO) ? (wv >> 2) : 0;    // its 32-channel half (NW = 8 on one channel tile)
+  const int cw = TWO ? (wv >> 2) : 0;                  // its channel tile (TWO)
   const int li = lane & 31, lh = lane >> 5;
   // position of (wave, r, lane) inside the halo patch, before the (ky, kx) tap offset
   const int lane_pos = W16 ? (li >> 4) * PW + (li & 15) : li;
@@ -178,7 +193,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_conv3h(const Conv3hArgs a) 
     }
   }
 #endif
-  const int cot = (int)cot_u;
+  const int cot = (int)cot_u * COTS;                   // first channel tile of the workgroup
   const int tile_id = (int)tile_u;
   const int b = (int)b_u;
   const int ty = a.tiles_x == 1 ? tile_id : (int)__umulhi((unsigned)tile_id, a.tiles_x_magic);
@@ -273,11 +288,16 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_conv3h(const Conv3hArgs a) 
     f32x4 p[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) p[k] = pp[8 * h + k];
+#ifdef DS_PRE_UNSCALED       // measurement builds: what does the exponent cost the fused loader?
+#pragma unroll
+    for (int k = 0; k < 8; ++k) xr[i][k] = fast_silu((xr[i][k] - p[k][0]) * p[k][1] + p[k][2]);
+#else
     // the sample's activation exponent rides in the table's fourth column (2^-k, the same in every row; 0 = none): scalar select
     const float inv = p[0][3] == 0.f ? 1.0f : p[0][3];
     ascale.inv_scale = inv;                                          // the epilogue undoes it (unscale_from_inv)
 #pragma unroll
     for (int k = 0; k < 8; ++k) xr[i][k] = ds_h3::fast_silu_scaled((xr[i][k] - p[k][0]) * p[k][1] + p[k][2], inv);
+#endif
   };
   auto x_store = [&](int buf) __attribute__((always_inline)) {                       // [normalise + SiLU,] split to fp16 pieces, write the LDS image
     u32x4* xb = Xs + buf * XBV;
@@ -307,14 +327,17 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_conv3h(const Conv3hArgs a) 
   };
   auto w_fetch = [&](int step, int slot) __attribute__((always_inline)) {            // LDS-DMA of slab `step` into ring slot (= step % 3)
     const u32x4* src = wp + (size_t)step * WSLAB_VEC;
-    u32x4* dst = Ws + slot * WSLAB_VEC;
+    u32x4* dst = Ws + slot * WSV;
 #pragma unroll
-    for (int i = 0; i < (WPIECES + NW - 1) / NW; ++i) {
+    for (int i = 0; i < (COTS * WPIECES + NW - 1) / NW; ++i) {
       const int k = wv + NW * i;                      // wave-uniform
-      if (k < WPIECES)
+      if (k < COTS * WPIECES) {
+        // TWO: pieces WPIECES.. belong to the second channel tile, whose slabs start n_steps slabs further on
+        const int kc = (TWO && k >= WPIECES) ? 1 : 0, kk = k - kc * WPIECES;
         __builtin_amdgcn_global_load_lds(
-            (const __attribute__((address_space(1))) void*)(src + 64 * k + lane),
-            (__attribute__((address_space(3))) void*)(dst + 64 * k), 16, 0, 0);
+            (const __attribute__((address_space(1))) void*)(src + (size_t)kc * n_steps * WSLAB_VEC + 64 * kk + lane),
+            (__attribute__((address_space(3))) void*)(dst + kc * WSLAB_VEC + 64 * kk), 16, 0, 0);
+      }
     }
   };
 
@@ -405,18 +428,19 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_conv3h(const Conv3hArgs a) 
 
   // ---- prologue: patch 0, weight slabs 0 and 1 ----
   // (scalar loads share one counter: issued any earlier, the first wait for a kernel argument would wait for this load too)
-  __builtin_amdgcn_sched_barrier(0);
+  if constexpr (!IMGIN && !PRE) __builtin_amdgcn_sched_barrier(0);      // raw-input launches only: the others carry no exponent load
   const unsigned amax_bits = ds_epi::act_bits((IMGIN || PRE) ? nullptr : a.in_amax, b);
   if constexpr (IMGIN) x_dma(0, 0); else
   x_fetch(0);
-  const float bias_shift = ds_epi::fetch_bias_shift(a.bias, a.shift, a.shift_stride, b, cot * COT, a.Cout);
+  // bias / shift of the workgroup's channel tile(s): threads 0-127 (TWO: 0-255, 128 per tile)
+  const float bias_shift = ds_epi::fetch_bias_shift(a.bias, a.shift, a.shift_stride, b, (cot + (TWO ? (tid >> 7) & 1 : 0)) * COT, a.Cout, COTS);
   w_fetch(0, 0);
   if (n_steps > 1) w_fetch(1, 1);
   STAMP(1);
-  __builtin_amdgcn_sched_barrier(0);
+  if constexpr (!IMGIN && !PRE) __builtin_amdgcn_sched_barrier(0);
   ascale = ds_epi::act_scale_of(PRE ? 0u : amax_bits, a.wshift);   // PRE: the table carries the exponent (x_activate)
   if constexpr (!IMGIN) x_store(0);
-  ds_epi::commit_bias_shift(BS, bias_shift);
+  ds_epi::commit_bias_shift(BS, bias_shift, COTS);
   __syncthreads();
   STAMP(2);
   STAMP_CLK(6);
@@ -432,7 +456,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_conv3h(const Conv3hArgs a) 
     const int i16 = lane & 15, h16 = (lane >> 4) & 1;
     const bool tapB = lane >= 32;                        // lane groups 2, 3 read the pair's second tap
     // lane part of the operand addresses: weights [piece][kx][h][co], input [piece][h][position]
-    const int wlane = h16 * COT + i16 + 32 * mh;        // eight waves: the wave's 32-channel half
+    const int wlane = h16 * COT + i16 + 32 * mh + cw * WSLAB_VEC;   // eight waves: the wave's 32-channel half, or (TWO) its channel tile's slab
     int xlane[4];
 #pragma unroll
     for (int n = 0; n < 4; ++n)
@@ -440,7 +464,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_conv3h(const Conv3hArgs a) 
     struct F16 { f16x8 a[2][M16]; f16x8 b[2][4]; };
     // one K = 32 group: taps (slot, ky, kx, X buffer) A and B of the pair; every argument is a compile-time constant
     auto pair = [&](int slotA, int kyA, int kxA, int xbA, int slotB, int kyB, int kxB, int xbB) __attribute__((always_inline)) {
-      const int wofs = (tapB ? slotB * WSLAB_VEC + kxB * 2 * COT : slotA * WSLAB_VEC + kxA * 2 * COT) + wlane;
+      const int wofs = (tapB ? slotB * WSV + kxB * 2 * COT : slotA * WSV + kxA * 2 * COT) + wlane;
       const int xofs = tapB ? xbB * XBV + kyB * PW + kxB : xbA * XBV + kyA * PW + kxA;
       F16 f;
 #pragma unroll
@@ -558,20 +582,27 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_conv3h(const Conv3hArgs a) 
     e.unscale = PRE ? ds_epi::unscale_from_inv(ascale.inv_scale, a.wshift) : ds_epi::unscale_from_in(ascale.in_scale, a.wshift);
     e.shift_stride = a.shift_stride;
     e.out_amax = a.out_amax ? a.out_amax + b : nullptr;
-    e.b = b; e.co_base = cot * COT + 32 * mh; e.y0 = y0 + wave_row; e.x0 = x0;
+    e.b = b; e.co_base = (cot + cw) * COT + 32 * mh; e.y0 = y0 + wave_row; e.x0 = x0;
     e.Cout = a.Cout; e.H = a.H; e.W = a.W;
     e.tile_stats = a.tile_stats; e.tile = ty * a.tiles_x + tx; e.ntiles = a.tiles_x * a.tiles_y;
     constexpr int WTILE = 32 * MT * 2 * 32;                           // floats of the wave's private transpose region
     float* tile = reinterpret_cast<float*>(smem) + wv * WTILE;
     if constexpr (S16) {
-      ds_epi::store_tile16<W16, MT>(acc16, tile, BS + 32 * mh, e);
+      ds_epi::store_tile16<W16, MT>(acc16, tile, BS + 32 * mh + 128 * cw, e);
     } else {
       ds_epi::store_tile<W16, MT>(acc, tile, BS + 32 * mh, e);
     }
     if (a.tile_stats) {
       __syncthreads();
-      e.co_base = cot * COT;
-      ds_epi::store_tile_stats<MT>(reinterpret_cast<const float*>(smem), WTILE, e);
+      if constexpr (TWO) {                      // threads 0-63 combine the first channel tile's four waves, 64-127 the second's
+        if (tid < 128) {
+          e.co_base = (cot + (tid >> 6)) * COT;
+          ds_epi::store_tile_stats<2>(reinterpret_cast<const float*>(smem) + (tid >> 6) * 4 * WTILE, WTILE, e, tid & 63);
+        }
+      } else {
+        e.co_base = cot * COT;
+        ds_epi::store_tile_stats<MT>(reinterpret_cast<const float*>(smem), WTILE, e);
+      }
     }
   }
 #ifdef DS_STAMP
@@ -603,18 +634,18 @@ __global__ void k_pack3h(_Float16* packed, const float* __restrict__ w, int Cout
   packed[i] = piece == 0 ? hi : lo;
 }
 
-template <int MODE, bool W16, bool PRE, bool CIRC, int NW, bool S16 = false, bool IMGIN = false>
+template <int MODE, bool W16, bool PRE, bool CIRC, int NW, bool S16 = false, bool IMGIN = false, bool TWO = false>
 int launch_conv3h_w(const Conv3hArgs& a, hipStream_t s) {
-  constexpr int LDSB = S16 ? LDS_BYTES16 : LDS_BYTES;
+  constexpr int LDSB = TWO ? LDS_BYTES_TWO : (S16 ? LDS_BYTES16 : LDS_BYTES);
   {
-    const int rc = ds::ensure_dynamic_lds<&k_conv3h<MODE, W16, PRE, CIRC, NW, S16, IMGIN>>(LDSB, "hipFuncSetAttribute(conv3h)");
+    const int rc = ds::ensure_dynamic_lds<&k_conv3h<MODE, W16, PRE, CIRC, NW, S16, IMGIN, TWO>>(LDSB, "hipFuncSetAttribute(conv3h)");
     if (rc != DS_OK) return rc;
   }
   const long long tiles = (long long)a.tiles_y * a.tiles_x;
   DS_REQUIRE(tiles > 0 && tiles < 65536 && a.B < 65536, DS_ERR_SHAPE,
              "ds_conv2d_h3: %lld pixel tiles x %d samples exceed the grid limits (65535 each)", tiles, a.B);
-  hipLaunchKernelGGL((k_conv3h<MODE, W16, PRE, CIRC, NW, S16, IMGIN>), dim3((unsigned)a.n_cot, (unsigned)tiles, (unsigned)a.B), dim3(64 * NW),
-                     LDSB, s, a);
+  hipLaunchKernelGGL((k_conv3h<MODE, W16, PRE, CIRC, NW, S16, IMGIN, TWO>), dim3((unsigned)(TWO ? a.n_cot / 2 : a.n_cot), (unsigned)tiles, (unsigned)a.B),
+                     dim3(64 * NW), LDSB, s, a);
   DS_CHECK_LAUNCH("ds_conv2d_h3");
   return DS_OK;
 }
@@ -643,8 +674,21 @@ inline int conv3h_waves16() {
   return v;
 }
 
+// Two channel tiles per workgroup (TWO): default for the fused norm + SiLU loader at exactly two channel tiles (the 128-channel
+// level: the activation is otherwise computed once per tile); DS_CONV_TWO=0 switches it off, =2 extends it to every even tile
+// count and to the plain loader (A/B runs).
+inline int conv3h_two() {
+  static const int v = [] { const char* e = getenv("DS_CONV_TWO"); return e ? atoi(e) : 1; }();
+  return v;
+}
+
 template <int MODE, bool W16, bool PRE, bool CIRC>
 int launch_conv3h_c(const Conv3hArgs& a, hipStream_t s) {
+  if constexpr (MODE == DS_LOAD_PLAIN) {
+    const int two = conv3h_two();
+    if (conv3h_shape16() && a.n_chunks % 2 == 0 && a.n_cot % 2 == 0 && ((two == 1 && PRE && a.n_cot == 2) || two == 2))
+      return launch_conv3h_w<MODE, W16, PRE, CIRC, 8, true, false, true>(a, s);
+  }
   if (conv3h_shape16() && a.n_chunks % 2 == 0) {
     if constexpr (PRE && MODE == DS_LOAD_PLAIN) {
       if (conv3h_waves16() == 8 && a.n_chunks <= 8) return launch_conv3h_w<MODE, W16, PRE, CIRC, 8, true>(a, s);   // up to 128 input channels

@@ -480,8 +480,8 @@ __device__ __forceinline__ void store_tile_rows(float* tile, const Args& e, cons
 // __syncthreads().  MT = 2: four waves, each with [64][4]; MT = 1: eight waves, waves 4..7 hold channels 32..63
 // ([32][4] each).  e.co_base: first channel of the WORKGROUP's 64-channel tile.
 template <int MT = 2>
-__device__ __forceinline__ void store_tile_stats(const float* tiles, int wave_stride, const Args& e) {
-  const int t = threadIdx.x;
+__device__ __forceinline__ void store_tile_stats(const float* tiles, int wave_stride, const Args& e, int t = -1) {
+  if (t < 0) t = threadIdx.x;                             // t: the channel this thread combines (callers with several channel tiles pass it)
   if (t < 64 && e.co_base + t < e.Cout) {
     f32x4 p[4];
     const int w0 = MT == 1 ? 4 * (t >> 5) : 0, tl = MT == 1 ? (t & 31) : t;
@@ -504,19 +504,20 @@ __device__ __forceinline__ void store_tile_stats(const float* tiles, int wave_st
 // bs[0..63] = bias (or 0), bs[64..127] = shift row (or 0) for the workgroup's channel tile, in two halves so that the load
 // rides behind the first patch's loads instead of in front of them (a load + wait + LDS store at the top of the kernel put one
 // more memory round trip into every workgroup's prologue: 2.8 us before the patch loads were even issued at level 0).
+// cots channel tiles: threads 128c .. 128c+127 serve tile c (the caller passes THAT tile's co_base), bs is [cots][2][64]
 __device__ __forceinline__ float fetch_bias_shift(const float* bias, const float* shift, int shift_stride, int b, int co_base,
-                                                   int Cout) {
+                                                   int Cout, int cots = 1) {
   const int t = threadIdx.x;
   const int co = co_base + (t & 63);
   float v = 0.f;
-  if (t < 128 && co < Cout) {
-    if (t < 64) v = bias ? bias[co] : 0.f;
+  if (t < 128 * cots && co < Cout) {
+    if ((t & 127) < 64) v = bias ? bias[co] : 0.f;
     else v = shift ? shift[(size_t)b * shift_stride + co] : 0.f;
   }
   return v;
 }
-__device__ __forceinline__ void commit_bias_shift(float* bs, float v) {
-  if (threadIdx.x < 128) bs[threadIdx.x] = v;
+__device__ __forceinline__ void commit_bias_shift(float* bs, float v, int cots = 1) {
+  if (threadIdx.x < 128 * cots) bs[threadIdx.x] = v;
 }
 
 }  // namespace ds_epi

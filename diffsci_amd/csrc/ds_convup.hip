@@ -359,14 +359,14 @@ __global__ __launch_bounds__(NT, 2) void k_convup(const UpArgs a) {
   };
 
   // ---- prologue: patch 0, weight slabs 0 and 1 ----
-  __builtin_amdgcn_sched_barrier(0);
+  if constexpr (!IMGIN && !PRE) __builtin_amdgcn_sched_barrier(0);      // raw-input launches only: the others carry no exponent load
   const unsigned amax_bits = ds_epi::act_bits((IMGIN || PRE) ? nullptr : a.in_amax, b);   // see ds_conv3h.hip: issued here, consumed behind the first loads
   if constexpr (IMGIN) x_dma(0, 0); else
   x_fetch(0);
   const float bias_shift = ds_epi::fetch_bias_shift(a.bias, a.shift, a.shift_stride, b, cot * COT, a.Cout);
   w_fetch(0, 0);
   w_fetch(1, 1);                                                 // n_steps >= 4 always
-  __builtin_amdgcn_sched_barrier(0);
+  if constexpr (!IMGIN && !PRE) __builtin_amdgcn_sched_barrier(0);
   ascale = ds_epi::act_scale_of(PRE ? 0u : amax_bits, a.wshift);   // PRE: the table carries the exponent (x_activate)
   if constexpr (!IMGIN) x_store(0);
   ds_epi::commit_bias_shift(BS, bias_shift);

@@ -474,13 +474,14 @@ def test_conv_direct_small_cout(dev, case):
         ops.conv_direct(x.to(dev), torch.randn(5, Cin, 3, 3, device=dev))
 
 
-@pytest.mark.parametrize("env", [{}, {"DS_CONV_SHAPE": "32"}, {"DS_CONV_WAVES16": "8"}],
-                         ids=["shipped", "mfma-32x32x16", "16x16x32-eight-waves"])
+@pytest.mark.parametrize("env", [{}, {"DS_CONV_SHAPE": "32"}, {"DS_CONV_WAVES16": "8"}, {"DS_CONV_TWO": "2"}, {"DS_CONV_TWO": "0"}],
+                         ids=["shipped", "mfma-32x32x16", "16x16x32-eight-waves", "two-channel-tiles-everywhere", "one-channel-tile"])
 def test_convolution_family_fuzz(env):
     """A short run of tools/conv_fuzz.py: random shapes through every load / padding / fusion combination -- with the
-    shipped kernel selection and with the two alternatives the library keeps behind environment switches (the 32x32x16
-    instruction shape incl. its eight-wave fused-loader instances; the eight-wave form of the 16x16x32 variant), which are
-    read once per process: hence the subprocess."""
+    shipped kernel selection and with the alternatives the library keeps behind environment switches (the 32x32x16
+    instruction shape incl. its eight-wave fused-loader instances; the eight-wave form of the 16x16x32 variant; the
+    two-channel-tiles-per-workgroup kernel on every even tile count and both loaders, and off), which are read once per
+    process: hence the subprocess."""
     import subprocess
     import sys
     import os
