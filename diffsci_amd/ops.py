@@ -692,8 +692,6 @@ def conv(x, pw, **kw):
     3x3 blocks accumulated in place (the first launch carries bias / shift / residuals, the last one the statistics)."""
     if pw.subs is None:
         return conv2d(x, pw.data, pw.Cout, pw.ks, kind=pw.kind, wshift=pw.wshift, w_up=pw.up, up_wshift=pw.up_wshift, **kw)
-    if kw.get("circular", False):
-        raise NotImplementedError("periodic padding with kernels larger than 3x3")
     if kw.get("res1_upsampled", False):
         raise NotImplementedError("res1_upsampled with kernels larger than 3x3")
     stats, out, out_amax = kw.pop("tile_stats", None), kw.pop("out", None), kw.pop("out_amax", None)
@@ -846,8 +844,8 @@ def conv2d(x, w_packed, Cout, ks, bias=None, shift=None, res1=None, res2=None,
     tap = 0
     if tap_offset is not None and tuple(tap_offset) != (0, 0):
         oy, ox = (int(v) for v in tap_offset)
-        if kind != "fp16x3" or ks != 3 or circular or not (-8 <= oy <= 7 and -8 <= ox <= 7):
-            raise ValueError("tap_offset: fp16x3 3x3 convolution, zero padding, offsets in [-8, 7]")
+        if kind != "fp16x3" or ks != 3 or not (-8 <= oy <= 7 and -8 <= ox <= 7):
+            raise ValueError("tap_offset: fp16x3 3x3 convolution, offsets in [-8, 7]")
         tap = ((oy & 15) << 8) | ((ox & 15) << 12)                      # DS_TAP_OFFSET(oy, ox)
         w_up = None                                                      # the parity kernel has no offset form
     if kind == "fp16x3" and ks == 1:

@@ -72,13 +72,14 @@ def conv3x3(sd, name, x, circular=False):
     if circular == "mp":
         return conv(x, mp_effective(sd[name + ".weight"]), sd.get(name + ".bias"), padding="same")
     if circular:
+        p = sd[name + ".conv.weight"].shape[-1] // 2            # self.padding = kernel_size // 2, commonlayers.py:941
         if x.dim() == 5:                                     # W, then H, then D
-            x = F.pad(x, (1, 1, 0, 0, 0, 0), mode="circular")
-            x = F.pad(x, (0, 0, 1, 1, 0, 0), mode="circular")
-            x = F.pad(x, (0, 0, 0, 0, 1, 1), mode="circular")
-        else:
-            x = F.pad(x, (1, 1, 0, 0), mode="circular")
-            x = F.pad(x, (0, 0, 1, 1), mode="circular")
+            x = F.pad(x, (p, p, 0, 0, 0, 0), mode="circular")
+            x = F.pad(x, (0, 0, p, p, 0, 0), mode="circular")
+            x = F.pad(x, (0, 0, 0, 0, p, p), mode="circular")
+        elif p:
+            x = F.pad(x, (p, p, 0, 0), mode="circular")
+            x = F.pad(x, (0, 0, p, p), mode="circular")
         return conv(x, sd[name + ".conv.weight"], sd.get(name + ".conv.bias"))
     return conv(x, sd[name + ".weight"], sd.get(name + ".bias"), padding="same")      # bias=False: no bias keys
 

@@ -676,6 +676,8 @@ def variants():
         # kernel sizes other than 3 (punetg_config.py:19-25)
         "k5": dict(kernel_size=5, in_out_kernel_size=1, transition_kernel_size=5),
         "k7": dict(kernel_size=1, in_out_kernel_size=7, transition_kernel_size=7),
+        # round 3: kernel sizes other than 3 WITH periodic padding (CircularConv2d pads k//2 circularly, commonlayers.py:918-971)
+        "k5_circular": dict(kernel_size=5, in_out_kernel_size=5, transition_kernel_size=7, convolution_type="circular"),
     }
     only = os.environ.get("VARIANTS_ONLY")
     for i, (tag, over) in enumerate(cases.items()):

@@ -682,6 +682,7 @@ def test_punetg_circular_convolutions(M, dev, grids):
     ("extra_res", dict()),
     ("k5", dict(kernel_size=5, in_out_kernel_size=1, transition_kernel_size=5)),
     ("k7", dict(kernel_size=1, in_out_kernel_size=7, transition_kernel_size=7)),
+    ("k5_circular", dict(kernel_size=5, in_out_kernel_size=5, transition_kernel_size=7, convolution_type="circular")),   # round 3
 ])
 def test_punetg_layer_variants(M, dev, grids, tag, over, fuse):
     """magnitude-preserving convolutions / linears / attention (weights folded when packed)

@@ -336,6 +336,7 @@ VARIANTS = {
     "extra_res": dict(),                                    # extra_residual = AvgPool2d(3, 1, 1) shared by every block
     "k5": dict(kernel_size=5, in_out_kernel_size=1, transition_kernel_size=5),
     "k7": dict(kernel_size=1, in_out_kernel_size=7, transition_kernel_size=7),
+    "k5_circular": dict(kernel_size=5, in_out_kernel_size=5, transition_kernel_size=7, convolution_type="circular"),   # round 3
 }
 EXTRA_RES = torch.nn.AvgPool2d(3, stride=1, padding=1)
 
@@ -349,7 +350,7 @@ def test_punetg_layer_variants(tag):
     cfg = punetg_ref.default_config(model_channels=8, **over)
     er = EXTRA_RES if tag == "extra_res" else None
     cfg["extra_residual"] = er
-    kind = "mp" if tag == "mp" else False
+    kind = "mp" if tag == "mp" else (over.get("convolution_type") == "circular")
     norms = (over.get("first_resblock_norm", "GroupLN"), over.get("second_resblock_norm", "GroupRMS"))
     if not over.get("affine_norm", True):
         assert not any("gnorm" in k for k in sd)
