@@ -213,9 +213,8 @@ def dominant_kernel_roofline(module, args, dev, reps=40):
         "fp32": ("k_conv<3,PLAIN> (ds_conv2d 3x3, exact-fp32 MFMA)", MFMA_F32_PEAK_TFLOPS)}[net.conv_precision]
     achieved = flops / (ms * 1e-3) / 1e12
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r02_dominant_kernel_traffic.json")
-    if not os.path.exists(tpath):
-        tpath = os.path.join(ROOT, "profiles", "r01_dominant_kernel_traffic.json")
+    tpath = next((q for q in (os.path.join(ROOT, "profiles", f"{r}_dominant_kernel_traffic.json") for r in ("r03", "r02", "r01"))
+                  if os.path.exists(q)), "")
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))

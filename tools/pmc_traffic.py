@@ -27,6 +27,7 @@ def main():
     ap.add_argument("write")
     ap.add_argument("--last", type=int, default=29)
     ap.add_argument("--write-json", action="store_true")
+    ap.add_argument("--round", default="r03", help="profiles/<round>_dominant_kernel_traffic.json is written (seeded from the previous round's)")
     a = ap.parse_args()
     f, nf, rows = last_sum(a.fetch, "FETCH_SIZE", a.last)
     w, nw, _ = last_sum(a.write, "WRITE_SIZE", a.last)
@@ -35,8 +36,10 @@ def main():
     write = w * 1024 / a.last
     print(f"fetch {fetch/1e6:.1f} MB + write {write/1e6:.1f} MB = {(fetch+write)/1e6:.1f} MB per launch over {a.last} launches")
     if a.write_json:
-        p = os.path.join(ROOT, "profiles", "r02_dominant_kernel_traffic.json")
-        j = json.load(open(p)) if os.path.exists(p) else json.load(open(os.path.join(ROOT, "profiles", "r01_dominant_kernel_traffic.json")))
+        p = os.path.join(ROOT, "profiles", f"{a.round}_dominant_kernel_traffic.json")
+        prev = [q for q in (p, os.path.join(ROOT, "profiles", "r02_dominant_kernel_traffic.json"),
+                            os.path.join(ROOT, "profiles", "r01_dominant_kernel_traffic.json")) if os.path.exists(q)][0]
+        j = json.load(open(prev))
         j.update(fetch_size_kib_sum=f, write_size_kib_sum=w, fetch_bytes_per_launch_corrected=int(fetch),
                  write_bytes_per_launch=int(write), hbm_bytes_per_launch=int(fetch + write), launches=a.last)
         json.dump(j, open(p, "w"), indent=1)
