@@ -746,6 +746,21 @@ class PUNetG(torch.nn.Module):
         ws.give(a)
         return y, os_
 
+    def _consumes_stats(self, blk, C, H, W):
+        """Does _res(blk, x [., C, H, W], xs=...) read the tile statistics of its input?  (The folded-loader route and the
+        table -> images route do; the image route and the standalone norms compute their own.)  Producers ask before they spend
+        epilogue work on statistics nobody reads: at config 2 that was every launch of the 256-channel level, the last block of
+        every level (its result feeds a Down / UpSampler) and the attention's output projection."""
+        if blk is None or not self._fused() or self.extra_residual is not None:
+            return False
+        k1, k2 = self.norm_kinds
+        if (C + 63) // 64 <= self.fuse_max_cot and k1 != 3 and k2 != 3 and self.config.kernel_size == 3:
+            return True
+        windowed = k1 in (0, 1) and k2 in (0, 1) and self._norms_in_window(blk)
+        if windowed and self._norm_images_ok(blk, C, H, W, k1, k2):
+            return False
+        return windowed and self._table_images_ok(blk, C, k1, k2)
+
     def _act_amax(self, a, windowed):
         """in_amax of a standalone norm + SiLU output: none needed inside the fp16x3 window, else a reduction into an arena row
         (a row of the current forward's arena; outside a forward -- never -- ops reduces into a fresh tensor)."""
@@ -847,6 +862,15 @@ class PUNetG(torch.nn.Module):
                 ws.give(ones)
                 x = xe
             ndown = len(self.downward_blocks)
+            bottom = list(self.before_block) + list(self.attn_resnet_block) + list(self.after_block)
+
+            def stats_for(nxt, C_, H_, W_):                                          # a statistics buffer only if the consumer reads it
+                return self._stats_buf(ws, B, C_, H_, W_, dev) if self._consumes_stats(nxt, C_, H_, W_) else None
+
+            def first_block_after_level(lv):
+                if lv + 1 < ndown and len(self.downward_blocks[lv + 1]):
+                    return self.downward_blocks[lv + 1][0]
+                return bottom[0] if bottom else None
             if isinstance(self.convin, _FourierInput):
                 hs = None                                                            # no producer statistics: standalone first norm
                 h = ops.fourier_channels(x, self.convin.W, out=ws.take((B, cfg.model_channels, H, W), dev))
@@ -856,7 +880,8 @@ class PUNetG(torch.nn.Module):
                 hs = None
                 h = ops.conv(x, pk[(id(self.convin), "exact")], bias=self.convin.bias, out=ws.take((B, cfg.model_channels, H, W), dev))
             else:
-                hs = self._stats_buf(ws, B, cfg.model_channels, H, W, dev)
+                first = self.downward_blocks[0][0] if (ndown and len(self.downward_blocks[0])) else (bottom[0] if bottom else None)
+                hs = stats_for(first, cfg.model_channels, H, W)
                 h = self._conv(self.convin, x, pk, tile_stats=hs, out=ws.take((B, cfg.model_channels, H, W), dev),
                                in_amax=am.of_input(x, precision.input_layer_flag(self, dev), pk[(id(self.convin), "wmax")]) if h3 else None)
             ha = None
@@ -866,7 +891,9 @@ class PUNetG(torch.nn.Module):
             for lv, blocks in enumerate(self.downward_blocks):                      # punetg.py:356-365
                 for j, blk in enumerate(blocks):
                     ha2 = slot(j == len(blocks) - 1)                                 # the level's last block feeds the DownSampler
-                    h2, hs2 = self._res(blk, h, sh(), pk, ws, xs=hs, out_amax=ha2)
+                    nxt = blocks[j + 1] if j + 1 < len(blocks) else None             # ... and the skip: nobody normalises its result
+                    h2, hs2 = self._res(blk, h, sh(), pk, ws, xs=hs, out_amax=ha2,
+                                        want_stats=self._consumes_stats(nxt, h.shape[1], h.shape[2], h.shape[3]))
                     give(h, hs)
                     h, hs, ha = h2, hs2, ha2
                 skips.append(h)
@@ -874,14 +901,16 @@ class PUNetG(torch.nn.Module):
                     ws.give(hs)                                                      # the skip is only added, never normalised
                 ds = self.downsamplers[lv].conv
                 Ho, Wo = h.shape[2] // 2, h.shape[3] // 2
-                hs = self._stats_buf(ws, B, ds.out_channels, Ho, Wo, dev)
+                hs = stats_for(first_block_after_level(lv), ds.out_channels, Ho, Wo)
                 h = self._conv(ds, h, pk, load_mode=DS_LOAD_MAXPOOL2, tile_stats=hs,
                                out=ws.take((B, ds.out_channels, Ho, Wo), dev), in_amax=amax_of(h, ha))
                 ha = None
             nattn, nafter = len(self.attn_resnet_block), len(self.after_block)
             for j, blk in enumerate(self.before_block):                               # punetg.py:378-387
                 ha2 = slot(j == len(self.before_block) - 1 and nattn == 0 and nafter == 0 and ndown > 0)
-                h2, hs2 = self._res(blk, h, sh(), pk, ws, xs=hs, out_amax=ha2)
+                nxt = bottom[j + 1] if (j + 1 < len(self.before_block) or nattn > 0) else None
+                h2, hs2 = self._res(blk, h, sh(), pk, ws, xs=hs, out_amax=ha2,
+                                    want_stats=self._consumes_stats(nxt, h.shape[1], h.shape[2], h.shape[3]))
                 give(h, hs)
                 h, hs, ha = h2, hs2, ha2
             xa, xas, xaa = h, hs, ha
@@ -890,13 +919,18 @@ class PUNetG(torch.nn.Module):
                 attn_next = i < len(self.attn_block)
                 # x + xa is folded into the last residual block's epilogue when no attention follows it
                 xaa2 = slot(attn_next or (last and nafter == 0 and ndown > 0))
+                # its result feeds the attention (no statistics read), the next block of this group, or -- the last -- after_block
+                nb = len(self.before_block)
+                nxt = None if attn_next else (bottom[nb + i + 1] if nb + i + 1 < len(bottom) else None)
                 xa2, xas2 = self._res(blk, xa, sh(), pk, ws, xs=xas,
-                                      res2=h if (last and not attn_next) else None, out_amax=xaa2)
+                                      res2=h if (last and not attn_next) else None, out_amax=xaa2,
+                                      want_stats=self._consumes_stats(nxt, xa.shape[1], xa.shape[2], xa.shape[3]))
                 if xa is not h:
                     give(xa, xas)
                 xa, xas, xaa = xa2, xas2, xaa2
                 if attn_next:
-                    xas2 = self._stats_buf(ws, B, xa.shape[1], xa.shape[2], xa.shape[3], dev)
+                    nxt = bottom[nb + i + 1] if nb + i + 1 < len(bottom) else None
+                    xas2 = stats_for(nxt, xa.shape[1], xa.shape[2], xa.shape[3])
                     xaa2 = slot(last and nafter == 0 and ndown > 0)
                     xa2 = self._attention(self.attn_block[i], xa, pk, ws, res2=h if last else None, tile_stats=xas2,
                                           in_amax=amax_of(xa, xaa), out_amax=xaa2)
@@ -908,7 +942,9 @@ class PUNetG(torch.nn.Module):
             h, hs, ha = xa, xas, xaa
             for j, blk in enumerate(self.after_block):
                 ha2 = slot(j == nafter - 1 and ndown > 0)                            # feeds the first UpSampler
-                h2, hs2 = self._res(blk, h, sh(), pk, ws, xs=hs, out_amax=ha2)
+                nxt = self.after_block[j + 1] if j + 1 < nafter else None
+                h2, hs2 = self._res(blk, h, sh(), pk, ws, xs=hs, out_amax=ha2,
+                                    want_stats=self._consumes_stats(nxt, h.shape[1], h.shape[2], h.shape[3]))
                 give(h, hs)
                 h, hs, ha = h2, hs2, ha2
             nup = len(self.upward_blocks)
@@ -916,7 +952,7 @@ class PUNetG(torch.nn.Module):
             for lv, blocks in enumerate(self.upward_blocks):                         # punetg.py:367-376
                 us = self.upsamplers[lv].conv
                 skip = skips.pop()
-                hs2 = self._stats_buf(ws, B, skip.shape[1], skip.shape[2], skip.shape[3], dev)
+                hs2 = stats_for(blocks[0] if len(blocks) else None, skip.shape[1], skip.shape[2], skip.shape[3])
                 h2 = self._conv(us, h, pk, load_mode=DS_LOAD_UPSAMPLE2, res1=skip, tile_stats=hs2,
                                 out=ws.take(skip.shape, dev), in_amax=amax_of(h, ha))
                 give(h, hs)
@@ -926,7 +962,9 @@ class PUNetG(torch.nn.Module):
                     lastb = j == len(blocks) - 1
                     final = lv == nup - 1 and lastb                                  # feeds convout: no norm follows
                     ha2 = slot(lastb and (not final or not direct_out))              # the next UpSampler, or a matrix-core output layer
-                    h2, hs2 = self._res(blk, h, sh(), pk, ws, xs=hs, want_stats=not final, out_amax=ha2)
+                    nxt = None if lastb else blocks[j + 1]                           # the last one feeds an UpSampler or convout: no norm follows
+                    h2, hs2 = self._res(blk, h, sh(), pk, ws, xs=hs, out_amax=ha2,
+                                        want_stats=self._consumes_stats(nxt, h.shape[1], h.shape[2], h.shape[3]))
                     give(h, hs)
                     h, hs, ha = h2, hs2, ha2
             y = self._out_conv(self.convout, h, pk, out, self.circular, in_amax=None if direct_out else amax_of(h, ha))
