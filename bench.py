@@ -158,6 +158,8 @@ def dominant_kernel_roofline(module, args, dev, reps=40):
     # block of a group: 5 of the 28 block launches) record max |out| in their epilogue
     h3 = net.conv_precision == "fp16x3"
     amax_kw = {}
+    groups_all = [list(g) for g in net.downward_blocks] + [list(net.attn_resnet_block), list(net.after_block)] + [list(g) for g in net.upward_blocks]
+    with_out_stats_off = {id(g[-1].conv2) for g in groups_all if len(g)}
     if h3:
         row_in = ops.absmax_rows(buf(mods[0].in_channels, S))
         row_out = ops.amax_new(B, dev)
@@ -184,14 +186,17 @@ def dominant_kernel_roofline(module, args, dev, reps=40):
                 ops.conv_img(imgs[(cin, s)], pk[id(m)], B, cin, s, s, bias=m.bias,
                              shift=shift[cout] if id(m) in conv1s else None,
                              res1=buf(cout, s, "res") if id(m) in conv2s else None,
-                             tile_stats=stats[(cout, s)] if fused else None, out=outs[(cout, s)],
+                             out=outs[(cout, s)],                   # no tile statistics: the image route's norms compute their own
                              **({"out_amax": akw["out_amax"]} if "out_amax" in akw else {}))
                 continue
             ops.conv(buf(cin, s), pk[id(m)], bias=m.bias,
                      shift=shift[cout] if id(m) in conv1s else None,
                      res1=buf(cout, s, "res") if id(m) in conv2s else None,
                      prenorm=tabs[(cin, s)] if (fused and block) else None,
-                     tile_stats=stats[(cout, s)] if (fused and m is not net.convout) else None,
+                     # statistics where the network asks for them: conv1 of a folded block (conv2's table reads them), conv2 unless its
+                     # result feeds a Down / UpSampler or the attention, the input layer
+                     tile_stats=stats[(cout, s)] if (fused and m is not net.convout and (m is net.convin or block)
+                                                     and id(m) not in with_out_stats_off) else None,
                      out=outs[(cout, s)], **akw)
     run()
     torch.cuda.synchronize()

@@ -58,6 +58,7 @@ _PROTOS = {
     "ds_absmax_rows": (c_int, [_P, _P, c_int, c_size_t, c_size_t, _P]),
     "ds_amax_merge": (c_int, [_P, _P, _P, c_int, _P]),
     "ds_absmax_channels": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_size_t, c_int, _P]),
+    "ds_input_amax": (c_int, [_P, c_int, c_int, _P, _P, _P, c_int, c_int, c_size_t, c_int, _P]),
     "ds_fill_u32": (c_int, [_P, c_uint32, c_size_t, _P]),
     "ds_conv2d_h3_up_supported": (c_int, [c_int, c_int]),
     "ds_conv2d_h3_up_packed_bytes": (c_size_t, [c_int, c_int]),

@@ -81,6 +81,56 @@ __global__ void k_amax_channels(unsigned* __restrict__ out, unsigned* __restrict
   if (bad) atomicOr(flag, 1u);
 }
 
+// One launch for a network input of moderate size (C <= 64): block b reduces sample b's C planes (per-channel maxima in LDS, no
+// global atomics), applies ds_absmax_channels' criterion, zeroes column b of the forward's amax arena [arena_rows][B] and writes
+// the sample's maximum into arena row `out_row` -- in place of a fill, a reduction and a combine launch per evaluation.
+__global__ __launch_bounds__(NT) void k_input_amax(unsigned* __restrict__ arena, int arena_rows, int out_row, unsigned* __restrict__ flag,
+                                                   const float* __restrict__ x, const float* __restrict__ wmax, int B, int C,
+                                                   size_t HW, int gap) {
+  __shared__ unsigned cmax[64];
+  const int b = blockIdx.x;
+  for (int r = threadIdx.x; r < arena_rows; r += NT)
+    if (r != out_row) arena[(size_t)r * B + b] = 0u;
+  if (threadIdx.x < 64) cmax[threadIdx.x] = 0u;
+  __syncthreads();
+  for (int c = 0; c < C; ++c) {
+    const float* row = x + ((size_t)b * C + c) * HW;
+    float v = 0.f;
+    if (((reinterpret_cast<uintptr_t>(row) | (HW * 4)) & 15u) == 0) {
+      const f32x4* r4 = reinterpret_cast<const f32x4*>(row);
+      for (size_t i = threadIdx.x; i < HW / 4; i += NT) {
+        const f32x4 t = r4[i];
+        v = fmaxf(v, fmaxf(fmaxf(__builtin_fabsf(t.x), __builtin_fabsf(t.y)), fmaxf(__builtin_fabsf(t.z), __builtin_fabsf(t.w))));
+      }
+    } else {
+      for (size_t i = threadIdx.x; i < HW; i += NT) v = fmaxf(v, __builtin_fabsf(row[i]));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(&cmax[c], __builtin_bit_cast(unsigned, v));      // LDS: the block's four waves
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  unsigned m = 0;
+  double P = 0.0;
+  for (int c = 0; c < C; ++c) {
+    const unsigned v = cmax[c];
+    m = v > m ? v : m;
+    if (wmax) { const double p = (double)__builtin_bit_cast(float, v) * (double)wmax[c]; P = p > P ? p : P; }
+  }
+  arena[(size_t)out_row * B + b] = m;
+  const int em = (int)((m >> 23) & 0xffu);
+  if (em == 0 || em == 255 || !flag) return;
+  bool bad = false;
+  const double md = (double)__builtin_bit_cast(float, m), lim = ldexp(P, gap);
+  for (int c = 0; c < C; ++c) {
+    const unsigned v = cmax[c];
+    if (v == 0) continue;
+    if (wmax ? (md * (double)wmax[c] > lim) : ((int)((v >> 23) & 0xffu) < em - gap)) bad = true;
+  }
+  if (bad) atomicOr(flag, 1u);
+}
+
 }  // namespace
 
 extern "C" {
@@ -120,6 +170,18 @@ int ds_absmax_channels(unsigned* out, unsigned* flag, unsigned* scratch, const f
   if (rc != DS_OK) return rc;
   hipLaunchKernelGGL(k_amax_channels, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, ds::as_stream(stream), out, flag, scratch, wmax, B, C, gap);
   DS_CHECK_LAUNCH("ds_absmax_channels");
+  return DS_OK;
+}
+
+int ds_input_amax(unsigned* arena, int arena_rows, int out_row, unsigned* flag, const float* x, const float* wmax, int B, int C,
+                  size_t HW, int gap, void* stream) {
+  DS_REQUIRE(arena && x, DS_ERR_NULL, "ds_input_amax: NULL pointer");
+  DS_REQUIRE(B >= 0 && B < 65536 && C > 0 && C <= 64 && arena_rows > 0 && out_row >= 0 && out_row < arena_rows, DS_ERR_SHAPE,
+             "ds_input_amax: B=%d C=%d rows=%d out_row=%d", B, C, arena_rows, out_row);
+  if (B == 0) return DS_OK;
+  hipLaunchKernelGGL(k_input_amax, dim3((unsigned)B), dim3(NT), 0, ds::as_stream(stream), arena, arena_rows, out_row, flag, x, wmax, B, C,
+                     HW, gap);
+  DS_CHECK_LAUNCH("ds_input_amax");
   return DS_OK;
 }
 

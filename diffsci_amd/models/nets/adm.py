@@ -699,12 +699,14 @@ class ADM(torch.nn.Module):
         # activation exponents of the raw-input launches (input layer, every block's convresidual, the attention, a wide
         # output layer): rows of one arena per forward, filled by the producers' epilogues -- see PUNetG.forward_with_shifts
         h3 = self.conv_precision == "fp16x3"
-        am = self._am = _AmaxArena(ws, B, dev) if h3 else None
+        am = self._am = _AmaxArena(ws, B, dev, zero=self.exact_input_layer) if h3 else None     # else zeroed by the input layer's reduction
 
         def slot():
             return am.row() if h3 else None
 
         try:
+            x_amax = (am.of_input(x, precision.input_layer_flag(self, dev), pk[(id(self.input_layer), "wmax")])
+                      if (h3 and not self.exact_input_layer) else None)             # first: this launch also zeroes the arena
             ha = slot()
             if h3 and self.exact_input_layer:                                       # see PUNetG.forward_with_shifts
                 hs = None
@@ -714,8 +716,7 @@ class ADM(torch.nn.Module):
             else:
                 hs = self._stats_buf(ws, B, cfg.model_channels, H, W, dev)
                 h = self._conv(self.input_layer, x, pk, tile_stats=hs, out=ws.take((B, cfg.model_channels, H, W), dev),
-                               in_amax=am.of_input(x, precision.input_layer_flag(self, dev), pk[(id(self.input_layer), "wmax")]) if h3 else None,
-                               out_amax=ha)
+                               in_amax=x_amax, out_amax=ha)
             skips = [(h, hs, ha)]                                                   # adm.py:667-675
             for lay in self.encoder.layers:
                 for blk in lay.input_blocks:

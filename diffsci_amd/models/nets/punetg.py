@@ -240,12 +240,18 @@ class _AmaxArena:
     row (out_amax), the raw-input consumer reads it (in_amax)."""
     ROWS = 256
 
-    def __init__(self, ws, B, dev):
+    def __init__(self, ws, B, dev, zero=True):
         self.ws, self.buf = ws, ws.take((self.ROWS, max(B, 1)), dev)
-        self.i32 = ops.amax_zero(self.buf.view(torch.int32))
+        self.i32 = self.buf.view(torch.int32)
+        if zero:                                  # zero=False: the caller's first act is of_input(), which zeroes the arena itself
+            ops.amax_zero(self.i32)
+        self.zeroed = zero
         self.n = 0
 
     def row(self):
+        if not self.zeroed:
+            ops.amax_zero(self.i32)
+            self.zeroed = True
         if self.n >= self.ROWS:
             raise RuntimeError("amax arena exhausted")
         self.n += 1
@@ -253,6 +259,9 @@ class _AmaxArena:
 
     def rows(self, n):
         """n consecutive rows as one [n * B] tensor."""
+        if not self.zeroed:
+            ops.amax_zero(self.i32)
+            self.zeroed = True
         if self.n + n > self.ROWS:
             raise RuntimeError("amax arena exhausted")
         self.n += n
@@ -266,6 +275,12 @@ class _AmaxArena:
         """The same for a network input x [B, C, ...] (c_in * x next to raw user fields): per-channel maxima first, `flag` raised
         when one exponent per sample cannot serve the input layer given its weights (ops.absmax_channels; precision.input_layer_flag)."""
         C = x.shape[1]
+        if not self.zeroed:
+            if self.n == 0 and C <= 64 and x[0].numel() <= ops.INPUT_AMAX_MAX_FLOATS and x.shape[0] == self.i32.shape[1]:
+                self.n, self.zeroed = 1, True
+                return ops.input_amax(self.i32, 0, x, flag, wmax)      # one launch: zero the arena, reduce, apply the channel criterion
+            ops.amax_zero(self.i32)
+            self.zeroed = True
         if self.n + C + 1 > self.ROWS:
             return self.of(x)
         out = self.row()
@@ -842,7 +857,9 @@ class PUNetG(torch.nn.Module):
         # its producer's epilogue left in a row of this arena (ha travels with h like the tile statistics hs), or a reduction
         # over the tensor where the producer is not one of our epilogues (the network input).
         h3 = self.conv_precision == "fp16x3"
-        am = self._am = _AmaxArena(ws, B, dev) if h3 else None
+        # (the arena is zeroed by the input layer's own reduction launch when that is the first thing the forward does)
+        lazy = h3 and not isinstance(self.convin, _FourierInput) and not self.exact_input_layer
+        am = self._am = _AmaxArena(ws, B, dev, zero=not lazy) if h3 else None
 
         def slot(needed=True):
             return am.row() if (h3 and needed) else None

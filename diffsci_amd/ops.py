@@ -133,6 +133,23 @@ def absmax_channels(x, out, scratch, flag=None, wmax=None, gap=CHANNEL_GAP):
     return out
 
 
+INPUT_AMAX_MAX_FLOATS = 1 << 20      # per sample: above this one workgroup per sample would be the slow way
+
+
+def input_amax(arena, out_row, x, flag=None, wmax=None, gap=CHANNEL_GAP):
+    """One launch at the head of a network evaluation: zero the amax arena (int32 [rows, B]) and fill its row `out_row` with the
+    per-sample maxima of the input x [B, C, *spatial] (C <= 64, C * spatial <= INPUT_AMAX_MAX_FLOATS), with absmax_channels'
+    channel criterion.  Returns the row."""
+    require_device(x, "x")
+    rows, B = arena.shape
+    C = x.shape[1]
+    if x.shape[0] != B or not x.is_contiguous() or not arena.is_contiguous() or arena.dtype != torch.int32:
+        raise ValueError("input_amax: arena int32 [rows, B] and a contiguous x [B, C, ...]")
+    N.check(N.lib().ds_input_amax(arena.data_ptr(), rows, int(out_row), _pi(flag, 1, "flag"), x.data_ptr(), _p(wmax, "wmax"), B, C,
+                                  x.numel() // max(B * C, 1), int(gap), _stream()), "ds_input_amax")
+    return arena[out_row]
+
+
 def amax_merge(out, a, b=None):
     """out[i] = max(out[i], a[i], b[i]): the amax of a channel concatenation from those of its parts."""
     n = out.numel()

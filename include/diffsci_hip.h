@@ -243,6 +243,10 @@ int ds_fill_u32(unsigned* p, unsigned value, size_t n, void* stream);          /
  * re-runs the input layer on the exact-fp32 kernel (nets/precision.py). */
 int ds_absmax_channels(unsigned* out, unsigned* flag, unsigned* scratch, const float* x, const float* wmax, int B, int C,
                        size_t HW, int gap, void* stream);
+/* The same in ONE launch for inputs of moderate size (C <= 64; one workgroup per sample): also zeroes the forward's amax arena
+ * [arena_rows][B] (every row but out_row) -- a network evaluation starts with this call instead of ds_fill_u32 + ds_absmax_channels. */
+int ds_input_amax(unsigned* arena, int arena_rows, int out_row, unsigned* flag, const float* x, const float* wmax, int B, int C,
+                  size_t HW, int gap, void* stream);
 /* Two optional fusions of the normalisation around the convolution (NULL = off):
  *   prenorm    [B, ceil16(Cin), 4] = (M, A, C, -), rows past Cin zero: the loader applies SiLU((x - M)*A + C) to every input element
  *              before the convolution (zero padding stays zero) -- the norm -> act of ResnetBlockC /
