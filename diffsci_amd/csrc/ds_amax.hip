@@ -10,6 +10,10 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int NT = 256;
 
+__device__ __forceinline__ float abs_max4(f32x4 v) {
+  return fmaxf(fmaxf(__builtin_fabsf(v.x), __builtin_fabsf(v.y)), fmaxf(__builtin_fabsf(v.z), __builtin_fabsf(v.w)));
+}
+
 __device__ __forceinline__ void block_commit(unsigned* slot, float m) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
@@ -84,12 +88,13 @@ __global__ void k_amax_channels(unsigned* __restrict__ out, unsigned* __restrict
 // One launch for a network input of moderate size (C <= 64): block b reduces sample b's C planes (per-channel maxima in LDS, no
 // global atomics), applies ds_absmax_channels' criterion, zeroes column b of the forward's amax arena [arena_rows][B] and writes
 // the sample's maximum into arena row `out_row` -- in place of a fill, a reduction and a combine launch per evaluation.
-__global__ __launch_bounds__(NT) void k_input_amax(unsigned* __restrict__ arena, int arena_rows, int out_row, unsigned* __restrict__ flag,
-                                                   const float* __restrict__ x, const float* __restrict__ wmax, int B, int C,
-                                                   size_t HW, int gap) {
+constexpr int NTI = 1024;   // one workgroup has to pull a whole sample: 16 waves with four 16-byte loads in flight each
+__global__ __launch_bounds__(NTI) void k_input_amax(unsigned* __restrict__ arena, int arena_rows, int out_row, unsigned* __restrict__ flag,
+                                                    const float* __restrict__ x, const float* __restrict__ wmax, int B, int C,
+                                                    size_t HW, int gap) {
   __shared__ unsigned cmax[64];
   const int b = blockIdx.x;
-  for (int r = threadIdx.x; r < arena_rows; r += NT)
+  for (int r = threadIdx.x; r < arena_rows; r += NTI)
     if (r != out_row) arena[(size_t)r * B + b] = 0u;
   if (threadIdx.x < 64) cmax[threadIdx.x] = 0u;
   __syncthreads();
@@ -98,16 +103,19 @@ __global__ __launch_bounds__(NT) void k_input_amax(unsigned* __restrict__ arena,
     float v = 0.f;
     if (((reinterpret_cast<uintptr_t>(row) | (HW * 4)) & 15u) == 0) {
       const f32x4* r4 = reinterpret_cast<const f32x4*>(row);
-      for (size_t i = threadIdx.x; i < HW / 4; i += NT) {
-        const f32x4 t = r4[i];
-        v = fmaxf(v, fmaxf(fmaxf(__builtin_fabsf(t.x), __builtin_fabsf(t.y)), fmaxf(__builtin_fabsf(t.z), __builtin_fabsf(t.w))));
+      const size_t n4 = HW / 4;
+      size_t i = threadIdx.x;
+      for (; i + 3 * NTI < n4; i += 4 * NTI) {
+        const f32x4 t0 = r4[i], t1 = r4[i + NTI], t2 = r4[i + 2 * NTI], t3 = r4[i + 3 * NTI];
+        v = fmaxf(v, fmaxf(fmaxf(abs_max4(t0), abs_max4(t1)), fmaxf(abs_max4(t2), abs_max4(t3))));
       }
+      for (; i < n4; i += NTI) v = fmaxf(v, abs_max4(r4[i]));
     } else {
-      for (size_t i = threadIdx.x; i < HW; i += NT) v = fmaxf(v, __builtin_fabsf(row[i]));
+      for (size_t i = threadIdx.x; i < HW; i += NTI) v = fmaxf(v, __builtin_fabsf(row[i]));
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    if ((threadIdx.x & 63) == 0) atomicMax(&cmax[c], __builtin_bit_cast(unsigned, v));      // LDS: the block's four waves
+    if ((threadIdx.x & 63) == 0) atomicMax(&cmax[c], __builtin_bit_cast(unsigned, v));      // LDS: the block's sixteen waves
   }
   __syncthreads();
   if (threadIdx.x != 0) return;
@@ -179,7 +187,7 @@ int ds_input_amax(unsigned* arena, int arena_rows, int out_row, unsigned* flag, 
   DS_REQUIRE(B >= 0 && B < 65536 && C > 0 && C <= 64 && arena_rows > 0 && out_row >= 0 && out_row < arena_rows, DS_ERR_SHAPE,
              "ds_input_amax: B=%d C=%d rows=%d out_row=%d", B, C, arena_rows, out_row);
   if (B == 0) return DS_OK;
-  hipLaunchKernelGGL(k_input_amax, dim3((unsigned)B), dim3(NT), 0, ds::as_stream(stream), arena, arena_rows, out_row, flag, x, wmax, B, C,
+  hipLaunchKernelGGL(k_input_amax, dim3((unsigned)B), dim3(NTI), 0, ds::as_stream(stream), arena, arena_rows, out_row, flag, x, wmax, B, C,
                      HW, gap);
   DS_CHECK_LAUNCH("ds_input_amax");
   return DS_OK;
