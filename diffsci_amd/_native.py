@@ -10,7 +10,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_longlong, c_s
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DIFFSCI_HIP_LIB") or os.path.join(_HERE, "_lib", "libdiffsci_hip.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 DS_IN_NETWORK, DS_IN_SCORE, DS_IN_DRIFT, DS_IN_FLOW = 0, 1, 2, 3
 DS_LOAD_PLAIN, DS_LOAD_MAXPOOL2, DS_LOAD_UPSAMPLE2, DS_LOAD_AVGPOOL2 = 0, 1, 2, 3
 DS_PAD_CIRCULAR = 16
@@ -22,7 +22,8 @@ class EvalCoef(Structure):
     _fields_ = [("c_out", c_float), ("c_skip", c_float), ("sigma_sq", c_float),
                 ("neg_mult", c_float), ("neg_lang", c_float), ("guidance", c_float),
                 ("one_minus_guidance", c_float), ("input_kind", c_int), ("stochastic", c_int),
-                ("scaled", c_int), ("scale", c_float), ("scale_mult", c_float), ("next_scale", c_float), ("xin_copies", c_int)]
+                ("scaled", c_int), ("scale", c_float), ("scale_mult", c_float), ("next_scale", c_float), ("xin_copies", c_int),
+                ("nonfinite", c_void_p)]
 
 
 class NativeLibraryError(RuntimeError):

@@ -22,7 +22,7 @@ struct ds_graph {
 
 extern "C" {
 
-int ds_version(void) { return 3; }
+int ds_version(void) { return 4; }
 
 const char* ds_last_error(void) { return ds::get_error(); }
 

@@ -47,6 +47,15 @@ __device__ __forceinline__ float next_input(float r, float c_in_next, float next
   return (next_scale == 1.0f || next_scale == 0.0f) ? c_in_next * r : c_in_next * (r / next_scale);   // 0: a zero-initialised struct
 }
 
+// the range guard's result check folded into the run's last step (nets/precision.py): inf / NaN in what this lane wrote raises
+// the word; one atomic per wave that saw any, none on a finite run
+__device__ __forceinline__ bool not_finite(float v) { return !(__builtin_fabsf(v) <= 3.402823466e+38f); }
+__device__ __forceinline__ void raise_nonfinite(unsigned* word, bool bad) {
+  if (word == nullptr) return;
+  const unsigned long long m = __builtin_amdgcn_ballot_w64(bad);                 // called outside the loops: all lanes arrive
+  if (m != 0ull && (int)(threadIdx.x & 63) == __builtin_ctzll(m)) atomicOr(word, 1u);
+}
+
 inline int grid_for(size_t n4) {
   size_t g = (n4 + kThreads - 1) / kThreads;
   if (g > 2048) g = 2048;
@@ -141,6 +150,7 @@ __global__ __launch_bounds__(kThreads) void k_euler(float* x_out, float* xin_out
   constexpr bool HAS_EPS = NOISE != 0;
   size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x;
   size_t stride = (size_t)gridDim.x * kThreads;
+  bool bad = false;
   for (; i < n4; i += stride) {
     float4 vx = reinterpret_cast<const float4*>(x)[i];
     float4 vf = reinterpret_cast<const float4*>(f)[i];
@@ -153,6 +163,7 @@ __global__ __launch_bounds__(kThreads) void k_euler(float* x_out, float* xin_out
     euler_one<HAS_U, HAS_EPS>(vx.y, vf.y, vu.y, ve.y, k, dt, noise_coef, sq, c_in_next, o.y, q.y);
     euler_one<HAS_U, HAS_EPS>(vx.z, vf.z, vu.z, ve.z, k, dt, noise_coef, sq, c_in_next, o.z, q.z);
     euler_one<HAS_U, HAS_EPS>(vx.w, vf.w, vu.w, ve.w, k, dt, noise_coef, sq, c_in_next, o.w, q.w);
+    bad = bad || not_finite(o.x) || not_finite(o.y) || not_finite(o.z) || not_finite(o.w);
     if (x_out) reinterpret_cast<float4*>(x_out)[i] = o;
     if (xin_out) {
       reinterpret_cast<float4*>(xin_out)[i] = q;
@@ -163,12 +174,14 @@ __global__ __launch_bounds__(kThreads) void k_euler(float* x_out, float* xin_out
     float o, q;
     const float e = NOISE == 1 ? eps[t] : NOISE == 2 ? philox_normal1(rng, rng_offset, t) : 0.f;
     euler_one<HAS_U, HAS_EPS>(x[t], f[t], HAS_U ? fu[t] : 0.f, e, k, dt, noise_coef, sq, c_in_next, o, q);
+    bad = bad || not_finite(o);
     if (x_out) x_out[t] = o;
     if (xin_out) {
       xin_out[t] = q;
       if (k.xin_copies == 2) xin_out[n + t] = q;
     }
   }
+  raise_nonfinite(k.nonfinite, bad);
 }
 
 template <bool HAS_U>
@@ -190,6 +203,7 @@ __global__ __launch_bounds__(kThreads) void k_heun(float* x_out, float* xin_out,
                                                    size_t n4, size_t n) {
   size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x;
   size_t stride = (size_t)gridDim.x * kThreads;
+  bool bad = false;
   for (; i < n4; i += stride) {
     float4 vx = reinterpret_cast<const float4*>(x)[i];
     float4 a = reinterpret_cast<const float4*>(f1)[i];
@@ -204,6 +218,7 @@ __global__ __launch_bounds__(kThreads) void k_heun(float* x_out, float* xin_out,
     heun_one<HAS_U>(vx.y, a.y, au.y, b.y, bu.y, k1, k2, dt, c_in_next, o.y, q.y);
     heun_one<HAS_U>(vx.z, a.z, au.z, b.z, bu.z, k1, k2, dt, c_in_next, o.z, q.z);
     heun_one<HAS_U>(vx.w, a.w, au.w, b.w, bu.w, k1, k2, dt, c_in_next, o.w, q.w);
+    bad = bad || not_finite(o.x) || not_finite(o.y) || not_finite(o.z) || not_finite(o.w);
     reinterpret_cast<float4*>(x_out)[i] = o;
     if (xin_out) {
       reinterpret_cast<float4*>(xin_out)[i] = q;
@@ -213,12 +228,14 @@ __global__ __launch_bounds__(kThreads) void k_heun(float* x_out, float* xin_out,
   for (size_t t = n4 * 4 + (size_t)blockIdx.x * kThreads + threadIdx.x; t < n; t += stride) {
     float o, q;
     heun_one<HAS_U>(x[t], f1[t], HAS_U ? f1u[t] : 0.f, f2[t], HAS_U ? f2u[t] : 0.f, k1, k2, dt, c_in_next, o, q);
+    bad = bad || not_finite(o);
     x_out[t] = o;
     if (xin_out) {
       xin_out[t] = q;
       if (k2.xin_copies == 2) xin_out[n + t] = q;
     }
   }
+  raise_nonfinite(k2.nonfinite, bad);
 }
 
 template <bool HAS_U, bool SCORE_ONLY>

@@ -363,8 +363,11 @@ class SIModule(torch.nn.Module):
             return self._integrate_generic(x, time_schedule, y, guidance, return_history, integrate_on_sigma, scale)
         table = self._table(time_schedule, integrate_on_sigma)
 
+        checked = [False]
+
         def run():
             src = self._source(y, guidance, x)
+            checked[0] = src.nonfinite_word is not None and len(table.rows) > 0      # the last step kernel looks at the result
             if src.planned and self.use_graph:
                 return self._run_planned(table, src, x, y, guidance, return_history, integrate_on_sigma, scale)
             loop = Loop(table, src, x, return_history)
@@ -373,7 +376,7 @@ class SIModule(torch.nn.Module):
             return loop.result()
 
         out = run()
-        if precision.needs_escalation(self.model, out, x):      # an activation left the fp16x3 range: nets/precision.py
+        if precision.needs_escalation(self.model, out, x, result_checked=checked[0]):     # an activation left the fp16x3 range: nets/precision.py
             precision.escalate(self.model)
             out = run()
         if return_history:                                                        # initial_norm.unnorm, flowfield.py:742-747

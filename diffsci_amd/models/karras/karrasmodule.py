@@ -351,8 +351,11 @@ class KarrasModule(torch.nn.Module, LatentSpaceAutoregressive):
                 sch.unset_temporary_integrator()
         injected = eps is not None
 
+        checked = [False]
+
         def run():
             src = ModuleSource(self, y, guidance, x.shape[0], x)
+            checked[0] = src.nonfinite_word is not None and len(table.rows) > 0      # the last step kernel looks at the result
 
             def make_loop():
                 return Loop(table, src, x, record_history, injected_noise=injected, noise_shard=self.noise_shard)
@@ -370,7 +373,7 @@ class KarrasModule(torch.nn.Module, LatentSpaceAutoregressive):
             return loop.result()
 
         out = run()
-        if precision.needs_escalation(self.model, out, x):      # an activation left the fp16x3 range: see nets/precision.py
+        if precision.needs_escalation(self.model, out, x, result_checked=checked[0]):     # an activation left the fp16x3 range: see nets/precision.py
             precision.escalate(self.model)
             out = run()
         return out

@@ -39,14 +39,16 @@ class EvalRow:
     scale: float = 1.0
     scale_mult: float = 0.0
 
-    def coef(self, input_kind=DS_IN_NETWORK, guidance=1.0, next_scale=1.0, xin_copies=1):
+    def coef(self, input_kind=DS_IN_NETWORK, guidance=1.0, next_scale=1.0, xin_copies=1, nonfinite=None):
         """next_scale: s at the evaluation the emitted network input feeds (xin = c_in * (x / s)); xin_copies: 2 when that
-        evaluation is a batched-guidance one reading the input twice ([2B, ...])."""
+        evaluation is a batched-guidance one reading the input twice ([2B, ...]); nonfinite: int32 [1] device word the step
+        kernel taking this struct raises when its x_out holds inf / NaN (the run's last step only)."""
         return EvalCoef(c_out=self.c_out, c_skip=self.c_skip, sigma_sq=self.sigma_sq,
                         neg_mult=self.neg_mult, neg_lang=self.neg_lang, guidance=float(guidance),
                         one_minus_guidance=float(1 - guidance), input_kind=int(input_kind),
                         stochastic=int(self.stochastic), scaled=int(self.scaled), scale=self.scale,
-                        scale_mult=self.scale_mult, next_scale=float(next_scale), xin_copies=int(xin_copies))
+                        scale_mult=self.scale_mult, next_scale=float(next_scale), xin_copies=int(xin_copies),
+                        nonfinite=None if nonfinite is None else nonfinite.data_ptr())
 
 
 @dataclass

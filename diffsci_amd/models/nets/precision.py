@@ -25,43 +25,61 @@ import torch
 RANGE_FREE = "bf16x6"
 
 
-def needs_escalation(model, out, *inputs):
+def needs_escalation(model, out, *inputs, result_checked=False):
     """True when the run has to be repeated: the input layer's channel-disparity flag is up (`escalate` then moves that layer
     to the exact kernel), or `out` holds inf / NaN although every input is finite and `model` computes in fp16x3 with
-    auto_precision on.  One device reduction and two host reads: call it once per run, not per evaluation; not at all while a
-    stream capture is in progress (a user capturing net(x, t) in a graph of their own takes the kernels' raw behaviour)."""
+    auto_precision on.  result_checked: the run's last step kernel already looked at the result (ds_eval_coef.nonfinite ->
+    `result_word`), so the two guard words arrive in ONE host read and no reduction runs; otherwise isfinite(out) is reduced
+    here.  Call it once per run, not per evaluation; not at all while a stream capture is in progress (a user capturing
+    net(x, t) in a graph of their own takes the kernels' raw behaviour)."""
     if getattr(model, "conv_precision", None) != "fp16x3" or not getattr(model, "auto_precision", False):
         return False
     if torch.cuda.is_current_stream_capturing():
         return False
-    if _input_flag_raised(model):
+    input_raised, result_raised = _read_guard_words(model)
+    if input_raised and not getattr(model, "exact_input_layer", True):
         model.__dict__["_input_due"] = True
         return True
-    if not torch.is_tensor(out) or bool(torch.isfinite(out).all()):
+    if result_checked:
+        if not result_raised:
+            return False
+    elif not torch.is_tensor(out) or bool(torch.isfinite(out).all()):
         return False
     return all(bool(torch.isfinite(t).all()) for t in inputs if torch.is_tensor(t) and t.is_floating_point())
 
 
-def input_layer_flag(model, device):
-    """The int32 [1] device word the input layer's channel reduction raises (ops.absmax_channels); one per (model, device),
-    a fixed address (captured graphs write to it)."""
-    flags = model.__dict__.setdefault("_input_flags", {})
-    f = flags.get(str(device))
+def guard_words(model, device):
+    """int32 [2] device words of one (model, device), at a fixed address (captured graphs write to them): [0] raised by the
+    input layer's channel reduction (ops.input_amax / absmax_channels), [1] by a run's last step kernel when its result holds
+    inf / NaN (ds_eval_coef.nonfinite)."""
+    words = model.__dict__.setdefault("_input_flags", {})
+    f = words.get(str(device))
     if f is None:
         with torch.inference_mode(False):
-            f = flags[str(device)] = torch.zeros(1, dtype=torch.int32, device=device)
+            f = words[str(device)] = torch.zeros(2, dtype=torch.int32, device=device)
     return f
 
 
-def _input_flag_raised(model):
-    if getattr(model, "exact_input_layer", True):            # no such layer, or already on the exact kernel
-        return False
-    raised = False
+def input_layer_flag(model, device):
+    return guard_words(model, device)[0:1]
+
+
+def result_word(model, device):
+    """The word a tabulated run's last step kernel raises, or None when `model` takes no part in the guard."""
+    if getattr(model, "conv_precision", None) != "fp16x3" or not getattr(model, "auto_precision", False):
+        return None
+    return guard_words(model, device)[1:2]
+
+
+def _read_guard_words(model):
+    """(input flag, result word) over the model's devices: one host read per device; raised words are cleared."""
+    inp = res = False
     for f in getattr(model, "_input_flags", {}).values():
-        if int(f.item()):
-            raised = True
+        a, b = f.tolist()
+        if a or b:
             f.zero_()
-    return raised
+        inp, res = inp or bool(a), res or bool(b)
+    return inp, res
 
 
 def _big_kernels(model):

@@ -83,6 +83,9 @@ typedef struct ds_eval_coef {
   int   xin_copies; /* 2: xin_out holds TWO copies back to back ([2n] floats): classifier-free guidance evaluates the
                        conditional and the unconditional branch as one evaluation of batch 2B on the same input
                        (karrasmodule.py:706-713); 0 / 1: one copy                                                         */
+  uint32_t* nonfinite; /* device word or NULL.  ds_karras_euler (k) / ds_karras_heun (k2) OR 1 into it when a value of x_out is
+                       inf or NaN: the run-level result check of the range guard (a host-side isfinite(out).all() in round 2)
+                       carried by the run's last step kernel; one atomic per wave that saw one, none on a finite run           */
 } ds_eval_coef;
 
 enum { DS_IN_NETWORK = 0, DS_IN_SCORE = 1, DS_IN_DRIFT = 2,

@@ -348,3 +348,67 @@ def test_vp_runs_the_tabulated_captured_loop(M, dev):
         o = module.propagate_white_noise(wn, nsteps=6, integrator="euler").cpu()
         assert rel_l2(o, v[f"{tag}_punetg_euler_N6"]) < tol
     assert nodes["vp"] <= nodes["ve"] + 1                                   # one extra launch: x / s in front of the first c_in * x
+
+
+@pytest.mark.parametrize("n", [4096, 1031])
+def test_step_kernels_raise_the_nonfinite_word(dev, ops, n):
+    """ds_eval_coef.nonfinite: the step kernel ORs 1 into the word when a value of x_out is inf or NaN, and leaves it alone on a
+    finite result (the range guard's result check, carried by a run's last step instead of a reduction + host read per run)."""
+    from diffsci_amd.models.karras.steptable import EvalRow
+    row = EvalRow(t=torch.tensor(1.0), sigma=1.0, c_in=1.0, c_out=1.0, c_skip=0.5, c_noise=0.0, sigma_sq=1.0, neg_mult=-1.0, neg_lang=0.0, stochastic=False)
+    g = torch.Generator().manual_seed(n)
+    x, f1, f2 = (torch.randn(n, generator=g).to(dev) for _ in range(3))
+    word = torch.zeros(1, dtype=torch.int32, device=dev)
+    for bad_value in (None, float("inf"), float("nan"), -float("inf")):
+        for where in (0, n - 1, n // 2):
+            fa, fb = f1.clone(), f2.clone()
+            if bad_value is not None:
+                fa[where] = bad_value
+            word.zero_()
+            out = ops.euler(x, fa, row.coef(nonfinite=word), 0.1, x_out=torch.empty_like(x))
+            assert int(word.item()) == (0 if bad_value is None else 1) and bool(torch.isfinite(out).all()) == (bad_value is None)
+            word.zero_()
+            if bad_value is not None:
+                fa, fb[where] = f1.clone(), bad_value                      # the corrector's input this time
+            out = ops.heun(x, fa, row.coef(), fb, row.coef(nonfinite=word), 0.1, x_out=torch.empty_like(x))
+            assert int(word.item()) == (0 if bad_value is None else 1) and bool(torch.isfinite(out).all()) == (bad_value is None)
+            word.zero_()
+            ops.heun(x, fa, row.coef(nonfinite=word), fb, row.coef(), 0.1, x_out=torch.empty_like(x))      # k1's word is not the result's
+            assert int(word.item()) == 0
+
+
+def test_range_guard_reads_the_result_word_of_a_captured_run(M, dev):
+    """Run level: a finite run leaves both guard words down and costs one host read; a result that overflows from finite inputs
+    (an output layer scaled to 1e38) raises the word inside the captured graph and switches the network once, with the warning;
+    a non-finite START is the caller's and switches nothing."""
+    import warnings
+    from diffsci_amd.models.nets import precision
+    from tests.golden_util import load
+    _, sd = load("punetg8_forward")
+
+    def module_of(scale_out=1.0):
+        net = M.PUNetG(M.PUNetGConfig(model_channels=8))
+        net.load_state_dict(sd)
+        with torch.no_grad():
+            net.convout.weight.mul_(scale_out)
+        return M.KarrasModule(net.to(dev).eval(), M.KarrasModuleConfig.from_edm())
+    g = torch.Generator().manual_seed(11)
+    wn = torch.randn(2, 1, 32, 32, generator=g).to(dev)
+    module = module_of()
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        a = module.propagate_white_noise(wn, nsteps=4)
+        b = module.propagate_white_noise(wn, nsteps=4)                     # the replay
+    assert torch.equal(a, b) and torch.isfinite(a).all() and len(module._plans.plans) == 1
+    assert precision.guard_words(module.model, dev).tolist() == [0, 0] and module.model.conv_precision == "fp16x3"
+    bad = wn.clone()
+    bad[1, 0, 3, 4] = float("nan")
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        c = module.propagate_white_noise(bad, nsteps=4)
+    assert not torch.isfinite(c[1]).all() and module.model.conv_precision == "fp16x3"
+    assert precision.guard_words(module.model, dev).tolist() == [0, 0]     # read and cleared
+    over = module_of(1e38)
+    with pytest.warns(RuntimeWarning, match="fp16x3 convolution range"):
+        d = over.propagate_white_noise(wn, nsteps=4)
+    assert over.model.conv_precision == "bf16x6" and not torch.isfinite(d).all()

@@ -339,3 +339,31 @@ def test_global_noise_skip_ahead_is_self_checked(monkeypatch):
     calls.clear()
     assert torch.equal(parallel.global_white_noise(6, [2, 4, 4], seed=3, rows=(2, 5)), full[2:5])
     assert calls[0][0] == 6                                     # the full draw
+
+
+def test_model_signature_follows_the_module_tree():
+    """engine.model_signature caches the walk over the module tree (the plan key is built once per run); the cache must see an
+    in-place update, a parameter assigned anew, and a submodule replaced, added or removed."""
+    import copy
+    import diffsci_amd.models as M
+    from diffsci_amd.models.karras import engine
+    net = M.PUNetG(M.PUNetGConfig(model_channels=8))
+    s0 = engine.model_signature(net)
+    assert engine.model_signature(net) == s0 and len(s0[0]) == len(list(net.parameters()))
+    with torch.no_grad():
+        net.convin.weight.add_(1.0)
+    s1 = engine.model_signature(net)
+    assert s1 != s0
+    net.convin.weight = torch.nn.Parameter(net.convin.weight.detach().clone())
+    s2 = engine.model_signature(net)
+    assert s2 != s1
+    net.convin = copy.deepcopy(net.convin)
+    s3 = engine.model_signature(net)
+    assert s3 != s2
+    net.extra_thing = torch.nn.Linear(3, 3)
+    s4 = engine.model_signature(net)
+    assert len(s4[0]) == len(s3[0]) + 2
+    del net.extra_thing
+    assert engine.model_signature(net) == s3
+    net.conv_precision = "fp32"
+    assert engine.model_signature(net) != s3

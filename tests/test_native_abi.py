@@ -37,7 +37,7 @@ def test_ctypes_binding_matches_header(built_lib):
     from diffsci_amd import _native
     assert _native.exported_symbols() == header_functions()
     L = _native.lib()
-    assert L.ds_version() == _native.ABI_VERSION == 3
+    assert L.ds_version() == _native.ABI_VERSION == 4
     assert L.ds_last_error() is not None
 
 
@@ -46,9 +46,11 @@ def test_struct_layout_matches_header():
     src = open(os.path.join(ROOT, "include", "diffsci_hip.h")).read()
     body = re.search(r"typedef struct ds_eval_coef \{(.*?)\} ds_eval_coef;", src, re.S).group(1)
     body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
-    fields = re.findall(r"\b(float|int)\s+([a-z_]+)\s*;", body)
+    fields = re.findall(r"\b(float|int|uint32_t\*)\s+([a-z_]+)\s*;", body)
     assert [n for _, n in fields] == [n for n, _ in EvalCoef._fields_]
-    assert ctypes.sizeof(EvalCoef) == 4 * len(fields)
+    kinds = {"float": ctypes.c_float, "int": ctypes.c_int, "uint32_t*": ctypes.c_void_p}
+    assert [kinds[k] for k, _ in fields] == [t for _, t in EvalCoef._fields_]
+    assert ctypes.sizeof(EvalCoef) == 4 * (len(fields) - 1) + 8 and EvalCoef.nonfinite.offset == 4 * (len(fields) - 1)
 
 
 def test_packed_weight_size_is_host_side(built_lib):
