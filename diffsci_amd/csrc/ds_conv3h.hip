@@ -675,10 +675,17 @@ inline int conv3h_waves16() {
 }
 
 // Two channel tiles per workgroup (TWO): default for the fused norm + SiLU loader at exactly two channel tiles (the 128-channel
-// level: the activation is otherwise computed once per tile); DS_CONV_TWO=0 switches it off, =2 extends it to every even tile
-// count and to the plain loader (A/B runs).
+// level: the activation is otherwise computed once per tile) WHEN the halved grid still fills the chip -- at least
+// DS_CONV_TWO_MIN (256: one per CU) workgroups.  Measured on MI355X: config 5's share (2048 such workgroups per launch)
+// 9.24 -> 9.13 ms per evaluation with it; a [4, 4, 32, 32] latent on a 32-channel network (a handful of workgroups: their
+// latency is the launch's) 21.85 -> 23.3 ms per 10-step forecast, so not there; the headline's 64 workgroups: +0.2 %, noise.
+// DS_CONV_TWO=0 switches it off, =2 extends it to every even tile count, the plain loader and any grid (A/B runs).
 inline int conv3h_two() {
   static const int v = [] { const char* e = getenv("DS_CONV_TWO"); return e ? atoi(e) : 1; }();
+  return v;
+}
+inline long long conv3h_two_min() {
+  static const long long v = [] { const char* e = getenv("DS_CONV_TWO_MIN"); return e ? atoll(e) : 256ll; }();
   return v;
 }
 
@@ -686,7 +693,7 @@ template <int MODE, bool W16, bool PRE, bool CIRC>
 int launch_conv3h_c(const Conv3hArgs& a, hipStream_t s) {
   if constexpr (MODE == DS_LOAD_PLAIN) {
     const int two = conv3h_two();
-    if (conv3h_shape16() && a.n_chunks % 2 == 0 && a.n_cot % 2 == 0 && ((two == 1 && PRE && a.n_cot == 2) || two == 2))
+    if (conv3h_shape16() && a.n_chunks % 2 == 0 && a.n_cot % 2 == 0 && ((two == 1 && PRE && a.n_cot == 2 && (long long)a.tiles_y * a.tiles_x * a.B >= conv3h_two_min()) || two == 2))
       return launch_conv3h_w<MODE, W16, PRE, CIRC, 8, true, false, true>(a, s);
   }
   if (conv3h_shape16() && a.n_chunks % 2 == 0) {
