@@ -106,15 +106,20 @@ class ModuleSource:
         self.cfg = self.conditional and self.guidance != 1.0
         self.planned = bool(getattr(self.model, "forward_with_shifts", None)) and getattr(self.model, "capturable", True) and (
             like.dim() == 4 or (like.dim() == 5 and getattr(self.model, "dim", 2) == 3))
-        if self.planned and self.conditional and getattr(self.model, "condition_is_field", None) and self.model.condition_is_field(y):
-            self.planned = False                 # per-pixel time shifts are computed inside every evaluation
+        # A field-valued conditional embedding (punetg.py:405-407): the time shifts are per-pixel MLPs of te(sigma) + ye, so they are
+        # computed inside every evaluation -- from the tabulated te row and a plan-owned copy of ye, out of the network's workspace
+        # (PUNetG.field_shifts), which keeps the run capturable
+        self.field = bool(self.planned and self.conditional and getattr(self.model, "condition_is_field", None)
+                          and self.model.condition_is_field(y))
+        if self.field and not getattr(self.model, "field_shifts", None):
+            self.planned = self.field = False
         # Classifier-free guidance evaluates the network twice on the same state; with tabulated conditioning the two
         # evaluations differ only in their time-shift rows, so they run as ONE evaluation of batch 2B (rows B.. are the
         # unconditional half): half the launches (config 5 at 16 samples per GPU: 9.05 -> 9.00 ms per pair sustained, 9.24 -> 8.84 on a cool chip).
         # Bit-identical to two evaluations: every kernel treats samples independently.  Not for PUNetGCond-style networks,
         # whose channel condition cannot be dropped (the reference's cannot run the unconditional branch either).
         self.batched_cfg = (self.planned and self.cfg and getattr(module, "batch_cfg", True)
-                            and not hasattr(self.model, "_split_condition"))
+                            and not hasattr(self.model, "_split_condition") and not self.field)
         # ... and the step kernels write the network input into both halves of the [2B, ...] buffer themselves (ds_eval_coef.xin_copies)
         self.xin_copies = 2 if self.batched_cfg else 1
         # the range guard's result check rides on the run's last step kernel (nets/precision.py)
@@ -144,7 +149,12 @@ class ModuleSource:
             m = self.model
             self._cn = cn.to(dev)
             ye = m.embed_condition(self.y) if self.conditional else None
-            self.shifts_c = self._tables(ye)
+            if self.field:
+                self.te_rows = m.embed_time(self._cn)              # [n_evals, C]: the Fourier features of every evaluation
+                self.ye_field = ye.clone()
+                self.shifts_c = []
+            else:
+                self.shifts_c = self._tables(ye)
             self.shifts_u = self._tables(None) if (self.cfg or not self.conditional) else None
             if not self.conditional:
                 self.shifts_c = self.shifts_u
@@ -172,6 +182,11 @@ class ModuleSource:
             return
         with torch.inference_mode():                 # the tables may have been created under inference_mode
             ye = self.model.embed_condition(y)       # PUNetGCond also refreshes its channel-field buffer here
+            if self.field:
+                if tuple(ye.shape) != tuple(self.ye_field.shape):
+                    raise RuntimeError("the condition changed shape under a captured plan (plan key out of date)")
+                self.ye_field.copy_(ye)
+                return
             new = self._tables(ye)
             if len(new) != len(self.shifts_c) or any(a.shape != b.shape for a, b in zip(new, self.shifts_c)):
                 raise RuntimeError("the condition changed shape under a captured plan (plan key out of date)")
@@ -195,7 +210,11 @@ class ModuleSource:
             f2 = self.model.forward_with_shifts(xin, self.shifts_cu, row=index, out=self._out[key])
             return f2[:B], f2[B:]
         if self.planned:
-            f = self.model.forward_with_shifts(xin, self.shifts_c, row=index, out=self._buf(slot, "c"))
+            if self.field:
+                shifts = self.model.field_shifts(self.te_rows[index:index + 1], self.ye_field, self.batch)
+                f = self.model.forward_with_shifts(xin, shifts, row=None, out=self._buf(slot, "c"))
+            else:
+                f = self.model.forward_with_shifts(xin, self.shifts_c, row=index, out=self._buf(slot, "c"))
             fu = None
             if self.cfg:
                 fu = self.model.forward_with_shifts(xin, self.shifts_u, row=index, out=self._buf(slot, "u"))

@@ -292,6 +292,51 @@ class _AmaxArena:
         self.ws.give(self.buf)
 
 
+class _FieldShifts:
+    """Per-pixel time shifts, computed where they are used.  A field-valued conditional embedding makes the time embedding a
+    field te [B, C, He, We] (punetg.py:405-410) and every block's ResnetTimeBlock a per-pixel MLP (commonlayers.py:537-546)
+    whose result the block brings to its own resolution by taking the top-left corner of every window (rescale_yt,
+    commonlayers.py:838-869).  The MLP is pointwise, so corner-pooling its INPUT gives the same values: each block evaluates
+    its three 1x1 convolutions at its own resolution (16x fewer pixels two levels down) from a pooled copy of te that the
+    blocks of a level share.  Every buffer comes from the network's workspace, so the evaluation can sit inside a captured run."""
+
+    def __init__(self, te, ws, h3, owned=False):
+        self.te, self.ws, self.te_owned = te, ws, owned
+        self.am = _AmaxArena(ws, te.shape[0], te.device) if h3 else None
+        self.levels = {}
+
+    def level(self, H, W):
+        """te at a block's resolution [B, C, H, W] and its amax row (fp16x3)."""
+        got = self.levels.get((H, W))
+        if got is None:
+            B, C, h, w = self.te.shape
+            if (h, w) == (H, W):
+                t, owned = self.te, False
+            elif h > H:
+                f = h // H
+                if H * f != h or W * f != w:
+                    raise ValueError(f"yt_dims {(h, w)} and y_dims {(H, W)} are not compatible")
+                t, owned = self.ws.take((B, C, H, W), self.te.device), True
+                t.copy_(self.te[:, :, ::f, ::f])                      # CornerPool2d(f): the top-left corner of every window
+            else:
+                raise NotImplementedError("a conditional-embedding field coarser than a block's resolution (the reference's "
+                                          "upscaling branch passes the factor as torch.nn.Upsample's size and fails as well)")
+            got = self.levels[(H, W)] = (t, self.am.of(t) if self.am is not None else None, owned)
+        return got[0], got[1]
+
+    def release(self):
+        for t, _, owned in self.levels.values():
+            if owned:
+                self.ws.give(t)
+        self.levels = {}
+        if self.am is not None:
+            self.am.release()
+            self.am = None
+        if self.te_owned:
+            self.ws.give(self.te)
+            self.te_owned = False
+
+
 class PUNetG(torch.nn.Module):
     def __init__(self,
                  config: PUNetGConfig,
@@ -406,8 +451,7 @@ class PUNetG(torch.nn.Module):
         B = x.shape[0]
         ye = self.embed_condition(y)
         if ye is not None and ye.dim() > 2:                       # a field of embeddings: per-pixel time shifts
-            te = self.embed_time_field(None if t is None else t.reshape(-1).to(x), ye, B)
-            shifts = self.time_shift_fields(te)
+            shifts = self.field_shifts(None if t is None else self.embed_time(t.reshape(-1).to(x)), ye, B)
         else:
             if t is None:                                          # punetg.py:398-399, 410: zeros (+ ye)
                 te = torch.zeros(B, self.config.model_channels, device=x.device)
@@ -428,7 +472,7 @@ class PUNetG(torch.nn.Module):
             if ye.shape[1] != self.config.model_channels:
                 raise ValueError("a field-valued conditional embedding must have model_channels channels")
             ops.require_device(ye, "conditional embedding")
-            return ye.to(torch.float32).contiguous()
+            return ye.detach().to(torch.float32).contiguous()         # inference only: the kernels carry no autograd graph
         if ye.dim() != 2:
             raise NotImplementedError("field-valued conditional embeddings are implemented for 2-D networks ([B, C, H, W])")
         return ye.to(torch.float32).contiguous()
@@ -439,30 +483,40 @@ class PUNetG(torch.nn.Module):
         ye = None if y is None else self.embed_condition(y)
         return ye is not None and ye.dim() > 2
 
-    def embed_time_field(self, t, ye, B):
-        """te.reshape(B, C, 1, 1) + ye (punetg.py:405-410) -> [B, C, He, We]."""
+    def field_shifts(self, te, ye, B):
+        """The time embedding as a field, te.reshape(B, C, 1, 1) + ye (punetg.py:405-410; te [1 or B, C] or None for zeros,
+        ye [1 or B, C, He, We]), wrapped for the blocks to evaluate their per-pixel time MLPs from (`_FieldShifts`).  All
+        buffers are workspace buffers: forward_with_shifts gives them back."""
         if ye.shape[0] not in (1, B):
             raise ValueError("conditional embedding batch must be 1 or match x")
-        if t is None:
-            te = torch.zeros(B, self.config.model_channels, device=ye.device)
+        if te is not None and te.shape[0] not in (1, B):
+            raise ValueError("time batch must be 1 or match x")
+        ws = self._ws
+        field = ws.take((B,) + tuple(ye.shape[1:]), ye.device)
+        if te is None:
+            field.copy_(ye.expand(B, -1, -1, -1))
         else:
-            te = ops.fourier_features(t.contiguous(), self.time_projection.W)
-            if te.shape[0] not in (1, B):
-                raise ValueError("time batch must be 1 or match x")
-        return (te[:, :, None, None] + ye).expand(B, -1, -1, -1).contiguous()
+            torch.add(te[:, :, None, None].expand(B, -1, 1, 1), ye, out=field)
+        return _FieldShifts(field, ws, self.conv_precision == "fp16x3", owned=True)
 
-    def time_shift_fields(self, te):
-        """ResnetTimeBlock on a field (commonlayers.py:537-546): the three linears as 1x1 convolutions on the matrix cores,
-        one [B, C_block, He, We] shift per block; _res brings it to the block's resolution."""
-        pk = self._timeblock_convs()
-        out = []
-        for blk in self._resblocks():
-            n = blk.timeblock.net
-            h = ops.conv(te, pk[id(n[0])], bias=n[0].bias)
-            ops.inorm_silu(h, None, None, kind=2, out=h)
-            h2 = ops.conv(h, pk[id(n[2])], bias=n[2].bias)
-            ops.inorm_silu(h2, None, None, kind=2, out=h2)
-            out.append(ops.conv(h2, pk[id(n[4])], bias=n[4].bias))
+    def _field_shift(self, blk, fs, H, W):
+        """ResnetTimeBlock of one block on the field at the block's resolution: the three linears as 1x1 convolutions on the
+        matrix cores, SiLU in between (commonlayers.py:537-546) -> [B, C_block, H, W] from the workspace (the caller gives it back)."""
+        pk, ws = self._timeblock_convs(), fs.ws
+        te, a0 = fs.level(H, W)
+        B, dev = te.shape[0], te.device
+        n = blk.timeblock.net
+        a1 = fs.am.row() if fs.am is not None else None
+        a2 = fs.am.row() if fs.am is not None else None
+        h = ops.conv(te, pk[id(n[0])], bias=n[0].bias, out=ws.take((B, n[0].out_features, H, W), dev),
+                     **self._amax_kw(in_amax=a0, out_amax=a1))
+        ops.inorm_silu(h, None, None, kind=2, out=h)                 # |SiLU(v)| <= |v|: a1 stays a valid bound
+        h2 = ops.conv(h, pk[id(n[2])], bias=n[2].bias, out=ws.take((B, n[2].out_features, H, W), dev),
+                      **self._amax_kw(in_amax=a1, out_amax=a2))
+        ops.inorm_silu(h2, None, None, kind=2, out=h2)
+        out = ops.conv(h2, pk[id(n[4])], bias=n[4].bias, out=ws.take((B, n[4].out_features, H, W), dev), **self._amax_kw(in_amax=a2))
+        ws.give(h)
+        ws.give(h2)
         return out
 
     def _timeblock_convs(self):
@@ -698,9 +752,19 @@ class PUNetG(torch.nn.Module):
             if out_amax is not None:
                 ops.absmax_rows(y, out=out_amax)
             return y, None                                          # no tile statistics of the sum: the consumer normalises standalone
+        if isinstance(shift, _FieldShifts):                # a field of time shifts: conv1's epilogue adds it as a residual
+            yt = self._field_shift(blk, shift, H, W)
+            got = self._res_body(blk, x, None, yt, pk, ws, res2, xs, want_stats, out_amax)
+            ws.give(yt)
+            return got
         yt = None
-        if shift is not None and shift.dim() == 4:         # a field of time shifts: conv1's epilogue adds it as a residual
+        if shift is not None and shift.dim() == 4:         # the same, handed over as a tensor [B, C, He, We]
             yt, shift = self._rescale_shift_field(shift, H, W), None
+        return self._res_body(blk, x, shift, yt, pk, ws, res2, xs, want_stats, out_amax)
+
+    def _res_body(self, blk, x, shift, yt, pk, ws, res2, xs, want_stats, out_amax):
+        B, C, H, W = x.shape
+        dev = x.device
         k1, k2 = self.norm_kinds                           # 0 GroupLN, 1 GroupRMS, 2 none, 3 GroupPix (not a table)
         w1, b1 = getattr(blk.gnorm1, "weight", None), getattr(blk.gnorm1, "bias", None)
         w2, b2 = getattr(blk.gnorm2, "weight", None), getattr(blk.gnorm2, "bias", None)
@@ -831,9 +895,12 @@ class PUNetG(torch.nn.Module):
         cfg = self.config
         B = x.shape[0]
         dev = x.device
-        it = iter(range(len(shifts)))
+        lazy_shifts = shifts if isinstance(shifts, _FieldShifts) else None
+        it = iter(range(len(shifts))) if lazy_shifts is None else None
 
         def sh():
+            if lazy_shifts is not None:                # per-pixel shifts: each block evaluates its own (_field_shift)
+                return lazy_shifts
             s = shifts[next(it)]
             if s.dim() == 4:                           # [B, C, He, We]: a field of shifts (eager evaluation only)
                 return s
@@ -991,6 +1058,8 @@ class PUNetG(torch.nn.Module):
             if am is not None:
                 am.release()
             self._am = None
+            if lazy_shifts is not None:
+                lazy_shifts.release()
 
     # ------------------------------------------------------------------ volumes (dimension = 3)
     def _forward3d(self, x, shifts, row=None, out=None):

@@ -437,8 +437,8 @@ def test_porosity_conditional_cfg_dict_y(M, dev, grids):
 def test_field_valued_conditional_embedding(M, dev, grids):
     """punetg.py:405-407 / commonlayers.py:537-546, 838-869: a conditional embedding that is a FIELD (here a user 1x1
     convolution of a two-channel condition) turns every block's time shift into a field -- the time MLP per pixel as 1x1
-    convolutions on the matrix cores, CornerPooled to the block's resolution and added through conv1's epilogue.  Such a
-    network is evaluated eagerly inside the sampler (no per-run table of shifts)."""
+    convolutions on the matrix cores at the block's resolution (from the CornerPooled time embedding: the MLP is pointwise) and added
+    through conv1's epilogue.  Round 3: out of the workspace, so the sampler captures such a run like any other."""
     from diffsci_amd.models.karras import engine
     v, sd = load("punetg8_spatial_cond")
     net = M.PUNetG(M.PUNetGConfig(model_channels=8), conditional_embedding=torch.nn.Conv2d(2, 8, kernel_size=1))
@@ -456,21 +456,34 @@ def test_field_valued_conditional_embedding(M, dev, grids):
     assert rel_l2(net(x, t).cpu(), v["out_uncond_f32"]) < REL
     # one block at level 1: the per-pixel shift of a 32 x 32 field, CornerPooled to 16 x 16
     te = v["resblock_te"].to(dev)
-    shifts = net.time_shift_fields(te)
-    k = len(net.downward_blocks[0])                                   # first block of level 1
+    from diffsci_amd.models.nets.punetg import _FieldShifts
     pk, ws = net.packed_weights(), net._ws
-    got, _ = net._res(net.downward_blocks[1][0], v["resblock_in"].to(dev), shifts[k], pk, ws, xs=None)
+    fs = _FieldShifts(te, ws, net.conv_precision == "fp16x3")
+    got, _ = net._res(net.downward_blocks[1][0], v["resblock_in"].to(dev), fs, pk, ws, xs=None)      # first block of level 1
     assert rel_l2(got.cpu(), v["resblock_l1"]) < REL
     with pytest.raises(NotImplementedError):
-        net._rescale_shift_field(torch.zeros(1, 8, 8, 8, device=dev), 16, 16)
+        _FieldShifts(torch.zeros(1, 8, 8, 8, device=dev), ws, False).level(16, 16)
+    fs.release()
     module = M.KarrasModule(net, M.KarrasModuleConfig.from_edm(), conditional=True).to(dev)
     _pin_grid(module, grids)
     src = engine.ModuleSource(module, y[:1], 1.0, 2, x)
-    assert not src.planned
+    assert src.planned and src.field and not src.batched_cfg
     wn = v["white_noise"].to(dev)
     for g in (1.0, 2.0):
-        h = module.propagate_white_noise(wn, y=y[0], guidance=g, nsteps=4, record_history=True).cpu()
-        assert rel_l2(h, v[f"hist_heun_N4_g{int(g)}_f32"]) < REL
+        runs = []
+        for use_graph in (False, True, True):
+            module.use_graph = use_graph
+            h = module.propagate_white_noise(wn, y=y[0], guidance=g, nsteps=4, record_history=True).cpu()
+            assert rel_l2(h, v[f"hist_heun_N4_g{int(g)}_f32"]) < REL
+            runs.append(h)
+        assert torch.equal(runs[0], runs[1]) and torch.equal(runs[1], runs[2])          # eager, capture + replay, replay
+    assert len(module._plans.plans) == 2
+    # a replay follows the condition's VALUES: the plan owns a copy of the embedded field that every replay refreshes
+    y2 = y[0] * 0.5 + 0.25
+    a = module.propagate_white_noise(wn, y=y2, guidance=2.0, nsteps=4, record_history=True)
+    module.use_graph = False
+    b = module.propagate_white_noise(wn, y=y2, guidance=2.0, nsteps=4, record_history=True)
+    assert len(module._plans.plans) == 2 and torch.equal(a, b) and not torch.equal(a.cpu(), runs[-1])
 
 
 def test_fused_and_standalone_norms_agree(M, net8, dev):
