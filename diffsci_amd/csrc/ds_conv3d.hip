@@ -240,16 +240,18 @@ __global__ __launch_bounds__(256) void k_from_slices(float* y, const float* __re
 
 // ---- the same two copies with the block's normalisation folded in (round 2) ----
 // k_to_slices_act: the copy applies SiLU((x - M) A + C) from a per-(sample, channel) table (ds_inorm_table's rows) -- the
-// standalone norm pass over the volume disappears; pad slices stay exactly zero.  Same expf / IEEE division as the
-// standalone norm kernels (ds_norm.hip).
+// standalone norm pass over the volume disappears; pad slices stay exactly zero, or hold the activated wrapped neighbours
+// (circular: periodic padding along the depth).  Same expf / IEEE division as the standalone norm kernels (ds_norm.hip).
 __global__ __launch_bounds__(256) void k_to_slices_act(float* S, const float* __restrict__ x, const float* __restrict__ table,
-                                                      int C, int Cpad, int D, size_t HW) {
+                                                      int C, int Cpad, int D, size_t HW, int circular) {
   const int zp = blockIdx.y % (D + 2);
   const int b = blockIdx.y / (D + 2);
   const int c = blockIdx.z;
   float* dst = S + (((size_t)b * (D + 2) + zp) * C + c) * HW;
-  const int z = zp - 1;
-  const bool zero = z < 0 || z >= D;
+  int z = zp - 1;
+  bool zero = false;
+  if (z < 0) { zero = !circular; z = D - 1; }
+  if (z >= D) { zero = !circular; z = 0; }
   const float4 t = reinterpret_cast<const float4*>(table)[(size_t)b * Cpad + c];
   const float* src = x + (((size_t)b * C + c) * D + (zero ? 0 : z)) * HW;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < HW; i += (size_t)gridDim.x * 256) {
@@ -308,11 +310,12 @@ __global__ __launch_bounds__(256) void k_from_slices_stats(float* y, const float
 // k_slice_tables: the norm table of a volume that STAYS slice-major between the two convolutions of a block.  Input: the
 // tile statistics the last depth-tap launch left, [2-D sample j = slice - 1][c][tile]; a sample's D real slices are
 // combined (fp64, fixed order) into one (M, A, C) row, written for each of them; pad slices get zero rows -- whatever the
-// tap launches computed there becomes SiLU(0) = 0 in the consumer's loader, i.e. the zero padding of the depth axis.
+// tap launches computed there becomes SiLU(0) = 0 in the consumer's loader, i.e. the zero padding of the depth axis -- or,
+// circular, the sample's row as well: the pad slices then hold wrapped copies of real slices (ds_wrap_pad_slices).
 // 16 lanes per (b, c).
 __global__ __launch_bounds__(256) void k_slice_tables(float* table, const float* __restrict__ ts, const float* __restrict__ w,
                                                      const float* __restrict__ bias, int B, int C, int Cpad, int D, int ntiles,
-                                                     double inv_n, float eps, int kind) {
+                                                     double inv_n, float eps, int kind, int circular) {
   const int row = blockIdx.x * 16 + (threadIdx.x >> 4);
   const int l = threadIdx.x & 15;
   const int b = row / Cpad, c = row - b * Cpad;
@@ -346,7 +349,17 @@ __global__ __launch_bounds__(256) void k_slice_tables(float* table, const float*
     o4 = make_float4(M, rs * ((w && kind != 2) ? w[c] : 1.f), (bias && kind != 2) ? bias[c] : 0.f, 0.f);
   }
   for (int zp = l; zp < D + 2; zp += 16)
-    reinterpret_cast<float4*>(table)[((size_t)b * (D + 2) + zp) * Cpad + c] = (zp >= 1 && zp <= D) ? o4 : make_float4(0.f, 0.f, 0.f, 0.f);
+    reinterpret_cast<float4*>(table)[((size_t)b * (D + 2) + zp) * Cpad + c] =
+        ((zp >= 1 && zp <= D) || circular) ? o4 : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+// Periodic depth padding of a slice-major volume that was PRODUCED slice-major (the intermediate of a folded block): pad slice 0
+// of every sample takes its last real slice, pad slice D + 1 its first.  grid (blocks, 2 B, C).
+__global__ __launch_bounds__(256) void k_wrap_pad_slices(float* S, int C, int D, size_t HW) {
+  const int b = blockIdx.y >> 1, hi = blockIdx.y & 1, c = blockIdx.z;
+  const float* src = S + (((size_t)b * (D + 2) + (hi ? 1 : D)) * C + c) * HW;
+  float* dst = S + (((size_t)b * (D + 2) + (hi ? D + 1 : 0)) * C + c) * HW;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < HW; i += (size_t)gridDim.x * 256) dst[i] = src[i];
 }
 
 // AvgPool3d(2) / nearest x2 upsampling of volumes, the resampling of ADM blocks on volumes (adm.py:352-384: AvgPool3d,
@@ -450,15 +463,26 @@ static unsigned slice_copy_blocks(size_t HW) {
 extern "C" int ds_volume_stat_tiles(int D, size_t HW) { return D <= 0 || HW == 0 ? 0 : D * (int)slice_copy_blocks(HW); }
 
 extern "C" int ds_volume_to_slices_act(float* slices, const float* x, const float* table, int B, int C, int D, size_t HW,
-                                       void* stream) {
+                                       int circular, void* stream) {
   DS_REQUIRE(slices && x && table, DS_ERR_NULL, "ds_volume_to_slices_act: NULL pointer");
   DS_REQUIRE(B >= 0 && C > 0 && D > 0 && HW > 0, DS_ERR_SHAPE, "ds_volume_to_slices_act: bad arguments B=%d C=%d D=%d", B, C, D);
   DS_REQUIRE((long long)B * (D + 2) < 65536 && C < 65536, DS_ERR_SHAPE, "ds_volume_to_slices_act: B*(D+2) and C must stay below 65536");
   DS_REQUIRE((reinterpret_cast<uintptr_t>(table) & 15u) == 0, DS_ERR_SHAPE, "ds_volume_to_slices_act: table must be 16-byte aligned");
   if (B == 0) return DS_OK;
   hipLaunchKernelGGL(k_to_slices_act, dim3(slice_copy_blocks(HW), (unsigned)(B * (D + 2)), (unsigned)C), dim3(256), 0,
-                     ds::as_stream(stream), slices, x, table, C, (C + 15) / 16 * 16, D, HW);
+                     ds::as_stream(stream), slices, x, table, C, (C + 15) / 16 * 16, D, HW, circular);
   DS_CHECK_LAUNCH("ds_volume_to_slices_act");
+  return DS_OK;
+}
+
+extern "C" int ds_wrap_pad_slices(float* slices, int B, int C, int D, size_t HW, void* stream) {
+  DS_REQUIRE(slices, DS_ERR_NULL, "ds_wrap_pad_slices: NULL pointer");
+  DS_REQUIRE(B >= 0 && C > 0 && D > 0 && HW > 0, DS_ERR_SHAPE, "ds_wrap_pad_slices: bad arguments B=%d C=%d D=%d", B, C, D);
+  DS_REQUIRE(2ll * B < 65536 && C < 65536, DS_ERR_SHAPE, "ds_wrap_pad_slices: 2*B and C must stay below 65536");
+  if (B == 0) return DS_OK;
+  hipLaunchKernelGGL(k_wrap_pad_slices, dim3(slice_copy_blocks(HW), (unsigned)(2 * B), (unsigned)C), dim3(256), 0, ds::as_stream(stream),
+                     slices, C, D, HW);
+  DS_CHECK_LAUNCH("ds_wrap_pad_slices");
   return DS_OK;
 }
 
@@ -476,7 +500,7 @@ extern "C" int ds_slices_to_volume_stats(float* y, const float* slices, const fl
 }
 
 extern "C" int ds_slice_tables(float* table, const float* tile_stats, const float* w, const float* b, int B, int C, int D,
-                               int ntiles, long long count, float eps, int kind, void* stream) {
+                               int ntiles, long long count, float eps, int kind, int circular, void* stream) {
   DS_REQUIRE(table && tile_stats, DS_ERR_NULL, "ds_slice_tables: NULL pointer");
   DS_REQUIRE(B >= 0 && C > 0 && D > 0 && ntiles > 0 && count > 0, DS_ERR_SHAPE, "ds_slice_tables: bad shape");
   DS_REQUIRE(kind >= 0 && kind <= 2, DS_ERR_UNSUPPORTED, "ds_slice_tables: kind %d (0 GroupLN, 1 GroupRMS, 2 none)", kind);
@@ -487,7 +511,7 @@ extern "C" int ds_slice_tables(float* table, const float* tile_stats, const floa
   const long long rows = (long long)B * Cpad;
   DS_REQUIRE(rows < (1ll << 31), DS_ERR_SHAPE, "ds_slice_tables: too many rows");
   hipLaunchKernelGGL(k_slice_tables, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, ds::as_stream(stream), table, tile_stats,
-                     w, b, B, C, Cpad, D, ntiles, 1.0 / (double)count, eps, kind);
+                     w, b, B, C, Cpad, D, ntiles, 1.0 / (double)count, eps, kind, circular);
   DS_CHECK_LAUNCH("ds_slice_tables");
   return DS_OK;
 }

@@ -1091,13 +1091,12 @@ class PUNetG(torch.nn.Module):
                 raise ValueError("time embedding batch does not match x")
             return s
 
-        # Norm folding on volumes (round 2; fp16x3, zero padding, 3x3x3 kernels): every activation travels with the partial
+        # Norm folding on volumes (round 2; fp16x3, 3x3x3 kernels; round 3: periodic padding too): every activation travels with the partial
         # sums its producer's slice -> volume copy left (hs); a block whose input has them runs ops.resblock3d_fused --
         # norm1 inside the volume -> slice copy, the intermediate slice-major with norm2 in conv2's loader -- 20 instead of
         # 52 bytes per element of norm / copy traffic per block.  Without statistics (after the thin input layer or the
         # attention) the block runs the standalone norms and leaves statistics for its successor.
-        fold = (self._fused() and not self.circular and self.extra_residual is None and k1 != 3 and k2 != 3
-                and cfg.kernel_size == 3)
+        fold = self._fused() and self.extra_residual is None and k1 != 3 and k2 != 3 and cfg.kernel_size == 3
 
         def stats_buf(shape):
             Bc, C, D, H, W = shape
@@ -1137,7 +1136,7 @@ class PUNetG(torch.nn.Module):
                 tab = ops.inorm_table(hs, w1, b1, k1, h[0, 0].numel(), eps=1e-5, out=ws.take((B, ops.table_channels(C), 4), dev))
                 os_ = stats_buf(h.shape) if want_stats else None
                 y = ops.resblock3d_fused(h, tab, p1, blk.conv1.bias, sh(), p2, blk.conv2.bias, w2, b2, k2, res2=res2,
-                                         out=ws.take(h.shape, dev), out_stats=os_, ws=ws)
+                                         out=ws.take(h.shape, dev), out_stats=os_, ws=ws, circular=self.circular)
                 ws.give(tab)
                 return y, os_
             a = ops.inorm_silu(h, w1, b1, kind=k1, eps=1e-5, out=ws.take(h.shape, dev))

@@ -444,14 +444,17 @@ def _from_slices(out, s_out, res1, res2, B, C, D, HW, out_stats=None):
 
 
 def resblock3d_fused(h, tab1, packs1, bias1, shift, packs2, bias2, w2, b2, kind2, res2=None, out=None, out_stats=None,
-                     ws=None, eps=1e-5):
+                     ws=None, eps=1e-5, circular=False):
     """ResnetBlockC on a volume (commonlayers.py:824-833) with both norms folded and the intermediate kept slice-major:
         S1 = SiLU(norm1(h))         by the volume -> slice copy (tab1 = ds_inorm_table rows of h's statistics)
         S2 = conv1(S1) + shift      three depth-tap launches; the last one leaves S2's tile statistics
         T  = per-slice table of norm2 over the sample's real slices, zero rows for the pad slices (ds_slice_tables)
         S3 = conv2(SiLU(norm2(S2))) three launches with the fused loader reading S2 in place
         out = S3 + h [+ res2]       by the slice -> volume copy, which also leaves out's statistics (out_stats)
-    against norm, copy, 3 launches, copy, norm, copy, 3 launches, copy.  Zero padding, plain loads, fp16x3 packings."""
+    against norm, copy, 3 launches, copy, norm, copy, 3 launches, copy.  Plain loads, fp16x3 packings.  circular: periodic
+    padding on all three axes (commonlayers.py:918-971) -- in the plane by the convolution's loader, along the depth by pad
+    slices that hold wrapped copies: S1's from the volume -> slice copy, S2's from one small copy after conv1 (the pad rows of T
+    are then the sample's row, not zeros)."""
     require_device(h, "h")
     B, C, D, H, W = h.shape
     if packs1[0].Cout != C or packs2[0].Cout != C:
@@ -463,18 +466,22 @@ def resblock3d_fused(h, tab1, packs1, bias1, shift, packs2, bias2, w2, b2, kind2
     if out is None:
         out = torch.empty_like(h)
     s1 = take((ns, C, H, W))
-    N.check(N.lib().ds_volume_to_slices_act(_p(s1), _p(h.contiguous()), _p(tab1), B, C, D, H * W, _stream()),
+    circ = 1 if circular else 0
+    N.check(N.lib().ds_volume_to_slices_act(_p(s1), _p(h.contiguous()), _p(tab1), B, C, D, H * W, circ, _stream()),
             "ds_volume_to_slices_act")
     s2 = take((ns, C, H, W))
-    s2[0].zero_()                                           # the outermost pad slices are never written by the launches
-    s2[ns - 1].zero_()
+    if not circular:
+        s2[0].zero_()                                       # the outermost pad slices are never written by the launches
+        s2[ns - 1].zero_()
     ts = take((ns - 2, C, conv_tile_count(H, W), 4))
     rows, rows_buf = _slice_rows(shift, B, D, C, ws)
-    _depth_taps(s1, s2, packs1, bias1, rows, N.DS_LOAD_PLAIN, False, tile_stats=ts, in_amax=NORMALISED)   # S1 = SiLU(norm1(h))
+    _depth_taps(s1, s2, packs1, bias1, rows, N.DS_LOAD_PLAIN, bool(circular), tile_stats=ts, in_amax=NORMALISED)   # S1 = SiLU(norm1(h))
+    if circular:
+        N.check(N.lib().ds_wrap_pad_slices(_p(s2), B, C, D, H * W, _stream()), "ds_wrap_pad_slices")
     tab2 = take((ns, table_channels(C), 4))
     N.check(N.lib().ds_slice_tables(_p(tab2), _p(ts), _p(w2), _p(b2), B, C, D, ts.shape[2], D * H * W, float(eps), int(kind2),
-                                    _stream()), "ds_slice_tables")
-    _depth_taps(s2, s1, packs2, bias2, None, N.DS_LOAD_PLAIN, False, prenorm=tab2)          # S1 is dead: reuse it for S3
+                                    circ, _stream()), "ds_slice_tables")
+    _depth_taps(s2, s1, packs2, bias2, None, N.DS_LOAD_PLAIN, bool(circular), prenorm=tab2)  # S1 is dead: reuse it for S3
     _from_slices(out, s1, h, res2, B, C, D, H * W, out_stats)
     if ws is not None:
         for t in (s1, s2, ts, tab2, rows_buf):

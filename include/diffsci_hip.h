@@ -365,19 +365,25 @@ int ds_slices_to_volume(float* y, const float* slices, const float* res1, const 
 
 /* The same copies with the residual block's normalisation folded in (commonlayers.py:824-833 on volumes):
  *   ds_volume_to_slices_act: S = SiLU((x - M) A + C) with (M, A, C) = table[b][c] (ds_inorm_table rows, [B, ceil16(C), 4]);
- *     pad slices zero -- the block's first GroupNorm / GroupRMSNorm + SiLU without a pass of its own.
+ *     pad slices zero, or (circular) the activated wrapped neighbours -- the block's first GroupNorm / GroupRMSNorm + SiLU
+ *     without a pass of its own.
  *   ds_slices_to_volume_stats: ds_slices_to_volume that also leaves the shifted partial sums (K, S, Q, n) of the stored values,
  *     stats [B, C, ds_volume_stat_tiles(D, HW), 4], for ds_inorm_table (count = D*HW) -- the NEXT block's first norm.
  *   ds_slice_tables: for a volume that stays slice-major between the two convolutions of a block: the tile statistics of the
  *     last depth-tap launch (ds_conv2d_h3's tile_stats over the 2-D batch B*(D+2) - 2, sample j = slice j + 1) -> one
  *     (M, A, C) row per (slice, channel), table [B*(D+2), ceil16(C), 4]; pad slices get zero rows, so the consumer's fused
- *     loader (prenorm = table + (1 + dz) rows) reads SiLU(0) = 0 there: the depth axis' zero padding.  count = D*HW. */
+ *     loader (prenorm = table + (1 + dz) rows) reads SiLU(0) = 0 there: the depth axis' zero padding.  count = D*HW.
+ *     circular: the pad slices get the sample's row too, and the caller fills them with wrapped copies first:
+ *   ds_wrap_pad_slices: S [B, D+2, C, HW] produced slice-major (interior written by the tap launches): pad slice 0 of every
+ *     sample <- its slice D, pad slice D+1 <- its slice 1 -- the periodic depth padding (commonlayers.py:918-971 on volumes). */
 int ds_volume_stat_tiles(int D, size_t HW);
-int ds_volume_to_slices_act(float* slices, const float* x, const float* table, int B, int C, int D, size_t HW, void* stream);
+int ds_volume_to_slices_act(float* slices, const float* x, const float* table, int B, int C, int D, size_t HW, int circular,
+                            void* stream);
+int ds_wrap_pad_slices(float* slices, int B, int C, int D, size_t HW, void* stream);
 int ds_slices_to_volume_stats(float* y, const float* slices, const float* res1, const float* res2, float* stats, int B, int C,
                               int D, size_t HW, void* stream);
 int ds_slice_tables(float* table, const float* tile_stats, const float* w, const float* b, int B, int C, int D, int ntiles,
-                    long long count, float eps, int kind, void* stream);
+                    long long count, float eps, int kind, int circular, void* stream);
 
 /* Resampling of volumes in ADM blocks with dimension = 3 (make_downsample / make_upsample, adm.py:352-384):
  *   ds_avgpool3d:  AvgPool3d(2): x [planes, 2Do, 2Ho, 2Wo] -> out [planes, Do, Ho, Wo] (sum of the 8 voxels in (z, y, x) order, / 8);

@@ -343,7 +343,7 @@ def test_volume_norm_folding(M, dev):
     assert torch.allclose(tab[:, :C, 0].double(), mean, rtol=1e-5, atol=1e-6)
     assert torch.allclose(tab[:, :C, 1].double(), w1.double() / torch.sqrt(var + 1e-5), rtol=1e-5)
     s_act = torch.empty_like(s_plain)
-    ops.N.check(ops.N.lib().ds_volume_to_slices_act(ops._p(s_act), ops._p(back), ops._p(tab), B, C, D, H * W, ops._stream()), "to_slices_act")
+    ops.N.check(ops.N.lib().ds_volume_to_slices_act(ops._p(s_act), ops._p(back), ops._p(tab), B, C, D, H * W, 0, ops._stream()), "to_slices_act")
     want = torch.nn.functional.silu(torch.nn.functional.group_norm(back, C, w1, b1, 1e-5))
     got = s_act.view(B, D + 2, C, H, W)
     assert float(got[:, 0].abs().max()) == 0.0 and float(got[:, D + 1].abs().max()) == 0.0
@@ -368,6 +368,74 @@ def test_volume_norm_folding(M, dev):
     assert rel_l2(folded, plain) < 3e-6
     assert rel_l2(folded, g["out_f32"]) < 1e-5
     assert rel_l2(folded, g["out_f64"]) < max(4 * rel_l2(g["out_f32"], g["out_f64"]), 2e-6)
+
+
+def test_volume_norm_folding_with_periodic_padding(M, dev):
+    """Round 3 (SURVEY 8f-4 residue): the same folding under convolution_type='circular' (commonlayers.py:918-971 on volumes).
+    Pad slices cannot be zero rows there: the activated copy wraps the depth axis itself, the slice-major intermediate gets its
+    pad slices from ds_wrap_pad_slices and the per-slice table carries the sample's row on them."""
+    from diffsci_amd import ops
+    from tests.golden_util import load, rel_l2
+    torch.manual_seed(12)
+    B, C, D, H, W = 2, 8, 5, 16, 16
+    h = torch.randn(B, C, D, H, W, device=dev) * 1.3 - 0.2
+    w1, b1 = torch.randn(C, device=dev), torch.randn(C, device=dev)
+    tab = torch.zeros(B, ops.table_channels(C), 4, device=dev)
+    v = h.double()
+    mean, var = v.mean(dim=(2, 3, 4)), v.var(dim=(2, 3, 4), unbiased=False)
+    tab[:, :C, 0], tab[:, :C, 1], tab[:, :C, 2] = mean.float(), (w1.double() / torch.sqrt(var + 1e-5)).float(), b1
+    s_act = torch.empty(B * (D + 2), C, H, W, device=dev)
+    ops.N.check(ops.N.lib().ds_volume_to_slices_act(ops._p(s_act), ops._p(h), ops._p(tab), B, C, D, H * W, 1, ops._stream()), "to_slices_act")
+    got = s_act.view(B, D + 2, C, H, W)
+    want = torch.nn.functional.silu(torch.nn.functional.group_norm(h, C, w1, b1, 1e-5)).permute(0, 2, 1, 3, 4)
+    assert rel_l2(got[:, 1:D + 1].cpu(), want.cpu()) < 2e-6
+    assert torch.equal(got[:, 0], got[:, D]) and torch.equal(got[:, D + 1], got[:, 1])          # wrapped, activated
+    s = torch.randn(B, D + 2, C, H, W, device=dev)
+    keep = s.clone()
+    ops.N.check(ops.N.lib().ds_wrap_pad_slices(ops._p(s), B, C, D, H * W, ops._stream()), "wrap")
+    assert torch.equal(s[:, 1:D + 1], keep[:, 1:D + 1]) and torch.equal(s[:, 0], keep[:, D]) and torch.equal(s[:, D + 1], keep[:, 1])
+    # one block against torch (fp64) on the same tensors
+    blk_w = [torch.randn(C, C, 3, 3, 3, device=dev) / (27 * C) ** 0.5 for _ in range(2)]
+    blk_b = [torch.randn(C, device=dev) * 0.1 for _ in range(2)]
+    w2, b2 = torch.randn(C, device=dev), torch.randn(C, device=dev)
+    shift = torch.randn(B, C, device=dev)
+    p1, p2 = ops.pack_conv3d(blk_w[0]), ops.pack_conv3d(blk_w[1])
+    out = ops.resblock3d_fused(h, tab, p1, blk_b[0], shift, p2, blk_b[1], w2, b2, 0, circular=True)
+    F = torch.nn.functional
+    pad = lambda t: F.pad(t, (1, 1, 1, 1, 1, 1), mode="circular")      # noqa: E731
+    a = F.silu(F.group_norm(h.double(), C, w1.double(), b1.double(), 1e-5))
+    y = F.conv3d(pad(a), blk_w[0].double(), blk_b[0].double()) + shift.double()[:, :, None, None, None]
+    a2 = F.silu(F.group_norm(y, C, w2.double(), b2.double(), 1e-5))
+    ref = F.conv3d(pad(a2), blk_w[1].double(), blk_b[1].double()) + h.double()
+    assert rel_l2(out.double().cpu(), ref.cpu()) < 3e-6
+    # the network: the folded block runs, and matches the standalone-norm route and the reference's golden
+    g, sd = load("punetg8_3d_circular")
+    net = M.PUNetG(M.PUNetGConfig(model_channels=8, dimension=3, convolution_type="circular"))
+    net.load_state_dict(sd, strict=True)
+    net = net.to(dev).eval()
+    x, t = g["x"].to(dev), g["t"].to(dev)
+    calls = []
+    orig = ops.resblock3d_fused
+    ops.resblock3d_fused = lambda *a, **k: (calls.append(k.get("circular")), orig(*a, **k))[1]
+    try:
+        folded = net(x, t).cpu()
+    finally:
+        ops.resblock3d_fused = orig
+    assert len(calls) >= 8 and all(calls), "the folded periodic block did not run"
+    net.fuse_norm = False
+    plain = net(x, t).cpu()
+    net.fuse_norm = True
+    assert rel_l2(folded, plain) < 3e-6
+    assert rel_l2(folded, g["out_f32"]) < 1e-5
+    assert rel_l2(folded, g["out_f64"]) < max(4 * rel_l2(g["out_f32"], g["out_f64"]), 2e-6)
+    # ... and a captured sampling run on it
+    module = M.KarrasModule(net, M.KarrasModuleConfig.from_edm())
+    wn = torch.randn(2, 1, 16, 16, 16, generator=torch.Generator().manual_seed(4)).to(dev)
+    runs = []
+    for use_graph in (False, True, True):
+        module.use_graph = use_graph
+        runs.append(module.propagate_white_noise(wn, nsteps=3))
+    assert torch.equal(runs[0], runs[1]) and torch.equal(runs[1], runs[2]) and len(module._plans.plans) == 1
 
 
 @pytest.mark.parametrize("integrator", ["karras", "euler-maruyama"])
