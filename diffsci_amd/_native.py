@@ -74,8 +74,8 @@ _PROTOS = {
     "ds_gnorm1_stats_tiles": (c_int, [_P, _P, c_int, c_int, _P, c_int, c_int, c_int, c_longlong, c_float, c_int, _P]),
     "ds_conv2d_direct": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "ds_conv3d_direct": (c_int, [_P, _P, _P, _P, _P, c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
-    "ds_volume_to_slices": (c_int, [_P, _P, c_int, c_int, c_int, c_size_t, c_int, c_int, _P]),
-    "ds_slices_to_volume": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_size_t, _P]),
+    "ds_volume_to_slices": (c_int, [_P, _P, c_int, c_int, c_int, c_size_t, c_int, c_int, c_int, _P]),
+    "ds_slices_to_volume": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_size_t, c_int, _P]),
     "ds_conv_images_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "ds_inorm_silu_images_supported": (c_int, [c_int, c_int]),
     "ds_inorm_silu_images": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_int, _P]),
@@ -84,7 +84,7 @@ _PROTOS = {
     "ds_volume_stat_tiles": (c_int, [c_int, c_size_t]),
     "ds_volume_to_slices_act": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_size_t, c_int, _P]),
     "ds_wrap_pad_slices": (c_int, [_P, c_int, c_int, c_int, c_size_t, _P]),
-    "ds_slices_to_volume_stats": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_size_t, _P]),
+    "ds_slices_to_volume_stats": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_size_t, c_int, _P]),
     "ds_slice_tables": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_longlong, c_float, c_int, c_int, _P]),
     "ds_avgpool3d": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "ds_upsample3d": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),

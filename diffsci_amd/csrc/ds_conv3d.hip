@@ -202,15 +202,16 @@ namespace {
 // depth_mode 0: copy; 1: max over the depth pairs (2z, 2z+1) -- the depth half of MaxPool3d(2), the (H, W) half is the
 // 2-D kernel's MAXPOOL2 loader; 2: nearest x2 in depth (z >> 1) -- likewise for the upsampling
 __global__ __launch_bounds__(256) void k_to_slices(float* S, const float* __restrict__ x, int C, int D, int Din, size_t HW,
-                                                  int depth_mode, int circular) {
-  const int zp = blockIdx.y % (D + 2);
-  const int b = blockIdx.y / (D + 2);
+                                                  int depth_mode, int circular, int pad) {
+  const int DP = D + 2 * pad;                       // pad slices on each side: k/2 of a k-tap depth axis
+  const int zp = blockIdx.y % DP;
+  const int b = blockIdx.y / DP;
   const int c = blockIdx.z;
-  float* dst = S + (((size_t)b * (D + 2) + zp) * C + c) * HW;
-  int z = zp - 1;
+  float* dst = S + (((size_t)b * DP + zp) * C + c) * HW;
+  int z = zp - pad;
   bool zero = false;
-  if (z < 0) { zero = !circular; z = D - 1; }
-  if (z >= D) { zero = !circular; z = 0; }
+  if (z < 0) { zero = !circular; z = circular ? z + D : 0; }      // pad <= D is checked on the host
+  if (z >= D) { zero = !circular; z = circular ? z - D : 0; }
   const float* src = x + ((size_t)b * C + c) * Din * HW;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < HW; i += (size_t)gridDim.x * 256) {
     float v = 0.f;
@@ -224,11 +225,11 @@ __global__ __launch_bounds__(256) void k_to_slices(float* S, const float* __rest
 }
 
 __global__ __launch_bounds__(256) void k_from_slices(float* y, const float* __restrict__ S, const float* __restrict__ r1,
-                                                    const float* __restrict__ r2, int C, int D, size_t HW) {
+                                                    const float* __restrict__ r2, int C, int D, size_t HW, int pad) {
   const int z = blockIdx.y % D;
   const int b = blockIdx.y / D;
   const int c = blockIdx.z;
-  const float* src = S + (((size_t)b * (D + 2) + z + 1) * C + c) * HW;
+  const float* src = S + (((size_t)b * (D + 2 * pad) + z + pad) * C + c) * HW;
   const size_t o = (((size_t)b * C + c) * D + z) * HW;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < HW; i += (size_t)gridDim.x * 256) {
     float v = src[i];
@@ -269,13 +270,13 @@ __global__ __launch_bounds__(256) void k_to_slices_act(float* S, const float* __
 // block's first norm needs no pass of its own over the volume.
 __global__ __launch_bounds__(256) void k_from_slices_stats(float* y, const float* __restrict__ S, const float* __restrict__ r1,
                                                           const float* __restrict__ r2, float* __restrict__ stats, int C,
-                                                          int D, size_t HW) {
+                                                          int D, size_t HW, int pad) {
   __shared__ float sk;
   __shared__ float red[3][4];
   const int z = blockIdx.y % D;
   const int b = blockIdx.y / D;
   const int c = blockIdx.z;
-  const float* src = S + (((size_t)b * (D + 2) + z + 1) * C + c) * HW;
+  const float* src = S + (((size_t)b * (D + 2 * pad) + z + pad) * C + c) * HW;
   const size_t o = (((size_t)b * C + c) * D + z) * HW;
   const size_t first = (size_t)blockIdx.x * 256;
   if (threadIdx.x == 0) {
@@ -427,30 +428,31 @@ extern "C" int ds_upsample3d(float* out, const float* x, int planes, int Di, int
 }
 
 extern "C" int ds_volume_to_slices(float* slices, const float* x, int B, int C, int D, size_t HW, int depth_mode,
-                                   int circular, void* stream) {
+                                   int circular, int pad, void* stream) {
   DS_REQUIRE(slices && x, DS_ERR_NULL, "ds_volume_to_slices: NULL pointer");
   DS_REQUIRE(B >= 0 && C > 0 && D > 0 && HW > 0 && depth_mode >= 0 && depth_mode <= 2, DS_ERR_SHAPE,
              "ds_volume_to_slices: bad arguments B=%d C=%d D=%d mode=%d", B, C, D, depth_mode);
   DS_REQUIRE(depth_mode != 2 || D % 2 == 0, DS_ERR_SHAPE, "ds_volume_to_slices: upsampling needs an even output depth");
-  DS_REQUIRE((long long)B * (D + 2) < 65536 && C < 65536, DS_ERR_SHAPE, "ds_volume_to_slices: B*(D+2) and C must stay below 65536");
+  DS_REQUIRE(pad >= 0 && pad <= 3 && (!circular || pad <= D), DS_ERR_SHAPE, "ds_volume_to_slices: pad=%d (0..3, at most D when circular)", pad);
+  DS_REQUIRE((long long)B * (D + 2 * pad) < 65536 && C < 65536, DS_ERR_SHAPE, "ds_volume_to_slices: B*(D+2*pad) and C must stay below 65536");
   if (B == 0) return DS_OK;
   const int Din = depth_mode == 1 ? 2 * D : (depth_mode == 2 ? D / 2 : D);
   const size_t gx = (HW + 1023) / 1024;
-  hipLaunchKernelGGL(k_to_slices, dim3((unsigned)(gx > 64 ? 64 : gx), (unsigned)(B * (D + 2)), (unsigned)C), dim3(256), 0,
-                     ds::as_stream(stream), slices, x, C, D, Din, HW, depth_mode, circular);
+  hipLaunchKernelGGL(k_to_slices, dim3((unsigned)(gx > 64 ? 64 : gx), (unsigned)(B * (D + 2 * pad)), (unsigned)C), dim3(256), 0,
+                     ds::as_stream(stream), slices, x, C, D, Din, HW, depth_mode, circular, pad);
   DS_CHECK_LAUNCH("ds_volume_to_slices");
   return DS_OK;
 }
 
 extern "C" int ds_slices_to_volume(float* y, const float* slices, const float* res1, const float* res2, int B, int C, int D,
-                                   size_t HW, void* stream) {
+                                   size_t HW, int pad, void* stream) {
   DS_REQUIRE(y && slices, DS_ERR_NULL, "ds_slices_to_volume: NULL pointer");
-  DS_REQUIRE(B >= 0 && C > 0 && D > 0 && HW > 0, DS_ERR_SHAPE, "ds_slices_to_volume: bad shape");
+  DS_REQUIRE(B >= 0 && C > 0 && D > 0 && HW > 0 && pad >= 0 && pad <= 3, DS_ERR_SHAPE, "ds_slices_to_volume: bad shape");
   DS_REQUIRE((long long)B * D < 65536 && C < 65536, DS_ERR_SHAPE, "ds_slices_to_volume: B*D and C must stay below 65536");
   if (B == 0) return DS_OK;
   const size_t gx = (HW + 1023) / 1024;
   hipLaunchKernelGGL(k_from_slices, dim3((unsigned)(gx > 64 ? 64 : gx), (unsigned)(B * D), (unsigned)C), dim3(256), 0,
-                     ds::as_stream(stream), y, slices, res1, res2, C, D, HW);
+                     ds::as_stream(stream), y, slices, res1, res2, C, D, HW, pad);
   DS_CHECK_LAUNCH("ds_slices_to_volume");
   return DS_OK;
 }
@@ -487,14 +489,14 @@ extern "C" int ds_wrap_pad_slices(float* slices, int B, int C, int D, size_t HW,
 }
 
 extern "C" int ds_slices_to_volume_stats(float* y, const float* slices, const float* res1, const float* res2, float* stats,
-                                         int B, int C, int D, size_t HW, void* stream) {
+                                         int B, int C, int D, size_t HW, int pad, void* stream) {
   DS_REQUIRE(y && slices && stats, DS_ERR_NULL, "ds_slices_to_volume_stats: NULL pointer");
-  DS_REQUIRE(B >= 0 && C > 0 && D > 0 && HW > 0, DS_ERR_SHAPE, "ds_slices_to_volume_stats: bad shape");
+  DS_REQUIRE(B >= 0 && C > 0 && D > 0 && HW > 0 && pad >= 0 && pad <= 3, DS_ERR_SHAPE, "ds_slices_to_volume_stats: bad shape");
   DS_REQUIRE((long long)B * D < 65536 && C < 65536, DS_ERR_SHAPE, "ds_slices_to_volume_stats: B*D and C must stay below 65536");
   DS_REQUIRE((reinterpret_cast<uintptr_t>(stats) & 15u) == 0, DS_ERR_SHAPE, "ds_slices_to_volume_stats: stats must be 16-byte aligned");
   if (B == 0) return DS_OK;
   hipLaunchKernelGGL(k_from_slices_stats, dim3(slice_copy_blocks(HW), (unsigned)(B * D), (unsigned)C), dim3(256), 0,
-                     ds::as_stream(stream), y, slices, res1, res2, stats, C, D, HW);
+                     ds::as_stream(stream), y, slices, res1, res2, stats, C, D, HW, pad);
   DS_CHECK_LAUNCH("ds_slices_to_volume_stats");
   return DS_OK;
 }

@@ -1113,7 +1113,11 @@ class PUNetG(torch.nn.Module):
             packs = pk.get((id(m), "3d"))
             # fp16x3 (default): three 2-D MFMA launches per convolution -- 0.30 vs 1.33 ms at 64 -> 64 channels, 8 x 32^3;
             # the thin input / output layers stay on the direct kernel (0.08 vs 0.14 ms for 1 -> 64)
-            if packs is not None and m.out_channels > 4 and m.in_channels > 4:
+            k = m.weight.shape[-1]
+            if packs is None and k != 3:
+                raise NotImplementedError(f"{k}x{k}x{k} kernels on volumes are implemented on the fp16x3 convolution only "
+                                          f"(conv_precision={self.conv_precision!r})")
+            if packs is not None and ((m.out_channels > 4 and m.in_channels > 4) or k != 3):
                 st = stats_buf(shape) if (fold and want_stats) else None
                 return ops.conv3d_mfma(h, packs, bias=m.bias, circular=self.circular, load_mode=load_mode, out=dst, ws=ws,
                                        out_stats=st, in_amax=ops.NORMALISED if normalised else None, **kw), st

@@ -59,8 +59,6 @@ class PUNetGConfig(object):
             (self.convolution_type in ("default", "circular", "mp"), "convolution_type 'default', 'circular' or 'mp'"),
             (all(k in (1, 3, 5, 7) for k in (self.kernel_size, self.in_out_kernel_size)) and self.transition_kernel_size in (3, 5, 7),
              "kernel_size / in_out_kernel_size 1, 3, 5 or 7, transition_kernel_size 3, 5 or 7"),
-            (all(k == 3 for k in (self.kernel_size, self.in_out_kernel_size, self.transition_kernel_size)) or self.dimension == 2,
-             "kernel sizes other than 3 only for 2-D fields"),
             (self.transition_scale_factor == 2, "transition_scale_factor=2"),
             (not self.in_embedding or not self.bias,
              "in_embedding only with bias=False (the reference's ConvolutionalFourierProjection raises with bias=True, "

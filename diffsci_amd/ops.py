@@ -384,10 +384,12 @@ def conv3d(x, w, bias=None, shift=None, res1=None, res2=None, load_mode=N.DS_LOA
 
 
 def pack_conv3d(w, upsampled=False):
-    """A 3x3x3 weight [Cout, Cin, 3, 3, 3] as three fp16x3-packed 3x3 weights, one per depth tap (see conv3d_mfma)."""
-    if w.dim() != 5 or tuple(w.shape[2:]) != (3, 3, 3):
-        raise ValueError("pack_conv3d: weight must be [Cout, Cin, 3, 3, 3]")
-    return [pack_conv(w[:, :, kz].contiguous(), "fp16x3", upsampled=upsampled) for kz in range(3)]
+    """A k x k x k weight [Cout, Cin, k, k, k] (k = 1, 3, 5, 7) as k fp16x3-packed k x k weights, one per depth tap (see
+    conv3d_mfma); the parity kernels of a nearest-x2 upsampled input (upsampled) exist for k = 3."""
+    k = w.shape[2] if w.dim() == 5 else 0
+    if w.dim() != 5 or tuple(w.shape[2:]) != (k, k, k) or k not in (1, 3, 5, 7):
+        raise ValueError("pack_conv3d: weight must be [Cout, Cin, k, k, k] with k in (1, 3, 5, 7)")
+    return [pack_conv(w[:, :, kz].contiguous(), "fp16x3", upsampled=upsampled and k == 3) for kz in range(k)]
 
 
 def volume_stat_tiles(D, HW):
@@ -395,51 +397,55 @@ def volume_stat_tiles(D, HW):
     return N.lib().ds_volume_stat_tiles(int(D), int(HW))
 
 
-def _slice_rows(shift, B, D, Cout, ws=None):
-    """Per-slice rows of a per-sample time shift for the 2-D batch of all slices but the outermost two -> (rows, buffer to give
-    back to ws or None).  With a pool the expansion lands in a pool buffer (a captured loop must not allocate)."""
+def _slice_rows(shift, B, D, Cout, ws=None, pad=1):
+    """Per-slice rows of a per-sample time shift for the 2-D batch of all slices but the outermost `pad` on each end -> (rows,
+    buffer to give back to ws or None).  With a pool the expansion lands in a pool buffer (a captured loop must not allocate)."""
     if shift is None:
         return None, None
     if shift.dim() != 2 or shift.shape[1] != Cout or shift.shape[0] not in (1, B):
         raise ValueError(f"shift must be [1 or B, Cout]; got {tuple(shift.shape)}")
     if shift.shape[0] == 1:
         return shift, None
-    ns = B * (D + 2)
+    DP = D + 2 * pad
+    ns = B * DP
     if ws is None:
-        return shift.repeat_interleave(D + 2, dim=0)[1:ns - 1].contiguous(), None
-    buf = ws.take((B, D + 2, Cout), shift.device)
-    buf.copy_(shift[:, None, :].expand(B, D + 2, Cout))
-    return buf.view(ns, Cout)[1:ns - 1], buf
+        return shift.repeat_interleave(DP, dim=0)[pad:ns - pad].contiguous(), None
+    buf = ws.take((B, DP, Cout), shift.device)
+    buf.copy_(shift[:, None, :].expand(B, DP, Cout))
+    return buf.view(ns, Cout)[pad:ns - pad], buf
 
 
 def _depth_taps(s_in, s_out, packs, bias, rows, load_mode, circular, prenorm=None, tile_stats=None, in_amax=None):
-    """The three depth-tap launches of a 3x3x3 convolution over slice-major volumes: the centre tap initialises the
-    accumulator (all slices of s_out but the outermost two), the others add to it; prenorm: per-SLICE table
-    [B*(D+2), ceil16(Cin), 4] (ds_slice_tables) for the fused norm + SiLU loader; tile_stats: filled by the last launch.
-    in_amax: per-SLICE max |s_in| [B*(D+2)] (every slice is a 2-D sample with its own exponent), NORMALISED, or None = computed
-    here."""
+    """The depth-tap launches of a k x k x k convolution over slice-major volumes (k = len(packs); three for 3x3x3): the centre
+    tap initialises the accumulator (all slices of s_out but the outermost k/2 on each end), the others add to it; prenorm:
+    per-SLICE table [B*(D+2), ceil16(Cin), 4] (ds_slice_tables) for the fused norm + SiLU loader; tile_stats: filled by the last
+    launch.  in_amax: per-SLICE max |s_in| [B*(D+2 pad)] (every slice is a 2-D sample with its own exponent), NORMALISED, or
+    None = computed here."""
     ns = s_in.shape[0]
-    acc = s_out[1:ns - 1]
+    P = len(packs) // 2
+    acc = s_out[P:ns - P]
     if prenorm is not None:
         in_amax = NORMALISED
     elif in_amax is None:
         in_amax = absmax_rows(s_in)
-    for n, dz in enumerate((0, -1, 1)):
-        conv(s_in[1 + dz:ns - 1 + dz], packs[dz + 1], bias=bias if n == 0 else None, shift=rows if n == 0 else None,
+    order = [0] + [d for q in range(1, P + 1) for d in (-q, q)]
+    for n, dz in enumerate(order):
+        conv(s_in[P + dz:ns - P + dz], packs[dz + P], bias=bias if n == 0 else None, shift=rows if n == 0 else None,
              res1=None if n == 0 else acc, load_mode=load_mode, circular=circular, out=acc,
-             prenorm=None if prenorm is None else prenorm[1 + dz:ns - 1 + dz], tile_stats=tile_stats if n == 2 else None,
-             in_amax=in_amax if in_amax is NORMALISED else in_amax[1 + dz:ns - 1 + dz])
+             prenorm=None if prenorm is None else prenorm[P + dz:ns - P + dz], tile_stats=tile_stats if n == len(order) - 1 else None,
+             in_amax=in_amax if in_amax is NORMALISED else in_amax[P + dz:ns - P + dz])
     return acc
 
 
-def _from_slices(out, s_out, res1, res2, B, C, D, HW, out_stats=None):
+def _from_slices(out, s_out, res1, res2, B, C, D, HW, out_stats=None, pad=1):
     if out_stats is None:
-        N.check(N.lib().ds_slices_to_volume(_p(out), _p(s_out), _p(res1), _p(res2), B, C, D, HW, _stream()), "ds_slices_to_volume")
+        N.check(N.lib().ds_slices_to_volume(_p(out), _p(s_out), _p(res1), _p(res2), B, C, D, HW, int(pad), _stream()),
+                "ds_slices_to_volume")
     else:
         if tuple(out_stats.shape) != (B, C, volume_stat_tiles(D, HW), 4):
             raise ValueError(f"out_stats must be {(B, C, volume_stat_tiles(D, HW), 4)}")
-        N.check(N.lib().ds_slices_to_volume_stats(_p(out), _p(s_out), _p(res1), _p(res2), _p(out_stats), B, C, D, HW, _stream()),
-                "ds_slices_to_volume_stats")
+        N.check(N.lib().ds_slices_to_volume_stats(_p(out), _p(s_out), _p(res1), _p(res2), _p(out_stats), B, C, D, HW, int(pad),
+                                                  _stream()), "ds_slices_to_volume_stats")
     return out
 
 
@@ -492,8 +498,9 @@ def resblock3d_fused(h, tab1, packs1, bias1, shift, packs2, bias2, w2, b2, kind2
 
 def conv3d_mfma(x, packs, bias=None, shift=None, res1=None, res2=None, load_mode=N.DS_LOAD_PLAIN, circular=False, out=None,
                 ws=None, out_stats=None, in_amax=None):
-    """3x3x3 'same' convolution of a volume on the matrix cores: three 2-D fp16x3 convolutions (one per depth tap) over
-    a slice-major, depth-padded copy of the volume (ds_volume_to_slices / ds_slices_to_volume).  Same arguments and
+    """k x k x k 'same' convolution of a volume on the matrix cores (k = len(packs): 1, 3, 5, 7): k 2-D fp16x3 convolutions
+    (one per depth tap; each a sum of shifted 3 x 3 blocks when k > 3) over a slice-major copy of the volume padded by k/2
+    slices in depth (ds_volume_to_slices / ds_slices_to_volume).  Same arguments and
     fusions as conv3d; packs = pack_conv3d(weight).  ws: an optional buffer pool (take(shape, device) / give(tensor)) for
     the two slice copies, so that a captured loop allocates nothing.  out_stats: [B, Cout, volume_stat_tiles(D, H*W), 4],
     filled with the result's shifted partial sums (the consumer's norm table, ds_inorm_table with count D*H*W).
@@ -517,15 +524,18 @@ def conv3d_mfma(x, packs, bias=None, shift=None, res1=None, res2=None, load_mode
     for r in (res1, res2):
         if r is not None and tuple(r.shape) != (B, Cout, D, H, W):
             raise ValueError("residual shape mismatch")
-    ns = B * (D + 2)
+    P = len(packs) // 2
+    if circular and P > D:
+        raise ValueError(f"periodic padding of {P} slices needs a depth of at least {P}; got {D}")
+    ns = B * (D + 2 * P)
 
     def take(shape):
         return torch.empty(shape, dtype=torch.float32, device=x.device) if ws is None else ws.take(shape, x.device)
     s_in = take((ns, Cin, Hi, Wi))
-    N.check(N.lib().ds_volume_to_slices(_p(s_in), _p(x.contiguous()), B, Cin, D, Hi * Wi, depth_mode, 1 if circular else 0,
+    N.check(N.lib().ds_volume_to_slices(_p(s_in), _p(x.contiguous()), B, Cin, D, Hi * Wi, depth_mode, 1 if circular else 0, P,
                                         _stream()), "ds_volume_to_slices")
     s_out = take((ns, Cout, H, W))
-    rows, rows_buf = _slice_rows(shift, B, D, Cout, ws)
+    rows, rows_buf = _slice_rows(shift, B, D, Cout, ws, pad=P)
     am_buf = None
     if in_amax is not NORMALISED:
         if ws is None:
@@ -534,7 +544,7 @@ def conv3d_mfma(x, packs, bias=None, shift=None, res1=None, res2=None, load_mode
             am_buf = ws.take((ns,), x.device)
             in_amax = absmax_rows(s_in, out=amax_zero(am_buf.view(torch.int32)))
     _depth_taps(s_in, s_out, packs, bias, rows, load_mode, circular, in_amax=in_amax)
-    _from_slices(out, s_out, res1, res2, B, Cout, D, H * W, out_stats)
+    _from_slices(out, s_out, res1, res2, B, Cout, D, H * W, out_stats, pad=P)
     if rows_buf is not None:
         ws.give(rows_buf)
     if am_buf is not None:

@@ -349,19 +349,19 @@ int ds_conv3d_direct(float* out, const float* in, const float* w, const float* b
                      int shift_stride, const float* res1, const float* res2, int B, int Cin, int Cout, int D, int H,
                      int W, int load_mode, void* stream);
 
-/* Volumes on the matrix cores: out[b,:,z] = sum_kz conv2d(in[b,:,z+kz-1], w[:,:,kz]) -- three launches of the 2-D
- * fp16x3 kernels per 3x3x3 convolution -- on a slice-major, depth-padded copy S[b][zp][c][y][x] (zp = z + 1 of D + 2
- * slices; pads zero, or the wrapped neighbours when circular), in which a depth slice is a 2-D sample and a depth tap a
- * pointer offset of one slice (C*HW floats).
+/* Volumes on the matrix cores: out[b,:,z] = sum_kz conv2d(in[b,:,z+kz-k/2], w[:,:,kz]) -- k launches of the 2-D
+ * fp16x3 kernels per k x k x k convolution (three for 3x3x3) -- on a slice-major, depth-padded copy S[b][zp][c][y][x]
+ * (zp = z + pad of D + 2 pad slices, pad = k/2; pads zero, or the wrapped neighbours when circular), in which a depth slice is
+ * a 2-D sample and a depth tap a pointer offset of one slice (C*HW floats).
  *   ds_volume_to_slices: x [B,C,Din,HW] -> S [B,D+2,C,HW]; depth_mode 0 copy (Din = D), 1 max of depth pairs (Din = 2D:
  *     the depth half of MaxPool3d(2); the 2-D loader's MAXPOOL2 does H, W), 2 nearest x2 in depth (Din = D/2).
  *   ds_slices_to_volume: y [B,C,D,HW] = S interior (+ res1 + res2, volume layout).
  * The caller runs ds_conv2d_h3 on batch B*(D+2) - 2, in = S_in + (1 + dz)*Cin*HW_in, out = S_out + Cout*HW,
  * accumulating the second and third tap through res1 = out. */
 int ds_volume_to_slices(float* slices, const float* x, int B, int C, int D, size_t HW, int depth_mode, int circular,
-                        void* stream);
+                        int pad /* 0..3 */, void* stream);
 int ds_slices_to_volume(float* y, const float* slices, const float* res1, const float* res2, int B, int C, int D,
-                        size_t HW, void* stream);
+                        size_t HW, int pad, void* stream);
 
 /* The same copies with the residual block's normalisation folded in (commonlayers.py:824-833 on volumes):
  *   ds_volume_to_slices_act: S = SiLU((x - M) A + C) with (M, A, C) = table[b][c] (ds_inorm_table rows, [B, ceil16(C), 4]);
@@ -381,7 +381,7 @@ int ds_volume_to_slices_act(float* slices, const float* x, const float* table, i
                             void* stream);
 int ds_wrap_pad_slices(float* slices, int B, int C, int D, size_t HW, void* stream);
 int ds_slices_to_volume_stats(float* y, const float* slices, const float* res1, const float* res2, float* stats, int B, int C,
-                              int D, size_t HW, void* stream);
+                              int D, size_t HW, int pad, void* stream);
 int ds_slice_tables(float* table, const float* tile_stats, const float* w, const float* b, int B, int C, int D, int ntiles,
                     long long count, float eps, int kind, int circular, void* stream);
 

@@ -853,10 +853,26 @@ class TinyCondNet(torch.nn.Module):
         return self.gain * x + (f * wts).sum(dim=1) + 0.1 * t.view(-1, 1, 1, 1)
 
 
-def volumes():
+SMALL_VOLUME_NET = dict(channel_expansion=[2], number_resnet_downward_block=1, number_resnet_upward_block=1,
+                        number_resnet_attn_block=1, number_resnet_before_attn_block=1, number_resnet_after_attn_block=1)
+VOLUME_CASES = (("3d", {}), ("3d_circular", dict(convolution_type="circular")),
+                # round 3: kernel sizes other than 3 on volumes (1^3 in / out layers, 5^3 blocks and transitions; 5^3 everywhere, periodic)
+                # -- on a two-level network with one block per stage: a 5^3 kernel has 125 taps, the fixture is mostly weights
+                ("3d_k5", dict(kernel_size=5, in_out_kernel_size=1, transition_kernel_size=5, **SMALL_VOLUME_NET)),
+                ("3d_k5_circular", dict(kernel_size=5, in_out_kernel_size=5, transition_kernel_size=5, convolution_type="circular",
+                                        **SMALL_VOLUME_NET)))
+
+
+def volumes_k5():
+    volumes(only=("3d_k5", "3d_k5_circular"))
+
+
+def volumes(only=None):
     """PUNetG with dimension = 3 (Conv3d / MaxPool3d / Upsample / ThreeDimensionalAttention), default
     and circular convolutions, 16^3 volumes."""
-    for i, (tag, over) in enumerate((("3d", {}), ("3d_circular", dict(convolution_type="circular")))):
+    for i, (tag, over) in enumerate(VOLUME_CASES):
+        if only is not None and tag not in only:
+            continue
         torch.manual_seed(150 + i)
         cfg = M.nets.PUNetGConfig(model_channels=8, dimension=3, **over)
         net = M.nets.PUNetG(cfg).eval()
@@ -874,7 +890,8 @@ def volumes():
             h = net.convin(x)
             arrs["convin"] = h
             arrs["down0"] = net.downsamplers[0](h)
-            arrs["up1"] = net.upsamplers[1](arrs["down0"])
+            if len(net.upsamplers) > 1:
+                arrs["up1"] = net.upsamplers[1](arrs["down0"])
             arrs["resblock"] = net.downward_blocks[0][0](h, net.time_projection(t))
         net64 = M.nets.PUNetG(cfg).double().eval()
         net64.load_state_dict({k: v.double() for k, v in sd.items()})

@@ -331,7 +331,7 @@ def test_volume_norm_folding(M, dev):
     w1, b1 = torch.randn(C, device=dev), torch.randn(C, device=dev)
     # the copy's statistics -> table -> activated slices
     s_plain = torch.empty(B * (D + 2), C, H, W, device=dev)
-    ops.N.check(ops.N.lib().ds_volume_to_slices(ops._p(s_plain), ops._p(h), B, C, D, H * W, 0, 0, ops._stream()), "to_slices")
+    ops.N.check(ops.N.lib().ds_volume_to_slices(ops._p(s_plain), ops._p(h), B, C, D, H * W, 0, 0, 1, ops._stream()), "to_slices")
     back = torch.empty_like(h)
     st = torch.empty(B, C, ops.volume_stat_tiles(D, H * W), 4, device=dev)
     r1 = torch.randn_like(h)

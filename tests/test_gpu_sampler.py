@@ -842,6 +842,49 @@ def test_punetg_volumes(M, dev, grids, tag):
             net(v["x"][:, :, 0].to(dev), v["t"].to(dev))
 
 
+SMALL_VOLUME_NET = dict(channel_expansion=[2], number_resnet_downward_block=1, number_resnet_upward_block=1,
+                        number_resnet_attn_block=1, number_resnet_before_attn_block=1, number_resnet_after_attn_block=1)
+VOLUME_K5 = {"3d_k5": dict(kernel_size=5, in_out_kernel_size=1, transition_kernel_size=5),
+             "3d_k5_circular": dict(kernel_size=5, in_out_kernel_size=5, transition_kernel_size=5, convolution_type="circular")}
+
+
+@pytest.mark.parametrize("tag", sorted(VOLUME_K5))
+def test_punetg_volumes_with_other_kernel_sizes(M, dev, tag):
+    """Round 3 (SURVEY 8f-4 residue; punetg_config.py:19-25, commonlayers.py:973-1034): kernel sizes other than 3 on volumes --
+    a k^3 convolution is k depth-tap launches over a slice copy padded by k/2 slices, each tap a k x k 2-D convolution (shifted
+    3 x 3 blocks when k > 3); 1^3 input / output layers, 5^3 blocks and transitions, zero and periodic padding -- against the
+    reference's goldens, eager and captured."""
+    from diffsci_amd import ops
+    v, sd = load("punetg8_" + tag)
+    circ = tag.endswith("circular")
+    net = M.PUNetG(M.PUNetGConfig(model_channels=8, dimension=3, **VOLUME_K5[tag], **SMALL_VOLUME_NET))
+    r = net.load_state_dict(sd, strict=True)
+    assert not r.missing_keys and not r.unexpected_keys
+    net = net.to(dev).eval()
+    # one convolution against torch in fp64 on the same tensors: 5^3, 16 -> 16 channels, with the time shift and a residual
+    g = torch.Generator().manual_seed(31)
+    x5 = torch.randn(2, 16, 6, 12, 20, generator=g).to(dev)
+    w5 = (torch.randn(16, 16, 5, 5, 5, generator=g) / (125 * 16) ** 0.5).to(dev)
+    b5, sh5, r5 = torch.randn(16, generator=g).to(dev), torch.randn(2, 16, generator=g).to(dev), torch.randn(2, 16, 6, 12, 20, generator=g).to(dev)
+    got = ops.conv3d_mfma(x5, ops.pack_conv3d(w5), bias=b5, shift=sh5, res1=r5, circular=circ)
+    xp = torch.nn.functional.pad(x5.double(), (2,) * 6, mode="circular" if circ else "constant")
+    want = torch.nn.functional.conv3d(xp, w5.double(), b5.double()) + sh5.double()[:, :, None, None, None] + r5.double()
+    assert rel_l2(got.double().cpu(), want.cpu()) < 2e-6
+    out = net(v["x"].to(dev), v["t"].to(dev)).cpu()
+    assert out.shape == (2, 1, 16, 16, 16) and rel_l2(out, v["out_f32"]) < REL
+    assert rel_l2(out, v["out_f64"]) < max(4 * rel_l2(v["out_f32"], v["out_f64"]), 2e-6)
+    module = M.KarrasModule(net, M.KarrasModuleConfig.from_edm())
+    wn = torch.randn(2, 1, 16, 16, 16, generator=g).to(dev)
+    runs = []
+    for use_graph in (False, True, True):
+        module.use_graph = use_graph
+        runs.append(module.propagate_white_noise(wn, nsteps=3))
+    assert torch.equal(runs[0], runs[1]) and torch.equal(runs[1], runs[2]) and len(module._plans.plans) == 1
+    net.conv_precision = "bf16x6"                                    # the other precisions keep 3^3 only, and say so
+    with pytest.raises(NotImplementedError):
+        net(v["x"].to(dev), v["t"].to(dev))
+
+
 @pytest.mark.parametrize("shape", [(2, 1, 20, 28), (1, 1, 36, 40), (3, 1, 64, 16)])
 def test_odd_field_sizes_against_oracle(M, dev, shape):
     """Ragged tiles everywhere: widths that are not multiples of 32, 16 or 4 (element-wise epilogue and

@@ -604,6 +604,27 @@ def test_punetg_volumes(tag):
             assert_exact_or_rel(hist, v["hist_heun_N4_f32"], "3-D trajectory", 2e-6)
 
 
+SMALL_VOLUME_NET = dict(channel_expansion=[2], number_resnet_downward_block=1, number_resnet_upward_block=1,
+                        number_resnet_attn_block=1, number_resnet_before_attn_block=1, number_resnet_after_attn_block=1)
+VOLUME_K5 = {"3d_k5": dict(kernel_size=5, in_out_kernel_size=1, transition_kernel_size=5),
+             "3d_k5_circular": dict(kernel_size=5, in_out_kernel_size=5, transition_kernel_size=5, convolution_type="circular")}
+
+
+@pytest.mark.parametrize("tag", sorted(VOLUME_K5))
+def test_punetg_volumes_with_other_kernel_sizes(tag):
+    """Round 3 (SURVEY 8f-4 residue): 1^3 and 5^3 kernels on volumes (punetg_config.py:19-25; Conv3d(padding='same') /
+    CircularConv3d with padding k//2, commonlayers.py:973-1034), on a two-level network with one block per stage."""
+    v, sd = load("punetg8_" + tag)
+    circ = tag.endswith("circular")
+    cfg = punetg_ref.default_config(model_channels=8, **VOLUME_K5[tag], **SMALL_VOLUME_NET)
+    with torch.inference_mode():
+        assert_exact_or_ulp(punetg_ref.conv3x3(sd, "convin", v["x"], circ), v["convin"], "k^3 convin")
+        te = punetg_ref.fourier_features(v["t"], sd["time_projection.W"])
+        r = punetg_ref.resnet_block(sd, "downward_blocks.0.0.", v["convin"], te, circ)
+        assert_exact_or_rel(r, v["resblock"], "5^3 resblock", 1e-6)
+        assert_exact_or_rel(punetg_ref.punetg_forward(sd, cfg, v["x"], v["t"]), v["out_f32"], "k^3 forward", 2e-6)
+
+
 def test_adm_circular_convolutions():
     from oracle import adm_ref
     v, sd = load("adm8_circular")
