@@ -749,9 +749,9 @@ int ds_conv2d_h3(float* out, const float* in, const void* w_packed, int wshift, 
   const int ox = (int)((load_mode >> 12) & 15) - (((load_mode >> 12) & 8) ? 16 : 0);
   load_mode &= ~(DS_PAD_CIRCULAR | DS_RES1_UPSAMPLED | 0xff00);
   // periodic padding with a tap offset (k x k kernels as shifted 3x3 blocks): the loader wraps once per edge, which covers a window
-  // that reaches |offset| + 1 pixels outside
-  DS_REQUIRE(!circular || (H > (oy < 0 ? -oy : oy) + 1 && W > (ox < 0 ? -ox : ox) + 1), DS_ERR_SHAPE,
-             "ds_conv2d_h3: periodic padding with tap offset (%d, %d) needs a field larger than the window's reach (%d x %d)", oy, ox, H, W);
+  // that reaches |offset| + 1 pixels outside on a plane at least that large (torch's own limit for F.pad(mode="circular"))
+  DS_REQUIRE(!circular || (H >= (oy < 0 ? -oy : oy) + 1 && W >= (ox < 0 ? -ox : ox) + 1), DS_ERR_SHAPE,
+             "ds_conv2d_h3: periodic padding with tap offset (%d, %d) needs a field at least as large as the window's reach (%d x %d)", oy, ox, H, W);
   DS_REQUIRE(!res1_up || (res1 && H % 2 == 0 && W % 2 == 0), DS_ERR_SHAPE, "ds_conv2d_h3: RES1_UPSAMPLED needs res1 and even H, W");
   DS_REQUIRE(load_mode >= 0 && load_mode <= 2, DS_ERR_UNSUPPORTED, "ds_conv2d_h3: load_mode %d", load_mode);
   DS_REQUIRE(load_mode != DS_LOAD_UPSAMPLE2 || (H % 2 == 0 && W % 2 == 0), DS_ERR_SHAPE,

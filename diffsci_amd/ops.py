@@ -680,18 +680,21 @@ def pack_conv(w, precision="bf16x6", upsampled=False):
     if k != k2 or k % 2 == 0:
         raise NotImplementedError(f"conv kernel {k}x{k2}: square kernels of odd size are implemented")
     if k > 3:
-        # k x k = sum of ceil(k/3)^2 shifted 3x3 convolutions over zero-padded blocks of the taps (DS_TAP_OFFSET):
-        # block (gy, gx) holds taps [3gy, 3gy+3) x [3gx, 3gx+3); its centre tap 3g+1 sits at offset 3g + 1 - k//2
+        # k x k = sum of ceil(k/3)^2 shifted 3x3 convolutions over blocks of the taps (DS_TAP_OFFSET).  Block g starts at tap
+        # min(3g, k - 3) -- the last block is pulled back inside the kernel, its taps already served by the previous block zeroed --
+        # so no block reaches further out than the kernel itself does (k // 2 pixels: what periodic padding can wrap on a plane
+        # that small); its centre tap start + 1 sits at offset start + 1 - k // 2
         if precision != "fp16x3":
             raise NotImplementedError(f"{k}x{k} kernels are implemented on the fp16x3 convolution only (conv_precision={precision!r})")
         ng = (k + 2) // 3
-        wp = torch.zeros((Cout, Cin, 3 * ng, 3 * ng), dtype=torch.float32, device=w.device)
-        wp[:, :, :k, :k] = w
+        starts = [min(3 * g, k - 3) for g in range(ng)]
         subs = []
-        for gy in range(ng):
-            for gx in range(ng):
-                blk = wp[:, :, 3 * gy:3 * gy + 3, 3 * gx:3 * gx + 3].contiguous()
-                subs.append((3 * gy + 1 - k // 2, 3 * gx + 1 - k // 2, pack_conv(blk, "fp16x3")))
+        for gy, sy in enumerate(starts):
+            for gx, sx in enumerate(starts):
+                blk = w[:, :, sy:sy + 3, sx:sx + 3].clone()
+                blk[:, :, :3 * gy - sy, :] = 0
+                blk[:, :, :, :3 * gx - sx] = 0
+                subs.append((sy + 1 - k // 2, sx + 1 - k // 2, pack_conv(blk.contiguous(), "fp16x3")))
         return PackedConv(None, Cout, Cin, k, "fp16x3", subs=subs)
     if precision == "bf16x6" and k == 3:
         nbytes = N.lib().ds_conv2d_x6_packed_bytes(Cout, Cin)

@@ -45,6 +45,13 @@ def main():
             H, W = min(H, 2 * unit), min(W, 3 * unit)
             x = torch.randn(B, cin, D, H, W)
         t = torch.rand(B) * 3 - 1.5
+        # round 3: the whole fp32 range of input magnitudes (per-sample activation exponents), one case in three
+        mag = 1.0
+        if ri(0, 2) == 0:
+            mag = 10.0 ** float(torch.empty(1).uniform_(-8.0, 5.0, generator=g))
+            x = x * mag
+            if B > 1 and ri(0, 1):
+                x[0] = x[0] * 1e-3                                   # and samples of different magnitude in one batch
         if family == "punetg":
             over = dict(model_channels=pick([4, 8, 16, 32]), channel_expansion=exp, input_channels=cin, output_channels=ri(1, 5),
                         number_resnet_downward_block=ri(1, 2), number_resnet_upward_block=ri(1, 2),
@@ -56,6 +63,12 @@ def main():
                         second_resblock_norm=pick(["GroupRMS", "GroupRMS", "GroupLN", "none"]),
                         affine_norm=bool(ri(0, 3)), bias=bool(ri(0, 3)), attn_type=pick(["default", "default", "cosine"]),
                         dimension=3 if vol else 2)
+            # kernel sizes other than 3 (a sum of shifted 3 x 3 blocks; on volumes k depth taps), one case in three; periodic
+            # padding needs every plane at least as large as the halo
+            small = min(x.shape[2:]) // unit
+            if ri(0, 2) == 0 and over["convolution_type"] != "mp" and (over["convolution_type"] != "circular" or small >= 3):
+                over.update(kernel_size=pick([1, 5, 5, 7] if not vol else [1, 5]), in_out_kernel_size=pick([1, 3, 5]),
+                            transition_kernel_size=pick([3, 5, 7] if not vol else [3, 5]))
             cfg = punetg_ref.default_config(**over)
             net = M.PUNetG(M.PUNetGConfig(**over))
             with torch.no_grad():
@@ -98,11 +111,11 @@ def main():
             errs.append(max(rel(got, want), rel(got, want64)))
         e = max(errs)
         worst = max(worst, e)
-        tag = f"{family}{'3d' if vol else ''} exp={exp} B={B} cin={cin} {'x'.join(map(str, x.shape[2:]))} " + " ".join(f"{k}={v}" for k, v in over.items() if k.startswith("number") or k in ("model_channels", "skip_integration_type", "convolution_type", "first_resblock_norm", "second_resblock_norm", "affine_norm", "bias", "decoder_type", "attn_type"))
+        tag = f"{family}{'3d' if vol else ''} exp={exp} B={B} cin={cin} {'x'.join(map(str, x.shape[2:]))} " + " ".join(f"{k}={v}" for k, v in over.items() if k.startswith("number") or k in ("model_channels", "skip_integration_type", "convolution_type", "first_resblock_norm", "second_resblock_norm", "affine_norm", "bias", "decoder_type", "attn_type", "kernel_size", "in_out_kernel_size", "transition_kernel_size")) + f" mag={mag:.1e}"
         if e > tol:
             print("FAIL", tag, errs, tol)
             sys.exit(1)
-        print(f"it {it}: ok {e:.2e}  {tag}", flush=True)
+        print(f"it {it}: ok {e:.2e} (oracle fp32 vs fp64 {rel(want, want64):.1e})  {tag}", flush=True)
     print(f"all {a.n} networks passed; worst relative error {worst:.2e}")
 
 
