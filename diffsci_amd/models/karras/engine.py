@@ -56,6 +56,22 @@ def condition_signature(y):
     return repr(type(y))
 
 
+def clone_condition(y):
+    """Plan-owned copy of a condition's tensors (same structure)."""
+    if isinstance(y, dict):
+        return {k: clone_condition(v) for k, v in y.items()}
+    return y.clone() if torch.is_tensor(y) else y
+
+
+def copy_condition(dst, src):
+    """Write src's values into dst's tensors (the structure is part of the plan key)."""
+    if isinstance(dst, dict):
+        for k in dst:
+            copy_condition(dst[k], src[k])
+    elif torch.is_tensor(dst):
+        dst.copy_(src)
+
+
 MODEL_SWITCHES = ("conv_precision", "fuse_norm", "fuse_max_cot", "direct_out", "upsample_parity", "norm_images", "tile_stats_norms",
                   "exact_input_layer", "capturable")
 
@@ -122,6 +138,9 @@ class ModuleSource:
                             and not hasattr(self.model, "_split_condition") and not self.field)
         # ... and the step kernels write the network input into both halves of the [2B, ...] buffer themselves (ds_eval_coef.xin_copies)
         self.xin_copies = 2 if self.batched_cfg else 1
+        # an evaluated-as-given network inside a captured run (KarrasModule.capture_eager): the condition the captured calls read
+        # is a plan-owned copy that refresh() rewrites
+        self.static_condition = False
         # the range guard's result check rides on the run's last step kernel (nets/precision.py)
         self.nonfinite_word = precision.result_word(self.model, like.device) if like.is_cuda else None
         self._out = {}
@@ -167,6 +186,8 @@ class ModuleSource:
                 self._fill_conditional_half()
         else:
             self.cnoise = cn[:, None].expand(len(evals), self.batch).contiguous().to(dev)
+            if self.static_condition:
+                self.y = clone_condition(self.y)
 
     def _fill_conditional_half(self):
         B = self.batch
@@ -177,6 +198,9 @@ class ModuleSource:
         """A new condition of the same structure for an existing (possibly captured) run: recompute what depends on
         y INTO the buffers the launch sequence already reads.  The unconditional tables depend only on the step
         table and the weights, both part of the plan key."""
+        if self.static_condition and not self.planned:
+            copy_condition(self.y, y)
+            return
         self.y = y
         if not (self.planned and self.conditional):
             return
@@ -389,6 +413,19 @@ class Loop:
         return self.history if self.record_history else self._final
 
 
+class _TorchGraph:
+    """loop.launch() captured by torch (see PlanCache.run)."""
+
+    def __init__(self, loop, stream):
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, stream=stream):
+            loop.launch()
+        self.nodes = -1
+
+    def launch(self):
+        self.graph.replay()
+
+
 class PlanCache:
     """Captured runs (static buffers + hipGraph), keyed by everything a capture bakes in; shared by KarrasModule and
     SIModule.  hipGraph capture needs a non-default stream: planned runs live on a side stream that is ordered after
@@ -402,7 +439,10 @@ class PlanCache:
     def clear(self):
         self.plans = {}
 
-    def run(self, key, make_loop, x, y=None, scale=None, eps=None):
+    def run(self, key, make_loop, x, y=None, scale=None, eps=None, torch_graph=False):
+        """torch_graph: capture with torch.cuda.CUDAGraph instead of ops.Graph -- torch's allocator then serves allocations made
+        inside the captured region from a pool the graph owns, which is what a run through user torch modules (extra_residual, an
+        evaluated-as-given network) needs; our own capture refuses allocations instead (ops.Graph)."""
         if self.stream is None or self.stream.device != x.device:
             self.stream = torch.cuda.Stream(device=x.device)
         caller = torch.cuda.current_stream(x.device)
@@ -418,8 +458,11 @@ class PlanCache:
                 # buffer shape, the second the chained form of the first evaluation
                 loop.launch(max_rows=2)
                 self.stream.synchronize()
-                with ops.Graph() as g:
-                    loop.launch()
+                if torch_graph:
+                    g = _TorchGraph(loop, self.stream)
+                else:
+                    with ops.Graph() as g:
+                        loop.launch()
                 plan = (loop, g)
                 if len(self.plans) >= self.capacity:
                     self.plans.pop(next(iter(self.plans)))

@@ -140,6 +140,10 @@ class KarrasModule(torch.nn.Module, LatentSpaceAutoregressive):
         self.edm_batch_norm = (edmbatchnorm.DimensionAgnosticBatchNorm(sigma=config.extra_args.get("sigma_data", 0.5))
                                if config.has_edm_batch_norm else None)
         self.use_graph = True          # capture the loop as a hipGraph for HIP-native networks
+        # Opt-in: also capture runs whose network is evaluated as given (an `extra_residual` user module, a torch network of the
+        # user's) with torch.cuda.CUDAGraph.  The user's modules must then be capture-safe (no host reads, no data-dependent
+        # control flow): torch.cuda.graph's contract.  Off: such runs are launched step by step, as the reference does.
+        self.capture_eager = False
         # (first element, total elements) of this process' rows inside a batch sampled by several ranks: set by
         # parallel.sample_sharded around a run so that the in-kernel noise of the stochastic integrators is the unsharded run's
         self.noise_shard = None
@@ -360,12 +364,13 @@ class KarrasModule(torch.nn.Module, LatentSpaceAutoregressive):
             def make_loop():
                 return Loop(table, src, x, record_history, injected_noise=injected, noise_shard=self.noise_shard)
 
-            if src.planned and self.use_graph:
-                key = (tuple(x.shape), str(x.device), nsteps, i0, i1, record_history, table.kind, injected,
+            if self.use_graph and x.is_cuda and (src.planned or self.capture_eager):
+                key = (src.planned, tuple(x.shape), str(x.device), nsteps, i0, i1, record_history, table.kind, injected,
                        (integ.s_schurn, integ.s_tmin, integ.s_tmax, integ.s_noise) if table.kind == "karras" else None,
                        float(guidance), condition_signature(y), float(sch.langevin_const), repr(sch.langevin_interval), self.noise_shard,
                        tuple(float(v) for v in table.t.tolist()), model_signature(self.model))
-                return self._plans.run(key, make_loop, x, y=y, scale=scale, eps=eps)
+                src.static_condition = not src.planned         # evaluated as given: the captured calls read a plan-owned condition
+                return self._plans.run(key, make_loop, x, y=y, scale=scale, eps=eps, torch_graph=not src.planned)
             loop = make_loop()
             loop.load(x, scale)
             loop.set_noise(eps)

@@ -412,3 +412,36 @@ def test_range_guard_reads_the_result_word_of_a_captured_run(M, dev):
     with pytest.warns(RuntimeWarning, match="fp16x3 convolution range"):
         d = over.propagate_white_noise(wn, nsteps=4)
     assert over.model.conv_precision == "bf16x6" and not torch.isfinite(d).all()
+
+
+def test_opt_in_capture_of_a_user_torch_network(M, dev):
+    """KarrasModule.capture_eager: a network evaluated as given (here a plain torch module with a dict condition, under
+    classifier-free guidance) captured by torch.cuda.CUDAGraph around the HIP step kernels.  The condition the captured calls
+    read is a plan-owned copy: replays follow new condition VALUES and new starts, bit-identical to the step-by-step run."""
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a = torch.nn.Conv2d(1, 8, 3, padding=1)
+            self.b = torch.nn.Conv2d(8, 1, 3, padding=1)
+            self.e = torch.nn.Linear(2, 8)
+
+        def forward(self, x, t, y=None):
+            h = self.a(x) + t.view(-1, 1, 1, 1)
+            if y is not None:
+                h = h + self.e(y["label"]).view(-1, 8, 1, 1)
+            return self.b(torch.nn.functional.silu(h))
+    torch.manual_seed(5)
+    module = M.KarrasModule(Net().to(dev).eval(), M.KarrasModuleConfig.from_edm(), conditional=True)
+    g = torch.Generator().manual_seed(6)
+    wn = torch.randn(3, 1, 16, 16, generator=g).to(dev)
+    y1, y2 = ({"label": torch.randn(2, generator=g).to(dev)} for _ in range(2))
+    with torch.inference_mode():
+        want1 = module.propagate_white_noise(wn, y=y1, guidance=2.0, nsteps=5)
+        want2 = module.propagate_white_noise(wn * 0.7, y=y2, guidance=2.0, nsteps=5)
+        assert len(module._plans.plans) == 0
+        module.capture_eager = True
+        got1 = module.propagate_white_noise(wn, y=y1, guidance=2.0, nsteps=5)
+        got2 = module.propagate_white_noise(wn * 0.7, y=y2, guidance=2.0, nsteps=5)          # a replay: new start, new condition
+        got1b = module.propagate_white_noise(wn, y=y1, guidance=2.0, nsteps=5)
+    assert len(module._plans.plans) == 1
+    assert torch.equal(got1, want1) and torch.equal(got2, want2) and torch.equal(got1b, want1) and not torch.equal(want1, want2)

@@ -735,8 +735,19 @@ def test_punetg_layer_variants(M, dev, grids, tag, over, fuse):
     module = M.KarrasModule(net, M.KarrasModuleConfig.from_edm())
     _pin_grid(module, grids)
     hist = module.propagate_white_noise(v["white_noise"].to(dev), nsteps=6, record_history=True).cpu()
-    if tag == "extra_res":       # a user torch module inside every block: evaluated launch by launch, never captured
+    if tag == "extra_res":       # a user torch module inside every block: evaluated launch by launch, not captured by default
         assert not net.capturable and len(module._plans.plans) == 0
+        # opt-in (round 3): the same run captured by torch.cuda.CUDAGraph -- torch's allocator serves the user module's
+        # allocations from the graph's pool; eager, capture + replay and a replay from another start agree bit for bit
+        module.capture_eager = True
+        a = module.propagate_white_noise(v["white_noise"].to(dev), nsteps=6, record_history=True).cpu()
+        b = module.propagate_white_noise(v["white_noise"].to(dev), nsteps=6, record_history=True).cpu()
+        assert len(module._plans.plans) == 1 and torch.equal(a, hist) and torch.equal(b, hist)
+        other = (v["white_noise"] * 0.5 + 0.1).to(dev)
+        c = module.propagate_white_noise(other, nsteps=6, record_history=True).cpu()
+        module.capture_eager = False
+        d = module.propagate_white_noise(other, nsteps=6, record_history=True).cpu()
+        assert len(module._plans.plans) == 1 and torch.equal(c, d) and not torch.equal(c, hist)
     if ref_err < REL:
         assert rel_l2(hist, v["hist_heun_N6_f32"]) < REL
     else:
