@@ -459,7 +459,12 @@ class PlanCache:
                 loop.launch(max_rows=2)
                 self.stream.synchronize()
                 if torch_graph:
-                    g = _TorchGraph(loop, self.stream)
+                    try:
+                        g = _TorchGraph(loop, self.stream)
+                    except Exception as e:
+                        raise RuntimeError("capture_eager: this run could not be captured by torch.cuda.CUDAGraph -- a module evaluated "
+                                           "as given must be capture-safe (no host reads such as .item(), no data-dependent control "
+                                           "flow); set capture_eager = False to run it step by step") from e
                 else:
                     with ops.Graph() as g:
                         loop.launch()
