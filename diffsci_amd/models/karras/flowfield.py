@@ -182,6 +182,7 @@ class SIModule(torch.nn.Module):
             self.freeze_autoencoder()
         self.set_initial_norm()
         self.use_graph = True
+        self.capture_eager = False      # opt-in capture of runs through a user torch network (see KarrasModule.capture_eager)
         self._plans = PlanCache()
 
     def freeze_autoencoder(self):
@@ -368,7 +369,8 @@ class SIModule(torch.nn.Module):
         def run():
             src = self._source(y, guidance, x)
             checked[0] = src.nonfinite_word is not None and len(table.rows) > 0      # the last step kernel looks at the result
-            if src.planned and self.use_graph:
+            if self.use_graph and x.is_cuda and (src.planned or self.capture_eager):
+                src.static_condition = not src.planned
                 return self._run_planned(table, src, x, y, guidance, return_history, integrate_on_sigma, scale)
             loop = Loop(table, src, x, return_history)
             loop.load(x, scale)
@@ -386,9 +388,9 @@ class SIModule(torch.nn.Module):
     def _run_planned(self, table, src, x, y, guidance, return_history, integrate_on_sigma, scale):
         """Capture the whole run once per (shape, schedule, guidance, condition structure) and replay it; what depends
         on the condition's values is refreshed in plan-owned buffers before every replay (engine.PlanCache)."""
-        key = (tuple(x.shape), tuple(float(v) for v in table.t), float(guidance), condition_signature(y), bool(return_history),
+        key = (src.planned, tuple(x.shape), tuple(float(v) for v in table.t), float(guidance), condition_signature(y), bool(return_history),
                bool(integrate_on_sigma), str(x.device), model_signature(self.model))
-        return self._plans.run(key, lambda: Loop(table, src, x, return_history), x, y=y, scale=scale)
+        return self._plans.run(key, lambda: Loop(table, src, x, return_history), x, y=y, scale=scale, torch_graph=not src.planned)
 
     def _integrate_generic(self, x, time_schedule, y, guidance, return_history, integrate_on_sigma, scale):
         """integrate_flow_field for preconditioners that cannot be tabulated: Heun steps, the last one Euler

@@ -445,3 +445,26 @@ def test_opt_in_capture_of_a_user_torch_network(M, dev):
         got1b = module.propagate_white_noise(wn, y=y1, guidance=2.0, nsteps=5)
     assert len(module._plans.plans) == 1
     assert torch.equal(got1, want1) and torch.equal(got2, want2) and torch.equal(got1b, want1) and not torch.equal(want1, want2)
+
+
+def test_opt_in_capture_of_a_user_torch_network_in_the_flow_sampler(M, dev):
+    """The same switch on SIModule (flow matching): a plain torch network evaluated as given, captured on request."""
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a = torch.nn.Conv2d(1, 6, 3, padding=1)
+            self.b = torch.nn.Conv2d(6, 1, 3, padding=1)
+
+        def forward(self, x, t, y=None):
+            return self.b(torch.tanh(self.a(x) + t.view(-1, 1, 1, 1)))
+    torch.manual_seed(8)
+    mod = M.SIModule(M.SIModuleConfig(scheduler="linear"), Net()).to(dev).eval()
+    noise = torch.randn(2, 1, 16, 16, generator=torch.Generator().manual_seed(9)).to(dev)
+    with torch.inference_mode():
+        want = mod.sample(2, [1, 16, 16], nsteps=5, orig_noise=noise)
+        want2 = mod.sample(2, [1, 16, 16], nsteps=5, orig_noise=noise * 0.5)
+        assert len(mod._plans.plans) == 0
+        mod.capture_eager = True
+        got = mod.sample(2, [1, 16, 16], nsteps=5, orig_noise=noise)
+        got2 = mod.sample(2, [1, 16, 16], nsteps=5, orig_noise=noise * 0.5)
+    assert len(mod._plans.plans) == 1 and torch.equal(got, want) and torch.equal(got2, want2) and not torch.equal(want, want2)
