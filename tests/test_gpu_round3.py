@@ -468,3 +468,40 @@ def test_opt_in_capture_of_a_user_torch_network_in_the_flow_sampler(M, dev):
         got = mod.sample(2, [1, 16, 16], nsteps=5, orig_noise=noise)
         got2 = mod.sample(2, [1, 16, 16], nsteps=5, orig_noise=noise * 0.5)
     assert len(mod._plans.plans) == 1 and torch.equal(got, want) and torch.equal(got2, want2) and not torch.equal(want, want2)
+
+
+@pytest.mark.parametrize("shape", [(3, 4, 16, 16), (2, 1, 7, 9), (5, 3, 33), (2, 64, 8, 8), (1, 2, 1024, 600)])
+def test_input_maxima_one_launch_and_fallback_agree(dev, ops, shape):
+    """ds_input_amax (one launch: zero the arena, reduce, channel criterion) against the three-launch route it replaces
+    (fill + ds_absmax_channels) and against torch: same rows, same flag -- on aligned, odd-sized and beyond-the-limit inputs
+    (the last shape exceeds INPUT_AMAX_MAX_FLOATS per sample, which the arena routes to the fallback)."""
+    from diffsci_amd.models.nets.punetg import _AmaxArena, _Workspace
+    g = torch.Generator().manual_seed(sum(shape))
+    B, C = shape[:2]
+    x = torch.randn(*shape, generator=g).to(dev)
+    x[0] *= 2.0 ** -20
+    want = _bits_of_max(x)
+    for case in ("benign", "tiny channel, big weights", "no weights"):
+        xx = x.clone()
+        wmax = None if case == "no weights" else torch.rand(C, generator=g).to(dev) + 0.5
+        expect_flag = 0
+        if C > 1 and case != "benign":
+            xx[:, 0] *= 2.0 ** -30                               # a channel thirty binades below the others
+            if wmax is not None:
+                wmax[0] = 2.0 ** 30                              # ... whose weights make it matter
+            expect_flag = 1
+        want = _bits_of_max(xx)
+        ws = _Workspace()
+        flags = torch.zeros(2, dtype=torch.int32, device=dev)
+        arena = _AmaxArena(ws, B, dev, zero=False)
+        arena.i32.fill_(123)                                     # stale slots: the launch has to zero them
+        row = arena.of_input(xx, flags[0:1], wmax)
+        one_launch = xx[0].numel() <= ops.INPUT_AMAX_MAX_FLOATS and C <= 64
+        assert torch.equal(row, want) and int(flags[0]) == expect_flag and int(flags[1]) == 0, (case, shape)
+        used = 1 if one_launch else 1 + C
+        assert arena.n == used and int(arena.i32[used:].abs().max()) == 0
+        # the route the one-launch kernel replaced, on a fresh arena
+        flags2 = torch.zeros(2, dtype=torch.int32, device=dev)
+        out, scratch = torch.zeros(B, dtype=torch.int32, device=dev), torch.zeros(B * C, dtype=torch.int32, device=dev)
+        ops.absmax_channels(xx, out, scratch, flags2[0:1], wmax)
+        assert torch.equal(out, want) and int(flags2[0]) == expect_flag
