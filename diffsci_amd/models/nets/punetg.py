@@ -478,8 +478,8 @@ class PUNetG(torch.nn.Module):
         return ye.to(torch.float32).contiguous()
 
     def condition_is_field(self, y):
-        """True when conditional_embedding(y) is a field: every evaluation then computes per-pixel time shifts, which are not
-        tabulated per run (the sampler evaluates such a network eagerly, engine.ModuleSource)."""
+        """True when conditional_embedding(y) is a field: every evaluation then computes per-pixel time shifts (they depend on
+        sigma, so nothing is tabulated per run; engine.ModuleSource evaluates them out of the workspace through `field_shifts`)."""
         ye = None if y is None else self.embed_condition(y)
         return ye is not None and ye.dim() > 2
 
@@ -902,7 +902,7 @@ class PUNetG(torch.nn.Module):
             if lazy_shifts is not None:                # per-pixel shifts: each block evaluates its own (_field_shift)
                 return lazy_shifts
             s = shifts[next(it)]
-            if s.dim() == 4:                           # [B, C, He, We]: a field of shifts (eager evaluation only)
+            if s.dim() == 4:                           # [B, C, He, We]: a field of shifts handed over as a tensor (allocates: not for captured runs)
                 return s
             if row is not None:
                 if s.dim() == 3:                       # [n_evals, B, C]: per-sample conditions in the planned sampler
