@@ -35,6 +35,15 @@ constexpr int RING_BYTES = (NXB * XBUF_VEC + NWS * WSLAB_VEC) * 16;     // 61,44
 constexpr int EPI_BYTES = 4 * 64 * 2 * 32 * 4;                          // the epilogue's 4 x 16 KiB transposition tiles
 constexpr int STAGE_BYTES = RING_BYTES > EPI_BYTES ? RING_BYTES : EPI_BYTES;
 constexpr int LDS_BYTES = STAGE_BYTES + 128 * 4;
+// TWO (round 3): the workgroup owns two 64-channel tiles of the same pixel tile -- eight waves, waves 0-3 the first tile, 4-7 the
+// second; the chunk's 16 input channels are fetched and split ONCE for both (thread t: pixel t & 255, channel half t >> 8), so the
+// split's vector work per output halves: with more than two output tiles per pixel tile the one-tile kernel is bound by it
+// (200-235 TF/s-equivalent whatever the shape).  Ring: three X images + three pairs of slabs (73,728 B); the epilogue's eight
+// 16 KiB wave tiles (131,072 B) reach past it; one workgroup per CU.
+constexpr int TWO_RING_BYTES = (NXB * XBUF_VEC + NWS * 2 * WSLAB_VEC) * 16;
+constexpr int TWO_EPI_BYTES = 8 * 64 * 2 * 32 * 4;
+static_assert(TWO_EPI_BYTES >= TWO_RING_BYTES, "bias / shift rows behind the larger of the two");
+constexpr int LDS_BYTES_TWO = TWO_EPI_BYTES + 2 * 128 * 4;
 constexpr int NXCD = 8;
 
 struct Conv1hArgs {
@@ -54,6 +63,7 @@ struct Conv1hArgs {
   int shift_stride;
   int B, Cin, Cout, H, W, Hin, Win;
   int tiles_x, tiles_y, n_cot, n_chunks;
+  int n_cot_wg;           // workgroups per pixel tile: n_cot, or n_cot / 2 with two channel tiles per workgroup
   unsigned n_blocks;
 };
 
@@ -74,16 +84,21 @@ __device__ __forceinline__ void step_barrier() {
 }
 
 // W16: the 256 pixels of the tile are 16 rows x 16 columns (narrow feature maps) instead of 8 x 32.
-template <int MODE, bool W16>
-__global__ __launch_bounds__(NT, 2) void k_conv1h(const Conv1hArgs a) {
+template <int MODE, bool W16, bool TWO = false>
+__global__ __launch_bounds__(TWO ? 2 * NT : NT, 2) void k_conv1h(const Conv1hArgs a) {
   constexpr int TW = W16 ? 16 : 32, TH = W16 ? 16 : 8;
+  constexpr int COTS = TWO ? 2 : 1;
+  constexpr int KR = TWO ? KC / 2 : KC;                              // channel values a thread fetches per chunk
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   u32x4* Xs = reinterpret_cast<u32x4*>(smem);                        // [buf 3][piece][h][pos]
-  u32x4* Ws = Xs + NXB * XBUF_VEC;                                   // [slot 3][piece][h][co]
-  float* BS = reinterpret_cast<float*>(smem + STAGE_BYTES);
+  u32x4* Ws = Xs + NXB * XBUF_VEC;                                   // [slot 3][channel tile][piece][h][co]
+  float* BS = reinterpret_cast<float*>(smem + (TWO ? TWO_EPI_BYTES : STAGE_BYTES));      // [channel tile][2][64] bias, shift
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cw = TWO ? wv >> 2 : 0;                                  // the wave's channel tile; the thread's channel half when staging
+  const int wq = wv & 3;                                             // the wave's pixel rows
+  const int pix = tid & (NT - 1);
   const int li = lane & 31, lh = lane >> 5;
 
   // XCD-aware order: hardware sends workgroup i to XCD i % 8; give each XCD a contiguous run of
@@ -94,7 +109,7 @@ __global__ __launch_bounds__(NT, 2) void k_conv1h(const Conv1hArgs a) {
     const unsigned per = a.n_blocks / NXCD, rem = a.n_blocks % NXCD;
     bid = x * per + (x < rem ? x : rem) + k;
   }
-  const int cot = bid % a.n_cot; bid /= a.n_cot;
+  const int cot = (int)(bid % a.n_cot_wg) * COTS; bid /= a.n_cot_wg;     // first channel tile of the workgroup
   const int tx = bid % a.tiles_x; bid /= a.tiles_x;
   const int ty = bid % a.tiles_y; bid /= a.tiles_y;
   const int b = bid;
@@ -106,7 +121,7 @@ __global__ __launch_bounds__(NT, 2) void k_conv1h(const Conv1hArgs a) {
   // channels past Cin of a ragged last chunk are fetched from clamped (valid) addresses and NOT
   // zeroed: a 1x1 convolution has no halo, so an out-of-range pixel only feeds outputs that are
   // never stored, and the padded weight rows of the channels past Cin are zero.
-  const int gy = y0 + (W16 ? tid >> 4 : tid >> 5), gx = x0 + (W16 ? tid & 15 : tid & 31);
+  const int gy = y0 + (W16 ? pix >> 4 : pix >> 5), gx = x0 + (W16 ? pix & 15 : pix & 31);
   const bool ok = gy < a.H && gx < a.W;
   unsigned off;
   if (MODE == DS_LOAD_PLAIN) off = gy * a.Win + gx;
@@ -118,12 +133,12 @@ __global__ __launch_bounds__(NT, 2) void k_conv1h(const Conv1hArgs a) {
   const u32x4* wp = a.wp + (size_t)cot * n * WSLAB_VEC;
   ds_epi::ActScale ascale;
 
-  auto x_fetch = [&](float (&R)[KC], int chunk) {
-    const int cbase = chunk * KC;
+  auto x_fetch = [&](float (&R)[KR], int chunk) {
+    const int cbase = chunk * KC + (TWO ? KR * cw : 0);
     unsigned ob = offb;
     asm volatile("" : "+v"(ob));       // keep the zero-extension next to the loads (scalar-base + 32-bit offset form)
 #pragma unroll
-    for (int c = 0; c < KC; ++c) {
+    for (int c = 0; c < KR; ++c) {
       const int ch = cbase + c < a.Cin ? cbase + c : a.Cin - 1;        // scalar clamp
       // uniform base, pinned to an SGPR pair (opaque to the optimiser, which would otherwise fold the
       // lane offset into a hoisted 64-bit vector base and pay a 64-bit VALU add per load)
@@ -138,26 +153,28 @@ __global__ __launch_bounds__(NT, 2) void k_conv1h(const Conv1hArgs a) {
       }
     }
   };
-  auto x_store = [&](const float (&R)[KC], int buf) {
+  auto x_store = [&](const float (&R)[KR], int buf) {
     u32x4* xb = Xs + buf * XBUF_VEC;
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int hr = 0; hr < KR / 8; ++hr) {
+      const int h = TWO ? cw : hr;                                     // TWO: the thread holds one channel half
       u32x4 qh, ql;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         unsigned ph, pl;
-        split2(R[8 * h + 2 * k] * ascale.in_scale, R[8 * h + 2 * k + 1] * ascale.in_scale, ph, pl);   // exact (power of two)
+        split2(R[8 * hr + 2 * k] * ascale.in_scale, R[8 * hr + 2 * k + 1] * ascale.in_scale, ph, pl);   // exact (power of two)
         qh[k] = ph; ql[k] = pl;
       }
-      xb[h * NPOS + tid] = qh;
-      xb[(2 + h) * NPOS + tid] = ql;
+      xb[h * NPOS + pix] = qh;
+      xb[(2 + h) * NPOS + pix] = ql;
     }
   };
   // the 4 KiB weight slab of a chunk is one 16-byte vector per thread; it rides along with the
   // thread's pixel through the same register prefetch (no LDS-DMA: the compiler orders every later
   // ds_read behind an LDS-DMA with a full vmcnt wait, which would serialise the prefetch)
-  auto w_fetch = [&](u32x4& Wr, int chunk) { Wr = wp[(size_t)chunk * WSLAB_VEC + tid]; };
-  auto w_store = [&](const u32x4& Wr, int slot) { Ws[slot * WSLAB_VEC + tid] = Wr; };
+  // (TWO: threads 256.. carry the second channel tile's slab, n slabs further on)
+  auto w_fetch = [&](u32x4& Wr, int chunk) { Wr = wp[((size_t)cw * n + chunk) * WSLAB_VEC + pix]; };
+  auto w_store = [&](const u32x4& Wr, int slot) { Ws[(slot * COTS + cw) * WSLAB_VEC + pix] = Wr; };
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -168,7 +185,7 @@ __global__ __launch_bounds__(NT, 2) void k_conv1h(const Conv1hArgs a) {
       for (int q = 0; q < 16; ++q) acc[m][r][q] = 0.f;
 
   auto mma = [&](int slot, int buf) {
-    const u32x4* wb = Ws + slot * WSLAB_VEC;
+    const u32x4* wb = Ws + (slot * COTS + cw) * WSLAB_VEC;
     const u32x4* xb = Xs + buf * XBUF_VEC;
     f16x8 fa[2][2], fb[2][2];
 #pragma unroll
@@ -176,7 +193,7 @@ __global__ __launch_bounds__(NT, 2) void k_conv1h(const Conv1hArgs a) {
 #pragma unroll
       for (int m = 0; m < 2; ++m) fa[p][m] = *reinterpret_cast<const f16x8*>(&wb[(p * 2 + lh) * COT + 32 * m + li]);
 #pragma unroll
-      for (int r = 0; r < 2; ++r) fb[p][r] = *reinterpret_cast<const f16x8*>(&xb[(p * 2 + lh) * NPOS + (2 * wv + r) * 32 + li]);
+      for (int r = 0; r < 2; ++r) fb[p][r] = *reinterpret_cast<const f16x8*>(&xb[(p * 2 + lh) * NPOS + (2 * wq + r) * 32 + li]);
     }
     constexpr int PA[3] = {1, 0, 0};
     constexpr int PB[3] = {0, 1, 0};
@@ -189,9 +206,9 @@ __global__ __launch_bounds__(NT, 2) void k_conv1h(const Conv1hArgs a) {
           acc[m][r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[PA[t]][m], fb[PB[t]][r], acc[m][r], 0, 0, 0);
   };
 
-  float R0[KC], R1[KC];
+  float R0[KR], R1[KR];
   u32x4 W0, W1;
-  const float bias_shift = ds_epi::fetch_bias_shift(a.bias, a.shift, a.shift_stride, b, cot * COT, a.Cout);
+  const float bias_shift = ds_epi::fetch_bias_shift(a.bias, a.shift, a.shift_stride, b, (cot + (TWO ? (tid >> 7) & 1 : 0)) * COT, a.Cout, COTS);
   __builtin_amdgcn_sched_barrier(0);
   const unsigned amax_bits = ds_epi::act_bits(a.in_amax, b);   // every input of this kernel is a raw tensor; consumed behind the first loads
   w_fetch(W0, 0);
@@ -202,12 +219,12 @@ __global__ __launch_bounds__(NT, 2) void k_conv1h(const Conv1hArgs a) {
   ascale = ds_epi::act_scale_of(amax_bits, a.wshift);
   w_store(W0, 0);
   x_store(R0, 0);
-  ds_epi::commit_bias_shift(BS, bias_shift);
+  ds_epi::commit_bias_shift(BS, bias_shift, COTS);
   __syncthreads();
 
   // chunk k: fetched into R[k & 1] at step k-2, split into image k % 3 at step k-1, used at step k
   int buf = 0;
-  auto step = [&](float (&Ra)[KC], u32x4& Wa, float (&Rb)[KC], u32x4& Wb, int g) {
+  auto step = [&](float (&Ra)[KR], u32x4& Wa, float (&Rb)[KR], u32x4& Wb, int g) {
     // unconditional (clamped to the last chunk: a redundant, never-consumed fetch in the last two
     // steps) so the number of loads in flight is static and the waits below stay partial
     const int gf = g + 2 < n ? g + 2 : n - 1;
@@ -232,15 +249,22 @@ __global__ __launch_bounds__(NT, 2) void k_conv1h(const Conv1hArgs a) {
     ds_epi::Args e;
     e.out = a.out; e.bias = a.bias; e.shift = a.shift; e.res1 = a.res1; e.res2 = a.res2; e.res1_up = a.res1_up;
     e.unscale = ds_epi::unscale_from_in(ascale.in_scale, a.wshift); e.shift_stride = a.shift_stride;
-    e.out_amax = a.out_amax ? a.out_amax + b + ((a.amax_split > 0 && cot * COT >= a.amax_split) ? a.B : 0) : nullptr;
-    e.b = b; e.co_base = cot * COT; e.y0 = y0 + (W16 ? 4 : 2) * wv; e.x0 = x0;
+    e.out_amax = a.out_amax ? a.out_amax + b + ((a.amax_split > 0 && (cot + cw) * COT >= a.amax_split) ? a.B : 0) : nullptr;
+    e.b = b; e.co_base = (cot + cw) * COT; e.y0 = y0 + (W16 ? 4 : 2) * wq; e.x0 = x0;
     e.Cout = a.Cout; e.H = a.H; e.W = a.W;
     e.tile_stats = a.tile_stats; e.tile = ty * a.tiles_x + tx; e.ntiles = a.tiles_x * a.tiles_y;
     float* tile = reinterpret_cast<float*>(smem) + wv * (64 * 2 * 32);
-    ds_epi::store_tile<W16>(acc, tile, BS, e);
+    ds_epi::store_tile<W16>(acc, tile, BS + 128 * cw, e);
     if (a.tile_stats) {
       __syncthreads();
-      ds_epi::store_tile_stats(reinterpret_cast<const float*>(smem), 64 * 2 * 32, e);
+      if constexpr (TWO) {                      // threads 0-63 combine the first channel tile's four waves, 64-127 the second's
+        if (tid < 128) {
+          e.co_base = (cot + (tid >> 6)) * COT;
+          ds_epi::store_tile_stats(reinterpret_cast<const float*>(smem) + (tid >> 6) * 4 * (64 * 2 * 32), 64 * 2 * 32, e, tid & 63);
+        }
+      } else {
+        ds_epi::store_tile_stats(reinterpret_cast<const float*>(smem), 64 * 2 * 32, e);
+      }
     }
   }
 }
@@ -265,12 +289,36 @@ __global__ void k_pack1h(_Float16* packed, const float* __restrict__ w, int Cout
   packed[i] = piece == 0 ? hi : lo;
 }
 
+// Two channel tiles per workgroup where the output has an even number of them and the halved grid still fills the chip
+// (DS_CONV1_TWO_MIN workgroups, 256 = one per CU).  Measured on MI355X (tools/conv1h_time.py, batch 32): 512 -> 256 at 128^2
+// 626 -> 565 us, 768 -> 384 at 64^2 331 -> 292, 1024 -> 512 at 32^2 142 -> 118, 384 -> 128 at 256^2 1070 -> 962, the attention
+// in-projection 256 -> 768 at 32^2 (batch 64) 127.5 -> 114.  DS_CONV1_TWO=0 switches it off, =2 drops the grid condition (A/B runs).
+inline int conv1h_two() {
+  static const int v = [] { const char* e = getenv("DS_CONV1_TWO"); return e ? atoi(e) : 1; }();
+  return v;
+}
+inline long long conv1h_two_min() {
+  static const long long v = [] { const char* e = getenv("DS_CONV1_TWO_MIN"); return e ? atoll(e) : 256ll; }();
+  return v;
+}
+
 template <int MODE, bool W16>
-int launch_conv1h(const Conv1hArgs& a, hipStream_t s) {
+int launch_conv1h(Conv1hArgs a, hipStream_t s) {
+  const int two = conv1h_two();
+  if (a.n_cot % 2 == 0 && ((two == 1 && (long long)a.n_blocks / 2 >= conv1h_two_min()) || two == 2)) {
+    const int rc = ds::ensure_dynamic_lds<&k_conv1h<MODE, W16, true>>((int)(LDS_BYTES_TWO), "hipFuncSetAttribute(conv1h two)");
+    if (rc != DS_OK) return rc;
+    a.n_cot_wg = a.n_cot / 2;
+    a.n_blocks /= 2;
+    hipLaunchKernelGGL((k_conv1h<MODE, W16, true>), dim3(a.n_blocks), dim3(2 * NT), LDS_BYTES_TWO, s, a);
+    DS_CHECK_LAUNCH("ds_conv1x1_h3");
+    return DS_OK;
+  }
   {
     const int rc = ds::ensure_dynamic_lds<&k_conv1h<MODE, W16>>((int)(LDS_BYTES), "hipFuncSetAttribute(conv1h)");
     if (rc != DS_OK) return rc;
   }
+  a.n_cot_wg = a.n_cot;
   hipLaunchKernelGGL((k_conv1h<MODE, W16>), dim3(a.n_blocks), dim3(NT), LDS_BYTES, s, a);
   DS_CHECK_LAUNCH("ds_conv1x1_h3");
   return DS_OK;

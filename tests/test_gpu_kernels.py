@@ -474,7 +474,8 @@ def test_conv_direct_small_cout(dev, case):
         ops.conv_direct(x.to(dev), torch.randn(5, Cin, 3, 3, device=dev))
 
 
-@pytest.mark.parametrize("env", [{}, {"DS_CONV_SHAPE": "32"}, {"DS_CONV_WAVES16": "8"}, {"DS_CONV_TWO": "2"}, {"DS_CONV_TWO": "0"}],
+@pytest.mark.parametrize("env", [{}, {"DS_CONV_SHAPE": "32"}, {"DS_CONV_WAVES16": "8"}, {"DS_CONV_TWO": "2", "DS_CONV1_TWO": "2"},
+                                 {"DS_CONV_TWO": "0", "DS_CONV1_TWO": "0"}],
                          ids=["shipped", "mfma-32x32x16", "16x16x32-eight-waves", "two-channel-tiles-everywhere", "one-channel-tile"])
 def test_convolution_family_fuzz(env):
     """A short run of tools/conv_fuzz.py: random shapes through every load / padding / fusion combination -- with the
