@@ -529,6 +529,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} rank(s)")
+    # DIFFSCI_BENCH_SHARE_GPU=1 (rehearsals on a one-GPU box): the ranks share the visible devices round-robin and rendezvous /
+    # gather over gloo -- RCCL refuses two ranks on one device.  Never set by the driver; the line then reports the backend.
+    share = os.environ.get("DIFFSCI_BENCH_SHARE_GPU") == "1"
+    if share:
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -542,7 +547,10 @@ def main():
                 sk.bind(("127.0.0.1", 0))
                 os.environ.setdefault("MASTER_PORT", str(sk.getsockname()[1]))
             os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK=str(local_rank))
-        dist.init_process_group("nccl", device_id=dev)
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     from diffsci_amd.parallel import gather_samples, global_white_noise, shard_rows
     module, sd, cfg = build_module(args, dev)
     if args.roofline_only:
@@ -592,6 +600,7 @@ def main():
                                    f"{args.nsteps}-step Heun deterministic sampler ({2*args.nsteps-1} network evaluations)",
                        "global_batch": B * world, "parallelism": f"dp{world} (batch shards, all-gather of samples)",
                        "rccl_world_size": dist.get_world_size() if dist is not None else 1,
+                       **({"rehearsal": "ranks share one GPU, gloo instead of RCCL"} if share else {}),
                        "hipgraph": not args.no_graph},
         }
         print(f"[bench] {value:.3f} samples/s, {dt / args.steps * 1e3:.1f} ms per {B}-sample batch", file=sys.stderr, flush=True)

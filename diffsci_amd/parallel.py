@@ -111,6 +111,9 @@ def gather_samples(out, nsamples=None):
     world = dist.get_world_size()          # a one-rank group still goes through the collective (RCCL on the GPU)
     if nsamples is None:
         nsamples = out.shape[0] * world
+    if out.is_cuda and dist.get_backend() == "gloo":
+        # a rehearsal of the N > 1 path with several ranks on ONE GPU (RCCL refuses two ranks on a device): gloo moves host memory
+        return gather_samples(out.cpu(), nsamples).to(out.device)
     if nsamples % world == 0:
         full = torch.empty((nsamples,) + tuple(out.shape[1:]), dtype=out.dtype, device=out.device)
         dist.all_gather_into_tensor(full, out.contiguous())

@@ -316,6 +316,34 @@ def test_bench_multi_rank_code_on_one_rank(launcher):
     assert "dp1" in line["config"]["parallelism"] and line["config"]["global_batch"] == 8
 
 
+def test_bench_with_two_ranks_sharing_the_gpu():
+    """bench.py under the driver's launcher line with TWO ranks (DIFFSCI_BENCH_SHARE_GPU=1: both on the box's one GPU, gloo for
+    the rendezvous / gather / barrier / MAX-reduction since RCCL refuses two ranks on a device): the weak-scaling accounting --
+    per-rank batch, global batch, one line from rank 0 -- executed with GPU compute."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--nsteps", "4",
+           "--batch", "8", "--size", "64", "--no-cpu-baseline", "--no-other-precisions", "--no-other-configs"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", DIFFSCI_BENCH_SHARE_GPU="1")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                                               # rank 0 alone prints
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["rccl_world_size"] == 2 and line["config"]["global_batch"] == 16
+    assert line["scaling"] == "weak" and line["value"] > 0 and "dp2" in line["config"]["parallelism"]
+    assert abs(line["value"] - 16 * 2 / (line["ms_per_step"] * 2 / 1e3)) < 0.01 * line["value"]      # whole-job samples over the max time
+
+
 def test_vp_runs_the_tabulated_captured_loop(M, dev):
     """VP (non-constant scaling s(t), Scheduler.rhs schedulers.py:275-293) on the fused stepper: the step rows carry s, s'/s and the
     multiplier, the kernels divide the state by s on the way into the network, and the run is captured like an EDM one -- same
@@ -505,3 +533,68 @@ def test_input_maxima_one_launch_and_fallback_agree(dev, ops, shape):
         out, scratch = torch.zeros(B, dtype=torch.int32, device=dev), torch.zeros(B * C, dtype=torch.int32, device=dev)
         ops.absmax_channels(xx, out, scratch, flags2[0:1], wmax)
         assert torch.equal(out, want) and int(flags2[0]) == expect_flag
+
+
+def _two_rank_worker(rank, world, port, nsamples, q):
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import diffsci_amd.models as M
+        from diffsci_amd.parallel import sample_sharded
+        from tests.golden_util import load
+        dev = torch.device("cuda:0")                                  # both ranks share the box's one GPU
+        _, sd = load("punetg8_forward")
+        net = M.PUNetG(M.PUNetGConfig(model_channels=8))
+        net.load_state_dict(sd)
+        module = M.KarrasModule(net, M.KarrasModuleConfig.from_edm()).to(dev).eval()
+        out = {}
+        for integrator in ("heun", "karras"):
+            torch.manual_seed(11)                                     # every rank holds the same generator state
+            out[integrator] = sample_sharded(module, nsamples, [1, 32, 32], nsteps=4, seed=7, integrator=integrator).cpu()
+        q.put((rank, out))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("nsamples", [6, 5])
+def test_two_ranks_on_one_gpu_reproduce_the_single_process_batch(M, dev, nsamples):
+    """The N > 1 path executed with GPU compute as far as a one-GPU box allows: two processes (gloo rendezvous and gather -- RCCL
+    refuses two ranks on one device) shard the global noise, run their rows through the captured sampler on the same card and
+    gather; every rank must hold the single-process batch bit for bit -- for the deterministic sampler and for the sigma-churn one,
+    whose in-kernel noise is addressed by GLOBAL element index (even and ragged splits)."""
+    import socket
+    import torch.multiprocessing as mp
+    from diffsci_amd.parallel import global_white_noise
+    from tests.golden_util import load
+    _, sd = load("punetg8_forward")
+    net = M.PUNetG(M.PUNetGConfig(model_channels=8))
+    net.load_state_dict(sd)
+    module = M.KarrasModule(net, M.KarrasModuleConfig.from_edm()).to(dev).eval()
+    wn = global_white_noise(nsamples, [1, 32, 32], 7).to(dev)
+    want = {}
+    for integrator in ("heun", "karras"):
+        torch.manual_seed(11)
+        want[integrator] = module.propagate_white_noise(wn, nsteps=4, integrator=integrator).cpu()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = [ctx.Process(target=_two_rank_worker, args=(r, 2, port, nsamples, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert sorted(r for r, _ in got) == [0, 1]
+    for _, out in got:
+        for integrator in ("heun", "karras"):
+            assert torch.equal(out[integrator], want[integrator]), integrator
+    assert not torch.equal(want["heun"], want["karras"])
