@@ -179,9 +179,15 @@ def main():
             want = F.conv2d(src.double(), w.double(), bias.double()) + r1.double()
             nt = ops.conv_tile_count(H, W)
             ts = torch.zeros(B, Cout, nt, 4, device=dev) if W % 4 == 0 or True else None
+            # the output's per-sample maxima (out_amax), optionally split at a 64-channel boundary (the attention's q, k | v)
+            split = 64 * ri(1, (Cout - 1) // 64) if Cout > 64 and ri(0, 1) else 0
+            am = torch.zeros((2, B) if split else (B,), dtype=torch.int32, device=dev)
             got = ops.conv(x.to(dev), ops.pack_conv(w.to(dev), "fp16x3"), bias=bias.to(dev), res1=r1.to(dev), load_mode=mode,
-                           tile_stats=ts).cpu()
+                           tile_stats=ts, out_amax=am.view(-1), amax_split=split).cpu()
             e = rel(got, want)
+            parts = [got[:, :split], got[:, split:]] if split else [got]
+            bits = torch.stack([p_.reshape(B, -1).abs().amax(dim=1).contiguous().view(torch.int32) for p_ in parts]).view(am.shape)
+            assert torch.equal(am.cpu(), bits), f"out_amax differs: 1x1 Cout={Cout} split={split}"
             K, S, Q, n = ts.cpu().double().unbind(-1)
             sx = (n * K + S).sum(-1)
             e = max(e, float((sx - want.sum(dim=(2, 3))).abs().max() / (want.abs().sum(dim=(2, 3)).max() + 1e-300)))
@@ -207,9 +213,11 @@ def main():
             want = want + shift.double()[..., None, None] + r1.double()
             nt = ops.conv_tile_count(H, W)
             ts = torch.full((B, Cout, nt, 4), float("nan"), device=dev)
+            am = torch.zeros(B, dtype=torch.int32, device=dev)
             got = ops.conv(x.to(dev), ops.pack_conv(w.to(dev), "fp16x3"), bias=bias.to(dev), shift=shift.to(dev), res1=r1.to(dev),
-                           load_mode=mode, circular=circ, prenorm=None if tab is None else tab.to(dev), tile_stats=ts).cpu()
+                           load_mode=mode, circular=circ, prenorm=None if tab is None else tab.to(dev), tile_stats=ts, out_amax=am).cpu()
             e = rel(got, want)
+            assert torch.equal(am.cpu(), got.reshape(B, -1).abs().amax(dim=1).contiguous().view(torch.int32)), "out_amax differs: 3x3"
             K, S, Q, n = ts.cpu().double().unbind(-1)
             assert torch.isfinite(ts).all(), "tile statistics not fully written"
             assert torch.equal(n.sum(-1), torch.full_like(n.sum(-1), H * W)), "tile pixel counts"
