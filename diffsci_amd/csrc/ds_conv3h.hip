@@ -678,7 +678,8 @@ inline int conv3h_waves16() {
 // level: the activation is otherwise computed once per tile) WHEN the halved grid still fills the chip -- at least
 // DS_CONV_TWO_MIN (256: one per CU) workgroups.  Measured on MI355X: config 5's share (2048 such workgroups per launch)
 // 9.24 -> 9.13 ms per evaluation with it; a [4, 4, 32, 32] latent on a 32-channel network (a handful of workgroups: their
-// latency is the launch's) 21.85 -> 23.3 ms per 10-step forecast, so not there; the headline's 64 workgroups: +0.2 %, noise.
+// latency is the launch's) 21.85 -> 23.3 ms per 10-step forecast, so not there; the headline's level-1 launches (1024 such workgroups at
+// batch 64): 79.9 -> 80.45 samples/s with it.
 // DS_CONV_TWO=0 switches it off, =2 extends it to every even tile count, the plain loader and any grid (A/B runs).
 inline int conv3h_two() {
   static const int v = [] { const char* e = getenv("DS_CONV_TWO"); return e ? atoi(e) : 1; }();
