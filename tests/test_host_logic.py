@@ -367,3 +367,22 @@ def test_model_signature_follows_the_module_tree():
     assert engine.model_signature(net) == s3
     net.conv_precision = "fp32"
     assert engine.model_signature(net) != s3
+
+
+def test_condition_copies_keep_structure_and_follow_values():
+    """engine.clone_condition / copy_condition: the plan-owned copy of a condition (dicts of tensors, nested, with non-tensor
+    entries) that a captured evaluated-as-given run reads and every replay rewrites."""
+    from diffsci_amd.models.karras.engine import clone_condition, condition_signature, copy_condition
+    y = {"label": torch.tensor([1.0, 2.0]), "nested": {"field": torch.ones(2, 3)}, "tag": "abc", "n": 3}
+    c = clone_condition(y)
+    assert condition_signature(c) == condition_signature(y)
+    assert c["label"] is not y["label"] and torch.equal(c["label"], y["label"]) and c["tag"] == "abc" and c["n"] == 3
+    keep = (c["label"].data_ptr(), c["nested"]["field"].data_ptr())
+    y2 = {"label": torch.tensor([5.0, 6.0]), "nested": {"field": torch.full((2, 3), 7.0)}, "tag": "abc", "n": 3}
+    copy_condition(c, y2)
+    assert torch.equal(c["label"], y2["label"]) and torch.equal(c["nested"]["field"], y2["nested"]["field"])
+    assert keep == (c["label"].data_ptr(), c["nested"]["field"].data_ptr())          # same buffers: a captured graph reads them
+    t = torch.arange(4.0)
+    ct = clone_condition(t)
+    copy_condition(ct, t * 2)
+    assert torch.equal(ct, t * 2) and clone_condition(None) is None
