@@ -388,7 +388,7 @@ class SIModule(torch.nn.Module):
     def _run_planned(self, table, src, x, y, guidance, return_history, integrate_on_sigma, scale):
         """Capture the whole run once per (shape, schedule, guidance, condition structure) and replay it; what depends
         on the condition's values is refreshed in plan-owned buffers before every replay (engine.PlanCache)."""
-        key = (src.planned, tuple(x.shape), tuple(float(v) for v in table.t), float(guidance), condition_signature(y), bool(return_history),
+        key = (src.planned, tuple(x.shape), table.digest(), float(guidance), condition_signature(y), bool(return_history),
                bool(integrate_on_sigma), str(x.device), model_signature(self.model))
         return self._plans.run(key, lambda: Loop(table, src, x, return_history), x, y=y, scale=scale, torch_graph=not src.planned)
 

@@ -368,7 +368,7 @@ class KarrasModule(torch.nn.Module, LatentSpaceAutoregressive):
                 key = (src.planned, tuple(x.shape), str(x.device), nsteps, i0, i1, record_history, table.kind, injected,
                        (integ.s_schurn, integ.s_tmin, integ.s_tmax, integ.s_noise) if table.kind == "karras" else None,
                        float(guidance), condition_signature(y), float(sch.langevin_const), repr(sch.langevin_interval), self.noise_shard,
-                       tuple(float(v) for v in table.t.tolist()), model_signature(self.model))
+                       table.digest(), model_signature(self.model))
                 src.static_condition = not src.planned         # evaluated as given: the captured calls read a plan-owned condition
                 return self._plans.run(key, make_loop, x, y=y, scale=scale, eps=eps, torch_graph=not src.planned)
             loop = make_loop()

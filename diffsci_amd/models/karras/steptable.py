@@ -82,6 +82,15 @@ class StepTable:
     def needs_noise(self):
         return self.kind in ("euler-maruyama", "karras")
 
+    def digest(self):
+        """Every scalar a captured launch sequence bakes in as a kernel argument -- part of the plan key, so a scheduler,
+        preconditioner or integrator changed IN PLACE between two runs re-captures instead of replaying stale coefficients."""
+        def ev(e):
+            return None if e is None else (e.sigma, e.sigma_sq, e.neg_mult, e.neg_lang, e.stochastic, e.c_skip, e.c_out, e.c_in,
+                                           e.c_noise, e.scaled, e.scale, e.scale_mult)
+        return (self.kind,) + tuple((ev(r.first), ev(r.second), r.dt, r.churn_coef, r.churn_ratio, r.noise_coef, r.sqrt_abs_dt)
+                                    for r in self.rows)
+
 
 def _f(x):
     return float(x)

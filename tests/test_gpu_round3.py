@@ -598,3 +598,21 @@ def test_two_ranks_on_one_gpu_reproduce_the_single_process_batch(M, dev, nsample
         for integrator in ("heun", "karras"):
             assert torch.equal(out[integrator], want[integrator]), integrator
     assert not torch.equal(want["heun"], want["karras"])
+
+
+def test_plan_key_follows_the_step_coefficients(M, dev):
+    """The plan key carries every scalar the captured kernels take as arguments (StepTable.digest): a preconditioner changed IN
+    PLACE between two runs -- same grid, same network -- re-captures instead of replaying the old c_in / c_out / c_skip."""
+    from tests.golden_util import load
+    _, sd = load("punetg8_forward")
+    net = M.PUNetG(M.PUNetGConfig(model_channels=8))
+    net.load_state_dict(sd)
+    module = M.KarrasModule(net, M.KarrasModuleConfig.from_edm()).to(dev).eval()
+    wn = torch.randn(2, 1, 32, 32, generator=torch.Generator().manual_seed(3)).to(dev)
+    a = module.propagate_white_noise(wn, nsteps=4)
+    assert len(module._plans.plans) == 1
+    module.config.preconditioner.sigma_data.fill_(0.8)
+    b = module.propagate_white_noise(wn, nsteps=4)
+    module.use_graph = False
+    want = module.propagate_white_noise(wn, nsteps=4)
+    assert len(module._plans.plans) == 2 and torch.equal(b, want) and not torch.equal(a, b)
