@@ -78,14 +78,16 @@ MODEL_SWITCHES = ("conv_precision", "fuse_norm", "fuse_max_cot", "direct_out", "
 
 def _tree_slots(model):
     mods = list(model.modules())
-    shape = tuple((m._modules, len(m._modules), m._parameters, len(m._parameters)) for m in mods)
+    shape = tuple((d, len(d)) for m in mods for d in (m._modules, m._parameters, m._buffers))
     children = tuple((m._modules, name, c) for m in mods for name, c in m._modules.items())
-    params = tuple((m._parameters, name) for m in mods for name, p in m._parameters.items() if p is not None)
+    # parameters AND buffers: a plan's tables are computed from buffers too (the Fourier projection's W is one)
+    params = tuple((m._parameters, name) for m in mods for name, p in m._parameters.items() if p is not None) + \
+        tuple((m._buffers, name) for m in mods for name, p in m._buffers.items() if p is not None)
     return shape, children, params
 
 
 def model_signature(model):
-    """What a captured plan bakes in of the network: the parameters' addresses and versions and every attribute that selects
+    """What a captured plan bakes in of the network: the parameters' and buffers' addresses and versions and every attribute that selects
     kernels (the documented A/B switches, the precision the guards may have moved it to).  Shared by KarrasModule and SIModule.
     Called once per run, so the walk over the module tree (0.26 ms of the 0.32 ms this took for PUNetG-64's 212 parameters) is
     done once per tree: the cached list holds the modules' own `_parameters` / `_modules` dicts, so a parameter assigned anew
@@ -94,8 +96,7 @@ def model_signature(model):
     slots = model.__dict__.get("_signature_slots")
     if slots is not None:
         shape, children, params = slots
-        if not (all(len(dm) == nm and len(dp) == np_ for dm, nm, dp, np_ in shape)
-                and all(d.get(name) is c for d, name, c in children)):
+        if not (all(len(d) == n for d, n in shape) and all(d.get(name) is c for d, name, c in children)):
             slots = None
     if slots is None:
         slots = model.__dict__["_signature_slots"] = _tree_slots(model)

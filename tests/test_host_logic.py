@@ -349,7 +349,11 @@ def test_model_signature_follows_the_module_tree():
     from diffsci_amd.models.karras import engine
     net = M.PUNetG(M.PUNetGConfig(model_channels=8))
     s0 = engine.model_signature(net)
-    assert engine.model_signature(net) == s0 and len(s0[0]) == len(list(net.parameters()))
+    assert engine.model_signature(net) == s0 and len(s0[0]) == len(list(net.parameters())) + len(list(net.buffers()))
+    with torch.no_grad():
+        net.time_projection.W.mul_(1.5)                    # a buffer the plan's time-shift tables are computed from
+    assert engine.model_signature(net) != s0
+    s0 = engine.model_signature(net)
     with torch.no_grad():
         net.convin.weight.add_(1.0)
     s1 = engine.model_signature(net)
