@@ -365,7 +365,7 @@ class KarrasModule(torch.nn.Module, LatentSpaceAutoregressive):
                 return Loop(table, src, x, record_history, injected_noise=injected, noise_shard=self.noise_shard)
 
             if self.use_graph and x.is_cuda and (src.planned or self.capture_eager):
-                key = (src.planned, tuple(x.shape), str(x.device), nsteps, i0, i1, record_history, table.kind, injected,
+                key = (src.planned, src.batched_cfg, tuple(x.shape), str(x.device), nsteps, i0, i1, record_history, table.kind, injected,
                        (integ.s_schurn, integ.s_tmin, integ.s_tmax, integ.s_noise) if table.kind == "karras" else None,
                        float(guidance), condition_signature(y), float(sch.langevin_const), repr(sch.langevin_interval), self.noise_shard,
                        table.digest(), model_signature(self.model))
