@@ -67,8 +67,8 @@ def main():
             # padding needs every plane at least as large as the halo
             small = min(x.shape[2:]) // unit
             if ri(0, 2) == 0 and over["convolution_type"] != "mp" and (over["convolution_type"] != "circular" or small >= 3):
-                over.update(kernel_size=pick([1, 5, 5, 7] if not vol else [1, 5]), in_out_kernel_size=pick([1, 3, 5]),
-                            transition_kernel_size=pick([3, 5, 7] if not vol else [3, 5]))
+                over.update(kernel_size=pick([1, 3, 5, 5, 7] if not vol else [1, 3, 5]), in_out_kernel_size=pick([1, 3, 5]),
+                            transition_kernel_size=pick([3, 5, 7] if not vol else [3, 5, 5]))
             cfg = punetg_ref.default_config(**over)
             net = M.PUNetG(M.PUNetGConfig(**over))
             with torch.no_grad():
