@@ -43,11 +43,22 @@ def dict_to(d, device):
     return dict_map(lambda x: x.to(device), d)
 
 
+_AR = ("autoregressive_loss_steps", "autoregressive_loss_diffusion_steps", "autoregressive_loss_guidance",
+       "autoregressive_loss_weights", "autoregressive_loss_maximum_batch_size", "autoregressive_loss_integrator",
+       "spatial_shape", "focus_radius")
+
+
 class KarrasModuleConfig(object):
+    # positional order and defaults of the reference (karrasmodule.py:40-94); the autoregressive_loss_* / spatial_shape /
+    # focus_radius arguments configure training losses: they are stored and exported, the sampling path does not read them
     def __init__(self, preconditioner, noisesampler, noisescheduler, loss_metric="huber",
                  tag: str = "custom", has_edm_batch_norm: bool = False,
                  dynamic_loss_weight: int | None = None, extra_args: None | dict[str, Any] = None,
-                 **legacy):
+                 autoregressive_loss_steps: int = 1, autoregressive_loss_diffusion_steps: int = 100,
+                 autoregressive_loss_guidance: float = 1.0, autoregressive_loss_weights=None,
+                 autoregressive_loss_maximum_batch_size=None, autoregressive_loss_integrator=None,
+                 spatial_shape=None, focus_radius=None):
+        given = locals()
         self.preconditioner = preconditioner
         self.noisesampler = noisesampler
         self.noisescheduler = noisescheduler
@@ -56,42 +67,66 @@ class KarrasModuleConfig(object):
         self.has_edm_batch_norm = has_edm_batch_norm
         self.dynamic_loss_weight = dynamic_loss_weight
         self.extra_args = dict() if extra_args is None else extra_args
-        for k, v in legacy.items():          # autoregressive_loss_*, spatial_shape, focus_radius
-            setattr(self, k, v)
+        for k in _AR:
+            setattr(self, k, given[k])
 
     @classmethod
     def from_edm(cls, sigma_data: float = 0.5, prior_mean: float = -1.2, prior_std: float = 1.2,
                  has_edm_batch_norm: bool = False, dynamic_loss_weight: int | None = None,
-                 loss_metric="huber", **kwargs):
+                 loss_metric="huber", autoregressive_loss_steps: int = 1, autoregressive_loss_diffusion_steps: int = 100,
+                 autoregressive_loss_guidance: float = 1.0, autoregressive_loss_weights=None,
+                 autoregressive_loss_maximum_batch_size=None, autoregressive_loss_integrator=None,
+                 spatial_shape=None, focus_radius=None):
         """karrasmodule.py:96-175."""
-        extra_args = dict(sigma_data=sigma_data, prior_mean=prior_mean, prior_std=prior_std,
-                          loss_metric=loss_metric, **kwargs)
+        given = locals()
+        ar = {k: given[k] for k in _AR}
+        extra_args = dict(sigma_data=sigma_data, prior_mean=prior_mean, prior_std=prior_std, loss_metric=loss_metric, **ar)
         return cls(preconditioner=preconditioners.EDMPreconditioner(sigma_data=sigma_data),
                    noisesampler=noisesamplers.EDMNoiseSampler(sigma_data=sigma_data, prior_mean=prior_mean,
                                                               prior_std=prior_std),
                    noisescheduler=schedulers.EDMScheduler(),
                    loss_metric=loss_metric, tag="edm", has_edm_batch_norm=has_edm_batch_norm,
-                   dynamic_loss_weight=dynamic_loss_weight, extra_args=extra_args, **kwargs)
+                   dynamic_loss_weight=dynamic_loss_weight, extra_args=extra_args, **ar)
 
     @classmethod
     def from_vp(cls, beta_data: float = 19.9, beta_min: float = 0.1, epsilon_min: float = 1e-3,
-                epsilon_sampler: float = 1e-5, M: int = 1000, loss_metric="huber", **kwargs):
+                epsilon_sampler: float = 1e-5, M: int = 1000, loss_metric="huber", autoregressive_loss_steps: int = 1,
+                autoregressive_loss_diffusion_steps: int = 100, autoregressive_loss_guidance: float = 1.0,
+                autoregressive_loss_weights=None, autoregressive_loss_maximum_batch_size=None,
+                autoregressive_loss_integrator=None, spatial_shape=None, focus_radius=None):
         """karrasmodule.py:177-237."""
+        given = locals()
+        ar = {k: given[k] for k in _AR}
         noisescheduler = schedulers.VPScheduler(epsilon_min=epsilon_min, beta_data=beta_data, beta_min=beta_min)
         extra_args = dict(beta_data=beta_data, beta_min=beta_min, epsilon_min=epsilon_min,
-                          epsilon_sampler=epsilon_sampler, M=M, loss_metric=loss_metric, **kwargs)
+                          epsilon_sampler=epsilon_sampler, M=M, loss_metric=loss_metric, **ar)
         return cls(preconditioner=preconditioners.VPPreconditioner(scheduler=noisescheduler, M=M),
                    noisesampler=noisesamplers.VPNoiseSampler(noise_scheduler=noisescheduler, epsilon=epsilon_sampler),
-                   noisescheduler=noisescheduler, loss_metric=loss_metric, tag="vp", extra_args=extra_args, **kwargs)
+                   noisescheduler=noisescheduler, loss_metric=loss_metric, tag="vp", extra_args=extra_args, **ar)
 
     @classmethod
-    def from_ve(cls, sigma_min: float = 0.02, sigma_max: float = 100, loss_metric="huber", **kwargs):
+    def from_ve(cls, sigma_min: float = 0.02, sigma_max: float = 100, loss_metric="huber", autoregressive_loss_steps: int = 1,
+                autoregressive_loss_diffusion_steps: int = 100, autoregressive_loss_guidance: float = 1.0,
+                autoregressive_loss_weights=None, autoregressive_loss_maximum_batch_size=None,
+                autoregressive_loss_integrator=None, spatial_shape=None, focus_radius=None):
         """karrasmodule.py:239-290."""
-        extra_args = dict(sigma_min=sigma_min, sigma_max=sigma_max, loss_metric=loss_metric, **kwargs)
+        given = locals()
+        ar = {k: given[k] for k in _AR}
+        extra_args = dict(sigma_min=sigma_min, sigma_max=sigma_max, loss_metric=loss_metric, **ar)
         return cls(preconditioner=preconditioners.VEPreconditioner(),
                    noisesampler=noisesamplers.VENoiseSampler(sigma_min=sigma_min, sigma_max=sigma_max),
                    noisescheduler=schedulers.VEScheduler(sigma_min=sigma_min, sigma_max=sigma_max),
-                   loss_metric=loss_metric, tag="ve", extra_args=extra_args, **kwargs)
+                   loss_metric=loss_metric, tag="ve", extra_args=extra_args, **ar)
+
+    @classmethod
+    def conditionalSR3(cls, sigma_min: float = 0.02, sigma_max: float = 100, loss_metric="huber",
+                       autoregressive_loss_steps: int = 1, autoregressive_loss_diffusion_steps: int = 100,
+                       autoregressive_loss_guidance: float = 1.0, autoregressive_loss_weights=None,
+                       autoregressive_loss_maximum_batch_size=None, autoregressive_loss_integrator=None,
+                       spatial_shape=None, focus_radius=None):
+        """karrasmodule.py:292-340.  The reference's own constructor raises (it hands sigma_min / sigma_max to EDMNoiseSampler,
+        which takes neither, noisesamplers.py:21-24); the same TypeError is raised here rather than inventing a sampler."""
+        raise TypeError("EDMNoiseSampler.__init__() got an unexpected keyword argument 'sigma_min'")
 
     def export_description(self) -> dict[str, Any]:
         return dict(tag=self.tag, extra_args=self.extra_args)
@@ -120,6 +155,28 @@ class KarrasModuleConfig(object):
 
 
 class KarrasModule(torch.nn.Module, LatentSpaceAutoregressive):
+    @classmethod
+    def load_from_checkpoint(cls, checkpoint_path, map_location=None, hparams_file=None, strict=None, **kwargs):
+        """karrasmodule.py:410-429 + Lightning's loader: a ``.ckpt`` written by the reference's Trainer is a dict whose
+        "state_dict" holds this module's keys ("model.*", "edm_batch_norm.*", "autoencoder.*").  The constructor arguments come
+        from the caller (``model=``, ``config=``, ...; the reference saves no hyper-parameters, scripts/testing/*.py pass them),
+        merged over any "hyper_parameters" the file carries; ``model`` and ``config`` are deep-copied as in the reference.
+        ``hparams_file`` is accepted for signature compatibility and must be None (nothing in this path reads one)."""
+        import copy
+        if hparams_file is not None:
+            raise NotImplementedError("hparams_file: the reference's modules save no hyper-parameters to read back")
+        ckpt = torch.load(checkpoint_path, map_location="cpu" if map_location is None else map_location, weights_only=False)
+        if not isinstance(ckpt, dict) or "state_dict" not in ckpt:
+            raise KeyError(f"{checkpoint_path}: not a Lightning checkpoint (no 'state_dict' entry)")
+        init = dict(ckpt.get("hyper_parameters") or {})
+        init.update(kwargs)
+        for k in ("model", "config"):
+            if init.get(k) is not None:
+                init[k] = copy.deepcopy(init[k])
+        module = cls(**init)
+        module.load_state_dict(ckpt["state_dict"], strict=True if strict is None else bool(strict))
+        return module
+
     def __init__(self, model: torch.nn.Module, config: KarrasModuleConfig, conditional: bool = False,
                  masked: bool = False, autoencoder: None | torch.nn.Module = None,
                  autoencoder_conditional: bool = False, encode_y: bool = False,
@@ -325,12 +382,40 @@ class KarrasModule(torch.nn.Module, LatentSpaceAutoregressive):
         return self._propagate(x, y, guidance, nsteps, record_history, integrator, eps, _scale, 0, None)
 
     def propagate_partial_toward_sample(self, x, initial_step: int, final_step: int = None, y=None,
-                                        nsteps: int = 100, record_history: bool = False,
-                                        guidance: float = 1.0, integrator=None, eps=None):
-        """karrasmodule.py:933-976."""
+                                        nsteps: int = 100, record_history: bool = False, integrator=None,
+                                        analytical_score=None, interp_fn=None, guidance: float = 1.0, eps=None):
+        """karrasmodule.py:933-976.  interp_fn / analytical_score: the score handed to the integrator is
+        alpha * trained + (1 - alpha) * analytical_score(x.cpu(), sigma.cpu()) with alpha = interp_fn(sigma), evaluated step by
+        step exactly as the reference does (the analytic score is host code).  guidance, eps: extensions (keyword)."""
         final_step = nsteps if final_step is None else final_step
-        return self._propagate(x, y, guidance, nsteps, record_history, integrator, eps, None,
-                               initial_step, final_step)
+        if interp_fn is None:
+            return self._propagate(x, y, guidance, nsteps, record_history, integrator, eps, None,
+                                   initial_step, final_step)
+        if analytical_score is None:
+            raise AssertionError("interp_fn needs analytical_score")
+        yy = None if y is None else dict_unsqueeze(y, 0)
+
+        def rhs(xx, sigma):
+            trained = self.get_score(xx, sigma, yy, guidance)
+            alpha = interp_fn(sigma).unsqueeze(-1).to(trained.device).to(trained.dtype)
+            analytic = analytical_score(xx.cpu().detach(), sigma.cpu().detach()).to(trained).contiguous()
+            al = alpha.reshape(-1)
+            out = torch.empty_like(trained)
+            if bool((al == al[0]).all()):
+                return ops.axpby(trained, float(al[0]), analytic, 1.0 - float(al[0]), out=out)
+            if al.numel() != trained.shape[0]:
+                raise ValueError("interp_fn must return one weight per sample")
+            for b in range(trained.shape[0]):            # per-sample weights: one launch per sample (a diagnostic path)
+                ops.axpby(trained[b], float(al[b]), analytic[b], 1.0 - float(al[b]), out=out[b])
+            return out
+        sch = self.config.noisescheduler
+        if integrator is not None:
+            sch.set_temporary_integrator(integrator)
+        try:
+            return sch.propagate_partial(x, rhs, nsteps, initial_step, final_step, record_history=record_history)
+        finally:
+            if integrator is not None:
+                sch.unset_temporary_integrator()
 
     @ops.device_guard                              # launches go to x's GPU whatever the caller's current device is
     @torch.inference_mode()                        # sampling never differentiates; plan buffers live in one mode

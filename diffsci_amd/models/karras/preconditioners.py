@@ -65,6 +65,9 @@ class VPPreconditioner(KarrasPreconditioner):
 class VEPreconditioner(KarrasPreconditioner):
     """preconditioners.py:86-105."""
 
+    def __init__(self):
+        super().__init__()
+
     def skip_scaling(self, sigma):
         return 1 + 0.0 * sigma
 
@@ -80,6 +83,9 @@ class VEPreconditioner(KarrasPreconditioner):
 
 class NullPreconditioner(KarrasPreconditioner):
     """preconditioners.py:139-161: D = F(x, sigma)."""
+
+    def __init__(self):
+        super().__init__()
 
     def skip_scaling(self, sigma):
         return 0.0 * sigma

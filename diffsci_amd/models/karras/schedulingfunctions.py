@@ -29,6 +29,12 @@ class SchedulingFunctions(torch.nn.Module):
     def noise_fn_deriv(self, t):
         raise NotImplementedError
 
+    def pf_score_multiplier(self, t):
+        raise NotImplementedError
+
+    def pf_scale_multiplier(self, t):
+        raise NotImplementedError
+
 
 class EDMSchedulingFunctions(SchedulingFunctions):
     """schedulingfunctions.py:41-63."""

@@ -41,12 +41,15 @@ _FIELDS = dict(
 class ADMConfig(object):
     """adm.py:8-116 -- same arguments and defaults."""
 
-    def __init__(self, **kwargs):
-        unknown = set(kwargs) - set(_FIELDS)
-        if unknown:
-            raise TypeError(f"ADMConfig got unexpected arguments {sorted(unknown)}")
-        for k, default in _FIELDS.items():
-            v = kwargs.get(k, default)
+    def __init__(self, input_channels=1, output_channels=1, dimension=2, model_channels=64, time_embed_dim=64, output_embed_dim=256,
+                 channel_expansion=(2, 4), number_resnet_downward_block=2, number_resnet_upward_block=2,
+                 number_resnet_attn_block=2, number_resnet_before_attn_block=2, number_resnet_after_attn_block=2, kernel_size=3,
+                 time_projection_scale=30.0, transition_scale_factor=2, transition_kernel_size=3, dropout=0.0, cond_dropout=0.0,
+                 first_resblock_norm="GroupLN", second_resblock_norm="GroupRMS", affine_norm=True, convolution_type="default",
+                 num_groups=1, skip_integration_type="concat", attn_residual=True, decoder_type=1):
+        given = locals()                                 # positional order and defaults of the reference's constructor (adm.py:8-40)
+        for k in _FIELDS:
+            v = given[k]
             if k == "channel_expansion":
                 v = list(v)
             setattr(self, k, v)
@@ -313,6 +316,226 @@ class ADMDecoderBlock(ADMBaseBlock):
                          skip_integration_type=skip_integration_type)
 
 
+class ADMEncoderLayer(torch.nn.Module):
+    """adm.py:526-598: nblocks encoder blocks, the last one widening and down-sampling; returns (x, skip)."""
+
+    def __init__(self, channels_in: int, channels_out: int, channels_embed: int, nblocks: int = 2, conv_type: str = 'default',
+                 has_residual: bool = True, has_attn: bool = False, first_norm: str = 'GroupLN', second_norm: str = 'GroupRMS',
+                 dimension: int = 2, num_groups: int = 1, pdrop: float = 0.0, downsample_type: str = 'avg',
+                 downsample_factor: int = 2, attn_type: str = 'default', attn_heads: int = 1, attn_residual: bool = True):
+        super().__init__()
+        self.channels_in, self.channels_out, self.channels_embed, self.nblocks = channels_in, channels_out, channels_embed, nblocks
+        self.input_blocks = torch.nn.ModuleList([
+            ADMEncoderBlock(channels_in, channels_in if i != nblocks - 1 else channels_out, channels_embed, conv_type=conv_type,
+                            has_downsample=i == nblocks - 1, has_residual=has_residual, has_attn=has_attn, first_norm=first_norm,
+                            second_norm=second_norm, dimension=dimension, num_groups=num_groups, pdrop=pdrop,
+                            downsample_type=downsample_type, downsample_factor=downsample_factor, attn_type=attn_type,
+                            attn_heads=attn_heads, attn_residual=attn_residual) for i in range(nblocks)])
+
+    def forward(self, x, te):
+        for block in self.input_blocks:
+            x = block(x, te)
+        return x, x                                      # the reference hands out a clone; nothing here writes in place
+
+
+class ADMEncoder(torch.nn.Module):
+    """adm.py:602-688."""
+
+    def __init__(self, model_channels: int, channels_embed: int, channels_mult: list[int] = [1, 2, 4],
+                 nblocks_per_layer: int | list[int] = 2, conv_type: str = 'default', has_residual: bool = True,
+                 has_attn: bool | list[bool] = False, first_norm: str = 'GroupLN', second_norm: str = 'GroupRMS',
+                 dimension: int = 2, num_groups: int = 1, pdrop: float = 0.0, downsample_type: str = 'avg',
+                 downsample_factor: int | list[int] = 2, attn_type: str = 'default', attn_heads: int = 1,
+                 attn_residual: bool = True):
+        super().__init__()
+        self.model_channels, self.channels_mult, self.channels_embed = model_channels, channels_mult, channels_embed
+        n = self.nlayers
+        nblocks_per_layer = nblocks_per_layer if isinstance(nblocks_per_layer, list) else [nblocks_per_layer] * n
+        downsample_factor = downsample_factor if isinstance(downsample_factor, list) else [downsample_factor] * n
+        has_attn = has_attn if isinstance(has_attn, list) else [has_attn] * n
+        assert len(nblocks_per_layer) == n and len(downsample_factor) == n
+        self.layers = torch.nn.ModuleList([
+            ADMEncoderLayer(self.channels_in[i], self.channels_outs[i], channels_embed, nblocks=nblocks_per_layer[i],
+                            conv_type=conv_type, has_residual=has_residual, has_attn=has_attn[i], first_norm=first_norm,
+                            second_norm=second_norm, dimension=dimension, num_groups=num_groups, pdrop=pdrop,
+                            downsample_type=downsample_type, downsample_factor=downsample_factor[i], attn_type=attn_type,
+                            attn_heads=attn_heads, attn_residual=attn_residual) for i in range(n)])
+
+    def forward(self, x, te):
+        intermediate_outputs = [x]
+        for layer in self.layers:
+            x, xskip = layer(x, te)
+            intermediate_outputs.append(xskip)
+        return x, intermediate_outputs
+
+    @property
+    def channels_in(self):
+        return [self.model_channels * i for i in self.channels_mult[:-1]]
+
+    @property
+    def channels_outs(self):
+        return [self.model_channels * i for i in self.channels_mult[1:]]
+
+    @property
+    def nlayers(self):
+        return len(self.channels_mult) - 1
+
+
+class ADMDecoderLayer1(torch.nn.Module):
+    """adm.py:690-776: the skip joins once, in front of the layer."""
+
+    def __init__(self, channels_in: int, channels_out: int, channels_embed: int, channels_skip: int, nblocks: int = 2,
+                 conv_type: str = 'default', has_residual: bool = True, has_attn: bool = False, first_norm: str = 'GroupLN',
+                 second_norm: str = 'GroupRMS', dimension: int = 2, num_groups: int = 1, pdrop: float = 0.0,
+                 upsample_factor: int = 2, attn_type: str = 'default', attn_heads: int = 1, attn_residual: bool = True,
+                 skip_integration_type: str = 'concat'):
+        super().__init__()
+        self.skip_integration_type = skip_integration_type
+        cin = channels_in + channels_skip if skip_integration_type == 'concat' else channels_in
+        self.input_blocks = torch.nn.ModuleList([
+            ADMDecoderBlock(cin, cin if i != nblocks - 1 else channels_out, channels_embed, channels_skip=None,
+                            conv_type=conv_type, has_upsample=i == nblocks - 1, has_residual=has_residual, has_attn=has_attn,
+                            first_norm=first_norm, second_norm=second_norm, dimension=dimension, num_groups=num_groups,
+                            pdrop=pdrop, upsample_factor=upsample_factor, attn_type=attn_type, attn_heads=attn_heads,
+                            attn_residual=attn_residual) for i in range(nblocks)])
+
+    @ops.device_guard
+    def forward(self, x, te, skip):
+        if self.skip_integration_type == 'concat':
+            xh = ops.concat2(x.contiguous(), skip.contiguous())
+        elif self.skip_integration_type == 'add':
+            xh = ops.add(x.contiguous(), skip.contiguous())
+        else:
+            raise ValueError(f"Invalid skip integration type {self.skip_integration_type}")
+        for block in self.input_blocks:
+            xh = block(xh, te)
+        return xh
+
+
+class ADMDecoderLayer2(torch.nn.Module):
+    """adm.py:777-852: every block of the layer integrates the same skip again."""
+
+    def __init__(self, channels_in: int, channels_out: int, channels_embed: int, channels_skip: int, nblocks: int = 2,
+                 conv_type: str = 'default', has_residual: bool = True, has_attn: bool = False, first_norm: str = 'GroupLN',
+                 second_norm: str = 'GroupRMS', dimension: int = 2, num_groups: int = 1, pdrop: float = 0.0,
+                 upsample_factor: int = 2, attn_type: str = 'default', attn_heads: int = 1, attn_residual: bool = True,
+                 skip_integration_type: str = 'concat'):
+        super().__init__()
+        self.input_blocks = torch.nn.ModuleList([
+            ADMDecoderBlock(channels_in, channels_in if i != nblocks - 1 else channels_out, channels_embed,
+                            channels_skip=channels_skip, conv_type=conv_type, has_upsample=i == nblocks - 1,
+                            has_residual=has_residual, has_attn=has_attn, first_norm=first_norm, second_norm=second_norm,
+                            dimension=dimension, num_groups=num_groups, pdrop=pdrop, upsample_factor=upsample_factor,
+                            attn_type=attn_type, attn_heads=attn_heads, attn_residual=attn_residual,
+                            skip_integration_type=skip_integration_type) for i in range(nblocks)])
+
+    def forward(self, x, te, skip):
+        for block in self.input_blocks:
+            x = block(x, te, skip)
+        return x
+
+
+class ADMDecoder(torch.nn.Module):
+    """adm.py:853-956."""
+
+    def __init__(self, model_channels: int, channels_embed: int, channels_mult: list[int] = [4, 2, 1],
+                 nblocks_per_layer: int | list[int] = 2, conv_type: str = 'default', has_residual: bool = True,
+                 has_attn: bool | list[bool] = False, first_norm: str = 'GroupLN', second_norm: str = 'GroupRMS',
+                 dimension: int = 2, num_groups: int = 1, pdrop: float = 0.0, upsample_factor: int | list[int] = 2,
+                 attn_type: str = 'default', attn_heads: int = 1, attn_residual: bool = True,
+                 skip_integration_type: str = 'concat', decoder_type: int = 1):
+        super().__init__()
+        self.model_channels, self.channels_mult, self.channels_embed = model_channels, channels_mult, channels_embed
+        self.decoder_type = decoder_type
+        n = self.nlayers
+        nblocks_per_layer = nblocks_per_layer if isinstance(nblocks_per_layer, list) else [nblocks_per_layer] * n
+        upsample_factor = upsample_factor if isinstance(upsample_factor, list) else [upsample_factor] * n
+        has_attn = has_attn if isinstance(has_attn, list) else [has_attn] * n
+        assert len(nblocks_per_layer) == n and len(upsample_factor) == n and len(has_attn) == n
+        self.layers = torch.nn.ModuleList([
+            self.decoder_fn(channels_in=self.channels_ins[i], channels_out=self.channels_outs[i], channels_embed=channels_embed,
+                            channels_skip=self.channels_ins[i], nblocks=nblocks_per_layer[i], conv_type=conv_type,
+                            has_residual=has_residual, has_attn=has_attn[i], first_norm=first_norm, second_norm=second_norm,
+                            dimension=dimension, num_groups=num_groups, pdrop=pdrop, upsample_factor=upsample_factor[i],
+                            attn_type=attn_type, attn_heads=attn_heads, attn_residual=attn_residual,
+                            skip_integration_type=skip_integration_type) for i in range(n)])
+
+    def forward(self, x, te, intermediate_outputs, pop=True):
+        for i, layer in enumerate(self.layers):
+            h = intermediate_outputs.pop() if pop else intermediate_outputs[-(i + 1)]
+            x = layer(x, te, h)
+        return x
+
+    @property
+    def decoder_fn(self):
+        if self.decoder_type == 1:
+            return ADMDecoderLayer1
+        if self.decoder_type == 2:
+            return ADMDecoderLayer2
+        raise ValueError(f"Invalid decoder type {self.decoder_type}")
+
+    @property
+    def channels_ins(self):
+        return [self.model_channels * i for i in self.channels_mult[:-1]]
+
+    @property
+    def channels_outs(self):
+        return [self.model_channels * i for i in self.channels_mult[1:]]
+
+    @property
+    def nlayers(self):
+        return len(self.channels_mult) - 1
+
+
+class ADMMiddleBlock(torch.nn.Module):
+    """adm.py:958-1011: nblocks same-width encoder blocks, attention in all but the last by default."""
+
+    def __init__(self, channels: int, channels_embed: int, nblocks: int = 2, conv_type: str = 'default',
+                 has_residual: bool = True, has_attn: bool | list[bool] | str = 'default', first_norm: str = 'GroupLN',
+                 second_norm: str = 'GroupRMS', dimension: int = 2, num_groups: int = 1, pdrop: float = 0.0,
+                 attn_type: str = 'default', attn_heads: int = 1, attn_residual: bool = True):
+        super().__init__()
+        if isinstance(has_attn, str):
+            if has_attn != 'default':
+                raise ValueError(f"Invalid has_attn {has_attn}")
+            has_attn = [True] * (nblocks - 1) + [False]
+        if not isinstance(has_attn, list):
+            has_attn = [has_attn] * nblocks
+        assert len(has_attn) == nblocks
+        self.middle_blocks = torch.nn.ModuleList([
+            ADMEncoderBlock(channels, channels, channels_embed, conv_type=conv_type, has_downsample=False,
+                            has_residual=has_residual, has_attn=has_attn[i], first_norm=first_norm, second_norm=second_norm,
+                            dimension=dimension, num_groups=num_groups, pdrop=pdrop, attn_type=attn_type,
+                            attn_heads=attn_heads, attn_residual=attn_residual) for i in range(nblocks)])
+
+    def forward(self, x, te):
+        for block in self.middle_blocks:
+            x = block(x, te)
+        return x
+
+
+class ADMTimeEmbedding(torch.nn.Module):
+    """adm.py:1014-1053: SiLU(mlp(fourier(t)) + ye).  State-dict keys projection.W, mlp.{0,2}.{weight,bias}."""
+
+    def __init__(self, embed_dim: int, output_dim: int, projection_scale: float = 30.0):
+        super().__init__()
+        self.projection = _Fourier(embed_dim, projection_scale)
+        self.mlp = torch.nn.Sequential(torch.nn.Linear(embed_dim, output_dim), torch.nn.Identity(),
+                                       torch.nn.Linear(output_dim, output_dim))
+
+    @ops.device_guard
+    def forward(self, t, ye=None):
+        ops.require_device(t, "t")
+        if ye is not None and ye.shape[0] not in (1, t.numel()):
+            raise ValueError("conditional embedding batch must be 1 or match t")
+        f = ops.fourier_features(t.contiguous(), self.projection.W)
+        h = ops.linear(f, self.mlp[0].weight, self.mlp[0].bias, act=1)
+        if ye is None:
+            return ops.linear(h, self.mlp[2].weight, self.mlp[2].bias, act=1)
+        h = ops.linear(h, self.mlp[2].weight, self.mlp[2].bias, act=0)
+        return ops.add_act(h, ye.to(h).contiguous(), act=1)
+
+
 class _Layer(torch.nn.Module):
     def __init__(self, blocks):
         super().__init__()
@@ -331,16 +554,6 @@ class _Middle(torch.nn.Module):
         self.middle_blocks = torch.nn.ModuleList(blocks)
 
 
-class _TimeEmbedding(torch.nn.Module):
-    """ADMTimeEmbedding parameters (adm.py:1014-1045)."""
-
-    def __init__(self, embed_dim, output_dim, scale):
-        super().__init__()
-        self.projection = _Fourier(embed_dim, scale)
-        self.mlp = torch.nn.Sequential(torch.nn.Linear(embed_dim, output_dim), torch.nn.Identity(),
-                                       torch.nn.Linear(output_dim, output_dim))
-
-
 class ADM(torch.nn.Module):
     def __init__(self, config: ADMConfig, conditional_embedding: torch.nn.Module | None = None):
         super().__init__()
@@ -351,7 +564,7 @@ class ADM(torch.nn.Module):
         self.conditional_embedding = conditional_embedding
         mc, ce = config.model_channels, config.output_embed_dim
         mult = config.extended_channel_expansion
-        self.time_embedding = _TimeEmbedding(config.time_embed_dim, ce, config.time_projection_scale)
+        self.time_embedding = ADMTimeEmbedding(config.time_embed_dim, ce, config.time_projection_scale)
         circ = config.convolution_type == "circular"           # the blocks' convolutions; input/output layers stay zero-padded
         # ADMConfig.affine_norm never reaches the blocks in the reference (ADMEncoder / ADMMiddleBlock / ADMDecoder do
         # not forward it, adm.py:455-520,540-834): the norms are always affine, and checkpoints carry their weights
@@ -437,15 +650,7 @@ class ADM(torch.nn.Module):
 
     def embed_time(self, t, ye=None):
         """ADMTimeEmbedding.forward (adm.py:1047-1053) -> [M, output_embed_dim]."""
-        te = self.time_embedding
-        if ye is not None and ye.shape[0] not in (1, t.numel()):
-            raise ValueError("conditional embedding batch must be 1 or match t")
-        f = ops.fourier_features(t.contiguous(), te.projection.W)
-        h = ops.linear(f, te.mlp[0].weight, te.mlp[0].bias, act=1)
-        if ye is None:
-            return ops.linear(h, te.mlp[2].weight, te.mlp[2].bias, act=1)
-        h = ops.linear(h, te.mlp[2].weight, te.mlp[2].bias, act=0)
-        return ops.add_act(h, ye, act=1)
+        return self.time_embedding(t, ye)
 
     def time_shifts(self, te):
         """Per-block embed_linear(te) (adm.py:333-334): list of [M, 2*C_out] FiLM rows."""

@@ -368,34 +368,13 @@ class PUNetG(torch.nn.Module):
         self.norm_kinds = tuple(NORM_KINDS.get(n, 2) for n in norms)
         # bias=False: no convolution biases; a constant-one input channel is appended instead (punetg.py:190-191,390-394)
         dim = self.dim = config.dimension
-        if config.in_embedding:                           # fixed Fourier input embedding instead of a convolution, punetg.py:194-202
-            self.convin = _FourierInput(config.input_channels + (0 if hb else 1), mc, config.input_projection_scale)
-        else:
-            self.convin = make_conv(config.input_channels + (0 if hb else 1), mc, config.in_out_kernel_size, circ, hb, dim)
-        self.convout = make_conv(mc, config.output_channels, config.in_out_kernel_size, circ, hb, dim)
-        kres, ktr = config.kernel_size, config.transition_kernel_size
-
-        def blocks(m, n):
-            bl = [_ResBlock(m * mc, mc, circ, hb, norms, bool(config.affine_norm), dim, kres) for _ in range(n)]
-            if extra_residual is not None:
-                for b in bl:
-                    b.extra_residual = extra_residual          # the reference registers the shared module in every block
-            return torch.nn.ModuleList(bl)
-
-        self.downward_blocks = torch.nn.ModuleList(
-            [blocks(mult[i], config.number_resnet_downward_block) for i in range(len(mult) - 1)])
-        self.downsamplers = torch.nn.ModuleList(
-            [_Sampler(mult[i] * mc, mult[i + 1] * mc, circ, hb, dim, ktr) for i in range(len(mult) - 1)])
-        rmult = list(reversed(mult))
-        self.upward_blocks = torch.nn.ModuleList(
-            [blocks(rmult[i + 1], config.number_resnet_upward_block) for i in range(len(mult) - 1)])
-        self.upsamplers = torch.nn.ModuleList(
-            [_Sampler(rmult[i] * mc, rmult[i + 1] * mc, circ, hb, dim, ktr) for i in range(len(mult) - 1)])
-        self.before_block = blocks(mult[-1], config.number_resnet_before_attn_block)
-        self.after_block = blocks(mult[-1], config.number_resnet_after_attn_block)
-        self.attn_resnet_block = blocks(mult[-1], config.number_resnet_attn_block)
-        self.attn_block = torch.nn.ModuleList(
-            [_Attn(mult[-1] * mc, self.mp, self.cosine_attn) for _ in range(config.number_resnet_attn_block - 1)])
+        # the reference's construction sequence and builder names (punetg.py:94-106); the builders return parameter CONTAINERS
+        # with the reference's state_dict keys -- the tensor work is in forward_with_shifts
+        self.convin, self.convout = self.make_convin_and_convout()
+        self.downward_blocks, self.downsamplers = self.make_downward_blocks()
+        self.upward_blocks, self.upsamplers = self.make_upward_blocks()
+        self.before_block, self.after_block = self.make_non_attn_bottom_blocks()
+        self.attn_resnet_block, self.attn_block = self.make_attn_bottom_blocks()
         # Arithmetic of the 3x3 convolutions -- all three give fp32-level error (tests/test_gpu_kernels.py):
         #   "fp16x3": fp16 hi+lo split, 3 MFMA products (default; inputs must stay below 65504 in magnitude)
         #   "bf16x6": exact 3-way bf16 split, 6 MFMA products (no range limit, half the speed)
@@ -422,6 +401,136 @@ class PUNetG(torch.nn.Module):
         self._window_cache = {}
         # set by precision.escalate_input when the input's channels differ by more than 2^14 in magnitude within a sample
         self.exact_input_layer = False
+
+    # ------------------------------------------------------------------ builders (punetg.py:122-334: same names and arguments)
+    def choose_conv_cls(self):
+        """punetg.py:217-236: the convolution constructor of this configuration -- here a callable
+        (in_channels, out_channels, kernel_size, bias=True) that builds the parameter container of that convolution type."""
+        if self.config.dimension not in (2, 3):
+            raise NotImplementedError("1D convolution not implemented yet") if self.config.dimension == 1 \
+                else ValueError(f"Invalid dimension {self.config.dimension}")
+        kind, dim = self.config.convolution_type, self.config.dimension
+
+        def conv_cls(in_channels, out_channels, kernel_size, bias=True, **_):
+            return make_conv(in_channels, out_channels, kernel_size, kind, bias, dim)
+        return conv_cls
+
+    def make_convin_and_convout(self):
+        """punetg.py:188-215.  bias=False: no convolution biases; a constant-one input channel is appended instead."""
+        c = self.config
+        conv_cls = self.choose_conv_cls()
+        cin = c.input_channels + (0 if c.bias else 1)
+        if c.in_embedding:                               # fixed Fourier input embedding instead of a convolution, punetg.py:194-202
+            convin = _FourierInput(cin, c.model_channels, c.input_projection_scale)
+        else:
+            convin = conv_cls(cin, c.model_channels, c.in_out_kernel_size, bias=bool(c.bias))
+        convout = conv_cls(c.model_channels, c.output_channels, c.in_out_kernel_size, bias=bool(c.bias))
+        return convin, convout
+
+    def resnet_fn(self, input_multiplier: int):
+        """punetg.py:238-261: one ResnetBlockC's parameters."""
+        c = self.config
+        blk = _ResBlock(input_multiplier * c.model_channels, c.model_channels, c.convolution_type, bool(c.bias),
+                        (c.first_resblock_norm, c.second_resblock_norm), bool(c.affine_norm), c.dimension, c.kernel_size)
+        if self.extra_residual is not None:
+            blk.extra_residual = self.extra_residual        # the reference registers the shared module in every block
+        return blk
+
+    def resnet_block_fn(self, input_multiplier: int, number_resnet_per_block: int):
+        return torch.nn.ModuleList([self.resnet_fn(input_multiplier) for _ in range(number_resnet_per_block)])
+
+    def attn_fn(self, input_multiplier: int):
+        """punetg.py:272-289."""
+        if self.config.dimension not in (2, 3):
+            raise NotImplementedError("1D attention not implemented yet") if self.config.dimension == 1 \
+                else ValueError(f"Invalid dimension {self.config.dimension}")
+        return _Attn(input_multiplier * self.config.model_channels, self.config.magnitude_preserving,
+                     self.config.attn_type == "cosine")
+
+    def attn_block_fn(self, input_multiplier: int, number_resnet_attn_block: int):
+        return torch.nn.ModuleList([self.attn_fn(input_multiplier) for _ in range(number_resnet_attn_block - 1)])
+
+    def downsampler_fn(self, input_multiplier: int, output_multiplier: int):
+        """punetg.py:300-316: DownSampler (max-pool, then convolution)."""
+        c = self.config
+        return _Sampler(input_multiplier * c.model_channels, output_multiplier * c.model_channels, c.convolution_type,
+                        bool(c.bias), c.dimension, c.transition_kernel_size)
+
+    def upsampler_fn(self, input_multiplier: int, output_multiplier: int):
+        """punetg.py:318-334: UpSampler (nearest upsampling, then convolution): the same parameters as a DownSampler."""
+        return self.downsampler_fn(input_multiplier, output_multiplier)
+
+    def make_downward_blocks(self):
+        mult = self.config.extended_channel_expansion
+        blocks, samplers = torch.nn.ModuleList(), torch.nn.ModuleList()
+        for i, m in enumerate(mult[:-1]):
+            blocks.append(self.resnet_block_fn(m, self.config.number_resnet_downward_block))
+            samplers.append(self.downsampler_fn(m, mult[i + 1]))
+        return blocks, samplers
+
+    def make_upward_blocks(self):
+        rmult = list(reversed(self.config.extended_channel_expansion))
+        blocks, samplers = torch.nn.ModuleList(), torch.nn.ModuleList()
+        for i, m in enumerate(rmult[:-1]):
+            samplers.append(self.upsampler_fn(m, rmult[i + 1]))
+            blocks.append(self.resnet_block_fn(rmult[i + 1], self.config.number_resnet_upward_block))
+        return blocks, samplers
+
+    def make_non_attn_bottom_blocks(self):
+        m = self.config.extended_channel_expansion[-1]
+        return (self.resnet_block_fn(m, self.config.number_resnet_before_attn_block),
+                self.resnet_block_fn(m, self.config.number_resnet_after_attn_block))
+
+    def make_attn_bottom_blocks(self):
+        m, n = self.config.extended_channel_expansion[-1], self.config.number_resnet_attn_block
+        return self.resnet_block_fn(m, n), self.attn_block_fn(m, n)
+
+    def calculate_receptive_field(self) -> dict:
+        """punetg.py:423-628: theoretical receptive field of the network in input pixels.  A convolution of size k at cumulative
+        stride s widens it by (k - 1) s, a residual block by twice that, a max-pool of size p by (p - 1) s before multiplying
+        the stride by p; nearest upsampling only divides the stride; global attention makes it infinite."""
+        c = self.config
+        trace = []
+        n_attn = c.number_resnet_attn_block - 1
+        if n_attn > 0:
+            trace.append(f"{n_attn} global attention layer(s): every output pixel sees every input pixel")
+            return {'rf': float('inf'), 'has_attention': True, 'num_attention_layers': n_attn, 'trace': trace,
+                    'feasible_chunking': False,
+                    'config_summary': {'number_resnet_attn_block': c.number_resnet_attn_block, 'kernel_size': c.kernel_size,
+                                       'in_out_kernel_size': c.in_out_kernel_size, 'channel_expansion': c.channel_expansion}}
+        rf, stride = 1, 1
+
+        def widen(k, name, times=1):
+            nonlocal rf
+            rf += times * (k - 1) * stride
+            trace.append(f"{name}: {times} x (k = {k}) at stride {stride} -> {rf}")
+        if c.in_embedding:
+            trace.append("convin is a per-pixel Fourier embedding: unchanged")
+        else:
+            widen(c.in_out_kernel_size, "convin")
+        levels = len(c.channel_expansion)
+        for lv in range(levels):
+            for b in range(c.number_resnet_downward_block):
+                widen(c.kernel_size, f"down[{lv}].resnet[{b}]", 2)
+            widen(c.transition_scale_factor, f"down[{lv}].maxpool")
+            stride *= c.transition_scale_factor
+            widen(c.transition_kernel_size, f"down[{lv}].conv")
+        for name, n in (("before_block", c.number_resnet_before_attn_block), ("attn_resnet_block", c.number_resnet_attn_block),
+                        ("after_block", c.number_resnet_after_attn_block)):
+            for b in range(n):
+                widen(c.kernel_size, f"{name}[{b}]", 2)
+        for lv in range(levels - 1, -1, -1):
+            stride //= c.transition_scale_factor
+            widen(c.transition_kernel_size, f"up[{lv}].conv")
+            for b in range(c.number_resnet_upward_block):
+                widen(c.kernel_size, f"up[{lv}].resnet[{b}]", 2)
+        widen(c.in_out_kernel_size, "convout")
+        return {'rf': rf, 'has_attention': False, 'num_attention_layers': 0, 'trace': trace, 'feasible_chunking': True,
+                'downsampling_factor': c.transition_scale_factor ** levels,
+                'config_summary': {k: getattr(c, k) for k in (
+                    'number_resnet_attn_block', 'number_resnet_downward_block', 'number_resnet_upward_block',
+                    'number_resnet_before_attn_block', 'number_resnet_after_attn_block', 'kernel_size', 'in_out_kernel_size',
+                    'transition_kernel_size', 'transition_scale_factor', 'channel_expansion')}}
 
     # ------------------------------------------------------------------ reference surface
     def export_description(self) -> dict[str, Any]:

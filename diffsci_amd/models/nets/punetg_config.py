@@ -22,12 +22,17 @@ _FIELDS = dict(
 
 
 class PUNetGConfig(object):
-    def __init__(self, **kwargs):
-        unknown = set(kwargs) - set(_FIELDS)
-        if unknown:
-            raise TypeError(f"PUNetGConfig got unexpected arguments {sorted(unknown)}")
-        for k, default in _FIELDS.items():
-            v = kwargs.get(k, default)
+    # positional order and defaults of the reference's constructor (punetg_config.py:8-38)
+    def __init__(self, input_channels=1, output_channels=1, dimension=2, model_channels=64, channel_expansion=(2, 4),
+                 number_resnet_downward_block=2, number_resnet_upward_block=2, number_resnet_attn_block=2,
+                 number_resnet_before_attn_block=2, number_resnet_after_attn_block=2, kernel_size=3, in_out_kernel_size=3,
+                 in_embedding=False, time_projection_scale=30.0, input_projection_scale=1.0, transition_scale_factor=2,
+                 transition_kernel_size=3, dropout=0.0, cond_dropout=0.0, cond_drop=0.0, cond_drop_learnable=True,
+                 first_resblock_norm="GroupLN", second_resblock_norm="GroupRMS", affine_norm=True, convolution_type="default",
+                 num_groups=1, attn_residual=False, attn_type="default", bias=True):
+        given = locals()
+        for k in _FIELDS:
+            v = given[k]
             if k == "channel_expansion":
                 v = list(v)
             setattr(self, k, v)

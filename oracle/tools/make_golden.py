@@ -965,7 +965,130 @@ def latent():
     npz("latent8", **arrs)
 
 
+# ---------------------------------------------------------------- API surface of the mirrored classes
+SURFACE_CLASSES = {      # module (under diffsci.models) -> classes
+    "karras.karrasmodule": ["KarrasModule", "KarrasModuleConfig"],
+    "karras.flowfield": ["SIModule", "SIModuleConfig", "SIScheduler"],
+    "karras.schedulers": ["Scheduler", "EDMScheduler", "VPScheduler", "VEScheduler"],
+    "karras.integrators": ["Integrator", "EulerIntegrator", "HeunIntegrator", "EulerMaruyamaIntegrator", "KarrasIntegrator"],
+    "karras.preconditioners": ["KarrasPreconditioner", "EDMPreconditioner", "NullPreconditioner", "SR3Preconditioner",
+                               "VPPreconditioner", "VEPreconditioner"],
+    "karras.noisesamplers": ["NoiseSampler", "EDMNoiseSampler", "VPNoiseSampler", "VENoiseSampler", "UniformNoiseSampler"],
+    "karras.schedulingfunctions": ["SchedulingFunctions", "EDMSchedulingFunctions", "VPSchedulingFunctions",
+                                   "VESchedulingFunctions"],
+    "karras.autoregressivesample": ["LatentSpaceAutoregressive"],
+    "nets.punetg": ["PUNetG", "PUNetGCond"],
+    "nets.punetg_config": ["PUNetGConfig"],
+    "nets.adm": ["ADM", "ADMConfig", "ADMBaseBlock", "ADMEncoderBlock", "ADMDecoderBlock", "ADMEncoder", "ADMDecoder",
+                 "ADMMiddleBlock", "ADMTimeEmbedding"],
+    "nets.mlp": ["MLPUncond", "MLPCond"],
+    "nets.embedder": ["PorosityEmbedder"],
+}
+SURFACE_FUNCTIONS = {"karras.integrators": ["name_to_integrator"], "karras.schedulingfunctions": ["name_to_scheduling_functions"]}
+
+
+def _default_repr(v):
+    import inspect
+    if v is inspect.Parameter.empty:
+        return "<required>"
+    if v is None or isinstance(v, (bool, int, float, str)):
+        return v
+    if isinstance(v, (list, tuple)) and all(x is None or isinstance(x, (bool, int, float, str)) for x in v):
+        return list(v)
+    return "<" + type(v).__name__ + ">"
+
+
+def _signature(fn):
+    import inspect
+    out = []
+    for name, p in inspect.signature(fn).parameters.items():
+        if name == "self":
+            continue
+        out.append([name, p.kind.name, _default_repr(p.default)])
+    return out
+
+
+def api_surface():
+    """class -> {method -> [[parameter, kind, default], ...]} for every public method the reference's classes define themselves
+    (torch.nn.Module / Lightning machinery excluded), plus the module-level factory functions.  Data only: names and defaults."""
+    import inspect
+    import json
+    import importlib
+    surface = {"classes": {}, "functions": {}, "exports": {}}
+    wanted = set()
+    for ns, names in SURFACE_CLASSES.items():
+        mod = importlib.import_module("diffsci.models." + ns)
+        for cname in names:
+            cls = getattr(mod, cname)
+            wanted.add(cname)
+            methods = {}
+            for klass in cls.__mro__:
+                if not klass.__module__.startswith("diffsci."):
+                    continue
+                for mname, obj in vars(klass).items():
+                    if mname.startswith("_") and mname != "__init__":
+                        continue
+                    if mname in methods:
+                        continue                       # the most derived definition wins
+                    kind = "method"
+                    if isinstance(obj, staticmethod):
+                        obj, kind = obj.__func__, "staticmethod"
+                    elif isinstance(obj, classmethod):
+                        obj, kind = obj.__func__, "classmethod"
+                    elif isinstance(obj, property):
+                        methods[mname] = {"kind": "property"}
+                        continue
+                    if not inspect.isfunction(obj):
+                        continue
+                    sig = _signature(obj)
+                    if kind == "classmethod" and sig and sig[0][0] == "cls":
+                        sig = sig[1:]
+                    methods[mname] = {"kind": kind, "params": sig}
+            surface["classes"][ns + "." + cname] = {
+                "bases": [b.__name__ for b in cls.__mro__[1:] if b.__module__.startswith("diffsci.")], "methods": methods}
+    for ns, names in SURFACE_FUNCTIONS.items():
+        mod = importlib.import_module("diffsci.models." + ns)
+        for fname in names:
+            wanted.add(fname)
+            surface["functions"][ns + "." + fname] = _signature(getattr(mod, fname))
+    # which of those names the package namespaces re-export
+    for ns in ("", "karras", "nets"):
+        mod = importlib.import_module("diffsci.models" + ("." + ns if ns else ""))
+        surface["exports"][ns] = sorted(n for n in wanted if hasattr(mod, n))
+    path = os.path.join(OUT, "api_surface.json")
+    with open(path, "w") as f:
+        json.dump(surface, f, indent=1, sort_keys=True)
+    print(f"api_surface: {os.path.getsize(path)/1024:.1f} KiB, {len(surface['classes'])} classes")
+
+
+# ---------------------------------------------------------------- a Lightning-format checkpoint (karrasmodule.py:410-429)
+def checkpoint():
+    """What a reference user holds: a .ckpt written by Lightning's Trainer -- a dict whose "state_dict" carries the module's
+    keys ("model.*", "edm_batch_norm.*").  Written here from a reference KarrasModule in that format (Lightning itself is absent
+    from the image: the dict layout is its documented one), next to what the reference samples from those weights."""
+    torch.manual_seed(120)
+    cfg = M.nets.PUNetGConfig(model_channels=8)
+    net = M.nets.PUNetG(cfg).eval()
+    with torch.no_grad():
+        for k, v in net.state_dict().items():
+            if "gnorm" in k:
+                v.add_(0.25 * torch.randn_like(v))
+    module = M.KarrasModule(net, M.KarrasModuleConfig.from_edm(has_edm_batch_norm=True)).eval()
+    module.edm_batch_norm.running_mean = torch.tensor([0.15])
+    module.edm_batch_norm.running_var = torch.tensor([1.7])
+    ckpt = {"epoch": 3, "global_step": 1234, "pytorch-lightning_version": "2.2.0",
+            "state_dict": {k: v.clone() for k, v in module.state_dict().items()},
+            "loops": {}, "callbacks": {}, "optimizer_states": [], "lr_schedulers": [], "hyper_parameters": {}}
+    path = os.path.join(OUT, "ckpt8_lightning.ckpt")
+    torch.save(ckpt, path)
+    print(f"ckpt8_lightning.ckpt: {os.path.getsize(path)/1024:.1f} KiB, {len(ckpt['state_dict'])} tensors")
+    torch.manual_seed(121)
+    wn = torch.randn(2, 1, 32, 32)
+    npz("ckpt8", white_noise=wn, sample_N4=module.propagate_white_noise(wn, nsteps=4),
+        keys=np.array(sorted(ckpt["state_dict"])))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["schedule", "toy", "punetg", "porosity", "inpaint", "vpve", "circular", "si", "punetgcond", "langevin", "adm", "variants", "latent", "adm_norms", "autoregressive", "si_latent", "si_inpaint", "volumes", "si_generic", "vp_karras", "adm_blocks", "spatial_cond"]
+    which = sys.argv[1:] or ["schedule", "toy", "punetg", "porosity", "inpaint", "vpve", "circular", "si", "punetgcond", "langevin", "adm", "variants", "latent", "adm_norms", "autoregressive", "si_latent", "si_inpaint", "volumes", "si_generic", "vp_karras", "adm_blocks", "spatial_cond", "api_surface", "checkpoint"]
     for name in which:
         globals()[name]()
