@@ -43,6 +43,56 @@ def host_cores():
     return max(1, min(n, 16))
 
 
+def _stats(ms):
+    v = sorted(ms)
+    return {"min": round(v[0], 3), "median": round(v[len(v) // 2] if len(v) % 2 else 0.5 * (v[len(v) // 2 - 1] + v[len(v) // 2]), 3),
+            "max": round(v[-1], 3)}
+
+
+def gpu_state(dev_index=0):
+    """Shader clock (the starred pp_dpm_sclk level, MHz) and board power (hwmon power1_average, W) of the device this rank runs on, read
+    from sysfs in Python -- no tool is launched.  None where the box does not show them.  (MI355X_MICROARCH.md, DVFS give-back: the
+    in-kernel clock under dense MFMA can sit up to 10 % below pp_dpm_sclk, so this explains box-to-box spread, it does not replace stamps.)"""
+    import glob
+    out = {"sclk_mhz": None, "power_w": None, "power_cap_w": None}
+    try:
+        want = None
+        try:
+            pr = torch.cuda.get_device_properties(dev_index)
+            want = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+        except Exception:
+            pass
+        cards = []
+        for d in sorted(glob.glob("/sys/class/drm/card[0-9]*/device")):
+            if not os.path.exists(os.path.join(d, "pp_dpm_sclk")):
+                continue
+            slot = ""
+            try:
+                for ln in open(os.path.join(d, "uevent")):
+                    if ln.startswith("PCI_SLOT_NAME="):
+                        slot = ln.strip().split("=", 1)[1].lower()
+            except Exception:
+                pass
+            cards.append((d, slot))
+        pick = next((d for d, slot in cards if want and slot == want), None) or (cards[dev_index][0] if dev_index < len(cards) else None)
+        if pick is None:
+            return out
+        for ln in open(os.path.join(pick, "pp_dpm_sclk")):
+            if "*" in ln:
+                out["sclk_mhz"] = int("".join(ch for ch in ln.split(":")[1] if ch.isdigit()))
+        for h in glob.glob(os.path.join(pick, "hwmon", "hwmon*")):
+            for key, name in (("power_w", "power1_average"), ("power_w", "power1_input"), ("power_cap_w", "power1_cap")):
+                f = os.path.join(h, name)
+                if out[key] is None and os.path.exists(f):
+                    try:
+                        out[key] = round(int(open(f).read().strip()) / 1e6, 1)
+                    except Exception:
+                        pass
+    except Exception:
+        pass
+    return out
+
+
 def conv_flops(B, Cin, Cout, H, W, ks):
     return 2.0 * B * Cout * Cin * ks * ks * H * W
 
@@ -212,13 +262,13 @@ def dominant_kernel_roofline(module, args, dev, reps=40):
     ms = e0.elapsed_time(e1) / reps
     n = len(launches)
     kname, peak = {
-        "fp16x3": ("k_conv3h<PLAIN> (ds_conv2d_h3 / ds_conv2d_h3_img, 3x3, fp32 via 3 fp16 MFMA products"
+        "fp16x3": ("k_conv3h<PLAIN> / k_conv3p (ds_conv2d_h3 / ds_conv2d_h3_img, 3x3, fp32 via 3 fp16 MFMA products; the level-0 fused-loader launches as persistent producer / consumer workgroups"
                    + (", norm+SiLU in the loader or pre-split image input, tile statistics in the epilogue)" if fused else ")"), BF16_PEAK_TFLOPS / 3.0),
         "bf16x6": ("k_conv6<PLAIN> (ds_conv2d_x6, 3x3, fp32 via 6 bf16 MFMA products)", BF16_PEAK_TFLOPS / 6.0),
         "fp32": ("k_conv<3,PLAIN> (ds_conv2d 3x3, exact-fp32 MFMA)", MFMA_F32_PEAK_TFLOPS)}[net.conv_precision]
     achieved = flops / (ms * 1e-3) / 1e12
     traffic = None
-    tpath = next((q for q in (os.path.join(ROOT, "profiles", f"{r}_dominant_kernel_traffic.json") for r in ("r03", "r02", "r01"))
+    tpath = next((q for q in (os.path.join(ROOT, "profiles", f"{r}_dominant_kernel_traffic.json") for r in ("r04", "r03", "r02", "r01"))
                   if os.path.exists(q)), "")
     if os.path.exists(tpath):
         try:
@@ -399,6 +449,61 @@ class _FlopCounter:
         return False
 
 
+def adm_conv_roofline(net, B, S, dev, reps=6):
+    """Event-timed launch set of config 3's dominant kernel family (the fp16x3 3x3 convolutions): conv2 of every residual block --
+    Cout -> Cout at the block's output resolution, with the loader the network uses at that width (norm + SiLU folded into the
+    loader up to fuse_max_cot channel tiles, plain above), tile statistics where folded -- against its algorithmic FLOPs."""
+    from diffsci_amd import ops
+    pk = net.packed_weights()
+    launches, side = [], S
+    mult = net.config.extended_channel_expansion
+    nb_d, nb_u = net.config.number_resnet_downward_block, net.config.number_resnet_upward_block
+    sides = []
+    for i in range(len(mult) - 1):                               # encoder layer i: nb - 1 blocks at `side`, the last one halves it
+        sides += [side] * (nb_d - 1) + [side // 2]
+        side //= 2
+    sides += [side] * net.config.num_blocks_middle_block
+    for i in range(len(mult) - 1):                               # decoder layer: the last block doubles
+        sides += [side] * (nb_u - 1) + [side * 2]
+        side *= 2
+    blocks = list(net._blocks())
+    assert len(blocks) == len(sides)
+    bufs, tabs, stats, outs = {}, {}, {}, {}
+    for blk, sd_ in zip(blocks, sides):
+        co = blk.conv2.out_channels
+        fold = net._fused() and (co + 63) // 64 <= net.fuse_max_cot
+        key = (co, sd_)
+        if key not in bufs:
+            bufs[key] = torch.randn(B, co, sd_, sd_, device=dev)
+            outs[key] = torch.empty(B, co, sd_, sd_, device=dev)
+            t = torch.zeros(B, ops.table_channels(co), 4, device=dev)
+            t[:, :co, 1] = 1.0
+            t[:, :, 3] = 2.0 ** -10
+            tabs[key] = t
+            stats[key] = torch.empty(B, co, ops.conv_tile_count(sd_, sd_), 4, device=dev)
+        launches.append((blk.conv2, co, sd_, fold))
+    flops = sum(conv_flops(B, co, co, sd_, sd_, 3) for _, co, sd_, _ in launches)
+
+    def run():
+        for m, co, sd_, fold in launches:
+            k = (co, sd_)
+            ops.conv(bufs[k], pk[id(m)], bias=m.bias, prenorm=tabs[k] if fold else None, tile_stats=stats[k] if fold else None,
+                     in_amax=None if fold else ops.NORMALISED, out=outs[k])
+    run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    ach, peak = flops / (ms * 1e-3) / 1e12, BF16_PEAK_TFLOPS / 3.0
+    return {"bound": "mfma", "kernel": "k_conv3h<PLAIN> (ds_conv2d_h3: conv2 of every ADM residual block, folded norm + SiLU loader where the network folds)",
+            "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+            "launches": len(launches), "avg_launch_ms": round(ms / len(launches), 4)}
+
+
 def other_configs(dev):
     """BASELINE.json configs[2] and configs[4] (one GPU's share) on this box, after the timed region: one capture run and ONE
     timed run each (the driver sees them next to the headline; tools/bench_adm.py / bench_cfg5.py are the stand-alone forms).
@@ -408,17 +513,22 @@ def other_configs(dev):
     from diffsci_amd import ops
     out = {}
 
+    REPLAYS = 3
+
     def timed(module, wn, evals, **kw):
         t0 = time.perf_counter()
         o = module.propagate_white_noise(wn, **kw)                  # eager pass + capture + first replay
         torch.cuda.synchronize()
         first = time.perf_counter() - t0
-        t0 = time.perf_counter()
-        o = module.propagate_white_noise(wn, **kw)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
+        dts = []
+        for _ in range(REPLAYS):
+            t0 = time.perf_counter()
+            o = module.propagate_white_noise(wn, **kw)
+            torch.cuda.synchronize()
+            dts.append(time.perf_counter() - t0)
         assert bool(torch.isfinite(o).all())
-        return dt, first
+        dts.sort()
+        return dts[len(dts) // 2], first, dts
 
     def price(net, x, t, y, dt, evals, per_eval_batch):
         with torch.inference_mode(), _FlopCounter(ops) as fc:
@@ -436,10 +546,11 @@ def other_configs(dev):
         module = M.KarrasModule(net, M.KarrasModuleConfig.from_edm()).to(dev).eval()
         wn = torch.randn(B, 3, S, S, device=dev)
         evals = 2 * N - 1
-        dt, first = timed(module, wn, evals, nsteps=N, integrator="karras")
+        dt, first, dts = timed(module, wn, evals, nsteps=N, integrator="karras")
         out["config3_adm128"] = {
             "workload": f"ADM-{c} (concat skips, attention at 16^2), [{B},3,{S},{S}], {N}-step sigma-churn (KarrasIntegrator, noise generated in the kernels)",
             "samples/s": round(B / dt, 3), "ms_per_eval": round(1e3 * dt / evals, 2), "first_call_s": round(first, 2),
+            "timed_replays": REPLAYS, "ms_per_run": _stats([1e3 * d for d in dts]), "roofline": adm_conv_roofline(net, B, S, dev),
             "dominant_kernel": "k_conv3h / k_convup (fp16x3 3x3 convolutions: folded norm loader, image input, parity upsampling)",
             "eval_equiv": price(net, wn[:2], torch.tensor([0.5, 1.0], device=dev), None, dt, evals, B)}
         del module, net, wn
@@ -454,8 +565,11 @@ def other_configs(dev):
         wn = torch.randn(B, 4, S, S, device=dev)
         y = {"porosity": torch.tensor([0.2], device=dev)}
         evals = 2 * N - 1                                                # guided evaluations: each is one launch set on batch 2B
-        dt, first = timed(module, wn, evals, y=y, guidance=g, nsteps=N)
+        dt, first, dts = timed(module, wn, evals, y=y, guidance=g, nsteps=N)
+        a5 = argparse.Namespace(batch=2 * B, size=S, channels=64)
         out["config5_share_cond_punetg64"] = {
+            "timed_replays": REPLAYS, "ms_per_run": _stats([1e3 * d for d in dts]),
+            "roofline": dominant_kernel_roofline(module, a5, dev, reps=6),
             "workload": f"conditional PUNetG-64 (PorosityEmbedder), [{B},4,{S},{S}] per GPU, classifier-free guidance {g} "
                         f"(conditional + unconditional evaluation as one of batch {2 * B}), {N}-step Heun",
             "samples/s": round(B / dt, 3), "ms_per_eval": round(1e3 * dt / evals, 2), "network_calls": 2 * evals,
@@ -560,12 +674,23 @@ def main():
     B = args.batch
     lo, hi = shard_rows(B * world, world, rank)
     # inputs resident in HBM before the timed region: this rank's rows of the global noise tensor
+    t_noise = time.perf_counter()
     noise = [global_white_noise(B * world, shape, seed=s, rows=(lo, hi)).to(dev)
              for s in range(args.steps + args.warmup)]
+    torch.cuda.synchronize()
+    noise_draw_ms = (time.perf_counter() - t_noise) * 1e3 / (args.steps + args.warmup)    # host draw of this rank's rows + upload, per step
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]   # step start, gather start, step end
 
-    def one_step(i):
+    def one_step(i, timed=False):
+        if timed:
+            ev[i][0].record()
         out = module.propagate_white_noise(noise[i], nsteps=args.nsteps)
-        return gather_samples(out) if dist is not None else out
+        if timed:
+            ev[i][1].record()
+        out = gather_samples(out) if dist is not None else out
+        if timed:
+            ev[i][2].record()
+        return out
 
     for i in range(args.warmup):
         one_step(args.steps + i)
@@ -573,18 +698,28 @@ def main():
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
+    state0 = gpu_state(local_rank)
     t0 = time.perf_counter()
     for i in range(args.steps):
-        out = one_step(i)
+        out = one_step(i, timed=True)
     torch.cuda.synchronize()
+    state1 = gpu_state(local_rank)                      # right behind the last kernel: the clock / power the loop ran at
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    dt_rank = dt
+    step_ms = [ev[i][0].elapsed_time(ev[i][2]) for i in range(args.steps)]        # device time per step, events on the launch stream
+    gather_ms = [ev[i][1].elapsed_time(ev[i][2]) for i in range(args.steps)]
+    per_rank = None
     if dist is not None:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        mine = torch.tensor([dt_rank * 1e3 / args.steps, sum(gather_ms) / len(gather_ms), noise_draw_ms], device=dev, dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [[round(float(v), 3) for v in r.tolist()] for r in allr]
     assert out.shape[0] == B * world and bool(torch.isfinite(out).all())
     if rank == 0:
         value = B * world * args.steps / dt
@@ -592,6 +727,10 @@ def main():
             "metric": "samples/sec (50-step Karras Heun), PUNetG 64ch 128x128",
             "value": round(value, 3), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
+            # device time of each timed step (events on the launch stream): the spread inside one run, next to the clock / power the
+            # box held -- what separates a slower build from a slower box
+            "ms_per_step_min": _stats(step_ms)["min"], "ms_per_step_median": _stats(step_ms)["median"], "ms_per_step_max": _stats(step_ms)["max"],
+            "gpu_state": {"before": state0, "after": state1},
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": {"fp32": "f32", "bf16x6": "f32 (3x3 convs: exact 3-way bf16 split, 6 bf16 MFMA products, fp32 accumulate)",
                       "fp16x3": "f32 (3x3 convs: fp16 hi+lo split, 3 fp16 MFMA products, fp32 accumulate)"}[args.precision],
@@ -599,10 +738,16 @@ def main():
             "config": {"workload": f"PUNetG {args.channels}-base-ch, 1x{args.size}x{args.size} fields, batch {B} per GPU, "
                                    f"{args.nsteps}-step Heun deterministic sampler ({2*args.nsteps-1} network evaluations)",
                        "global_batch": B * world, "parallelism": f"dp{world} (batch shards, all-gather of samples)",
-                       "rccl_world_size": dist.get_world_size() if dist is not None else 1,
+                       "world_size": dist.get_world_size() if dist is not None else 1,
+                       "backend": ("gloo (rehearsal)" if share else "nccl (RCCL)") if dist is not None else "none (one process)",
                        **({"rehearsal": "ranks share one GPU, gloo instead of RCCL"} if share else {}),
                        "hipgraph": not args.no_graph},
         }
+        if dist is not None:
+            # what a scaling curve will be read from: per rank [ms per step, all-gather ms per step (events), host noise draw + upload ms per step]
+            line["multi_gpu"] = {"per_rank_ms_per_step": [r[0] for r in per_rank], "gather_ms": [r[1] for r in per_rank],
+                                 "noise_draw_ms": [r[2] for r in per_rank],
+                                 "gather_bytes_per_rank": int(B * args.size * args.size * 4)}
         print(f"[bench] {value:.3f} samples/s, {dt / args.steps * 1e3:.1f} ms per {B}-sample batch", file=sys.stderr, flush=True)
         line["roofline"] = dominant_kernel_roofline(module, args, dev)
         print(f"[bench] roofline {line['roofline']}", file=sys.stderr, flush=True)

@@ -9,9 +9,11 @@
 // pre-multiplied by a per-layer power of two (undone exactly in the epilogue) so that their low
 // pieces are normal numbers.  Measured representation error of a 64->64 3x3 convolution: 8.5e-8
 // relative (torch's own fp32 convolution: 2.2e-7 from accumulation order alone).  Cost: 3 MFMAs
-// per k-slab instead of 6 (bf16x6) or 8x8 (exact-fp32 MFMA).  Domain: |input| < 65504 (fp16
-// range); larger magnitudes produce inf/nan, never a silently wrong finite value.  The bf16x6
-// kernel (ds_conv6.hip) has no such limit.
+// per k-slab instead of 6 (bf16x6) or 8x8 (exact-fp32 MFMA).  Domain: the whole fp32 range of
+// magnitudes -- every launch scales each SAMPLE by a power of two that puts its max |x| at 2^13
+// (in_amax, or the fourth column of the prenorm table) and undoes it exactly in the epilogue
+// (ds_conv_epilogue.h, ActScale); only an input whose channels lie more than 2^14 apart within one
+// sample AND meet compensating weights is escalated to the exact-fp32 kernel (nets/precision.py).
 //
 // Pipeline (workgroup = 4 waves, tile = 64 channels x 8 rows x 32 columns, 2 workgroups per CU):
 //   K walks in steps (chunk of 16 input channels, ky).  LDS holds
@@ -706,6 +708,7 @@ int ds_conv2d_h3(float* out, const float* in, const void* w_packed, int wshift, 
   if (B == 0) return DS_OK;
   Conv3hArgs a;
   a.prenorm = prenorm; a.tile_stats = tile_stats; a.circular = circular; a.res1_up = res1_up; a.oy = oy; a.ox = ox;
+  a.ntiles_magic40 = 0; a.ncot_magic40 = 0; a.pc_prio = 0;      // set by ds_conv3p.hip's launcher when it takes the launch
   a.out = out; a.in = in; a.wp = reinterpret_cast<const u32x4*>(w_packed); a.bias = bias; a.shift = shift;
   a.res1 = res1; a.res2 = res2; a.shift_stride = shift_stride;
   a.wshift = wshift; a.in_amax = in_amax; a.out_amax = out_amax;

@@ -64,6 +64,10 @@ struct Conv3hArgs {
   int B, Cin, Cout, H, W, Hin, Win;
   int tiles_x, tiles_y, n_cot, n_chunks;
   unsigned tiles_x_magic;   // floor(2^32 / tiles_x) + 1
+  // ds_conv3p.hip only: floor(2^40 / d) + 1 for d = tiles_x * tiles_y and d = n_cot -- (n * magic) >> 40 is n / d exactly for n < 2^22,
+  // d < 2^18 (the persistent kernel decodes an item index several times per tile: hardware has no integer divide)
+  unsigned long long ntiles_magic40, ncot_magic40;
+  int pc_prio;              // ds_conv3p.hip only: s_setprio level of the producer waves (DS_CONV_PC_PRIO, A/B runs)
 #ifdef DS_STAMP
   unsigned long long* stamps;   // diagnostic build only (tools/conv3h_stamp.hip)
   unsigned stagger_lo, stagger_hi, stagger_ticks;   // experiment: workgroups with dispatch index in [lo, hi) start `ticks` x 10 ns late

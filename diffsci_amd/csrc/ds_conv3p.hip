@@ -46,33 +46,38 @@ static_assert(P_LDS <= 160 * 1024, "one workgroup per CU");
 #else
 #define PSTAMP(slot) do {} while (0)
 #endif
+#ifdef DS_STAMP
+// inside one step of the second item's last chunk pair (producer wave 4): slots 48..
+#define PSTAMP_FINE(k) do { if (it == 1 && last_of_item) PSTAMP(48 + (k)); } while (0)
+#else
+#define PSTAMP_FINE(k) do {} while (0)
+#endif
 
-// Wait until all but the `young` youngest vector-memory operations of this wave have completed (rounded down to a multiple of four:
-// waiting for more than asked is always safe), and for every LDS operation; then the workgroup barrier.
+// Wait until all but the `young` youngest vector-memory operations of this wave have completed (the exact count: rounded down to a
+// multiple of four, 24 loads behind a 3-instruction DMA made the barrier wait for the DMA just issued), and for every LDS operation;
+// then the workgroup barrier.
+#define DS_VMCNT_CASE(n) case n: asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory"); break;
 __device__ __forceinline__ void bar_counted(int young) {
-  const int y = __builtin_amdgcn_readfirstlane(young) >> 2;
-  switch (y) {
-    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-    case 1: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-    case 2: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-    case 3: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
-    case 4: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
-    case 5: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
-    case 6: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
-    case 7: asm volatile("s_waitcnt vmcnt(28)" ::: "memory"); break;
-    case 8: asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); break;
-    case 9: asm volatile("s_waitcnt vmcnt(36)" ::: "memory"); break;
-    case 10: asm volatile("s_waitcnt vmcnt(40)" ::: "memory"); break;
-    case 11: asm volatile("s_waitcnt vmcnt(44)" ::: "memory"); break;
-    default: asm volatile("s_waitcnt vmcnt(48)" ::: "memory"); break;
+  const int y = __builtin_amdgcn_readfirstlane(young);
+  switch (y < 63 ? y : 63) {
+    DS_VMCNT_CASE(0) DS_VMCNT_CASE(1) DS_VMCNT_CASE(2) DS_VMCNT_CASE(3) DS_VMCNT_CASE(4) DS_VMCNT_CASE(5) DS_VMCNT_CASE(6) DS_VMCNT_CASE(7)
+    DS_VMCNT_CASE(8) DS_VMCNT_CASE(9) DS_VMCNT_CASE(10) DS_VMCNT_CASE(11) DS_VMCNT_CASE(12) DS_VMCNT_CASE(13) DS_VMCNT_CASE(14) DS_VMCNT_CASE(15)
+    DS_VMCNT_CASE(16) DS_VMCNT_CASE(17) DS_VMCNT_CASE(18) DS_VMCNT_CASE(19) DS_VMCNT_CASE(20) DS_VMCNT_CASE(21) DS_VMCNT_CASE(22) DS_VMCNT_CASE(23)
+    DS_VMCNT_CASE(24) DS_VMCNT_CASE(25) DS_VMCNT_CASE(26) DS_VMCNT_CASE(27) DS_VMCNT_CASE(28) DS_VMCNT_CASE(29) DS_VMCNT_CASE(30) DS_VMCNT_CASE(31)
+    DS_VMCNT_CASE(32) DS_VMCNT_CASE(33) DS_VMCNT_CASE(34) DS_VMCNT_CASE(35) DS_VMCNT_CASE(36) DS_VMCNT_CASE(37) DS_VMCNT_CASE(38) DS_VMCNT_CASE(39)
+    DS_VMCNT_CASE(40) DS_VMCNT_CASE(41) DS_VMCNT_CASE(42) DS_VMCNT_CASE(43) DS_VMCNT_CASE(44) DS_VMCNT_CASE(45) DS_VMCNT_CASE(46) DS_VMCNT_CASE(47)
+    DS_VMCNT_CASE(48) DS_VMCNT_CASE(49) DS_VMCNT_CASE(50) DS_VMCNT_CASE(51) DS_VMCNT_CASE(52) DS_VMCNT_CASE(53) DS_VMCNT_CASE(54) DS_VMCNT_CASE(55)
+    DS_VMCNT_CASE(56) DS_VMCNT_CASE(57) DS_VMCNT_CASE(58) DS_VMCNT_CASE(59) DS_VMCNT_CASE(60) DS_VMCNT_CASE(61) DS_VMCNT_CASE(62)
+    default: asm volatile("s_waitcnt vmcnt(63)" ::: "memory"); break;
   }
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
+#undef DS_VMCNT_CASE
 
 struct Item { int cot, b, y0, x0, tile; };
 
-struct Packed { u32x4 h[3], l[3]; };
-struct ResRegs { f32x4 r1[4], r2[4]; };
+template <int XI> struct Packed { u32x4 h[XI], l[XI]; };
+template <int BK> struct ResRegs { f32x4 r1[BK], r2[BK]; };
 struct Frag { f16x8 a[2][4], b[2][4]; };             // one K = 32 group's operands: [piece][16-channel tile], [piece][16-position tile]
 
 // The weight slabs' LDS-DMA as inline assembly: global_load_lds is FLAT-encoded and touches both memories, which hipcc's wait-count
@@ -95,8 +100,16 @@ __device__ __forceinline__ unsigned const_u32(const void* p, size_t i) {
 // NRES: residual tensors added in the store phase (0, 1 = res1, 2 = res1 and res2) -- a template parameter so that the residual
 // loads are unconditional instructions: hipcc counts only those when it sizes the wait for a loaded register, and a wait sized
 // vmcnt(0) in the store phase also waits for the previous batch's STORES to complete (about 8,000 cycles, stamped).
-template <bool PRE, bool CIRC, int NRES>
-__global__ __launch_bounds__(512, 2) void k_conv3p(const Conv3hArgs a) {
+// NPW: producer waves, 4 (two waves per SIMD: 256 registers each) or 8 (three per SIMD: 168 registers each; the consumer then keeps
+// ONE operand set and fetches a group's operands right in front of its matrix instructions -- it has the time: the producers pace
+// this kernel -- and every producer wave stages and stores half as much).
+template <bool PRE, bool CIRC, int NRES, int NPW>
+__global__ __launch_bounds__(256 + 64 * NPW, NPW == 4 ? 2 : 3) void k_conv3p(const Conv3hArgs a) {
+  static_assert(NPW == 4 || NPW == 8, "four or eight producer waves");
+  constexpr int XI = NPW == 4 ? 3 : 2;                     // staging items per producer thread
+  constexpr int BK = NPW == 4 ? 4 : 2;                     // store instructions per batch (four batches per wave and item)
+  using Packed = ds_conv3::Packed<XI>;
+  using ResRegs = ds_conv3::ResRegs<BK>;
   constexpr int PW = Geo<false>::PW, NPOS = Geo<false>::NPOS;
   constexpr int HS = NPOS + HPAD16, PS = 2 * NPOS + HPAD16, XBV = XBUF_VEC16;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -108,7 +121,10 @@ __global__ __launch_bounds__(512, 2) void k_conv3p(const Conv3hArgs a) {
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool consumer = wv < 4;
   const int rw = wv & 3;                                   // consumer: its row pair; producer: the consumer whose tile it stores
-  const int ptid = tid & 255;
+  const int ptid = tid - 256;                              // producer thread (negative in the consumer waves: unused there)
+  const int pw = wv - 4;                                   // producer wave
+  const int rws = NPW == 4 ? rw : ((pw >> 1) & 3);         // the consumer whose tile this producer stores
+  const int joff = NPW == 4 ? 0 : 8 * (pw & 1);            // ... and its first store instruction (eight producers: 32 channels each)
 
   // ---- this workgroup's items: XCD x owns one contiguous run of the logical order (channel tile fastest, then pixel tile, then
   //      sample), dealt round-robin over the Q workgroups of the XCD, so the workgroups of an XCD work on neighbouring tiles ----
@@ -119,13 +135,18 @@ __global__ __launch_bounds__(512, 2) void k_conv3p(const Conv3hArgs a) {
   const unsigned first = xcd * per + (xcd < rem ? xcd : rem), cnt = per + (xcd < rem ? 1u : 0u);
   const int n_items = q < cnt ? (int)((cnt - q + Q - 1) / Q) : 0;
   if (n_items == 0) return;
+  // item index -> (channel tile, pixel tile, sample): divisions by multiplication with the launcher's 2^40 reciprocals (exact for the
+  // sizes the launcher admits).  Stamped before: the compiler's float-reciprocal division sequences made one decode cost more
+  // than a thousand cycles, five times per tile, on the producers' critical path.
+  auto div40 = [](unsigned n, unsigned long long magic) __attribute__((always_inline)) { return (unsigned)(((unsigned long long)n * magic) >> 40); };
   auto item_of = [&](int k) __attribute__((always_inline)) {
     const unsigned logical = first + q + Q * (unsigned)k;
     Item it;
-    it.cot = (int)(logical % (unsigned)a.n_cot);
-    const unsigned rest = logical / (unsigned)a.n_cot;
-    it.tile = (int)(rest % ntiles);
-    it.b = (int)(rest / ntiles);
+    const unsigned rest = div40(logical, a.ncot_magic40);
+    it.cot = (int)(logical - rest * (unsigned)a.n_cot);
+    const unsigned bb = div40(rest, a.ntiles_magic40);
+    it.tile = (int)(rest - bb * ntiles);
+    it.b = (int)bb;
     const int ty = a.tiles_x == 1 ? it.tile : (int)__umulhi((unsigned)it.tile, a.tiles_x_magic);
     const int tx = it.tile - ty * a.tiles_x;
     it.y0 = 8 * ty; it.x0 = 32 * tx;
@@ -210,13 +231,18 @@ __global__ __launch_bounds__(512, 2) void k_conv3p(const Conv3hArgs a) {
   // =========================== producer ===========================
   // staging items of a thread (ds_conv3h.hip's four-wave plan over the 256 producer threads): items 0 / 1 = position ptid of
   // channel half 0 / 1, item 2 = the patch's tail (positions 256 ..), half (producer wave / 2)
+  // eight producers: waves 0-3 channel half 0, waves 4-7 half 1; item 0 = positions 64 (pw & 3) + lane, item 1 = the tail,
+  // 21 positions per wave (256 + 21 (pw & 3) + lane, lanes 0-20)
   const int tail_h = (rw >> 1) & 1;
-  auto item_h = [&](int i) __attribute__((always_inline)) { return i == 0 ? 0 : (i == 1 ? 1 : tail_h); };
-  int xlds[3], xrow[3], xcol[3];
-  const bool live2 = NT + (ptid & (NT / 2 - 1)) < NPOS;     // the thread's tail item exists
+  auto item_h = [&](int i) __attribute__((always_inline)) { return NPW == 8 ? ((pw >> 2) & 1) : (i == 0 ? 0 : (i == 1 ? 1 : tail_h)); };
+  int xlds[XI], xrow[XI], xcol[XI];
+  const bool live_tail = NPW == 4 ? (NT + (ptid & (NT / 2 - 1)) < NPOS) : (lane < 21);     // the thread's tail item exists
+  auto live = [&](int i) __attribute__((always_inline)) { return i < XI - 1 || live_tail; };
 #pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    const int pos = i < 2 ? ptid : NT + (ptid & (NT / 2 - 1));
+  for (int i = 0; i < XI; ++i) {
+    int pos;
+    if (NPW == 4) pos = i < 2 ? (ptid & 255) : NT + (ptid & (NT / 2 - 1));
+    else pos = i == 0 ? 64 * (pw & 3) + lane : 256 + 21 * (pw & 3) + (lane < 21 ? lane : 20);
     xrow[i] = pos / PW;
     xcol[i] = pos - xrow[i] * PW;
     xlds[i] = item_h(i) * HS + pos;
@@ -225,13 +251,13 @@ __global__ __launch_bounds__(512, 2) void k_conv3p(const Conv3hArgs a) {
   // loaded again and dropped): a conditional load between a load and its use makes hipcc wait for vmcnt(0) at the use -- the
   // full HBM latency of the loads just issued, measured at 3000 cycles per chunk in the first version of this kernel.
   int f_k = 0, f_chunk = 0, f_b = 0;
-  int xoff[3] = {0, 0, 0};
+  int xoff[XI] = {};
   unsigned f_xvalid = 0;
   float f_in_scale = 1.f;
   auto plan_fetch = [&](const Item& it) __attribute__((always_inline)) {
     f_xvalid = 0;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < XI; ++i) {
       int gy = it.y0 + xrow[i] - 1 + a.oy, gx = it.x0 + xcol[i] - 1 + a.ox;
       if (CIRC) {
         gy = gy < 0 ? gy + a.H : (gy >= a.H ? gy - a.H : gy);
@@ -239,7 +265,7 @@ __global__ __launch_bounds__(512, 2) void k_conv3p(const Conv3hArgs a) {
         gy = gy >= a.H ? a.H - 1 : gy;
         gx = gx >= a.W ? a.W - 1 : gx;
       }
-      const bool ok = (i < 2 || live2) && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+      const bool ok = live(i) && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
       xoff[i] = ok ? gy * a.W + gx : 0;
       if (ok) f_xvalid |= 1u << i;
     }
@@ -257,19 +283,19 @@ __global__ __launch_bounds__(512, 2) void k_conv3p(const Conv3hArgs a) {
     f_src = a.in + ((size_t)f_b * a.Cin + (size_t)f_chunk * KC) * HW;
     if (valid && ++f_chunk == n_chunks) { f_chunk = 0; ++f_k; }
   };
-  auto fetch_item = [&](float (&xr)[3][8], int i) __attribute__((always_inline)) {
+  auto fetch_item = [&](float (&xr)[XI][8], int i) __attribute__((always_inline)) {
     const float* p0 = f_src + xoff[i] + (size_t)(8 * item_h(i)) * HW;
 #pragma unroll
     for (int k = 0; k < 8; ++k) xr[i][k] = p0[(size_t)k * HW];
   };
-  auto fetch = [&](float (&xr)[3][8], unsigned& tag, int& trow, float& tscale) __attribute__((always_inline)) {
+  auto fetch = [&](float (&xr)[XI][8], unsigned& tag, int& trow, float& tscale) __attribute__((always_inline)) {
     fetch_begin(tag, trow, tscale);
 #pragma unroll
-    for (int i = 0; i < 3; ++i) fetch_item(xr, i);
-    return 24;
+    for (int i = 0; i < XI; ++i) fetch_item(xr, i);
+    return 8 * XI;
   };
   // [norm + SiLU,] fp16 hi / lo split of one staging item of a fetched chunk, in registers
-  auto activate_item = [&](float (&xr)[3][8], unsigned tag, int trow, float tscale, Packed& pk, int i) __attribute__((always_inline)) {
+  auto activate_item = [&](float (&xr)[XI][8], unsigned tag, int trow, float tscale, Packed& pk, int i) __attribute__((always_inline)) {
     if constexpr (PRE) {
       typedef const __attribute__((address_space(4))) f32x4* cptr;
       cptr pp = (cptr)(reinterpret_cast<const f32x4*>(a.prenorm)) + trow;
@@ -292,30 +318,30 @@ __global__ __launch_bounds__(512, 2) void k_conv3p(const Conv3hArgs a) {
       pk.h[i][k] = ph; pk.l[i][k] = pl;
     }
   };
-  auto activate = [&](float (&xr)[3][8], unsigned tag, int trow, float tscale, Packed& pk) __attribute__((always_inline)) {
+  auto activate = [&](float (&xr)[XI][8], unsigned tag, int trow, float tscale, Packed& pk) __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < 3; ++i) activate_item(xr, tag, trow, tscale, pk, i);
+    for (int i = 0; i < XI; ++i) activate_item(xr, tag, trow, tscale, pk, i);
   };
   // the loads of one chunk and the vector work of another, item by item: the loads' issue is paced by the memory pipeline (a CU's
   // share of HBM), and a wave stuck behind 24 of them in a row activates nothing meanwhile
-  auto fetch_while_activating = [&](float (&xn)[3][8], unsigned& tagn, int& trown, float& tscn,
-                                    float (&xo)[3][8], unsigned tago, int trowo, float tsco, Packed& pk) __attribute__((always_inline)) {
+  auto fetch_while_activating = [&](float (&xn)[XI][8], unsigned& tagn, int& trown, float& tscn,
+                                    float (&xo)[XI][8], unsigned tago, int trowo, float tsco, Packed& pk) __attribute__((always_inline)) {
     fetch_begin(tagn, trown, tscn);
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < XI; ++i) {
       fetch_item(xn, i);
       __builtin_amdgcn_sched_barrier(0);
       activate_item(xo, tago, trowo, tsco, pk, i);
       __builtin_amdgcn_sched_barrier(0);
     }
-    return 24;
+    return 8 * XI;
   };
   auto store_x = [&](const Packed& pk, unsigned tag, int buf) __attribute__((always_inline)) {
     if (!(tag >> 31)) return;
     u32x4* xb = Xs + buf * XBV;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      if (i < 2 || live2) {
+    for (int i = 0; i < XI; ++i) {
+      if (live(i)) {
         xb[xlds[i]] = pk.h[i];
         xb[PS + xlds[i]] = pk.l[i];
       }
@@ -329,21 +355,21 @@ __global__ __launch_bounds__(512, 2) void k_conv3p(const Conv3hArgs a) {
     const u32x4* src = a.wp + ((size_t)w_cot * n_steps + w_step) * WSLAB_VEC;
     u32x4* dst = Ws + slot * WSLAB_VEC;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      const int k = rw + 4 * i;                       // wave-uniform piece
-      lds_dma16(src + 64 * k, 16u * (unsigned)lane, lds_address(dst + 64 * k));
+    for (int i = 0; i < 12 / NPW + (12 % NPW ? 1 : 0); ++i) {
+      const int k = pw + NPW * i;                     // wave-uniform piece of the slab's twelve
+      if (k < 12) lds_dma16(src + 64 * k, 16u * (unsigned)lane, lds_address(dst + 64 * k));
     }
     if (valid && ++w_step == n_steps) { w_step = 0; ++w_k; }
     return 0;                                          // the DMA is what the barrier waits for: never among the `young`
   };
   // bias / shift row of an item: one register per thread (threads 0-63: bias, 64-127: shift), committed a step later together
   // with the item's 2^-(wshift + k) (thread 128; read through the scalar cache, so nothing waits for vector memory here)
-  auto bs_fetch = [&](const Item& it) __attribute__((always_inline)) {
-    float v = 0.f;
+  // (both values in EVERY lane, in registers of their own: as one register written under two lane masks the second load had to wait
+  // for the first -- and with it for the 24 patch loads in front of it: 1,600 cycles in step (O,0), stamped)
+  auto bs_fetch = [&](const Item& it, float& vb, float& vs) __attribute__((always_inline)) {
     const int co = it.cot * COT + (ptid & 63);
-    if (ptid < 64) v = a.bias ? a.bias[co] : 0.f;
-    else if (ptid < 128) v = a.shift ? a.shift[(size_t)it.b * a.shift_stride + co] : 0.f;
-    return v;
+    vb = a.bias ? a.bias[co] : 0.f;
+    vs = a.shift ? a.shift[(size_t)it.b * a.shift_stride + co] : 0.f;
   };
   auto unscale_of = [&](const Item& it) __attribute__((always_inline)) {
     if constexpr (PRE) {
@@ -353,8 +379,8 @@ __global__ __launch_bounds__(512, 2) void k_conv3p(const Conv3hArgs a) {
       return ds_epi::act_scale_of(a.in_amax ? const_u32(a.in_amax, it.b) : 0u, a.wshift).unscale;
     }
   };
-  auto bs_commit = [&](float v, float unscale, int par) __attribute__((always_inline)) {
-    if (ptid < 128) BS[par * P_BS_FLOATS + ptid] = v;
+  auto bs_commit = [&](float vb, float vs, float unscale, int par) __attribute__((always_inline)) {
+    if (ptid < 128) BS[par * P_BS_FLOATS + ptid] = ptid < 64 ? vb : vs;
     else if (ptid == 128) BS[par * P_BS_FLOATS + 128] = unscale;
   };
 
@@ -362,16 +388,17 @@ __global__ __launch_bounds__(512, 2) void k_conv3p(const Conv3hArgs a) {
   // (ds_conv_epilogue.h: store_tile_rows' aligned path, full tiles).  The wave's statistics partials [64 channels][4] go to the
   // head of its own tile, behind the batch that has just read it.
   int s_b = 0, s_cot = 0, s_tile = 0;
+  f32x4 pend0[BK];                                   // eight producers: the statistics rows of batch 0, written with batch 1 (store_batch)
   size_t s_idx = 0;                                  // the lane's first output element
   const size_t s_step = 4 * (size_t)HW;
   float s_amax = 0.f;
   const int p4 = 4 * (lane & 7);
   const bool stats = a.tile_stats != nullptr, want_amax = a.out_amax != nullptr;
-  constexpr int nres = 4 * NRES;
+  constexpr int nres = BK * NRES;
   auto plan_store = [&](const Item& it) __attribute__((always_inline)) {
     s_b = it.b; s_cot = it.cot; s_tile = it.tile;
-    const int gy = it.y0 + 2 * rw + ((lane >> 3) & 1), gx = it.x0 + p4;
-    const size_t ch = (size_t)it.b * a.Cout + it.cot * COT + (lane >> 4);
+    const int gy = it.y0 + 2 * rws + ((lane >> 3) & 1), gx = it.x0 + p4;
+    const size_t ch = (size_t)it.b * a.Cout + it.cot * COT + 4 * joff + (lane >> 4);
     s_idx = ch * HW + (size_t)gy * a.W + gx;
     s_amax = 0.f;
   };
@@ -379,52 +406,61 @@ __global__ __launch_bounds__(512, 2) void k_conv3p(const Conv3hArgs a) {
   // registers, and hipcc then waits for vmcnt(0) in front of every residual load -- the launcher keeps such launches on ds_conv3h.hip.)
   auto res_prefetch = [&](ResRegs& R, int half) __attribute__((always_inline)) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int j = half * 4 + k;
+    for (int k = 0; k < BK; ++k) {
+      const int j = half * BK + k;
       if constexpr (NRES >= 1) R.r1[k] = *reinterpret_cast<const f32x4*>(a.res1 + s_idx + (size_t)j * s_step);
       if constexpr (NRES >= 2) R.r2[k] = *reinterpret_cast<const f32x4*>(a.res2 + s_idx + (size_t)j * s_step);
     }
     return nres;
   };
   auto store_batch = [&](const ResRegs& R, int half) __attribute__((always_inline)) {
-    float* tile = OUT + rw * 4096;
-    f32x4 v[4];
+    float* tile = OUT + rws * 4096;
+    f32x4 v[BK];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int seg = (half * 4 + k) * 8 + (lane >> 3);
+    for (int k = 0; k < BK; ++k) {
+      const int seg = (joff + half * BK + k) * 8 + (lane >> 3);
       v[k] = *reinterpret_cast<const f32x4*>(&tile[seg * 32 + p4]);
     }
     if constexpr (NRES >= 1) {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) v[k] = v[k] + R.r1[k];
+      for (int k = 0; k < BK; ++k) v[k] = v[k] + R.r1[k];
     }
     if constexpr (NRES >= 2) {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) v[k] = v[k] + R.r2[k];
+      for (int k = 0; k < BK; ++k) v[k] = v[k] + R.r2[k];
     }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) *reinterpret_cast<f32x4*>(a.out + s_idx + (size_t)(half * 4 + k) * s_step) = v[k];
+    for (int k = 0; k < BK; ++k) *reinterpret_cast<f32x4*>(a.out + s_idx + (size_t)(half * BK + k) * s_step) = v[k];
     if (want_amax) {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) s_amax = fmaxf(s_amax, ds_epi::abs_max4(v[k]));
+      for (int k = 0; k < BK; ++k) s_amax = fmaxf(s_amax, ds_epi::abs_max4(v[k]));
     }
     if (stats) {
-      f32x4 o[4];
+      f32x4 o[BK];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
+      for (int k = 0; k < BK; ++k) {
         const float K = ds_epi::row16_first(v[k].x);
         const f32x4 d = v[k] - K;
         const float sv = ds_epi::row16_sum((d.x + d.y) + (d.z + d.w));
         const float qv = ds_epi::row16_sum((d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w));
         o[k] = f32x4{K, sv, qv, 64.f};                                   // the wave's 2 x 32 pixels of the channel
       }
-      // rows 16 half .. +15 of [64][4] at the tile's head: inside batch 0's region, which every lane of this wave has read by now
-      if ((lane & 15) == 0) {
+      // row (channel) 4 j + lane / 16 of [64][4] at the tile's head, i.e. inside the region store instructions 0-3 read.  Four producers:
+      // that is this wave's own batch 0, read by now.  Eight producers: it is the FIRST wave's batches 0 / 1 -- the second wave of a
+      // tile (and, for one rule, the first) holds its batch-0 rows back until its batch 1, which the schedule runs a barrier later
+      if (NPW == 8 && half == 0) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) *reinterpret_cast<f32x4*>(&tile[4 * (4 * (half * 4 + k) + (lane >> 4))]) = o[k];
+        for (int k = 0; k < BK; ++k) pend0[k] = o[k];
+      } else if ((lane & 15) == 0) {
+        if (NPW == 8 && half == 1) {
+#pragma unroll
+          for (int k = 0; k < BK; ++k) *reinterpret_cast<f32x4*>(&tile[4 * (4 * (joff + k) + (lane >> 4))]) = pend0[k];
+        }
+#pragma unroll
+        for (int k = 0; k < BK; ++k) *reinterpret_cast<f32x4*>(&tile[4 * (4 * (joff + half * BK + k) + (lane >> 4))]) = o[k];
       }
     }
-    return 4;
+    return BK;
   };
   auto commit_amax_asm = [&]() __attribute__((always_inline)) {        // ds_epi::commit_amax with the atomic as assembly
     float m = s_amax;
@@ -449,13 +485,13 @@ __global__ __launch_bounds__(512, 2) void k_conv3p(const Conv3hArgs a) {
     *reinterpret_cast<f32x4*>(a.tile_stats + (((size_t)s_b * a.Cout + s_cot * COT + lane) * ntiles + s_tile) * 4) = f32x4{K, S, Qs, n};
   };
 
-  float xrA[3][8], xrB[3][8];
+  float xrA[XI][8], xrB[XI][8];
   unsigned tagA = 0, tagB = 0, tagP = 0;
   int trowA = 0, trowB = 0;
   float tscA = 1.f, tscB = 1.f;
   Packed pk;
   ResRegs RA, RB;
-  float bsv = 0.f;
+  float bsb = 0.f, bss = 0.f;
   Frag F0, F1;
 
   // Both roles run the SAME loop nest (one generic lambda, instantiated per role): every barrier is one program point of that
@@ -469,9 +505,10 @@ __global__ __launch_bounds__(512, 2) void k_conv3p(const Conv3hArgs a) {
     // everything else of step p + 1 (`young`) may stay in flight.  Loads, LDS-DMA and stores complete in issue order on gfx9
     // (hipcc's own counted waits rely on it), so "all but the N youngest" names exactly the operations in front of them.
     int young = 0, prev = 0;
+    const int ndma = NPW == 4 ? 3 : (pw < 4 ? 2 : 1);             // DMA instructions of this wave per step
     auto barrier = [&]() __attribute__((always_inline)) {
       if constexpr (CONS) bar_counted(0);
-      else { bar_counted(prev + 3 + young); prev = young; young = 0; }
+      else { bar_counted(prev + ndma + young); prev = young; young = 0; }
     };
     int stamp = 1;
     (void)stamp;
@@ -487,16 +524,39 @@ __global__ __launch_bounds__(512, 2) void k_conv3p(const Conv3hArgs a) {
     //   (O,2)  DMA         | commit the next item's bias / shift row
     // (batches = the PREVIOUS item's store phase, on the item's first chunk pair only.)  What a group reads is published one
     // barrier before the group that precedes it starts, because its operands are fetched during that predecessor.
+    // [A schedule that spreads the staging evenly over the six steps and the store phase over two chunk pairs -- fetches in (E,1)
+    //  and (E,2), activations in (E,0) and (O,0) -- measured WORSE (profiles/r04_pc_stamps.log, v7: 81.1 -> 81.1 samples/s against
+    //  +1.6 % for this one): with both chunks' 48 loads issued in consecutive steps next to the residual loads and stores the wave
+    //  runs into its 64 outstanding vector-memory operations and the loads' issue stalls.]
     auto chunk_pair = [&](auto base_tag, Frag& Fa, Frag& Fb, bool head, bool last_of_item, int it) __attribute__((always_inline)) {
       constexpr int B = decltype(base_tag)::value;
       constexpr int E0 = (B + 0) & 3, E1 = (B + 1) & 3, E2 = (B + 2) & 3;          // ring slots of chunk E's slabs
       constexpr int O0 = (B + 3) & 3, O1 = (B + 4) & 3, O2 = (B + 5) & 3;          // ... of chunk O's
       constexpr int N0 = (B + 6) & 3;                                              // ... of the next chunk pair's first
+      // the ten K = 32 groups in order: P0 .. P8 of this chunk pair and P0 of the next (slot, ky, kx, X buffer of taps A and B)
+      constexpr int G[10][8] = {{E0, 0, 0, 0, E0, 0, 1, 0}, {E0, 0, 2, 0, E1, 1, 0, 0}, {E1, 1, 1, 0, E1, 1, 2, 0}, {E2, 2, 0, 0, E2, 2, 1, 0},
+                                {E2, 2, 2, 0, O0, 0, 0, 1}, {O0, 0, 1, 1, O0, 0, 2, 1}, {O1, 1, 0, 1, O1, 1, 1, 1}, {O1, 1, 2, 1, O2, 2, 0, 1},
+                                {O2, 2, 1, 1, O2, 2, 2, 1}, {N0, 0, 0, 0, N0, 0, 1, 0}};
+      // group k: four producers -- multiply the set fetched during group k - 1 while fetching group k + 1 into the other set;
+      // eight producers -- one set: fetch, then multiply
+      auto group = [&](auto k_tag) __attribute__((always_inline)) {
+        constexpr int k = decltype(k_tag)::value;
+        if constexpr (NPW == 4) {
+          Frag& cur = (k & 1) ? Fb : Fa;
+          Frag& nxt = (k & 1) ? Fa : Fb;
+          load_pair(nxt, G[k + 1][0], G[k + 1][1], G[k + 1][2], G[k + 1][3], G[k + 1][4], G[k + 1][5], G[k + 1][6], G[k + 1][7]);
+          mma_pair(cur);
+          reads_between();
+        } else {
+          load_pair(Fa, G[k][0], G[k][1], G[k][2], G[k][3], G[k][4], G[k][5], G[k][6], G[k][7]);
+          mma_pair(Fa);
+        }
+      };
+#define DS_GROUP(k) group(std::integral_constant<int, k>{})
       // ---------------- step (E, 0) ----------------
       if constexpr (CONS) {
         if (head) park_tile((it - 1) & 1);
-        load_pair(Fb, E0, 0, 2, 0, E1, 1, 0, 0); mma_pair(Fa); reads_between();         // P0 | fetch P1
-        load_pair(Fa, E1, 1, 1, 0, E1, 1, 2, 0); mma_pair(Fb); reads_between();         // P1 | fetch P2
+        DS_GROUP(0); DS_GROUP(1);
       } else {
         wdma((B + 3) & 3);
         __builtin_amdgcn_sched_barrier(0);
@@ -504,11 +564,12 @@ __global__ __launch_bounds__(512, 2) void k_conv3p(const Conv3hArgs a) {
         young += fetch_while_activating(xrB, tagB, trowB, tscB, xrA, tagA, trowA, tscA, pk);   // chunk E + 2 | chunk O
         tagP = tagA;
       }
-      PSTAMP(stamp); ++stamp;
+      if (stamp < 48) PSTAMP(stamp);
+      ++stamp;
       barrier();
       // ---------------- step (E, 1) ----------------
       if constexpr (CONS) {
-        load_pair(Fb, E2, 2, 0, 0, E2, 2, 1, 0); mma_pair(Fa); reads_between();         // P2 | fetch P3
+        DS_GROUP(2);
       } else {
         wdma((B + 4) & 3);
         __builtin_amdgcn_sched_barrier(0);
@@ -519,12 +580,12 @@ __global__ __launch_bounds__(512, 2) void k_conv3p(const Conv3hArgs a) {
           young += res_prefetch(RA, 2);
         }
       }
-      PSTAMP(stamp); ++stamp;
+      if (stamp < 48) PSTAMP(stamp);
+      ++stamp;
       barrier();
       // ---------------- step (E, 2) ----------------
       if constexpr (CONS) {
-        load_pair(Fa, E2, 2, 2, 0, O0, 0, 0, 1); mma_pair(Fb); reads_between();         // P3 | fetch P4
-        load_pair(Fb, O0, 0, 1, 1, O0, 0, 2, 1); mma_pair(Fa); reads_between();         // P4 | fetch P5
+        DS_GROUP(3); DS_GROUP(4);
       } else {
         wdma((B + 5) & 3);
         __builtin_amdgcn_sched_barrier(0);
@@ -534,46 +595,58 @@ __global__ __launch_bounds__(512, 2) void k_conv3p(const Conv3hArgs a) {
           young += store_batch(RA, 2);
         }
       }
-      PSTAMP(stamp); ++stamp;
+      if (stamp < 48) PSTAMP(stamp);
+      ++stamp;
       barrier();
       // ---------------- step (O, 0) ----------------
       if constexpr (CONS) {
-        load_pair(Fa, O1, 1, 0, 1, O1, 1, 1, 1); mma_pair(Fb); reads_between();         // P5 | fetch P6
+        DS_GROUP(5);
       } else {
+        PSTAMP_FINE(0);
         wdma((B + 6) & 3);
         __builtin_amdgcn_sched_barrier(0);
+        PSTAMP_FINE(1);
         young += fetch(xrA, tagA, trowA, tscA);       // chunk O + 2
+        __builtin_amdgcn_sched_barrier(0);
+        PSTAMP_FINE(2);
         if (head) {
           young += store_batch(RB, 3);
           if (want_amax) commit_amax_asm();
         }
-        if (last_of_item && it + 1 < n_items) bsv = bs_fetch(item_of(it + 1));
+        if (last_of_item && it + 1 < n_items) bs_fetch(item_of(it + 1), bsb, bss);
       }
-      PSTAMP(stamp); ++stamp;
+      if (stamp < 48) PSTAMP(stamp);
+      ++stamp;
       barrier();
       // ---------------- step (O, 1) ----------------
       if constexpr (CONS) {
-        load_pair(Fb, O1, 1, 2, 1, O2, 2, 0, 1); mma_pair(Fa); reads_between();         // P6 | fetch P7
-        load_pair(Fa, O2, 2, 1, 1, O2, 2, 2, 1); mma_pair(Fb); reads_between();         // P7 | fetch P8
+        DS_GROUP(6); DS_GROUP(7);
       } else {
+        PSTAMP_FINE(4);
         wdma((B + 7) & 3);
         __builtin_amdgcn_sched_barrier(0);
+        PSTAMP_FINE(5);
         activate(xrB, tagB, trowB, tscB, pk);         // chunk E + 2
+        __builtin_amdgcn_sched_barrier(0);
+        PSTAMP_FINE(6);
         store_x(pk, tagB, 0);
         if (head && stats && wv == 4) store_stats();
       }
-      PSTAMP(stamp); ++stamp;
+      if (stamp < 48) PSTAMP(stamp);
+      ++stamp;
       barrier();
       // ---------------- step (O, 2) ----------------
       if constexpr (CONS) {
-        load_pair(Fb, N0, 0, 0, 0, N0, 0, 1, 0); mma_pair(Fa); reads_between();         // P8 | fetch the next chunk pair's P0
+        DS_GROUP(8);
       } else {
         wdma((B + 8) & 3);
         __builtin_amdgcn_sched_barrier(0);
-        if (last_of_item && it + 1 < n_items) bs_commit(bsv, unscale_of(item_of(it + 1)), (it + 1) & 1);
+        if (last_of_item && it + 1 < n_items) bs_commit(bsb, bss, unscale_of(item_of(it + 1)), (it + 1) & 1);
       }
-      PSTAMP(stamp); ++stamp;
+      if (stamp < 48) PSTAMP(stamp);
+      ++stamp;
       barrier();
+#undef DS_GROUP
     };
 
     // ---- start-up stagger: every workgroup runs the same schedule on the same amount of work, so unskewed they would all fetch,
@@ -590,11 +663,11 @@ __global__ __launch_bounds__(512, 2) void k_conv3p(const Conv3hArgs a) {
       wdma(2);
       fetch(xrB, tagB, trowB, tscB);
       fetch(xrA, tagA, trowA, tscA);
-      bsv = bs_fetch(item_of(0));
+      bs_fetch(item_of(0), bsb, bss);
       activate(xrB, tagB, trowB, tscB, pk);
       store_x(pk, tagB, 0);
-      bs_commit(bsv, unscale_of(item_of(0)), 0);
-      asm volatile("s_waitcnt vmcnt(20)" ::: "memory");                  // the three slabs and chunk 0; chunk 1's loads may stay in flight
+      bs_commit(bsb, bss, unscale_of(item_of(0)), 0);
+      asm volatile("s_waitcnt vmcnt(20)" ::: "memory");                  // the three slabs and chunk 0; chunk 1's loads may stay in flight (the bias / shift loads are younger still)
     } else {
 #pragma unroll
       for (int m = 0; m < 4; ++m)
@@ -606,13 +679,14 @@ __global__ __launch_bounds__(512, 2) void k_conv3p(const Conv3hArgs a) {
     PSTAMP(0);
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     young = 0; prev = 24;                             // behind the prologue's slabs: chunk 1's loads
-    if constexpr (CONS) load_pair(F0, 0, 0, 0, 0, 0, 0, 1, 0);         // P0 of the first chunk pair
+    if constexpr (CONS && NPW == 4) load_pair(F0, 0, 0, 0, 0, 0, 0, 1, 0);         // P0 of the first chunk pair
 
     const int ncp = n_chunks >> 1;                    // even (the launcher's rule): fragment sets and ring slots are back in place after an item
     for (int it = 0; it < n_items; ++it) {
       for (int cp = 0; cp < ncp; cp += 2) {
         chunk_pair(std::integral_constant<int, 0>{}, F0, F1, cp == 0 && it > 0, false, it);
-        chunk_pair(std::integral_constant<int, 6>{}, F1, F0, false, cp + 2 == ncp, it);
+        if constexpr (NPW == 4) chunk_pair(std::integral_constant<int, 6>{}, F1, F0, false, cp + 2 == ncp, it);
+        else chunk_pair(std::integral_constant<int, 6>{}, F0, F1, false, cp + 2 == ncp, it);
       }
     }
     // ---- drain: the last item's store phase (its own barriers, nothing staged, nothing multiplied) ----
@@ -626,6 +700,9 @@ __global__ __launch_bounds__(512, 2) void k_conv3p(const Conv3hArgs a) {
     if constexpr (!CONS) {
       store_batch(RA, 0);
       res_prefetch(RB, 1);
+    }
+    bar_counted(0);                                   // (eight producers: batch 1 writes the statistics rows batch 0 held back)
+    if constexpr (!CONS) {
       store_batch(RB, 1);
       res_prefetch(RA, 2);
       store_batch(RA, 2);
@@ -638,30 +715,53 @@ __global__ __launch_bounds__(512, 2) void k_conv3p(const Conv3hArgs a) {
       if (stats && wv == 4) store_stats();
     }
   };
-  if (consumer) run(std::true_type{});
-  else run(std::false_type{});
+  if (consumer) {
+    run(std::true_type{});
+  } else {
+    // the producers pace the kernel: let their vector / memory instructions win the issue arbitration against the consumer's
+    // matrix stream on the same SIMD (MI355X_MICROARCH.md, Two waves per SIMD: priority, then age)
+    if (a.pc_prio == 1) __builtin_amdgcn_s_setprio(1);
+    else if (a.pc_prio == 2) __builtin_amdgcn_s_setprio(2);
+    else if (a.pc_prio == 3) __builtin_amdgcn_s_setprio(3);
+    run(std::false_type{});
+  }
 }
 
-template <bool PRE, bool CIRC, int NRES>
-int launch_conv3p_r(const Conv3hArgs& a, int wgs, hipStream_t s) {
-  const int rc = ds::ensure_dynamic_lds<&k_conv3p<PRE, CIRC, NRES>>(P_LDS, "hipFuncSetAttribute(conv3p)");
+// DS_CONV_PC_WAVES = 4 | 8: producer waves per workgroup (A/B runs; the default is what measured faster)
+int conv3p_producer_waves() {
+  static const int v = [] { const char* e = getenv("DS_CONV_PC_WAVES"); const int n = e ? atoi(e) : 4; return n == 8 ? 8 : 4; }();
+  return v;
+}
+
+template <bool PRE, bool CIRC, int NRES, int NPW>
+int launch_conv3p_w(const Conv3hArgs& a, int wgs, hipStream_t s) {
+  const int rc = ds::ensure_dynamic_lds<&k_conv3p<PRE, CIRC, NRES, NPW>>(P_LDS, "hipFuncSetAttribute(conv3p)");
   if (rc != DS_OK) return rc;
-  hipLaunchKernelGGL((k_conv3p<PRE, CIRC, NRES>), dim3((unsigned)wgs), dim3(512), P_LDS, s, a);
+  hipLaunchKernelGGL((k_conv3p<PRE, CIRC, NRES, NPW>), dim3((unsigned)wgs), dim3(256 + 64 * NPW), P_LDS, s, a);
   DS_CHECK_LAUNCH("ds_conv2d_h3 (persistent)");
   return DS_OK;
 }
+template <bool PRE, bool CIRC, int NRES>
+int launch_conv3p_r(const Conv3hArgs& a, int wgs, hipStream_t s) {
+  return conv3p_producer_waves() == 8 ? launch_conv3p_w<PRE, CIRC, NRES, 8>(a, wgs, s) : launch_conv3p_w<PRE, CIRC, NRES, 4>(a, wgs, s);
+}
 template <bool PRE, bool CIRC>
 int launch_conv3p(Conv3hArgs a, int wgs, hipStream_t s) {
+  a.ntiles_magic40 = (1ull << 40) / (unsigned long long)(a.tiles_x * a.tiles_y) + 1ull;
+  a.ncot_magic40 = (1ull << 40) / (unsigned long long)a.n_cot + 1ull;
+  static const int prio = [] { const char* e = getenv("DS_CONV_PC_PRIO"); const int v = e ? atoi(e) : 0; return v < 0 || v > 3 ? 0 : v; }();
+  a.pc_prio = prio;
   if (!a.res1 && a.res2) { a.res1 = a.res2; a.res2 = nullptr; }      // one residual: the order of the additions is the same
   if (!a.res1) return launch_conv3p_r<PRE, CIRC, 0>(a, wgs, s);
   return a.res2 ? launch_conv3p_r<PRE, CIRC, 2>(a, wgs, s) : launch_conv3p_r<PRE, CIRC, 1>(a, wgs, s);
 }
 
-// DS_CONV_PC: 0 (default while the one-tile kernel still measures faster) = never, 1 = the fused-loader launches with one channel
-// tile, 2 = also in place of the two-channel-tile kernel, 3 = raw-input launches too.
+// DS_CONV_PC: 0 = never, 1 (default: +1.6 % on config 2, same-box A/B, profiles/r04_pc_ab_bench.log) = the fused-loader launches with
+// one channel tile, 2 = also in place of the two-channel-tile kernel (measured slower: that kernel stages the patch once for both
+// tiles), 3 = raw-input launches too.
 // DS_CONV_PC_MIN: fewest items per workgroup (default 4).
 int conv3p_mode() {
-  static const int v = [] { const char* e = getenv("DS_CONV_PC"); return e ? atoi(e) : 0; }();
+  static const int v = [] { const char* e = getenv("DS_CONV_PC"); return e ? atoi(e) : 1; }();
   return v;
 }
 int conv3p_min_items() {
@@ -692,7 +792,7 @@ int conv3p_try_launch(const Conv3hArgs& a, hipStream_t s, bool* launched) {
   if (a.Hin != a.H || a.Win != a.W || a.res1_up) return DS_OK;
   const long long total = (long long)a.n_cot * a.tiles_x * a.tiles_y * a.B;
   const int wgs = conv3p_cus() / 8 * 8;               // a multiple of the XCD count: the item order assumes round-robin dealing
-  if (wgs <= 0 || total < (long long)wgs * conv3p_min_items() || total >= (1ll << 31)) return DS_OK;
+  if (wgs <= 0 || total < (long long)wgs * conv3p_min_items() || total >= (1ll << 22)) return DS_OK;      // 2^22: the exactness bound of the item decode
   if (a.n_cot % 2 == 0 && a.prenorm && mode < 2) return DS_OK;     // the two-channel-tile kernel's launches
   if (!a.prenorm && mode < 3) return DS_OK;           // raw-input launches: measured separately (DS_CONV_PC=3)
   int rc;

@@ -43,31 +43,42 @@ class ScoreFnSource:
 
 
 def condition_signature(y):
-    """Structure of a condition (keys, shapes, dtypes) -- what a captured plan depends on.  The VALUES never enter a
-    plan key: everything derived from them lives in plan-owned buffers that `ModuleSource.refresh` rewrites before
+    """Structure of a condition (keys, shapes, dtypes) -- what a captured plan depends on.  The VALUES of its tensors never
+    enter a plan key: everything derived from them lives in plan-owned buffers that `ModuleSource.refresh` rewrites before
     every replay (an address- or checksum-based key cannot tell two one-hot labels, or a new tensor that reuses a
-    freed block, apart)."""
+    freed block, apart).  Leaves that are NOT tensors (Python scalars, strings, None inside a container) cannot be rewritten
+    in a captured graph, so their values ARE part of the key: a different scalar is a different plan.  Lists and tuples are
+    containers like dicts."""
     if y is None:
         return None
     if isinstance(y, dict):
-        return tuple((k, condition_signature(v)) for k, v in sorted(y.items()))
+        return ("dict",) + tuple((k, condition_signature(v)) for k, v in sorted(y.items()))
+    if isinstance(y, (list, tuple)):
+        return (type(y).__name__,) + tuple(condition_signature(v) for v in y)
     if torch.is_tensor(y):
         return (tuple(y.shape), str(y.dtype), str(y.device))
-    return repr(type(y))
+    if isinstance(y, (bool, int, float, str, bytes)):
+        return ("value", type(y).__name__, y)
+    return ("object", repr(type(y)), id(y))             # anything else: the very object (a plan cannot follow what it cannot read)
 
 
 def clone_condition(y):
-    """Plan-owned copy of a condition's tensors (same structure)."""
+    """Plan-owned copy of a condition's tensors (same structure; lists and tuples are rebuilt around the copies)."""
     if isinstance(y, dict):
         return {k: clone_condition(v) for k, v in y.items()}
+    if isinstance(y, (list, tuple)):
+        return type(y)(clone_condition(v) for v in y)
     return y.clone() if torch.is_tensor(y) else y
 
 
 def copy_condition(dst, src):
-    """Write src's values into dst's tensors (the structure is part of the plan key)."""
+    """Write src's values into dst's tensors (the structure, and the value of every non-tensor leaf, is part of the plan key)."""
     if isinstance(dst, dict):
         for k in dst:
             copy_condition(dst[k], src[k])
+    elif isinstance(dst, (list, tuple)):
+        for d, v in zip(dst, src):
+            copy_condition(d, v)
     elif torch.is_tensor(dst):
         dst.copy_(src)
 
@@ -449,7 +460,9 @@ class PlanCache:
         caller = torch.cuda.current_stream(x.device)
         self.stream.wait_stream(caller)
         with torch.cuda.stream(self.stream):
-            plan = self.plans.get(key)
+            plan = self.plans.pop(key, None)
+            if plan is not None:
+                self.plans[key] = plan                       # least recently USED goes first: a hit moves the plan to the back
             if plan is None:
                 loop = make_loop()
                 loop.load(x, scale)

@@ -29,7 +29,9 @@
  * the v_mfma_f32_32x32x16_f16 form of ds_conv2d_h3 / ds_conv2d_h3_up everywhere (default: 16x16x32 wherever the layer has
  * an even number of 16-channel chunks); DS_CONV_WAVES=4|8 = waves per workgroup of the 32x32x16 form (default: 8 with the
  * fused loader); DS_CONV_WAVES16=8 = eight waves for the 16x16x32 form with the fused loader (default 4); DS_ATTN_T =
- * rescaling threshold of ds_attention_h3's online softmax (default 8).
+ * rescaling threshold of ds_attention_h3's online softmax (default 8); DS_CONV_PC = 0|1|2|3 = which launches of ds_conv2d_h3 take the
+ * persistent producer / consumer form (ds_conv3p.hip: 0 none, 1 fused-loader launches with one channel tile, 2 also those with two,
+ * 3 raw-input launches too; bit-identical results), DS_CONV_PC_MIN = fewest items per workgroup for it (default 4).
  */
 #ifndef DIFFSCI_HIP_H
 #define DIFFSCI_HIP_H
@@ -50,7 +52,7 @@ typedef enum ds_status {
 } ds_status;
 
 /* Library / device introspection. */
-int ds_version(void);                       /* ABI version, currently 3 */
+int ds_version(void);                       /* ABI version, currently 4 (DS_ABI_VERSION in ds_api.hip, ABI_VERSION in diffsci_amd/_native.py) */
 const char* ds_last_error(void);            /* thread-local, never NULL */
 int ds_device_info(int* cu_count, int* lds_bytes_per_cu, char* arch_name, int arch_name_len);
 

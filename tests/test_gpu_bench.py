@@ -25,6 +25,14 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     r = d["roofline"]
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert d["roofline_hbm_class"]["heun_step_cfg2_4MiB"]["frac_hbm_peak"] > 0.2
+    assert d["ms_per_step_min"] <= d["ms_per_step_median"] <= d["ms_per_step_max"] and "gpu_state" in d
+    # configs 3 and 5 ride on the default line: neither may have failed silently, each carries three timed replays and a roofline
+    oc = d["other_configs"]
+    for name in ("config3_adm128", "config5_share_cond_punetg64"):
+        assert "error" not in oc[name], oc[name]
+        assert oc[name]["timed_replays"] >= 3 and oc[name]["ms_per_run"]["min"] <= oc[name]["ms_per_run"]["max"]
+        r = oc[name]["roofline"]
+        assert r["bound"] == "mfma" and 0.05 < r["frac"] < 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
 
 
 def test_graft_smoke():

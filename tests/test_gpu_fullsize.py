@@ -23,6 +23,21 @@ from tests.golden_util import rel_l2  # noqa: E402
 REL = 1e-5
 
 
+def _bounded(name, got, want32, want64, rel_tol=None, k32=4.0, k64=1.0):
+    """The stated tolerance max(REL, k x the oracle's own fp32-vs-fp64 distance), with the clause that binds printed and the
+    fp64 clause asserted on its own line: against the fp32 oracle the bound is usually the SECOND clause at these sizes (torch's
+    CPU fp32 is 2-3e-4 from its fp64), so the assertion that carries information is the fp64 one."""
+    rel_tol = REL if rel_tol is None else rel_tol
+    ref_err = rel_l2(want32, want64)
+    e32, e64 = rel_l2(got, want32), rel_l2(got, want64)
+    b32, b64 = max(rel_tol, k32 * ref_err), max(rel_tol, k64 * ref_err)
+    print(f"[{name}] oracle fp32 vs fp64 {ref_err:.2e} | HIP vs fp32 oracle {e32:.2e} <= {b32:.2e} "
+          f"({'REL' if rel_tol >= k32 * ref_err else f'{k32:g} x oracle error'} binds) | HIP vs fp64 oracle {e64:.2e} <= {b64:.2e} "
+          f"({'REL' if rel_tol >= k64 * ref_err else f'{k64:g} x oracle error'} binds)")
+    assert e64 < b64, f"{name}: HIP vs the fp64 oracle {e64:.3e} exceeds max(REL = {rel_tol:g}, {k64:g} x {ref_err:.3e}) -- the informative clause"
+    assert e32 < b32, f"{name}: HIP vs the fp32 oracle {e32:.3e} exceeds max(REL = {rel_tol:g}, {k32:g} x {ref_err:.3e})"
+
+
 @pytest.fixture(scope="module")
 def dev():
     assert torch.cuda.is_available()
@@ -108,8 +123,7 @@ def test_full_size_config3_adm128_sigma_churn(M, dev):
     got_t = h[:, r:r + 1].cpu()
     assert torch.equal(got_t[0], want_t[0])                                        # x * sigma_max is exact
     assert rel_l2(got_t[1], want_t[1]) < REL                                       # first step: well conditioned
-    ref_err = rel_l2(want_t, want_t64)
-    assert rel_l2(got_t, want_t) < max(REL, 4 * ref_err) and rel_l2(got_t, want_t64) < max(REL, 4 * ref_err)
+    _bounded("config 3, sigma-churn trajectory", got_t, want_t, want_t64, k64=4.0)
     # ---- samples are independent: permutation / split; replay of the captured plan is bit-reproducible
     out = h[-1]
     perm = torch.randperm(B, generator=g)
@@ -167,10 +181,7 @@ def test_full_size_config5_conditional_punetg_cfg(M, dev):
     # At this size torch's own fp32 CPU arithmetic is 1.9e-4 away from its fp64 result (tools/diag_cfg5.py: the HIP
     # path is 9e-6 from fp64, every stage 1e-7..2e-6 from the oracle), so the fp32 oracle is compared at the second
     # clause of the stated tolerance and the fp64 oracle at the first whenever the reference's own error allows
-    ref_err = rel_l2(want_d, want_d64)
-    print(f"[config 5] oracle fp32 vs fp64 {ref_err:.2e}; HIP vs fp64 {rel_l2(got_d, want_d64):.2e}, vs fp32 {rel_l2(got_d, want_d):.2e}")
-    assert rel_l2(got_d, want_d) < max(REL, 4 * ref_err)
-    assert rel_l2(got_d, want_d64) < max(REL, ref_err)            # no worse than the reference arithmetic itself
+    _bounded("config 5, one guided evaluation", got_d, want_d, want_d64)     # fp64 clause: no worse than the reference arithmetic itself
     # ---- 2-step Heun with guidance: full batch on the GPU, sample 9 on the oracle
     grid = module.config.noisescheduler.create_steps(3)
     h = module.propagate_white_noise(x, y=yd, guidance=2.0, nsteps=2, record_history=True)
@@ -183,10 +194,8 @@ def test_full_size_config5_conditional_punetg_cfg(M, dev):
                                            guidance=2.0, conditional=True, sigma_grid=grid.double(), record_history=True)
     print(f"[config 5] oracle: 2-step guided Heun of one sample, fp32 + fp64, in {time.time() - t0:.1f} s")
     got_t = h[:, r:r + 1].cpu()
-    ref_err = rel_l2(want_t, want_t64)
-    print(f"[config 5] trajectory: oracle fp32 vs fp64 {ref_err:.2e}; HIP vs fp64 {rel_l2(got_t, want_t64):.2e}, vs fp32 {rel_l2(got_t, want_t):.2e}")
-    assert rel_l2(got_t[1], want_t[1]) < max(REL, 4 * rel_l2(want_t[1], want_t64[1]))
-    assert rel_l2(got_t, want_t) < max(REL, 4 * ref_err) and rel_l2(got_t, want_t64) < max(REL, 4 * ref_err)
+    _bounded("config 5, first guided Heun step", got_t[1], want_t[1], want_t64[1], k64=4.0)
+    _bounded("config 5, 2-step guided trajectory", got_t, want_t, want_t64, k64=4.0)
     # ---- independence / replay on the full batch
     out = h[-1]
     perm = torch.randperm(B, generator=g)

@@ -312,7 +312,9 @@ def test_bench_multi_rank_code_on_one_rank(launcher):
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
-    assert line["config"]["rccl_world_size"] == 1 and line["n_gpus"] == 1 and line["value"] > 0
+    assert line["config"]["world_size"] == 1 and line["config"]["backend"].startswith("nccl") and line["n_gpus"] == 1 and line["value"] > 0
+    mg = line["multi_gpu"]
+    assert len(mg["per_rank_ms_per_step"]) == 1 and mg["gather_ms"][0] >= 0 and mg["noise_draw_ms"][0] > 0
     assert "dp1" in line["config"]["parallelism"] and line["config"]["global_batch"] == 8
 
 
@@ -339,7 +341,12 @@ def test_bench_with_two_ranks_sharing_the_gpu():
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1                                               # rank 0 alone prints
     line = json.loads(lines[0])
-    assert line["n_gpus"] == 2 and line["config"]["rccl_world_size"] == 2 and line["config"]["global_batch"] == 16
+    assert line["n_gpus"] == 2 and line["config"]["world_size"] == 2 and line["config"]["backend"].startswith("gloo")
+    assert line["config"]["global_batch"] == 16
+    mg = line["multi_gpu"]                                              # the fields a scaling curve will be read from, one entry per rank
+    assert len(mg["per_rank_ms_per_step"]) == 2 and len(mg["gather_ms"]) == 2 and len(mg["noise_draw_ms"]) == 2
+    assert all(v > 0 for v in mg["per_rank_ms_per_step"]) and mg["gather_bytes_per_rank"] == 8 * 64 * 64 * 4
+    assert max(mg["per_rank_ms_per_step"]) <= line["ms_per_step"] * 1.05
     assert line["scaling"] == "weak" and line["value"] > 0 and "dp2" in line["config"]["parallelism"]
     assert abs(line["value"] - 16 * 2 / (line["ms_per_step"] * 2 / 1e3)) < 0.01 * line["value"]      # whole-job samples over the max time
 

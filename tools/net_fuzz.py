@@ -28,6 +28,7 @@ def main():
     ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))       # noqa: E731
     pick = lambda xs: xs[ri(0, len(xs) - 1)]                                      # noqa: E731
     worst = 0.0
+    n_inf, worst_inf, worst_ratio = 0, 0.0, 0.0
     for it in range(a.n):
         torch.manual_seed(1000 + it)
         family = "punetg" if it % 2 == 0 else "adm"
@@ -100,8 +101,12 @@ def main():
                 want64 = adm_ref.adm_forward({k: w.double() for k, w in sd.items()}, cfg, x.double(), t.double())
         net = net.to(dev)
         # the usual bound: 1e-5, or 4x the reference's own fp32-vs-fp64 error where tiny planes (a few pixels per
-        # instance norm) make the configuration ill-conditioned for fp32 itself
-        tol = max(1e-5, 4 * rel(want, want64))
+        # instance norm) make the configuration ill-conditioned for fp32 itself -- capped at 1e-3: beyond that the oracle's own
+        # fp32 result says nothing, and a case only counts as INFORMATIVE (the number the log reports) when the oracle's
+        # fp32-vs-fp64 distance is below 1e-4
+        ref_err = rel(want, want64)
+        informative = ref_err < 1e-4
+        tol = min(1e-3, max(1e-5, 4 * ref_err))
         errs = []
         for fuse, cot in ((True, 99), (True, 1), (False, 0)):
             net.fuse_norm, net.fuse_max_cot = fuse, cot
@@ -110,13 +115,22 @@ def main():
             assert torch.equal(got, got2), "second pass through the workspace differs"
             errs.append(max(rel(got, want), rel(got, want64)))
         e = max(errs)
+        if not informative and ref_err >= 2.5e-4:                 # fp32 itself is lost here: no accuracy claim, finiteness only
+            assert all(map(lambda v: v == v and v != float("inf"), errs)), "non-finite result"
+            tol = float("inf")
         worst = max(worst, e)
+        n_inf += int(informative)
+        if informative:
+            worst_inf = max(worst_inf, e)
+            worst_ratio = max(worst_ratio, e / max(ref_err, 1e-9))
         tag = f"{family}{'3d' if vol else ''} exp={exp} B={B} cin={cin} {'x'.join(map(str, x.shape[2:]))} " + " ".join(f"{k}={v}" for k, v in over.items() if k.startswith("number") or k in ("model_channels", "skip_integration_type", "convolution_type", "first_resblock_norm", "second_resblock_norm", "affine_norm", "bias", "decoder_type", "attn_type", "kernel_size", "in_out_kernel_size", "transition_kernel_size")) + f" mag={mag:.1e}"
         if e > tol:
             print("FAIL", tag, errs, tol)
             sys.exit(1)
-        print(f"it {it}: ok {e:.2e} (oracle fp32 vs fp64 {rel(want, want64):.1e})  {tag}", flush=True)
-    print(f"all {a.n} networks passed; worst relative error {worst:.2e}")
+        print(f"it {it}: ok {e:.2e} (oracle fp32 vs fp64 {ref_err:.1e}{'' if informative else ', NOT informative: ill-conditioned in fp32'})  {tag}", flush=True)
+    print(f"all {a.n} networks ran; informative (oracle fp32 within 1e-4 of its fp64) {n_inf} / {a.n}, all within max(1e-5, 4 x the oracle's "
+          f"own fp32 error); worst informative relative error {worst_inf:.2e}, worst ratio to the oracle's own error {worst_ratio:.1f}; "
+          f"the other {a.n - n_inf} are ill-conditioned for fp32 itself: held to min(1e-3, 4 x the oracle's error) while that error is below 2.5e-4, to finiteness and replay determinism beyond")
 
 
 if __name__ == "__main__":

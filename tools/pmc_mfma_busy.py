@@ -23,11 +23,11 @@ def main():
     by = defaultdict(dict)
     meta = {}
     for r in csv.DictReader(open(a.counters)):
-        if "k_conv3h" not in r["Kernel_Name"]:
+        if "k_conv3h" not in r["Kernel_Name"] and "k_conv3p" not in r["Kernel_Name"]:
             continue
         d = int(r["Dispatch_Id"])
         by[d][r["Counter_Name"]] = by[d].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
-        meta[d] = (re.search(r"k_conv3h<[^>]*>", r["Kernel_Name"]).group(0), int(r["Grid_Size"]),
+        meta[d] = (re.search(r"k_conv3[hp]<[^>]*>", r["Kernel_Name"]).group(0), int(r["Grid_Size"]),
                    (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
     ids = sorted(by)[-a.last:]
     rows = []
