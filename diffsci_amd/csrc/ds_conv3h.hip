@@ -72,9 +72,19 @@ template <int MT> struct Frags { f16x8 a[2][MT]; f16x8 b[2][2]; };   // [piece][
 //         both: at 128 output channels every element is otherwise loaded, normalised and split twice.  One
 //         workgroup per CU (X buffers shared, weight ring doubled, eight 16 KiB epilogue tiles: 132 KB of LDS), 2 waves per SIMD
 //         as with two four-wave workgroups.
-template <int MODE, bool W16, bool PRE, bool CIRC, int NW, bool S16 = false, bool IMGIN = false, bool TWO = false>
+// VEC (round 4; S16, plain load, 32-wide tiles, W a multiple of 32, whole chunks, no column tap offset): the patch's 32 interior columns are
+//         fetched by 16-BYTE loads -- a staging unit is 2 channels x 4 consecutive pixels (two global_load_dwordx4, eight elements, eight
+//         ds_write_b32 of a packed channel pair) instead of 8 channels x 1 pixel (eight global_load_dword) -- and only the two halo
+//         columns keep the one-pixel items.  The texture-address path takes a wave's load instruction at the same rate whatever its
+//         width, so a chunk's patch costs 6 instead of 24 load instructions per lane.  Measured (profiles/r04_vec4_loads.log; outputs,
+//         tile statistics and maxima bit-identical to the one-pixel plan): -4.5 % per launch with two channel tiles (128 channels, 64 x 64),
+//         +-0 on the one-tile four-wave kernel at 64 channels, +0.9 % end to end on config 2 (same-box A/B, three alternating pairs).
+//         The unit's channel pair differs from lane to lane (q = lane & 3: that is what keeps the 4-byte LDS stores on distinct banks), so
+//         the norm's table rows come from LDS: wave 0 parks the chunk's 16 rows in the X buffer's pad vectors a step ahead.
+template <int MODE, bool W16, bool PRE, bool CIRC, int NW, bool S16 = false, bool IMGIN = false, bool TWO = false, bool VEC = false>
 __global__ __launch_bounds__(64 * NW, TWO ? 2 : NW / 2) void k_conv3h(const Conv3hArgs a) {
   static_assert(!TWO || (S16 && NW == 8 && !IMGIN), "two channel tiles per workgroup: the eight-wave 16x16x32 kernel");
+  static_assert(!VEC || (S16 && !IMGIN && !W16 && MODE == DS_LOAD_PLAIN && (TWO || NW == 4)), "16-byte patch loads: plain 32-wide 16x16x32 kernels");
   constexpr int COTS = TWO ? 2 : 1;
   constexpr int M16 = TWO ? 4 : 16 / NW;                             // S16: 16-channel tiles per wave (4, or 2 with eight waves on one tile)
   static_assert(!IMGIN || (S16 && NW == 4 && MODE == DS_LOAD_PLAIN && !PRE && !CIRC), "image input: plain 16x16x32 four-wave kernel");
@@ -179,6 +189,56 @@ __global__ __launch_bounds__(64 * NW, TWO ? 2 : NW / 2) void k_conv3h(const Conv
     if (ok) xvalid |= (1u << i);
     if (live) xlive |= (1u << i);
   }
+  // ---- VEC staging plan.  Interior unit u -> (h, patch row r, column group g, channel pair q): 32 consecutive units = 4 channel pairs x
+  //      2 column groups x 4 rows (rows 8, 9: x 4 column groups x 2 rows), which puts the 32 lanes of a ds_write_b32 group on 16 banks
+  //      twice (free, MI355X_MICROARCH.md LDS); 64 consecutive units share h.  Slot i of a thread = unit i * NTH + tid; the LAST slot of
+  //      waves 2 and 3 is a halo-column item instead (20 lanes each: row lane / 2, column 0 or 33, h = wave - 2; eight channels of one
+  //      position, as in the scalar plan), so every wave stages three (TWO: two) slots of eight elements. ----
+  static_assert(!VEC || (XI - 1) * NTH + 128 == 2 * 10 * 8 * 4, "640 interior units: all slots but the last, and the last slot of waves 0 and 1");
+  const bool edge_wave = VEC && (wv == 2 || wv == 3);
+  int voff[XI], vlds[XI], vrow[XI];                   // float offset inside the chunk, LDS byte address of pixel 0 (high piece, buffer 0), first table row
+  unsigned vvalid = 0, vlive = 0;
+  if constexpr (VEC) {
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+      const int u = i * NTH + tid;
+      voff[i] = 0; vlds[i] = 0; vrow[i] = 0;
+      if (i < XI - 1 || wv < 2) {
+        const int q = u & 3, G = u >> 5;
+        const int h = G >= 10 ? 1 : 0, Gp = G - 10 * h;
+        int r, g;
+        // (32 lanes = 4 channel pairs x the 8 column groups of ONE row -- whole 128-byte lines per channel, four-way store conflicts --
+        //  measured the same: profiles/r04_vec4_loads.log)
+        if (Gp < 8) { r = 4 * (Gp >> 2) + ((u >> 3) & 3); g = 2 * (Gp & 3) + ((u >> 2) & 1); }
+        else { r = 8 + ((u >> 3) & 1); g = 4 * (Gp - 8) + 2 * ((u >> 4) & 1) + ((u >> 2) & 1); }
+        int gy = y0 + r - 1 + a.oy;
+        if (CIRC) { gy = gy < 0 ? gy + a.H : (gy >= a.H ? gy - a.H : gy); gy = gy >= a.H ? a.H - 1 : gy; }
+        const bool ok = gy >= 0 && gy < a.H;
+        voff[i] = (8 * h + 2 * q) * HWin + (ok ? gy * a.Win + x0 + 4 * g : 0);
+        vlds[i] = 16 * (h * HS + r * PW + 1 + 4 * g) + 4 * q;
+        vrow[i] = 8 * h + 2 * q;
+        if (ok) vvalid |= 1u << i;
+        vlive |= 1u << i;
+      } else if (edge_wave) {
+        const int e = lane < 20 ? lane : 19, h = wv - 2;
+        const int r = e >> 1, col = (e & 1) ? PW - 1 : 0;
+        int gy = y0 + r - 1 + a.oy, gx = x0 + col - 1;
+        if (CIRC) {
+          gy = gy < 0 ? gy + a.H : (gy >= a.H ? gy - a.H : gy);
+          gx = gx < 0 ? gx + a.W : (gx >= a.W ? gx - a.W : gx);
+          gy = gy >= a.H ? a.H - 1 : gy;
+        }
+        const bool ok = lane < 20 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+        voff[i] = 8 * h * HWin + (ok ? gy * a.Win + gx : 0);
+        vlds[i] = 16 * (h * HS + r * PW + col);
+        vrow[i] = 8 * h;
+        if (ok) vvalid |= 1u << i;
+        if (lane < 20) vlive |= 1u << i;
+      }
+    }
+  }
+  // the pad vector that holds table row c of a chunk (12 pad vectors behind the h = 0 image of either piece)
+  auto pad_vec = [&](int c) __attribute__((always_inline)) { return c < HPAD16 ? NPOS + c : PS + NPOS + (c - HPAD16); };
   const float* in_b = a.in + (size_t)b * a.Cin * HWin;
   const u32x4* wp = a.wp + (size_t)cot * n_steps * WSLAB_VEC;
   // the sample's power-of-two activation scale, undone in the epilogue: a raw input is multiplied by it, the fused
@@ -193,6 +253,22 @@ __global__ __launch_bounds__(64 * NW, TWO ? 2 : NW / 2) void k_conv3h(const Conv
     const float* src = in_b + (size_t)cbase * HWin;
     xchunk = chunk;
     xnch = a.Cin - cbase < KC ? a.Cin - cbase : KC;   // uniform; < KC only for a ragged last chunk
+    if constexpr (VEC) {
+#pragma unroll
+      for (int i = 0; i < XI; ++i) {
+        const float* p0 = src + voff[i];
+        if (i < XI - 1 || wv < 2) {
+          const f32x4 t0 = *reinterpret_cast<const f32x4*>(p0);
+          const f32x4 t1 = *reinterpret_cast<const f32x4*>(p0 + HWin);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) { xr[i][k] = t0[k]; xr[i][4 + k] = t1[k]; }
+        } else if (edge_wave) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) xr[i][k] = p0[k * HWin];
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < XI; ++i) {
       const int h = item_h(i);
@@ -238,7 +314,80 @@ __global__ __launch_bounds__(64 * NW, TWO ? 2 : NW / 2) void k_conv3h(const Conv
     for (int k = 0; k < 8; ++k) xr[i][k] = ds_h3::fast_silu_scaled((xr[i][k] - p[k][0]) * p[k][1] + p[k][2], inv);
 #endif
   };
+  auto x_store_vec = [&](int buf) __attribute__((always_inline)) {
+    if constexpr (VEC) {
+      unsigned char* xbytes = smem + (size_t)buf * XBV * 16;
+      const u32x4* rows = Xs + buf * XBV;                    // the chunk's table rows in the buffer's pad vectors
+#pragma unroll
+      for (int i = 0; i < XI; ++i) {
+        const bool ok = (vvalid >> i) & 1u;
+        if (i < XI - 1 || wv < 2) {
+          // interior unit: xr[i][0..3] = four pixels of channel 2q, xr[i][4..7] = of channel 2q + 1
+          if constexpr (PRE) {
+            const f32x4 p0 = __builtin_bit_cast(f32x4, rows[pad_vec(vrow[i])]);
+            const f32x4 p1 = __builtin_bit_cast(f32x4, rows[pad_vec(vrow[i] + 1)]);
+            const float inv = p0[3] == 0.f ? 1.0f : p0[3];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              xr[i][k] = ds_h3::fast_silu_scaled((xr[i][k] - p0[0]) * p0[1] + p0[2], inv);
+              xr[i][4 + k] = ds_h3::fast_silu_scaled((xr[i][4 + k] - p1[0]) * p1[1] + p1[2], inv);
+            }
+          }
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            float v0 = ok ? xr[i][k] : 0.f;
+            float v1 = ok ? xr[i][4 + k] : 0.f;
+            if constexpr (!PRE) { v0 *= ascale.in_scale; v1 *= ascale.in_scale; }
+            unsigned ph, pl;
+            split2(v0, v1, ph, pl);
+            *reinterpret_cast<unsigned*>(xbytes + vlds[i] + 16 * k) = ph;
+            *reinterpret_cast<unsigned*>(xbytes + vlds[i] + 16 * k + PS * 16) = pl;
+          }
+        } else if (edge_wave) {
+          // halo-column item: eight channels of one position (wave-uniform h: the table rows through the scalar cache)
+          if constexpr (PRE) {
+            typedef const __attribute__((address_space(4))) f32x4* cptr;
+            cptr pp = (cptr)(reinterpret_cast<const f32x4*>(pre_b) + xchunk * KC) + 8 * (wv - 2);
+            f32x4 p[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) p[k] = pp[k];
+            const float inv = p[0][3] == 0.f ? 1.0f : p[0][3];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) xr[i][k] = ds_h3::fast_silu_scaled((xr[i][k] - p[k][0]) * p[k][1] + p[k][2], inv);
+          }
+          if ((vlive >> i) & 1u) {
+            u32x4 qh, ql;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              float v0 = ok ? xr[i][2 * k] : 0.f;
+              float v1 = ok ? xr[i][2 * k + 1] : 0.f;
+              if constexpr (!PRE) { v0 *= ascale.in_scale; v1 *= ascale.in_scale; }
+              unsigned ph, pl;
+              split2(v0, v1, ph, pl);
+              qh[k] = ph; ql[k] = pl;
+            }
+            *reinterpret_cast<u32x4*>(xbytes + vlds[i]) = qh;
+            *reinterpret_cast<u32x4*>(xbytes + vlds[i] + PS * 16) = ql;
+          }
+        }
+      }
+    }
+  };
+  // VEC + PRE: wave 0 fetches the 16 table rows of a chunk (one 16-byte load in its first 16 lanes) and parks them in the pad vectors of
+  // the X buffer the chunk is staged into, one barrier before the activation reads them
+  f32x4 prow = {0.f, 0.f, 0.f, 0.f};
+  auto rows_fetch = [&](int chunk) __attribute__((always_inline)) {
+    if constexpr (VEC && PRE) {
+      if (wv == 0) prow = reinterpret_cast<const f32x4*>(pre_b)[chunk * KC + (lane & 15)];
+    }
+  };
+  auto rows_park = [&](int buf) __attribute__((always_inline)) {
+    if constexpr (VEC && PRE) {
+      if (wv == 0 && lane < 16) Xs[buf * XBV + pad_vec(lane)] = __builtin_bit_cast(u32x4, prow);
+    }
+  };
   auto x_store = [&](int buf) __attribute__((always_inline)) {                       // [normalise + SiLU,] split to fp16 pieces, write the LDS image
+    if constexpr (VEC) { x_store_vec(buf); return; }
     u32x4* xb = Xs + buf * XBV;
     if (PRE) {
 #pragma unroll
@@ -371,6 +520,7 @@ __global__ __launch_bounds__(64 * NW, TWO ? 2 : NW / 2) void k_conv3h(const Conv
   const unsigned amax_bits = ds_epi::act_bits((IMGIN || PRE) ? nullptr : a.in_amax, b);
   if constexpr (IMGIN) x_dma(0, 0); else
   x_fetch(0);
+  rows_fetch(0);
   // bias / shift of the workgroup's channel tile(s): threads 0-127 (TWO: 0-255, 128 per tile)
   const float bias_shift = ds_epi::fetch_bias_shift(a.bias, a.shift, a.shift_stride, b, (cot + (TWO ? (tid >> 7) & 1 : 0)) * COT, a.Cout, COTS);
   w_fetch(0, 0);
@@ -378,6 +528,15 @@ __global__ __launch_bounds__(64 * NW, TWO ? 2 : NW / 2) void k_conv3h(const Conv
   STAMP(1);
   if constexpr (!IMGIN && !PRE) __builtin_amdgcn_sched_barrier(0);
   ascale = ds_epi::act_scale_of(PRE ? 0u : amax_bits, a.wshift);   // PRE: the table carries the exponent (x_activate)
+  if constexpr (VEC && PRE) {
+    // the exponent for the epilogue (the same in every row of the sample's table), through the scalar cache; chunk 0's rows into
+    // buffer 0's pads, published by a barrier of their own
+    typedef const __attribute__((address_space(4))) f32x4* cptr;
+    const float inv0 = ((cptr)(reinterpret_cast<const f32x4*>(pre_b)))[0][3];
+    ascale.inv_scale = inv0 == 0.f ? 1.0f : inv0;
+    rows_park(0);
+    __syncthreads();
+  }
   if constexpr (!IMGIN) x_store(0);
   ds_epi::commit_bias_shift(BS, bias_shift, COTS);
   __syncthreads();
@@ -437,7 +596,7 @@ __global__ __launch_bounds__(64 * NW, TWO ? 2 : NW / 2) void k_conv3h(const Conv
         // by the barrier that ends the step after this one (__syncthreads waits for the wave's outstanding DMA)
         if (ky == 0 && chunk + 1 < a.n_chunks) x_dma(chunk + 1, (chunk + 1) & 1);
       } else
-      if (fetch && ky == 0 && chunk + 1 < a.n_chunks) x_fetch(chunk + 1);
+      if (fetch && ky == 0 && chunk + 1 < a.n_chunks) { rows_fetch(chunk + 1); x_fetch(chunk + 1); }
       __builtin_amdgcn_sched_barrier(0);
     };
     auto stage_out = [&](int chunk, int ky, int xbuf) __attribute__((always_inline)) {
@@ -447,8 +606,10 @@ __global__ __launch_bounds__(64 * NW, TWO ? 2 : NW / 2) void k_conv3h(const Conv
 #else
       constexpr bool store = true;
 #endif
-      if constexpr (!IMGIN)
-      if (store && ky == 1 && chunk + 1 < a.n_chunks) x_store(xbuf ^ 1);
+      if constexpr (!IMGIN) {
+        if (store && ky == 0 && chunk + 1 < a.n_chunks) rows_park(xbuf ^ 1);
+        if (store && ky == 1 && chunk + 1 < a.n_chunks) x_store(xbuf ^ 1);
+      }
       __syncthreads();
     };
     for (int chunk = 0; chunk < a.n_chunks; chunk += 2) {          // n_chunks is even (checked by the launcher)
@@ -573,17 +734,17 @@ __global__ void k_pack3h(_Float16* packed, const float* __restrict__ w, int Cout
   packed[i] = piece == 0 ? hi : lo;
 }
 
-template <int MODE, bool W16, bool PRE, bool CIRC, int NW, bool S16 = false, bool IMGIN = false, bool TWO = false>
+template <int MODE, bool W16, bool PRE, bool CIRC, int NW, bool S16 = false, bool IMGIN = false, bool TWO = false, bool VEC = false>
 int launch_conv3h_w(const Conv3hArgs& a, hipStream_t s) {
   constexpr int LDSB = TWO ? LDS_BYTES_TWO : (S16 ? LDS_BYTES16 : LDS_BYTES);
   {
-    const int rc = ds::ensure_dynamic_lds<&k_conv3h<MODE, W16, PRE, CIRC, NW, S16, IMGIN, TWO>>(LDSB, "hipFuncSetAttribute(conv3h)");
+    const int rc = ds::ensure_dynamic_lds<&k_conv3h<MODE, W16, PRE, CIRC, NW, S16, IMGIN, TWO, VEC>>(LDSB, "hipFuncSetAttribute(conv3h)");
     if (rc != DS_OK) return rc;
   }
   const long long tiles = (long long)a.tiles_y * a.tiles_x;
   DS_REQUIRE(tiles > 0 && tiles < 65536 && a.B < 65536, DS_ERR_SHAPE,
              "ds_conv2d_h3: %lld pixel tiles x %d samples exceed the grid limits (65535 each)", tiles, a.B);
-  hipLaunchKernelGGL((k_conv3h<MODE, W16, PRE, CIRC, NW, S16, IMGIN, TWO>), dim3((unsigned)(TWO ? a.n_cot / 2 : a.n_cot), (unsigned)tiles, (unsigned)a.B),
+  hipLaunchKernelGGL((k_conv3h<MODE, W16, PRE, CIRC, NW, S16, IMGIN, TWO, VEC>), dim3((unsigned)(TWO ? a.n_cot / 2 : a.n_cot), (unsigned)tiles, (unsigned)a.B),
                      dim3(64 * NW), LDSB, s, a);
   DS_CHECK_LAUNCH("ds_conv2d_h3");
   return DS_OK;
@@ -629,17 +790,30 @@ inline long long conv3h_two_min() {
   return v;
 }
 
+// 16-byte patch loads (VEC): default on wherever the shape allows; DS_CONV_VEC=0 keeps the one-pixel staging items (A/B runs, and
+// the bit-for-bit comparison of the two staging plans in tools/conv_vec_check.py).
+inline bool conv3h_vec() {
+  static const bool on = [] { const char* e = getenv("DS_CONV_VEC"); return !(e && atoi(e) == 0); }();
+  return on;
+}
+
 template <int MODE, bool W16, bool PRE, bool CIRC>
 int launch_conv3h_c(const Conv3hArgs& a, hipStream_t s) {
+  bool vec = false;
+  if constexpr (MODE == DS_LOAD_PLAIN && !W16)
+    vec = conv3h_vec() && a.W % 32 == 0 && a.ox == 0 && a.Cin % KC == 0 && (reinterpret_cast<uintptr_t>(a.in) & 15u) == 0;
   if constexpr (MODE == DS_LOAD_PLAIN) {
     const int two = conv3h_two();
-    if (conv3h_shape16() && a.n_chunks % 2 == 0 && a.n_cot % 2 == 0 && ((two == 1 && PRE && a.n_cot == 2 && (long long)a.tiles_y * a.tiles_x * a.B >= conv3h_two_min()) || two == 2))
+    if (conv3h_shape16() && a.n_chunks % 2 == 0 && a.n_cot % 2 == 0 && ((two == 1 && PRE && a.n_cot == 2 && (long long)a.tiles_y * a.tiles_x * a.B >= conv3h_two_min()) || two == 2)) {
+      if constexpr (!W16) { if (vec) return launch_conv3h_w<MODE, W16, PRE, CIRC, 8, true, false, true, true>(a, s); }
       return launch_conv3h_w<MODE, W16, PRE, CIRC, 8, true, false, true>(a, s);
+    }
   }
   if (conv3h_shape16() && a.n_chunks % 2 == 0) {
     if constexpr (PRE && MODE == DS_LOAD_PLAIN) {
       if (conv3h_waves16() == 8 && a.n_chunks <= 8) return launch_conv3h_w<MODE, W16, PRE, CIRC, 8, true>(a, s);   // up to 128 input channels
     }
+    if constexpr (MODE == DS_LOAD_PLAIN && !W16) { if (vec) return launch_conv3h_w<MODE, W16, PRE, CIRC, 4, true, false, false, true>(a, s); }
     return launch_conv3h_w<MODE, W16, PRE, CIRC, 4, true>(a, s);
   }
   // the eight-wave max-pool loader would spill (180 B/lane of scratch at 128 VGPRs: four loads per element in flight): four waves

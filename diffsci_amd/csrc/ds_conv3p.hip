@@ -75,6 +75,7 @@ __device__ __forceinline__ void bar_counted(int young) {
 #undef DS_VMCNT_CASE
 
 struct Item { int cot, b, y0, x0, tile; };
+#define DS_LPI 8                                    // vector-memory loads per staging item
 
 template <int XI> struct Packed { u32x4 h[XI], l[XI]; };
 template <int BK> struct ResRegs { f32x4 r1[BK], r2[BK]; };
@@ -292,7 +293,7 @@ __global__ __launch_bounds__(256 + 64 * NPW, NPW == 4 ? 2 : 3) void k_conv3p(con
     fetch_begin(tag, trow, tscale);
 #pragma unroll
     for (int i = 0; i < XI; ++i) fetch_item(xr, i);
-    return 8 * XI;
+    return DS_LPI * XI;
   };
   // [norm + SiLU,] fp16 hi / lo split of one staging item of a fetched chunk, in registers
   auto activate_item = [&](float (&xr)[XI][8], unsigned tag, int trow, float tscale, Packed& pk, int i) __attribute__((always_inline)) {
@@ -334,7 +335,7 @@ __global__ __launch_bounds__(256 + 64 * NPW, NPW == 4 ? 2 : 3) void k_conv3p(con
       activate_item(xo, tago, trowo, tsco, pk, i);
       __builtin_amdgcn_sched_barrier(0);
     }
-    return 8 * XI;
+    return DS_LPI * XI;
   };
   auto store_x = [&](const Packed& pk, unsigned tag, int buf) __attribute__((always_inline)) {
     if (!(tag >> 31)) return;
@@ -667,7 +668,8 @@ __global__ __launch_bounds__(256 + 64 * NPW, NPW == 4 ? 2 : 3) void k_conv3p(con
       activate(xrB, tagB, trowB, tscB, pk);
       store_x(pk, tagB, 0);
       bs_commit(bsb, bss, unscale_of(item_of(0)), 0);
-      asm volatile("s_waitcnt vmcnt(20)" ::: "memory");                  // the three slabs and chunk 0; chunk 1's loads may stay in flight (the bias / shift loads are younger still)
+      asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+                 // the three slabs and chunk 0; chunk 1's loads may stay in flight (the bias / shift loads are younger still)
     } else {
 #pragma unroll
       for (int m = 0; m < 4; ++m)
@@ -678,7 +680,7 @@ __global__ __launch_bounds__(256 + 64 * NPW, NPW == 4 ? 2 : 3) void k_conv3p(con
     }
     PSTAMP(0);
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    young = 0; prev = 24;                             // behind the prologue's slabs: chunk 1's loads
+    young = 0; prev = DS_LPI * XI;                             // behind the prologue's slabs: chunk 1's loads
     if constexpr (CONS && NPW == 4) load_pair(F0, 0, 0, 0, 0, 0, 0, 1, 0);         // P0 of the first chunk pair
 
     const int ncp = n_chunks >> 1;                    // even (the launcher's rule): fragment sets and ring slots are back in place after an item

@@ -40,6 +40,17 @@ def test_persistent_convolution_is_bit_identical_to_the_one_tile_kernel():
     assert p.stdout.count(" ok") >= 10
 
 
+def test_sixteen_byte_patch_loads_are_bit_identical_to_the_one_pixel_staging_plan():
+    """ds_conv3h.hip's VEC staging plan (units of 2 channels x 4 pixels fetched by 16-byte loads, table rows through LDS) against its
+    one-pixel items (DS_CONV_VEC=0, child process), DS_CONV_PC=0 in both arms: 18 launch shapes -- one and two channel tiles, ragged
+    heights, row tap offsets, periodic padding on a single tile column, raw inputs, 32 ... 160 input channels -- bit for bit."""
+    env = {k: v for k, v in os.environ.items() if k not in ("DS_CONV_PC", "DS_CONV_PC_MIN", "DS_CONV_VEC")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "conv3p_check.py"), "--var", "DS_CONV_VEC"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0 and "ALL OK" in p.stdout, p.stdout[-3000:] + p.stderr[-2000:]
+    assert p.stdout.count(" ok") >= 18
+
+
 def test_lightning_checkpoint_samples_like_the_reference(M, dev):
     """karrasmodule.py:410-429: a .ckpt in Lightning's layout, written from a reference module by make_golden.py, loaded through
     the mirrored classmethod; four Heun steps from the recorded noise against what the reference sampled from those weights."""

@@ -30,6 +30,21 @@ CASES = [
 ]
 
 
+# --var DS_CONV_VEC: the 16-byte patch loads of ds_conv3h.hip (VEC) against its one-pixel staging items, same kernel otherwise
+# (both arms with DS_CONV_PC=0): more shapes whose staging differs -- ragged heights, a row tap offset, periodic padding with one tile
+# column (the halo columns wrap into the tile's own columns), a single tile, 96 and 32 input channels, raw inputs
+VEC_CASES = [
+    (3, 64, 64, 20, 32, 1, 1, 0, 0, 1, 1, 0, None),
+    (2, 32, 64, 8, 64, 1, 0, 0, 0, 1, 0, 1, None),
+    (2, 96, 128, 36, 96, 1, 1, 1, 0, 1, 1, 1, None),
+    (2, 64, 64, 24, 64, 0, 0, 0, 0, 0, 0, 0, (1, 0)),
+    (2, 64, 64, 24, 64, 0, 0, 0, 0, 0, 0, 0, (-1, 0)),
+    (1, 32, 64, 8, 32, 0, 1, 0, 0, 1, 1, 1, None),
+    (5, 128, 128, 16, 128, 1, 0, 0, 0, 1, 1, 0, None),
+    (2, 160, 64, 40, 32, 1, 0, 1, 0, 0, 1, 0, None),
+]
+
+
 def random_cases(n, seed):
     """n more launch shapes the persistent kernel takes (>= 256 items, full tiles, channel counts multiples of 64), every option drawn."""
     import random
@@ -91,16 +106,30 @@ def main():
         CASES[:] = random_cases(n, seed)
         globals().update(_RANDOM=True, _SEED=seed)
         del sys.argv[i:i + (3 if len(sys.argv) > i + 2 and sys.argv[i + 2].isdigit() else 2)]
+    var = "DS_CONV_PC"
+    if "--var" in sys.argv:                            # python tools/conv3p_check.py --var DS_CONV_VEC: that switch on (parent) against off (child)
+        i = sys.argv.index("--var")
+        var = sys.argv[i + 1]
+        del sys.argv[i:i + 2]
+        if not globals().get("_RANDOM"):
+            CASES.extend(VEC_CASES)
     if len(sys.argv) > 2 and sys.argv[1] == "--child":
         outs = run_cases(dev)
         torch.save([dict(out=o["out"], ts=o["ts"], oa=o["oa"]) for o in outs], sys.argv[2])
         return
-    os.environ.setdefault("DS_CONV_PC", "3")
-    os.environ.setdefault("DS_CONV_PC_MIN", "1")
+    if var == "DS_CONV_PC":
+        os.environ.setdefault("DS_CONV_PC", "3")
+        os.environ.setdefault("DS_CONV_PC_MIN", "1")
+        env = dict(os.environ, DS_CONV_PC="0")
+    else:
+        os.environ["DS_CONV_PC"] = "0"
+        os.environ[var] = "1"
+        env = dict(os.environ, **{var: "0"})
     with tempfile.TemporaryDirectory() as td:
         ref_path = os.path.join(td, "ref.pt")
-        env = dict(os.environ, DS_CONV_PC="0")
         extra = ["--random", str(len(CASES)), str(globals().get("_SEED", 0))] if globals().get("_RANDOM") else []
+        if var != "DS_CONV_PC":
+            extra += ["--var", var]
         subprocess.check_call([sys.executable, os.path.abspath(__file__)] + extra + ["--child", ref_path], env=env)
         ref = torch.load(ref_path)
     outs = run_cases(dev)
