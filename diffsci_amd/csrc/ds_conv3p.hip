@@ -104,9 +104,17 @@ __device__ __forceinline__ unsigned const_u32(const void* p, size_t i) {
 // NPW: producer waves, 4 (two waves per SIMD: 256 registers each) or 8 (three per SIMD: 168 registers each; the consumer then keeps
 // ONE operand set and fetches a group's operands right in front of its matrix instructions -- it has the time: the producers pace
 // this kernel -- and every producer wave stages and stores half as much).
-template <bool PRE, bool CIRC, int NRES, int NPW>
+// VEC (four producers): the patch's 32 interior columns are fetched by 16-byte loads, a staging unit = 2 channels x 4 pixels, the two
+// halo columns keep the one-pixel items in the last slot of producer waves 2 and 3 -- ds_conv3h.hip's VEC plan, lane for lane.  A
+// chunk costs a producer wave 7 or 13 vector-memory loads instead of 24 (their issue paces the fetch steps, see above).  The two kinds of
+// producer wave run their own instantiation of the loop (role 1: three interior slots, role 2: two and a halo slot), so that every load
+// stays an unconditional instruction of its wave's program.  The table rows of the fused norm come from LDS (the unit's channel pair
+// differs from lane to lane): every producer wave loads the chunk's 16 rows in front of the patch, producer wave 0 parks them in the
+// pad vectors of the X buffer the chunk is staged into, at least one barrier before the activation reads them.
+template <bool PRE, bool CIRC, int NRES, int NPW, bool VEC = false>
 __global__ __launch_bounds__(256 + 64 * NPW, NPW == 4 ? 2 : 3) void k_conv3p(const Conv3hArgs a) {
   static_assert(NPW == 4 || NPW == 8, "four or eight producer waves");
+  static_assert(!VEC || NPW == 4, "16-byte patch loads: the four-producer form");
   constexpr int XI = NPW == 4 ? 3 : 2;                     // staging items per producer thread
   constexpr int BK = NPW == 4 ? 4 : 2;                     // store instructions per batch (four batches per wave and item)
   using Packed = ds_conv3::Packed<XI>;
@@ -248,6 +256,35 @@ __global__ __launch_bounds__(256 + 64 * NPW, NPW == 4 ? 2 : 3) void k_conv3p(con
     xcol[i] = pos - xrow[i] * PW;
     xlds[i] = item_h(i) * HS + pos;
   }
+  // VEC plan (ds_conv3h.hip): slot i = interior unit u = 256 i + ptid -> (h, patch row, column group, channel pair); the last slot of
+  // producer waves 2 / 3 = halo item lane (20 lanes: row lane / 2, column 0 or 33) of h = 0 / 1
+  int vr[XI], vx[XI], vch[XI], vlds[XI], vrow[XI];
+  const bool halo_live = lane < 20;
+  if constexpr (VEC) {
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+      vr[i] = 0; vx[i] = 0; vch[i] = 0; vlds[i] = 0; vrow[i] = 0;
+      if (i < XI - 1 || pw < 2) {
+        const int u = i * 256 + (ptid & 255);
+        const int q = u & 3, G = u >> 5;
+        const int h = G >= 10 ? 1 : 0, Gp = G - 10 * h;
+        int r, g;
+        if (Gp < 8) { r = 4 * (Gp >> 2) + ((u >> 3) & 3); g = 2 * (Gp & 3) + ((u >> 2) & 1); }
+        else { r = 8 + ((u >> 3) & 1); g = 4 * (Gp - 8) + 2 * ((u >> 4) & 1) + ((u >> 2) & 1); }
+        vr[i] = r; vx[i] = 4 * g;
+        vch[i] = (8 * h + 2 * q) * HW;
+        vlds[i] = 16 * (h * HS + r * PW + 1 + 4 * g) + 4 * q;
+        vrow[i] = 8 * h + 2 * q;
+      } else {
+        const int e = halo_live ? lane : 19, h = pw - 2;
+        vr[i] = e >> 1; vx[i] = (e & 1) ? PW - 2 : -1;           // column offset from x0: the patch's column 33 / 0
+        vch[i] = 8 * h * HW;
+        vlds[i] = 16 * (h * HS + vr[i] * PW + vx[i] + 1);
+        vrow[i] = 8 * h;
+      }
+    }
+  }
+  auto pad_vec = [&](int c) __attribute__((always_inline)) { return c < HPAD16 ? NPOS + c : PS + NPOS + (c - HPAD16); };
   // fetch cursor: the next chunk to load.  The loads are UNCONDITIONAL (past the end of the list the last item's first chunk is
   // loaded again and dropped): a conditional load between a load and its use makes hipcc wait for vmcnt(0) at the use -- the
   // full HBM latency of the loads just issued, measured at 3000 cycles per chunk in the first version of this kernel.
@@ -257,6 +294,24 @@ __global__ __launch_bounds__(256 + 64 * NPW, NPW == 4 ? 2 : 3) void k_conv3p(con
   float f_in_scale = 1.f;
   auto plan_fetch = [&](const Item& it) __attribute__((always_inline)) {
     f_xvalid = 0;
+    if constexpr (VEC) {
+#pragma unroll
+      for (int i = 0; i < XI; ++i) {
+        const bool halo = i == XI - 1 && pw >= 2;
+        int gy = it.y0 + vr[i] - 1 + a.oy, gx = it.x0 + vx[i];
+        if (CIRC) {
+          gy = gy < 0 ? gy + a.H : (gy >= a.H ? gy - a.H : gy);
+          gx = gx < 0 ? gx + a.W : (gx >= a.W ? gx - a.W : gx);
+          gy = gy >= a.H ? a.H - 1 : gy;
+        }
+        const bool ok = (!halo || halo_live) && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+        xoff[i] = ok ? gy * a.W + gx : 0;
+        if (ok) f_xvalid |= 1u << i;
+      }
+      f_b = it.b;
+      if constexpr (!PRE) f_in_scale = ds_epi::act_scale_of(a.in_amax ? const_u32(a.in_amax, it.b) : 0u, a.wshift).in_scale;
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < XI; ++i) {
       int gy = it.y0 + xrow[i] - 1 + a.oy, gx = it.x0 + xcol[i] - 1 + a.ox;
@@ -284,23 +339,81 @@ __global__ __launch_bounds__(256 + 64 * NPW, NPW == 4 ? 2 : 3) void k_conv3p(con
     f_src = a.in + ((size_t)f_b * a.Cin + (size_t)f_chunk * KC) * HW;
     if (valid && ++f_chunk == n_chunks) { f_chunk = 0; ++f_k; }
   };
-  auto fetch_item = [&](float (&xr)[XI][8], int i) __attribute__((always_inline)) {
-    const float* p0 = f_src + xoff[i] + (size_t)(8 * item_h(i)) * HW;
+  // HALO (compile time): this producer wave's last slot is a halo item (VEC, producer waves 2 and 3)
+  auto fetch_item = [&](auto halo_tag, float (&xr)[XI][8], int i) __attribute__((always_inline)) {
+    constexpr bool HALO = decltype(halo_tag)::value;
+    if constexpr (VEC) {
+      const float* p0 = f_src + vch[i] + xoff[i];
+      if (HALO && i == XI - 1) {
 #pragma unroll
-    for (int k = 0; k < 8; ++k) xr[i][k] = p0[(size_t)k * HW];
+        for (int k = 0; k < 8; ++k) xr[i][k] = p0[(size_t)k * HW];
+      } else {
+        const f32x4 t0 = *reinterpret_cast<const f32x4*>(p0);
+        const f32x4 t1 = *reinterpret_cast<const f32x4*>(p0 + HW);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { xr[i][k] = t0[k]; xr[i][4 + k] = t1[k]; }
+      }
+    } else {
+      const float* p0 = f_src + xoff[i] + (size_t)(8 * item_h(i)) * HW;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) xr[i][k] = p0[(size_t)k * HW];
+    }
   };
-  auto fetch = [&](float (&xr)[XI][8], unsigned& tag, int& trow, float& tscale) __attribute__((always_inline)) {
+  // vector-memory loads of one fetched chunk, per wave
+  auto fetch_count = [&](auto halo_tag) __attribute__((always_inline)) {
+    constexpr bool HALO = decltype(halo_tag)::value;
+    return VEC ? (PRE ? 1 : 0) + (HALO ? 2 * (XI - 1) + 8 : 2 * XI) : DS_LPI * XI;
+  };
+  // VEC + PRE: the chunk's 16 table rows, one 16-byte load in front of the patch's (every producer wave, so the counts stay uniform)
+  auto rows_fetch = [&](f32x4& prow, int trow) __attribute__((always_inline)) {
+    if constexpr (VEC && PRE) prow = reinterpret_cast<const f32x4*>(a.prenorm)[trow + (lane & 15)];
+  };
+  auto rows_park = [&](const f32x4& prow, int buf) __attribute__((always_inline)) {
+    if constexpr (VEC && PRE) {
+      if (pw == 0 && lane < 16) Xs[buf * XBV + pad_vec(lane)] = __builtin_bit_cast(u32x4, prow);
+    }
+  };
+  auto fetch = [&](auto halo_tag, float (&xr)[XI][8], f32x4& prow, unsigned& tag, int& trow, float& tscale) __attribute__((always_inline)) {
     fetch_begin(tag, trow, tscale);
+    rows_fetch(prow, trow);
 #pragma unroll
-    for (int i = 0; i < XI; ++i) fetch_item(xr, i);
-    return DS_LPI * XI;
+    for (int i = 0; i < XI; ++i) fetch_item(halo_tag, xr, i);
+    return fetch_count(halo_tag);
   };
   // [norm + SiLU,] fp16 hi / lo split of one staging item of a fetched chunk, in registers
-  auto activate_item = [&](float (&xr)[XI][8], unsigned tag, int trow, float tscale, Packed& pk, int i) __attribute__((always_inline)) {
+  auto activate_item = [&](auto halo_tag, float (&xr)[XI][8], unsigned tag, int trow, float tscale, Packed& pk, int i, int buf) __attribute__((always_inline)) {
+    constexpr bool HALO = decltype(halo_tag)::value;
+    if constexpr (VEC) {
+      if (!(HALO && i == XI - 1)) {
+        // interior unit: xr[i][0..3] = four pixels of channel 2q, xr[i][4..7] = of channel 2q + 1; rows from the buffer's pad vectors
+        if constexpr (PRE) {
+          const u32x4* rows = Xs + buf * XBV;
+          const f32x4 p0 = __builtin_bit_cast(f32x4, rows[pad_vec(vrow[i])]);
+          const f32x4 p1 = __builtin_bit_cast(f32x4, rows[pad_vec(vrow[i] + 1)]);
+          const float inv = p0[3] == 0.f ? 1.0f : p0[3];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            xr[i][k] = ds_h3::fast_silu_scaled((xr[i][k] - p0[0]) * p0[1] + p0[2], inv);
+            xr[i][4 + k] = ds_h3::fast_silu_scaled((xr[i][4 + k] - p1[0]) * p1[1] + p1[2], inv);
+          }
+        }
+        const bool item_ok = (tag >> i) & 1u;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          float v0 = item_ok ? xr[i][k] : 0.f;
+          float v1 = item_ok ? xr[i][4 + k] : 0.f;
+          if constexpr (!PRE) { v0 *= tscale; v1 *= tscale; }
+          unsigned ph, pl;
+          split2(v0, v1, ph, pl);
+          pk.h[i][k] = ph; pk.l[i][k] = pl;
+        }
+        return;
+      }
+    }
     if constexpr (PRE) {
       typedef const __attribute__((address_space(4))) f32x4* cptr;
       cptr pp = (cptr)(reinterpret_cast<const f32x4*>(a.prenorm)) + trow;
-      const int h = item_h(i);
+      const int h = VEC ? pw - 2 : item_h(i);
       f32x4 p[8];
 #pragma unroll
       for (int k = 0; k < 8; ++k) p[k] = pp[8 * h + k];
@@ -319,26 +432,47 @@ __global__ __launch_bounds__(256 + 64 * NPW, NPW == 4 ? 2 : 3) void k_conv3p(con
       pk.h[i][k] = ph; pk.l[i][k] = pl;
     }
   };
-  auto activate = [&](float (&xr)[XI][8], unsigned tag, int trow, float tscale, Packed& pk) __attribute__((always_inline)) {
+  auto activate = [&](auto halo_tag, float (&xr)[XI][8], unsigned tag, int trow, float tscale, Packed& pk, int buf) __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < XI; ++i) activate_item(xr, tag, trow, tscale, pk, i);
+    for (int i = 0; i < XI; ++i) activate_item(halo_tag, xr, tag, trow, tscale, pk, i, buf);
   };
   // the loads of one chunk and the vector work of another, item by item: the loads' issue is paced by the memory pipeline (a CU's
   // share of HBM), and a wave stuck behind 24 of them in a row activates nothing meanwhile
-  auto fetch_while_activating = [&](float (&xn)[XI][8], unsigned& tagn, int& trown, float& tscn,
-                                    float (&xo)[XI][8], unsigned tago, int trowo, float tsco, Packed& pk) __attribute__((always_inline)) {
+  auto fetch_while_activating = [&](auto halo_tag, float (&xn)[XI][8], f32x4& prown, unsigned& tagn, int& trown, float& tscn,
+                                    float (&xo)[XI][8], unsigned tago, int trowo, float tsco, Packed& pk, int bufo) __attribute__((always_inline)) {
     fetch_begin(tagn, trown, tscn);
+    rows_fetch(prown, trown);
 #pragma unroll
     for (int i = 0; i < XI; ++i) {
-      fetch_item(xn, i);
+      fetch_item(halo_tag, xn, i);
       __builtin_amdgcn_sched_barrier(0);
-      activate_item(xo, tago, trowo, tsco, pk, i);
+      activate_item(halo_tag, xo, tago, trowo, tsco, pk, i, bufo);
       __builtin_amdgcn_sched_barrier(0);
     }
-    return DS_LPI * XI;
+    return fetch_count(halo_tag);
   };
-  auto store_x = [&](const Packed& pk, unsigned tag, int buf) __attribute__((always_inline)) {
+  auto store_x = [&](auto halo_tag, const Packed& pk, unsigned tag, int buf) __attribute__((always_inline)) {
+    constexpr bool HALO = decltype(halo_tag)::value;
     if (!(tag >> 31)) return;
+    if constexpr (VEC) {
+      unsigned char* xbytes = smem + (size_t)buf * XBV * 16;
+#pragma unroll
+      for (int i = 0; i < XI; ++i) {
+        if (HALO && i == XI - 1) {
+          if (halo_live) {
+            *reinterpret_cast<u32x4*>(xbytes + vlds[i]) = pk.h[i];
+            *reinterpret_cast<u32x4*>(xbytes + vlds[i] + PS * 16) = pk.l[i];
+          }
+        } else {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            *reinterpret_cast<unsigned*>(xbytes + vlds[i] + 16 * k) = pk.h[i][k];
+            *reinterpret_cast<unsigned*>(xbytes + vlds[i] + 16 * k + PS * 16) = pk.l[i][k];
+          }
+        }
+      }
+      return;
+    }
     u32x4* xb = Xs + buf * XBV;
 #pragma unroll
     for (int i = 0; i < XI; ++i) {
@@ -491,6 +625,7 @@ __global__ __launch_bounds__(256 + 64 * NPW, NPW == 4 ? 2 : 3) void k_conv3p(con
   int trowA = 0, trowB = 0;
   float tscA = 1.f, tscB = 1.f;
   Packed pk;
+  f32x4 prowA = {0.f, 0.f, 0.f, 0.f}, prowB = {0.f, 0.f, 0.f, 0.f};      // VEC + PRE: the table rows that go with xrA / xrB
   ResRegs RA, RB;
   float bsb = 0.f, bss = 0.f;
   Frag F0, F1;
@@ -500,7 +635,10 @@ __global__ __launch_bounds__(256 + 64 * NPW, NPW == 4 ? 2 : 3) void k_conv3p(con
   // own instantiation (as one loop with role branches inside, the allocator had to keep both roles' state alive at once: 256
   // VGPRs and 700 spilled).
   auto run = [&](auto role_tag) __attribute__((always_inline)) {
-    constexpr bool CONS = decltype(role_tag)::value;
+    // role 0: consumer; 1: producer; 2 (VEC only): producer whose last staging slot is a halo item (producer waves 2 and 3)
+    constexpr int ROLE = decltype(role_tag)::value;
+    constexpr bool CONS = ROLE == 0;
+    const std::integral_constant<bool, ROLE == 2> halo{};
     // Counted barrier wait of the producers.  A step's weight DMA (slab p + 3) is the FIRST vector-memory operation of step p and
     // must have landed by the END of step p + 1: everything issued behind it in step p (`prev`), step p + 1's own DMA (3) and
     // everything else of step p + 1 (`young`) may stay in flight.  Loads, LDS-DMA and stores complete in issue order on gfx9
@@ -562,7 +700,7 @@ __global__ __launch_bounds__(256 + 64 * NPW, NPW == 4 ? 2 : 3) void k_conv3p(con
         wdma((B + 3) & 3);
         __builtin_amdgcn_sched_barrier(0);
         if (head) { plan_store(item_of(it - 1)); young += res_prefetch(RA, 0); }
-        young += fetch_while_activating(xrB, tagB, trowB, tscB, xrA, tagA, trowA, tscA, pk);   // chunk E + 2 | chunk O
+        young += fetch_while_activating(halo, xrB, prowB, tagB, trowB, tscB, xrA, tagA, trowA, tscA, pk, 1);   // chunk E + 2 | chunk O
         tagP = tagA;
       }
       if (stamp < 48) PSTAMP(stamp);
@@ -574,7 +712,8 @@ __global__ __launch_bounds__(256 + 64 * NPW, NPW == 4 ? 2 : 3) void k_conv3p(con
       } else {
         wdma((B + 4) & 3);
         __builtin_amdgcn_sched_barrier(0);
-        store_x(pk, tagP, 1);
+        store_x(halo, pk, tagP, 1);
+        rows_park(prowB, 0);                          // chunk E + 2's table rows: read by its activation in (O, 1)
         if (head) {
           young += store_batch(RA, 0);
           young += res_prefetch(RB, 1);
@@ -607,7 +746,7 @@ __global__ __launch_bounds__(256 + 64 * NPW, NPW == 4 ? 2 : 3) void k_conv3p(con
         wdma((B + 6) & 3);
         __builtin_amdgcn_sched_barrier(0);
         PSTAMP_FINE(1);
-        young += fetch(xrA, tagA, trowA, tscA);       // chunk O + 2
+        young += fetch(halo, xrA, prowA, tagA, trowA, tscA);       // chunk O + 2
         __builtin_amdgcn_sched_barrier(0);
         PSTAMP_FINE(2);
         if (head) {
@@ -627,10 +766,11 @@ __global__ __launch_bounds__(256 + 64 * NPW, NPW == 4 ? 2 : 3) void k_conv3p(con
         wdma((B + 7) & 3);
         __builtin_amdgcn_sched_barrier(0);
         PSTAMP_FINE(5);
-        activate(xrB, tagB, trowB, tscB, pk);         // chunk E + 2
+        activate(halo, xrB, tagB, trowB, tscB, pk, 0);         // chunk E + 2
         __builtin_amdgcn_sched_barrier(0);
         PSTAMP_FINE(6);
-        store_x(pk, tagB, 0);
+        store_x(halo, pk, tagB, 0);
+        rows_park(prowA, 1);                          // chunk O + 2's table rows: read by its activation in the next (E, 0)
         if (head && stats && wv == 4) store_stats();
       }
       if (stamp < 48) PSTAMP(stamp);
@@ -662,15 +802,24 @@ __global__ __launch_bounds__(256 + 64 * NPW, NPW == 4 ? 2 : 3) void k_conv3p(con
       wdma(0);
       wdma(1);
       wdma(2);
-      fetch(xrB, tagB, trowB, tscB);
-      fetch(xrA, tagA, trowA, tscA);
+      fetch(halo, xrB, prowB, tagB, trowB, tscB);
+      fetch(halo, xrA, prowA, tagA, trowA, tscA);
       bs_fetch(item_of(0), bsb, bss);
-      activate(xrB, tagB, trowB, tscB, pk);
-      store_x(pk, tagB, 0);
+      if constexpr (VEC && PRE) {
+        // both chunks' table rows into the pads of their X buffers, published by a barrier of their own (once per workgroup: the
+        // full wait costs nothing that matters)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        rows_park(prowB, 0);
+        rows_park(prowA, 1);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      }
+      activate(halo, xrB, tagB, trowB, tscB, pk, 0);
+      store_x(halo, pk, tagB, 0);
       bs_commit(bsb, bss, unscale_of(item_of(0)), 0);
-      asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
-                 // the three slabs and chunk 0; chunk 1's loads may stay in flight (the bias / shift loads are younger still)
+      if constexpr (VEC) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(20)" ::: "memory");     // the three slabs and chunk 0; chunk 1's loads may stay in flight (the bias / shift loads are younger still)
     } else {
+      if constexpr (VEC && PRE) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // the producers' table-row barrier
 #pragma unroll
       for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -680,7 +829,7 @@ __global__ __launch_bounds__(256 + 64 * NPW, NPW == 4 ? 2 : 3) void k_conv3p(con
     }
     PSTAMP(0);
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    young = 0; prev = DS_LPI * XI;                             // behind the prologue's slabs: chunk 1's loads
+    young = 0; prev = VEC ? 0 : DS_LPI * XI;          // behind the prologue's slabs: chunk 1's loads (VEC: the prologue waited for everything)
     if constexpr (CONS && NPW == 4) load_pair(F0, 0, 0, 0, 0, 0, 0, 1, 0);         // P0 of the first chunk pair
 
     const int ncp = n_chunks >> 1;                    // even (the launcher's rule): fragment sets and ring slots are back in place after an item
@@ -718,14 +867,15 @@ __global__ __launch_bounds__(256 + 64 * NPW, NPW == 4 ? 2 : 3) void k_conv3p(con
     }
   };
   if (consumer) {
-    run(std::true_type{});
+    run(std::integral_constant<int, 0>{});
   } else {
     // the producers pace the kernel: let their vector / memory instructions win the issue arbitration against the consumer's
     // matrix stream on the same SIMD (MI355X_MICROARCH.md, Two waves per SIMD: priority, then age)
     if (a.pc_prio == 1) __builtin_amdgcn_s_setprio(1);
     else if (a.pc_prio == 2) __builtin_amdgcn_s_setprio(2);
     else if (a.pc_prio == 3) __builtin_amdgcn_s_setprio(3);
-    run(std::false_type{});
+    if (VEC && pw >= 2) run(std::integral_constant<int, VEC ? 2 : 1>{});
+    else run(std::integral_constant<int, 1>{});
   }
 }
 
@@ -735,17 +885,25 @@ int conv3p_producer_waves() {
   return v;
 }
 
-template <bool PRE, bool CIRC, int NRES, int NPW>
+template <bool PRE, bool CIRC, int NRES, int NPW, bool VEC = false>
 int launch_conv3p_w(const Conv3hArgs& a, int wgs, hipStream_t s) {
-  const int rc = ds::ensure_dynamic_lds<&k_conv3p<PRE, CIRC, NRES, NPW>>(P_LDS, "hipFuncSetAttribute(conv3p)");
+  const int rc = ds::ensure_dynamic_lds<&k_conv3p<PRE, CIRC, NRES, NPW, VEC>>(P_LDS, "hipFuncSetAttribute(conv3p)");
   if (rc != DS_OK) return rc;
-  hipLaunchKernelGGL((k_conv3p<PRE, CIRC, NRES, NPW>), dim3((unsigned)wgs), dim3(256 + 64 * NPW), P_LDS, s, a);
+  hipLaunchKernelGGL((k_conv3p<PRE, CIRC, NRES, NPW, VEC>), dim3((unsigned)wgs), dim3(256 + 64 * NPW), P_LDS, s, a);
   DS_CHECK_LAUNCH("ds_conv2d_h3 (persistent)");
   return DS_OK;
 }
+// DS_CONV_VEC=0: the one-pixel staging items (A/B runs; the same switch as ds_conv3h.hip's)
+bool conv3p_vec() {
+  static const bool on = [] { const char* e = getenv("DS_CONV_VEC"); return !(e && atoi(e) == 0); }();
+  return on;
+}
 template <bool PRE, bool CIRC, int NRES>
 int launch_conv3p_r(const Conv3hArgs& a, int wgs, hipStream_t s) {
-  return conv3p_producer_waves() == 8 ? launch_conv3p_w<PRE, CIRC, NRES, 8>(a, wgs, s) : launch_conv3p_w<PRE, CIRC, NRES, 4>(a, wgs, s);
+  if (conv3p_producer_waves() == 8) return launch_conv3p_w<PRE, CIRC, NRES, 8>(a, wgs, s);
+  // 16-byte patch loads: W is a multiple of 32 and Cin of 64 here (conv3p_try_launch); no column tap offset, an aligned input
+  if (conv3p_vec() && a.ox == 0 && (reinterpret_cast<uintptr_t>(a.in) & 15u) == 0) return launch_conv3p_w<PRE, CIRC, NRES, 4, true>(a, wgs, s);
+  return launch_conv3p_w<PRE, CIRC, NRES, 4>(a, wgs, s);
 }
 template <bool PRE, bool CIRC>
 int launch_conv3p(Conv3hArgs a, int wgs, hipStream_t s) {
