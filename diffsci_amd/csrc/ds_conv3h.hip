@@ -582,6 +582,7 @@ __global__ __launch_bounds__(64 * NW, TWO ? 2 : NW / 2) void k_conv3h(const Conv
           for (int n = 0; n < 4; ++n)
             acc16[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.a[PA[t]][m], f.b[PB[t]][n], acc16[m][n], 0, 0, 0);
     };
+    const bool early_stage = a.two_early != 0;
     // staging of a step (weights two steps ahead, the next patch at ky = 0 / 1), as in the 32x32x16 schedule
     auto stage_in = [&](int chunk, int ky) __attribute__((always_inline)) {
       const int g = chunk * 3 + ky;
@@ -597,6 +598,14 @@ __global__ __launch_bounds__(64 * NW, TWO ? 2 : NW / 2) void k_conv3h(const Conv
         if (ky == 0 && chunk + 1 < a.n_chunks) x_dma(chunk + 1, (chunk + 1) & 1);
       } else
       if (fetch && ky == 0 && chunk + 1 < a.n_chunks) { rows_fetch(chunk + 1); x_fetch(chunk + 1); }
+      // TWO: the eight waves run one program behind one barrier per step, so unshifted all of them multiply at the same time and all
+      // of them activate + split at the same time (profiles/r04_pmc_stalls.log: vector and matrix pipes co-executing 1.7 % of the
+      // launch).  Waves 0-3 therefore stage their share of the next patch BEFORE this step's matrix instructions, waves 4-7 (their SIMD
+      // partners) after them: each SIMD then holds one vector stream beside one matrix stream in both halves of the step
+      // (MI355X_MICROARCH.md, Two waves per SIMD, item 9).  Legal: the patch goes to the OTHER X buffer, which nobody reads in this step.
+      if constexpr (TWO && !IMGIN) {
+        if (early_stage && wv < 4 && fetch && ky == 1 && chunk + 1 < a.n_chunks) x_store((chunk & 1) ^ 1);
+      }
       __builtin_amdgcn_sched_barrier(0);
     };
     auto stage_out = [&](int chunk, int ky, int xbuf) __attribute__((always_inline)) {
@@ -608,7 +617,7 @@ __global__ __launch_bounds__(64 * NW, TWO ? 2 : NW / 2) void k_conv3h(const Conv
 #endif
       if constexpr (!IMGIN) {
         if (store && ky == 0 && chunk + 1 < a.n_chunks) rows_park(xbuf ^ 1);
-        if (store && ky == 1 && chunk + 1 < a.n_chunks) x_store(xbuf ^ 1);
+        if (store && ky == 1 && chunk + 1 < a.n_chunks && !(TWO && early_stage && wv < 4)) x_store(xbuf ^ 1);
       }
       __syncthreads();
     };
@@ -883,6 +892,10 @@ int ds_conv2d_h3(float* out, const float* in, const void* w_packed, int wshift, 
   Conv3hArgs a;
   a.prenorm = prenorm; a.tile_stats = tile_stats; a.circular = circular; a.res1_up = res1_up; a.oy = oy; a.ox = ox;
   a.ntiles_magic40 = 0; a.ncot_magic40 = 0; a.pc_prio = 0;      // set by ds_conv3p.hip's launcher when it takes the launch
+  {
+    static const int early = [] { const char* e = getenv("DS_CONV_TWO_EARLY"); return e ? atoi(e) : 1; }();   // A/B switch of the two-tile kernel's staging shift
+    a.two_early = early;
+  }
   a.out = out; a.in = in; a.wp = reinterpret_cast<const u32x4*>(w_packed); a.bias = bias; a.shift = shift;
   a.res1 = res1; a.res2 = res2; a.shift_stride = shift_stride;
   a.wshift = wshift; a.in_amax = in_amax; a.out_amax = out_amax;

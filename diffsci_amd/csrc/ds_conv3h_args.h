@@ -68,6 +68,7 @@ struct Conv3hArgs {
   // d < 2^18 (the persistent kernel decodes an item index several times per tile: hardware has no integer divide)
   unsigned long long ntiles_magic40, ncot_magic40;
   int pc_prio;              // ds_conv3p.hip only: s_setprio level of the producer waves (DS_CONV_PC_PRIO, A/B runs)
+  int two_early;            // ds_conv3h.hip, two channel tiles per workgroup: waves 0-3 stage the next patch before the step's matrix instructions (DS_CONV_TWO_EARLY)
 #ifdef DS_STAMP
   unsigned long long* stamps;   // diagnostic build only (tools/conv3h_stamp.hip)
   unsigned stagger_lo, stagger_hi, stagger_ticks;   // experiment: workgroups with dispatch index in [lo, hi) start `ticks` x 10 ns late
