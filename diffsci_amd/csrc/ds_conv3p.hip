@@ -75,6 +75,9 @@ __device__ __forceinline__ void bar_counted(int young) {
 #undef DS_VMCNT_CASE
 
 struct Item { int cot, b, y0, x0, tile; };
+#ifndef DS_PC_CDMA
+#define DS_PC_CDMA 1                                 // 0: the producers issue the weight DMA (measurement builds, tools/build_variant.sh)
+#endif
 #define DS_LPI 8                                    // vector-memory loads per staging item
 
 template <int XI> struct Packed { u32x4 h[XI], l[XI]; };
@@ -484,14 +487,18 @@ __global__ __launch_bounds__(256 + 64 * NPW, NPW == 4 ? 2 : 3) void k_conv3p(con
   };
   // weight cursor: the next slab to DMA.  Unconditional as well (past the end: the last item's first slab into a slot nobody reads).
   int w_k = 0, w_step = 0, w_cot = 0;
-  auto wdma = [&](int slot) __attribute__((always_inline)) {                       // slot = (slab index) & 3
+  // widx / nwv: the issuing wave's index among the nwv waves that share a slab's twelve pieces -- the producers, or (cdma) the four
+  // CONSUMERS: a weight DMA costs its wave 150-200 cycles to issue (stamped), three per step; the producers pace this kernel and the
+  // consumers wait for them at every barrier, so the consumers issue them, in front of the step's matrix instructions
+  constexpr bool cdma = DS_PC_CDMA != 0;            // compile time (as a kernel argument the two forms side by side cost 15 % -- measured)
+  auto wdma = [&](int slot, int widx, int nwv) __attribute__((always_inline)) {     // slot = (slab index) & 3
     const bool valid = w_k < n_items;
     if (valid && w_step == 0) w_cot = item_of(w_k).cot;
     const u32x4* src = a.wp + ((size_t)w_cot * n_steps + w_step) * WSLAB_VEC;
     u32x4* dst = Ws + slot * WSLAB_VEC;
 #pragma unroll
-    for (int i = 0; i < 12 / NPW + (12 % NPW ? 1 : 0); ++i) {
-      const int k = pw + NPW * i;                     // wave-uniform piece of the slab's twelve
+    for (int i = 0; i < 3; ++i) {
+      const int k = widx + nwv * i;                   // wave-uniform piece of the slab's twelve
       if (k < 12) lds_dma16(src + 64 * k, 16u * (unsigned)lane, lds_address(dst + 64 * k));
     }
     if (valid && ++w_step == n_steps) { w_step = 0; ++w_k; }
@@ -646,8 +653,10 @@ __global__ __launch_bounds__(256 + 64 * NPW, NPW == 4 ? 2 : 3) void k_conv3p(con
     int young = 0, prev = 0;
     const int ndma = NPW == 4 ? 3 : (pw < 4 ? 2 : 1);             // DMA instructions of this wave per step
     auto barrier = [&]() __attribute__((always_inline)) {
-      if constexpr (CONS) bar_counted(0);
-      else { bar_counted(prev + ndma + young); prev = young; young = 0; }
+      // (cdma: a consumer's only vector-memory operations are its three DMA per step -- those of the step that ends here may stay in
+      //  flight, the previous step's have landed; the producers then have nothing another wave waits for)
+      if constexpr (CONS) bar_counted(cdma ? 3 : 0);
+      else { bar_counted(cdma ? 63 : prev + ndma + young); prev = young; young = 0; }
     };
     int stamp = 1;
     (void)stamp;
@@ -694,10 +703,11 @@ __global__ __launch_bounds__(256 + 64 * NPW, NPW == 4 ? 2 : 3) void k_conv3p(con
 #define DS_GROUP(k) group(std::integral_constant<int, k>{})
       // ---------------- step (E, 0) ----------------
       if constexpr (CONS) {
+        if (cdma) { wdma((B + 3) & 3, rw, 4); __builtin_amdgcn_sched_barrier(0); }
         if (head) park_tile((it - 1) & 1);
         DS_GROUP(0); DS_GROUP(1);
       } else {
-        wdma((B + 3) & 3);
+        if (!cdma) wdma((B + 3) & 3, pw, NPW);
         __builtin_amdgcn_sched_barrier(0);
         if (head) { plan_store(item_of(it - 1)); young += res_prefetch(RA, 0); }
         young += fetch_while_activating(halo, xrB, prowB, tagB, trowB, tscB, xrA, tagA, trowA, tscA, pk, 1);   // chunk E + 2 | chunk O
@@ -708,9 +718,10 @@ __global__ __launch_bounds__(256 + 64 * NPW, NPW == 4 ? 2 : 3) void k_conv3p(con
       barrier();
       // ---------------- step (E, 1) ----------------
       if constexpr (CONS) {
+        if (cdma) { wdma((B + 4) & 3, rw, 4); __builtin_amdgcn_sched_barrier(0); }
         DS_GROUP(2);
       } else {
-        wdma((B + 4) & 3);
+        if (!cdma) wdma((B + 4) & 3, pw, NPW);
         __builtin_amdgcn_sched_barrier(0);
         store_x(halo, pk, tagP, 1);
         rows_park(prowB, 0);                          // chunk E + 2's table rows: read by its activation in (O, 1)
@@ -725,9 +736,10 @@ __global__ __launch_bounds__(256 + 64 * NPW, NPW == 4 ? 2 : 3) void k_conv3p(con
       barrier();
       // ---------------- step (E, 2) ----------------
       if constexpr (CONS) {
+        if (cdma) { wdma((B + 5) & 3, rw, 4); __builtin_amdgcn_sched_barrier(0); }
         DS_GROUP(3); DS_GROUP(4);
       } else {
-        wdma((B + 5) & 3);
+        if (!cdma) wdma((B + 5) & 3, pw, NPW);
         __builtin_amdgcn_sched_barrier(0);
         if (head) {
           young += store_batch(RB, 1);
@@ -740,10 +752,11 @@ __global__ __launch_bounds__(256 + 64 * NPW, NPW == 4 ? 2 : 3) void k_conv3p(con
       barrier();
       // ---------------- step (O, 0) ----------------
       if constexpr (CONS) {
+        if (cdma) { wdma((B + 6) & 3, rw, 4); __builtin_amdgcn_sched_barrier(0); }
         DS_GROUP(5);
       } else {
         PSTAMP_FINE(0);
-        wdma((B + 6) & 3);
+        if (!cdma) wdma((B + 6) & 3, pw, NPW);
         __builtin_amdgcn_sched_barrier(0);
         PSTAMP_FINE(1);
         young += fetch(halo, xrA, prowA, tagA, trowA, tscA);       // chunk O + 2
@@ -760,10 +773,11 @@ __global__ __launch_bounds__(256 + 64 * NPW, NPW == 4 ? 2 : 3) void k_conv3p(con
       barrier();
       // ---------------- step (O, 1) ----------------
       if constexpr (CONS) {
+        if (cdma) { wdma((B + 7) & 3, rw, 4); __builtin_amdgcn_sched_barrier(0); }
         DS_GROUP(6); DS_GROUP(7);
       } else {
         PSTAMP_FINE(4);
-        wdma((B + 7) & 3);
+        if (!cdma) wdma((B + 7) & 3, pw, NPW);
         __builtin_amdgcn_sched_barrier(0);
         PSTAMP_FINE(5);
         activate(halo, xrB, tagB, trowB, tscB, pk, 0);         // chunk E + 2
@@ -778,9 +792,10 @@ __global__ __launch_bounds__(256 + 64 * NPW, NPW == 4 ? 2 : 3) void k_conv3p(con
       barrier();
       // ---------------- step (O, 2) ----------------
       if constexpr (CONS) {
+        if (cdma) { wdma((B + 8) & 3, rw, 4); __builtin_amdgcn_sched_barrier(0); }
         DS_GROUP(8);
       } else {
-        wdma((B + 8) & 3);
+        if (!cdma) wdma((B + 8) & 3, pw, NPW);
         __builtin_amdgcn_sched_barrier(0);
         if (last_of_item && it + 1 < n_items) bs_commit(bsb, bss, unscale_of(item_of(it + 1)), (it + 1) & 1);
       }
@@ -799,9 +814,7 @@ __global__ __launch_bounds__(256 + 64 * NPW, NPW == 4 ? 2 : 3) void k_conv3p(con
     }
     // ---- prologue: slabs 0, 1, 2, chunk 0 in X buffer 0, chunk 1 in flight, the first item's bias / shift row ----
     if constexpr (!CONS) {
-      wdma(0);
-      wdma(1);
-      wdma(2);
+      if (!cdma) { wdma(0, pw, NPW); wdma(1, pw, NPW); wdma(2, pw, NPW); }
       fetch(halo, xrB, prowB, tagB, trowB, tscB);
       fetch(halo, xrA, prowA, tagA, trowA, tscA);
       bs_fetch(item_of(0), bsb, bss);
@@ -819,6 +832,7 @@ __global__ __launch_bounds__(256 + 64 * NPW, NPW == 4 ? 2 : 3) void k_conv3p(con
       if constexpr (VEC) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(20)" ::: "memory");     // the three slabs and chunk 0; chunk 1's loads may stay in flight (the bias / shift loads are younger still)
     } else {
+      if (cdma) { wdma(0, rw, 4); wdma(1, rw, 4); wdma(2, rw, 4); }
       if constexpr (VEC && PRE) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // the producers' table-row barrier
 #pragma unroll
       for (int m = 0; m < 4; ++m)
@@ -828,6 +842,7 @@ __global__ __launch_bounds__(256 + 64 * NPW, NPW == 4 ? 2 : 3) void k_conv3p(con
           for (int e = 0; e < 4; ++e) acc[m][n][e] = 0.f;
     }
     PSTAMP(0);
+    if constexpr (CONS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // (cdma) the first three slabs
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     young = 0; prev = VEC ? 0 : DS_LPI * XI;          // behind the prologue's slabs: chunk 1's loads (VEC: the prologue waited for everything)
     if constexpr (CONS && NPW == 4) load_pair(F0, 0, 0, 0, 0, 0, 0, 1, 0);         // P0 of the first chunk pair
