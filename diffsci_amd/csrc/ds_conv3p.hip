@@ -439,19 +439,22 @@ __global__ __launch_bounds__(256 + 64 * NPW, NPW == 4 ? 2 : 3) void k_conv3p(con
 #pragma unroll
     for (int i = 0; i < XI; ++i) activate_item(halo_tag, xr, tag, trow, tscale, pk, i, buf);
   };
-  // the loads of one chunk and the vector work of another, item by item: the loads' issue is paced by the memory pipeline (a CU's
-  // share of HBM), and a wave stuck behind 24 of them in a row activates nothing meanwhile
-  auto fetch_while_activating = [&](auto halo_tag, float (&xn)[XI][8], f32x4& prown, unsigned& tagn, int& trown, float& tscn,
+  // all staging slots of a chunk but the last (the last one rides beside the NEXT fetch: fetch_beside_last_slot)
+  auto activate_first_slots = [&](auto halo_tag, float (&xr)[XI][8], unsigned tag, int trow, float tscale, Packed& pk, int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < XI - 1; ++i) activate_item(halo_tag, xr, tag, trow, tscale, pk, i, buf);
+  };
+  // the loads of chunk n beside the vector work of the LAST slot of chunk o (whose other slots were activated a step earlier)
+  auto fetch_beside_last_slot = [&](auto halo_tag, float (&xn)[XI][8], f32x4& prown, unsigned& tagn, int& trown, float& tscn,
                                     float (&xo)[XI][8], unsigned tago, int trowo, float tsco, Packed& pk, int bufo) __attribute__((always_inline)) {
     fetch_begin(tagn, trown, tscn);
     rows_fetch(prown, trown);
 #pragma unroll
-    for (int i = 0; i < XI; ++i) {
-      fetch_item(halo_tag, xn, i);
-      __builtin_amdgcn_sched_barrier(0);
-      activate_item(halo_tag, xo, tago, trowo, tsco, pk, i, bufo);
-      __builtin_amdgcn_sched_barrier(0);
-    }
+    for (int i = 0; i < XI - 1; ++i) fetch_item(halo_tag, xn, i);
+    __builtin_amdgcn_sched_barrier(0);
+    activate_item(halo_tag, xo, tago, trowo, tsco, pk, XI - 1, bufo);
+    __builtin_amdgcn_sched_barrier(0);
+    fetch_item(halo_tag, xn, XI - 1);
     return fetch_count(halo_tag);
   };
   auto store_x = [&](auto halo_tag, const Packed& pk, unsigned tag, int buf) __attribute__((always_inline)) {
@@ -664,12 +667,15 @@ __global__ __launch_bounds__(256 + 64 * NPW, NPW == 4 ? 2 : 3) void k_conv3p(con
     // fetched (into the other fragment set) while group k multiplies; nine is odd, so the two sets swap roles from one chunk pair
     // to the next and the loop body below is two chunk pairs = 12 steps = three turns of the 4-slot weight ring (BASE = 0 / 6:
     // the step position of (E,0); slab of position p sits in slot p & 3).  Producer duties per step (chunk numbers relative to E):
-    //   (E,0)  DMA slab +3 | residuals of batch 0 | fetch chunk E+2 -> B  interleaved with  activate + split chunk O (A)
-    //   (E,1)  DMA         | store chunk O -> X1  | batch 0, residuals of batches 1, 2
-    //   (E,2)  DMA         | batches 1, 2, residuals of batch 3
-    //   (O,0)  DMA         | fetch chunk O+2 -> A | batch 3, output maxima | next item's bias / shift loads
-    //   (O,1)  DMA         | activate + split chunk E+2 (B), store -> X0  | statistics combine
-    //   (O,2)  DMA         | commit the next item's bias / shift row
+    //   (E,0)  fetch chunk E+2 -> B  beside  activate + split the LAST slot of chunk O (A) | residuals of batch 0
+    //   (E,1)  store chunk O -> X1, park chunk E+2's table rows | batch 0, residuals of batch 1
+    //   (E,2)  activate + split the first slots of chunk E+2 (B) | batch 1, residuals of batch 2
+    //   (O,0)  fetch chunk O+2 -> A  beside  the last slot of chunk E+2 | batch 2, residuals of batch 3 | next item's bias / shift loads
+    //   (O,1)  store chunk E+2 -> X0, park chunk O+2's table rows | batch 3, output maxima
+    //   (O,2)  activate + split the first slots of chunk O+2 (A) | statistics combine | commit the next item's bias / shift row
+    // (+ the slab's DMA at the head of every step when the producers issue it: DS_PC_CDMA=0.)  One slot-third of the vector work per
+    // step instead of a whole chunk in (E,0) and in (O,1): the consumer's steps are 1-2 K = 32 groups long, and a step lasts as long
+    // as the slower role (round 4, second session: profiles/r04_pc_smooth_schedule.log).
     // (batches = the PREVIOUS item's store phase, on the item's first chunk pair only.)  What a group reads is published one
     // barrier before the group that precedes it starts, because its operands are fetched during that predecessor.
     // [A schedule that spreads the staging evenly over the six steps and the store phase over two chunk pairs -- fetches in (E,1)
@@ -710,7 +716,7 @@ __global__ __launch_bounds__(256 + 64 * NPW, NPW == 4 ? 2 : 3) void k_conv3p(con
         if (!cdma) wdma((B + 3) & 3, pw, NPW);
         __builtin_amdgcn_sched_barrier(0);
         if (head) { plan_store(item_of(it - 1)); young += res_prefetch(RA, 0); }
-        young += fetch_while_activating(halo, xrB, prowB, tagB, trowB, tscB, xrA, tagA, trowA, tscA, pk, 1);   // chunk E + 2 | chunk O
+        young += fetch_beside_last_slot(halo, xrB, prowB, tagB, trowB, tscB, xrA, tagA, trowA, tscA, pk, 1);   // chunk E + 2 | chunk O's last slot
         tagP = tagA;
       }
       if (stamp < 48) PSTAMP(stamp);
@@ -728,7 +734,6 @@ __global__ __launch_bounds__(256 + 64 * NPW, NPW == 4 ? 2 : 3) void k_conv3p(con
         if (head) {
           young += store_batch(RA, 0);
           young += res_prefetch(RB, 1);
-          young += res_prefetch(RA, 2);
         }
       }
       if (stamp < 48) PSTAMP(stamp);
@@ -741,10 +746,11 @@ __global__ __launch_bounds__(256 + 64 * NPW, NPW == 4 ? 2 : 3) void k_conv3p(con
       } else {
         if (!cdma) wdma((B + 5) & 3, pw, NPW);
         __builtin_amdgcn_sched_barrier(0);
+        activate_first_slots(halo, xrB, tagB, trowB, tscB, pk, 0);      // chunk E + 2 (fetched in (E, 0), rows parked in (E, 1))
+        __builtin_amdgcn_sched_barrier(0);
         if (head) {
           young += store_batch(RB, 1);
-          young += res_prefetch(RB, 3);
-          young += store_batch(RA, 2);
+          young += res_prefetch(RA, 2);
         }
       }
       if (stamp < 48) PSTAMP(stamp);
@@ -759,12 +765,12 @@ __global__ __launch_bounds__(256 + 64 * NPW, NPW == 4 ? 2 : 3) void k_conv3p(con
         if (!cdma) wdma((B + 6) & 3, pw, NPW);
         __builtin_amdgcn_sched_barrier(0);
         PSTAMP_FINE(1);
-        young += fetch(halo, xrA, prowA, tagA, trowA, tscA);       // chunk O + 2
+        young += fetch_beside_last_slot(halo, xrA, prowA, tagA, trowA, tscA, xrB, tagB, trowB, tscB, pk, 0);       // chunk O + 2 | chunk E + 2's last slot
         __builtin_amdgcn_sched_barrier(0);
         PSTAMP_FINE(2);
         if (head) {
-          young += store_batch(RB, 3);
-          if (want_amax) commit_amax_asm();
+          young += store_batch(RA, 2);
+          young += res_prefetch(RB, 3);
         }
         if (last_of_item && it + 1 < n_items) bs_fetch(item_of(it + 1), bsb, bss);
       }
@@ -780,12 +786,13 @@ __global__ __launch_bounds__(256 + 64 * NPW, NPW == 4 ? 2 : 3) void k_conv3p(con
         if (!cdma) wdma((B + 7) & 3, pw, NPW);
         __builtin_amdgcn_sched_barrier(0);
         PSTAMP_FINE(5);
-        activate(halo, xrB, tagB, trowB, tscB, pk, 0);         // chunk E + 2
-        __builtin_amdgcn_sched_barrier(0);
+        store_x(halo, pk, tagB, 0);                   // chunk E + 2
         PSTAMP_FINE(6);
-        store_x(halo, pk, tagB, 0);
-        rows_park(prowA, 1);                          // chunk O + 2's table rows: read by its activation in the next (E, 0)
-        if (head && stats && wv == 4) store_stats();
+        rows_park(prowA, 1);                          // chunk O + 2's table rows: read by its activation from (O, 2) on
+        if (head) {
+          young += store_batch(RB, 3);
+          if (want_amax) commit_amax_asm();
+        }
       }
       if (stamp < 48) PSTAMP(stamp);
       ++stamp;
@@ -797,6 +804,9 @@ __global__ __launch_bounds__(256 + 64 * NPW, NPW == 4 ? 2 : 3) void k_conv3p(con
       } else {
         if (!cdma) wdma((B + 8) & 3, pw, NPW);
         __builtin_amdgcn_sched_barrier(0);
+        activate_first_slots(halo, xrA, tagA, trowA, tscA, pk, 1);      // chunk O + 2 (fetched in (O, 0), rows parked in (O, 1))
+        __builtin_amdgcn_sched_barrier(0);
+        if (head && stats && wv == 4) store_stats();  // the four waves' batch-3 partials are behind the barrier of (O, 1)
         if (last_of_item && it + 1 < n_items) bs_commit(bsb, bss, unscale_of(item_of(it + 1)), (it + 1) & 1);
       }
       if (stamp < 48) PSTAMP(stamp);
@@ -828,6 +838,7 @@ __global__ __launch_bounds__(256 + 64 * NPW, NPW == 4 ? 2 : 3) void k_conv3p(con
       }
       activate(halo, xrB, tagB, trowB, tscB, pk, 0);
       store_x(halo, pk, tagB, 0);
+      activate_first_slots(halo, xrA, tagA, trowA, tscA, pk, 1);        // chunk 1: as every (O, 2) leaves it
       bs_commit(bsb, bss, unscale_of(item_of(0)), 0);
       if constexpr (VEC) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(20)" ::: "memory");     // the three slabs and chunk 0; chunk 1's loads may stay in flight (the bias / shift loads are younger still)
