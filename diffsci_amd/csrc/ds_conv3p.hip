@@ -942,12 +942,12 @@ int launch_conv3p(Conv3hArgs a, int wgs, hipStream_t s) {
   return a.res2 ? launch_conv3p_r<PRE, CIRC, 2>(a, wgs, s) : launch_conv3p_r<PRE, CIRC, 1>(a, wgs, s);
 }
 
-// DS_CONV_PC: 0 = never, 1 (default: +1.6 % on config 2, same-box A/B, profiles/r04_pc_ab_bench.log) = the fused-loader launches with
-// one channel tile, 2 = also in place of the two-channel-tile kernel (measured slower: that kernel stages the patch once for both
-// tiles), 3 = raw-input launches too.
+// DS_CONV_PC: 0 = never, 1 = the fused-loader launches with one channel tile, 2 (default since the consumers issue the weight DMA and the
+// producers' schedule is smooth: +3.4 % end to end for mode 1 and +1.2 % more for mode 2 on config 2, same-box A/B,
+// profiles/r04_pc_ab_bench.log) = also in place of the two-channel-tile kernel, 3 = raw-input launches too.
 // DS_CONV_PC_MIN: fewest items per workgroup (default 4).
 int conv3p_mode() {
-  static const int v = [] { const char* e = getenv("DS_CONV_PC"); return e ? atoi(e) : 1; }();
+  static const int v = [] { const char* e = getenv("DS_CONV_PC"); return e ? atoi(e) : 2; }();
   return v;
 }
 int conv3p_min_items() {
