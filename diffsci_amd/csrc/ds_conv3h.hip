@@ -891,7 +891,7 @@ int ds_conv2d_h3(float* out, const float* in, const void* w_packed, int wshift, 
   if (B == 0) return DS_OK;
   Conv3hArgs a;
   a.prenorm = prenorm; a.tile_stats = tile_stats; a.circular = circular; a.res1_up = res1_up; a.oy = oy; a.ox = ox;
-  a.ntiles_magic40 = 0; a.ncot_magic40 = 0; a.pc_prio = 0;      // set by ds_conv3p.hip's launcher when it takes the launch
+  a.ntiles_magic40 = 0; a.ncot_magic40 = 0; a.pc_prio = 0; a.pc_skew_mask = 0;      // set by ds_conv3p.hip's launcher when it takes the launch
   {
     static const int early = [] { const char* e = getenv("DS_CONV_TWO_EARLY"); return e ? atoi(e) : 1; }();   // A/B switch of the two-tile kernel's staging shift
     a.two_early = early;
@@ -987,6 +987,11 @@ int ds_conv2d_h3_img(float* out, const void* images, const void* w_packed, int w
   a.stamps = g_stamps;
 #endif
   hipStream_t s = ds::as_stream(stream);
+  if (!w16) {
+    bool launched = false;
+    const int rc = conv3p_try_launch_img(a, s, &launched);
+    if (rc != DS_OK || launched) return rc;
+  }
   return w16 ? launch_conv3h_w<DS_LOAD_PLAIN, true, false, false, 4, true, true>(a, s)
              : launch_conv3h_w<DS_LOAD_PLAIN, false, false, false, 4, true, true>(a, s);
 }

@@ -68,6 +68,7 @@ struct Conv3hArgs {
   // d < 2^18 (the persistent kernel decodes an item index several times per tile: hardware has no integer divide)
   unsigned long long ntiles_magic40, ncot_magic40;
   int pc_prio;              // ds_conv3p.hip only: s_setprio level of the producer waves (DS_CONV_PC_PRIO, A/B runs)
+  int pc_skew_mask;         // ds_conv3p.hip only: mask of the start-up stagger (DS_CONV_PC_SKEW)
   int two_early;            // ds_conv3h.hip, two channel tiles per workgroup: waves 0-3 stage the next patch before the step's matrix instructions (DS_CONV_TWO_EARLY)
 #ifdef DS_STAMP
   unsigned long long* stamps;   // diagnostic build only (tools/conv3h_stamp.hip)
@@ -81,5 +82,7 @@ struct Conv3hArgs {
 // chunks, enough tiles to give every CU several).  Returns DS_OK and sets *launched when it took the launch; leaves *launched
 // false (and launches nothing) when the shape is not its own.
 int conv3p_try_launch(const Conv3hArgs& a, hipStream_t s, bool* launched);
+// ... the image-input form (ds_conv2d_h3_img; full 8 x 32 tiles, Cin and Cout multiples of 64, no half-resolution residual)
+int conv3p_try_launch_img(const Conv3hArgs& a, hipStream_t s, bool* launched);
 
 }  // namespace ds_conv3

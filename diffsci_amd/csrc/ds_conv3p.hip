@@ -75,6 +75,9 @@ __device__ __forceinline__ void bar_counted(int young) {
 #undef DS_VMCNT_CASE
 
 struct Item { int cot, b, y0, x0, tile; };
+#ifndef DS_PC_IMG_CDMA
+#define DS_PC_IMG_CDMA 0                             // image input: 1 = the consumers issue the weight DMA there too (measurement builds)
+#endif
 #ifndef DS_PC_CDMA
 #define DS_PC_CDMA 1                                 // 0: the producers issue the weight DMA (measurement builds, tools/build_variant.sh)
 #endif
@@ -114,10 +117,14 @@ __device__ __forceinline__ unsigned const_u32(const void* p, size_t i) {
 // stays an unconditional instruction of its wave's program.  The table rows of the fused norm come from LDS (the unit's channel pair
 // differs from lane to lane): every producer wave loads the chunk's 16 rows in front of the patch, producer wave 0 parks them in the
 // pad vectors of the X buffer the chunk is staged into, at least one barrier before the activation reads them.
-template <bool PRE, bool CIRC, int NRES, int NPW, bool VEC = false>
+// IMG: the input arrives as pre-split fp16 hi / lo images (ds_inorm_silu_images; ds_conv3h.hip, IMGIN) -- the 256-channel level of
+// config 2.  The producers then only issue DMA: an X buffer is filled by 22 wave-instructions (the one-shot kernel's plan, lane for
+// lane), the weight slabs stay with them too (DS_PC_CDMA applies to the staging forms only), and the consumers are pure matrix streams.
+template <bool PRE, bool CIRC, int NRES, int NPW, bool VEC = false, bool IMG = false>
 __global__ __launch_bounds__(256 + 64 * NPW, NPW == 4 ? 2 : 3) void k_conv3p(const Conv3hArgs a) {
   static_assert(NPW == 4 || NPW == 8, "four or eight producer waves");
   static_assert(!VEC || NPW == 4, "16-byte patch loads: the four-producer form");
+  static_assert(!IMG || (!PRE && !CIRC && !VEC && NPW == 4), "image input: plain zero-padded four-producer form");
   constexpr int XI = NPW == 4 ? 3 : 2;                     // staging items per producer thread
   constexpr int BK = NPW == 4 ? 4 : 2;                     // store instructions per batch (four batches per wave and item)
   using Packed = ds_conv3::Packed<XI>;
@@ -288,6 +295,41 @@ __global__ __launch_bounds__(256 + 64 * NPW, NPW == 4 ? 2 : 3) void k_conv3p(con
     }
   }
   auto pad_vec = [&](int c) __attribute__((always_inline)) { return c < HPAD16 ? NPOS + c : PS + NPOS + (c - HPAD16); };
+  // ---- IMG: DMA plan of an X buffer (ds_conv3h.hip: NINST = 22 instructions of 64 vectors, the last one moved back to end with the
+  //      buffer; lane -> linear index -> (image, position)), relative to the tile's origin: full tiles only, so no clamping ----
+  constexpr int NINST = (XBV + 63) / 64;
+  const int Wp = a.W + 2, Hp = a.H + 2;
+  unsigned dbase[6] = {};
+  if constexpr (IMG) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int k = pw + 4 * i;
+      const int L = (k < NINST - 1 ? 64 * k : XBV - 64) + lane;
+      const int piece = L >= PS ? 1 : 0, Lp = L - piece * PS;
+      const int hh = Lp >= HS ? 1 : 0;
+      int pos = Lp - hh * HS;
+      pos = pos < NPOS ? pos : NPOS - 1;
+      const int r = pos / PW, col = pos - r * PW;
+      dbase[i] = 16u * (unsigned)(((2 * piece + hh) * Hp + r) * Wp + col);        // bytes
+    }
+  }
+  int i_k = 0, i_chunk = 0, i_b = 0;
+  unsigned i_off = 0;
+  // the next chunk's images into X buffer `buf`; returns the wave's instruction count (unconditional past the end, like the fetch)
+  auto xdma = [&](int buf) __attribute__((always_inline)) {
+    const bool valid = i_k < n_items;
+    if (valid && i_chunk == 0) { const Item it = item_of(i_k); i_off = 16u * (unsigned)(it.y0 * Wp + it.x0); i_b = it.b; }
+    const u32x4* src = reinterpret_cast<const u32x4*>(a.in) + ((size_t)i_b * n_chunks + i_chunk) * 4 * (size_t)(Hp * Wp);
+    u32x4* dst = Xs + buf * XBV;
+    int n = 0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int k = pw + 4 * i;                        // wave-uniform
+      if (k < NINST) { lds_dma16(src, dbase[i] + i_off, lds_address(dst + (k < NINST - 1 ? 64 * k : XBV - 64))); ++n; }
+    }
+    if (valid && ++i_chunk == n_chunks) { i_chunk = 0; ++i_k; }
+    return n;
+  };
   // fetch cursor: the next chunk to load.  The loads are UNCONDITIONAL (past the end of the list the last item's first chunk is
   // loaded again and dropped): a conditional load between a load and its use makes hipcc wait for vmcnt(0) at the use -- the
   // full HBM latency of the loads just issued, measured at 3000 cycles per chunk in the first version of this kernel.
@@ -493,7 +535,7 @@ __global__ __launch_bounds__(256 + 64 * NPW, NPW == 4 ? 2 : 3) void k_conv3p(con
   // widx / nwv: the issuing wave's index among the nwv waves that share a slab's twelve pieces -- the producers, or (cdma) the four
   // CONSUMERS: a weight DMA costs its wave 150-200 cycles to issue (stamped), three per step; the producers pace this kernel and the
   // consumers wait for them at every barrier, so the consumers issue them, in front of the step's matrix instructions
-  constexpr bool cdma = DS_PC_CDMA != 0;            // compile time (as a kernel argument the two forms side by side cost 15 % -- measured)
+  constexpr bool cdma = DS_PC_CDMA != 0 && (!IMG || DS_PC_IMG_CDMA != 0);            // compile time (as a kernel argument the two forms side by side cost 15 % -- measured)
   auto wdma = [&](int slot, int widx, int nwv) __attribute__((always_inline)) {     // slot = (slab index) & 3
     const bool valid = w_k < n_items;
     if (valid && w_step == 0) w_cot = item_of(w_k).cot;
@@ -653,13 +695,18 @@ __global__ __launch_bounds__(256 + 64 * NPW, NPW == 4 ? 2 : 3) void k_conv3p(con
     // must have landed by the END of step p + 1: everything issued behind it in step p (`prev`), step p + 1's own DMA (3) and
     // everything else of step p + 1 (`young`) may stay in flight.  Loads, LDS-DMA and stores complete in issue order on gfx9
     // (hipcc's own counted waits rely on it), so "all but the N youngest" names exactly the operations in front of them.
-    int young = 0, prev = 0;
+    int young = 0, prev = 0, nx = 0;                  // nx (IMG): this step's image DMA, issued in front of its weight DMA
     const int ndma = NPW == 4 ? 3 : (pw < 4 ? 2 : 1);             // DMA instructions of this wave per step
     auto barrier = [&]() __attribute__((always_inline)) {
       // (cdma: a consumer's only vector-memory operations are its three DMA per step -- those of the step that ends here may stay in
       //  flight, the previous step's have landed; the producers then have nothing another wave waits for)
       if constexpr (CONS) bar_counted(cdma ? 3 : 0);
-      else { bar_counted(cdma ? 63 : prev + ndma + young); prev = young; young = 0; }
+      else {
+        // (image input: the producers' image DMA is the oldest operation of its step whoever issues the weights)
+        if constexpr (IMG) bar_counted(prev + nx + (cdma ? 0 : ndma) + young);
+        else bar_counted(cdma ? 63 : prev + ndma + young);
+        prev = young; young = 0; nx = 0;
+      }
     };
     int stamp = 1;
     (void)stamp;
@@ -713,11 +760,14 @@ __global__ __launch_bounds__(256 + 64 * NPW, NPW == 4 ? 2 : 3) void k_conv3p(con
         if (head) park_tile((it - 1) & 1);
         DS_GROUP(0); DS_GROUP(1);
       } else {
+        if constexpr (IMG) nx = xdma(1);              // chunk O -> X1: free since the barrier of the previous (O, 2), read from (E, 2) on
         if (!cdma) wdma((B + 3) & 3, pw, NPW);
         __builtin_amdgcn_sched_barrier(0);
         if (head) { plan_store(item_of(it - 1)); young += res_prefetch(RA, 0); }
-        young += fetch_beside_last_slot(halo, xrB, prowB, tagB, trowB, tscB, xrA, tagA, trowA, tscA, pk, 1);   // chunk E + 2 | chunk O's last slot
-        tagP = tagA;
+        if constexpr (!IMG) {
+          young += fetch_beside_last_slot(halo, xrB, prowB, tagB, trowB, tscB, xrA, tagA, trowA, tscA, pk, 1);   // chunk E + 2 | chunk O's last slot
+          tagP = tagA;
+        }
       }
       if (stamp < 48) PSTAMP(stamp);
       ++stamp;
@@ -729,8 +779,10 @@ __global__ __launch_bounds__(256 + 64 * NPW, NPW == 4 ? 2 : 3) void k_conv3p(con
       } else {
         if (!cdma) wdma((B + 4) & 3, pw, NPW);
         __builtin_amdgcn_sched_barrier(0);
-        store_x(halo, pk, tagP, 1);
-        rows_park(prowB, 0);                          // chunk E + 2's table rows: read by its activation in (O, 1)
+        if constexpr (!IMG) {
+          store_x(halo, pk, tagP, 1);
+          rows_park(prowB, 0);                        // chunk E + 2's table rows: read by its activation from (E, 2) on
+        }
         if (head) {
           young += store_batch(RA, 0);
           young += res_prefetch(RB, 1);
@@ -746,7 +798,7 @@ __global__ __launch_bounds__(256 + 64 * NPW, NPW == 4 ? 2 : 3) void k_conv3p(con
       } else {
         if (!cdma) wdma((B + 5) & 3, pw, NPW);
         __builtin_amdgcn_sched_barrier(0);
-        activate_first_slots(halo, xrB, tagB, trowB, tscB, pk, 0);      // chunk E + 2 (fetched in (E, 0), rows parked in (E, 1))
+        if constexpr (!IMG) activate_first_slots(halo, xrB, tagB, trowB, tscB, pk, 0);      // chunk E + 2 (fetched in (E, 0), rows parked in (E, 1))
         __builtin_amdgcn_sched_barrier(0);
         if (head) {
           young += store_batch(RB, 1);
@@ -762,10 +814,11 @@ __global__ __launch_bounds__(256 + 64 * NPW, NPW == 4 ? 2 : 3) void k_conv3p(con
         DS_GROUP(5);
       } else {
         PSTAMP_FINE(0);
+        if constexpr (IMG) nx = xdma(0);              // chunk E + 2 -> X0: free since the barrier of (E, 2), read from (O, 2) on
         if (!cdma) wdma((B + 6) & 3, pw, NPW);
         __builtin_amdgcn_sched_barrier(0);
         PSTAMP_FINE(1);
-        young += fetch_beside_last_slot(halo, xrA, prowA, tagA, trowA, tscA, xrB, tagB, trowB, tscB, pk, 0);       // chunk O + 2 | chunk E + 2's last slot
+        if constexpr (!IMG) young += fetch_beside_last_slot(halo, xrA, prowA, tagA, trowA, tscA, xrB, tagB, trowB, tscB, pk, 0);       // chunk O + 2 | chunk E + 2's last slot
         __builtin_amdgcn_sched_barrier(0);
         PSTAMP_FINE(2);
         if (head) {
@@ -786,9 +839,11 @@ __global__ __launch_bounds__(256 + 64 * NPW, NPW == 4 ? 2 : 3) void k_conv3p(con
         if (!cdma) wdma((B + 7) & 3, pw, NPW);
         __builtin_amdgcn_sched_barrier(0);
         PSTAMP_FINE(5);
-        store_x(halo, pk, tagB, 0);                   // chunk E + 2
+        if constexpr (!IMG) {
+          store_x(halo, pk, tagB, 0);                 // chunk E + 2
+          rows_park(prowA, 1);                        // chunk O + 2's table rows: read by its activation from (O, 2) on
+        }
         PSTAMP_FINE(6);
-        rows_park(prowA, 1);                          // chunk O + 2's table rows: read by its activation from (O, 2) on
         if (head) {
           young += store_batch(RB, 3);
           if (want_amax) commit_amax_asm();
@@ -804,7 +859,7 @@ __global__ __launch_bounds__(256 + 64 * NPW, NPW == 4 ? 2 : 3) void k_conv3p(con
       } else {
         if (!cdma) wdma((B + 8) & 3, pw, NPW);
         __builtin_amdgcn_sched_barrier(0);
-        activate_first_slots(halo, xrA, tagA, trowA, tscA, pk, 1);      // chunk O + 2 (fetched in (O, 0), rows parked in (O, 1))
+        if constexpr (!IMG) activate_first_slots(halo, xrA, tagA, trowA, tscA, pk, 1);      // chunk O + 2 (fetched in (O, 0), rows parked in (O, 1))
         __builtin_amdgcn_sched_barrier(0);
         if (head && stats && wv == 4) store_stats();  // the four waves' batch-3 partials are behind the barrier of (O, 1)
         if (last_of_item && it + 1 < n_items) bs_commit(bsb, bss, unscale_of(item_of(it + 1)), (it + 1) & 1);
@@ -819,14 +874,17 @@ __global__ __launch_bounds__(256 + 64 * NPW, NPW == 4 ? 2 : 3) void k_conv3p(con
     //      multiply and store in phase and the memory system would see the chip's whole demand in bursts; spread them over
     //      about one chunk pair's time ----
     {
-      const unsigned skew = (blockIdx.x * 11u) & 31u;
+      const unsigned skew = (blockIdx.x * 11u) & (unsigned)a.pc_skew_mask;
       for (unsigned i = 0; i < skew; ++i) __builtin_amdgcn_s_sleep(8);    // 8 x 64 clocks each
     }
     // ---- prologue: slabs 0, 1, 2, chunk 0 in X buffer 0, chunk 1 in flight, the first item's bias / shift row ----
     if constexpr (!CONS) {
+      if constexpr (IMG) xdma(0);                     // chunk 0 -> X0 (chunk 1 follows in the first (E, 0))
       if (!cdma) { wdma(0, pw, NPW); wdma(1, pw, NPW); wdma(2, pw, NPW); }
-      fetch(halo, xrB, prowB, tagB, trowB, tscB);
-      fetch(halo, xrA, prowA, tagA, trowA, tscA);
+      if constexpr (!IMG) {
+        fetch(halo, xrB, prowB, tagB, trowB, tscB);
+        fetch(halo, xrA, prowA, tagA, trowA, tscA);
+      }
       bs_fetch(item_of(0), bsb, bss);
       if constexpr (VEC && PRE) {
         // both chunks' table rows into the pads of their X buffers, published by a barrier of their own (once per workgroup: the
@@ -836,11 +894,13 @@ __global__ __launch_bounds__(256 + 64 * NPW, NPW == 4 ? 2 : 3) void k_conv3p(con
         rows_park(prowA, 1);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
       }
-      activate(halo, xrB, tagB, trowB, tscB, pk, 0);
-      store_x(halo, pk, tagB, 0);
-      activate_first_slots(halo, xrA, tagA, trowA, tscA, pk, 1);        // chunk 1: as every (O, 2) leaves it
+      if constexpr (!IMG) {
+        activate(halo, xrB, tagB, trowB, tscB, pk, 0);
+        store_x(halo, pk, tagB, 0);
+        activate_first_slots(halo, xrA, tagA, trowA, tscA, pk, 1);      // chunk 1: as every (O, 2) leaves it
+      }
       bs_commit(bsb, bss, unscale_of(item_of(0)), 0);
-      if constexpr (VEC) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if constexpr (VEC || IMG) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(20)" ::: "memory");     // the three slabs and chunk 0; chunk 1's loads may stay in flight (the bias / shift loads are younger still)
     } else {
       if (cdma) { wdma(0, rw, 4); wdma(1, rw, 4); wdma(2, rw, 4); }
@@ -855,7 +915,7 @@ __global__ __launch_bounds__(256 + 64 * NPW, NPW == 4 ? 2 : 3) void k_conv3p(con
     PSTAMP(0);
     if constexpr (CONS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // (cdma) the first three slabs
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    young = 0; prev = VEC ? 0 : DS_LPI * XI;          // behind the prologue's slabs: chunk 1's loads (VEC: the prologue waited for everything)
+    young = 0; prev = (VEC || IMG) ? 0 : DS_LPI * XI;          // behind the prologue's slabs: chunk 1's loads (VEC: the prologue waited for everything)
     if constexpr (CONS && NPW == 4) load_pair(F0, 0, 0, 0, 0, 0, 0, 1, 0);         // P0 of the first chunk pair
 
     const int ncp = n_chunks >> 1;                    // even (the launcher's rule): fragment sets and ring slots are back in place after an item
@@ -911,11 +971,11 @@ int conv3p_producer_waves() {
   return v;
 }
 
-template <bool PRE, bool CIRC, int NRES, int NPW, bool VEC = false>
+template <bool PRE, bool CIRC, int NRES, int NPW, bool VEC = false, bool IMG = false>
 int launch_conv3p_w(const Conv3hArgs& a, int wgs, hipStream_t s) {
-  const int rc = ds::ensure_dynamic_lds<&k_conv3p<PRE, CIRC, NRES, NPW, VEC>>(P_LDS, "hipFuncSetAttribute(conv3p)");
+  const int rc = ds::ensure_dynamic_lds<&k_conv3p<PRE, CIRC, NRES, NPW, VEC, IMG>>(P_LDS, "hipFuncSetAttribute(conv3p)");
   if (rc != DS_OK) return rc;
-  hipLaunchKernelGGL((k_conv3p<PRE, CIRC, NRES, NPW, VEC>), dim3((unsigned)wgs), dim3(256 + 64 * NPW), P_LDS, s, a);
+  hipLaunchKernelGGL((k_conv3p<PRE, CIRC, NRES, NPW, VEC, IMG>), dim3((unsigned)wgs), dim3(256 + 64 * NPW), P_LDS, s, a);
   DS_CHECK_LAUNCH("ds_conv2d_h3 (persistent)");
   return DS_OK;
 }
@@ -931,13 +991,21 @@ int launch_conv3p_r(const Conv3hArgs& a, int wgs, hipStream_t s) {
   if (conv3p_vec() && a.ox == 0 && (reinterpret_cast<uintptr_t>(a.in) & 15u) == 0) return launch_conv3p_w<PRE, CIRC, NRES, 4, true>(a, wgs, s);
   return launch_conv3p_w<PRE, CIRC, NRES, 4>(a, wgs, s);
 }
-template <bool PRE, bool CIRC>
-int launch_conv3p(Conv3hArgs a, int wgs, hipStream_t s) {
+void conv3p_fill_args(Conv3hArgs& a) {
   a.ntiles_magic40 = (1ull << 40) / (unsigned long long)(a.tiles_x * a.tiles_y) + 1ull;
   a.ncot_magic40 = (1ull << 40) / (unsigned long long)a.n_cot + 1ull;
   static const int prio = [] { const char* e = getenv("DS_CONV_PC_PRIO"); const int v = e ? atoi(e) : 0; return v < 0 || v > 3 ? 0 : v; }();
   a.pc_prio = prio;
+  // start-up stagger: workgroup w sleeps ((11 w) & mask) x 512 cycles before its prologue (DS_CONV_PC_SKEW = the mask: 0, 1, 3, 7, 15, 31).
+  // Default 0: inside the network a launch waits for its predecessor to drain, and the stagger is lost time at both ends (+0.7 % end
+  // to end without it, profiles/r04_pc_ab_bench.log)
+  static const int skew = [] { const char* e = getenv("DS_CONV_PC_SKEW"); const int v = e ? atoi(e) : 0; return v < 0 || v > 31 ? 0 : v; }();
+  a.pc_skew_mask = skew;
   if (!a.res1 && a.res2) { a.res1 = a.res2; a.res2 = nullptr; }      // one residual: the order of the additions is the same
+}
+template <bool PRE, bool CIRC>
+int launch_conv3p(Conv3hArgs a, int wgs, hipStream_t s) {
+  conv3p_fill_args(a);
   if (!a.res1) return launch_conv3p_r<PRE, CIRC, 0>(a, wgs, s);
   return a.res2 ? launch_conv3p_r<PRE, CIRC, 2>(a, wgs, s) : launch_conv3p_r<PRE, CIRC, 1>(a, wgs, s);
 }
@@ -969,6 +1037,25 @@ int conv3p_cus() {
 }
 
 }  // namespace
+
+// Image input (ds_conv2d_h3_img): DS_CONV_PC_IMG=0 keeps the one-shot kernel (A/B runs).
+int conv3p_try_launch_img(const Conv3hArgs& a0, hipStream_t s, bool* launched) {
+  *launched = false;
+  static const bool on = [] { const char* e = getenv("DS_CONV_PC_IMG"); return !(e && atoi(e) == 0); }();
+  if (!on || conv3p_mode() == 0 || conv3p_producer_waves() != 4) return DS_OK;
+  if (a0.H % 8 != 0 || a0.W % 32 != 0 || a0.Cout % COT != 0 || a0.Cin % (4 * KC) != 0 || a0.res1_up) return DS_OK;
+  const long long total = (long long)a0.n_cot * a0.tiles_x * a0.tiles_y * a0.B;
+  const int wgs = conv3p_cus() / 8 * 8;
+  if (wgs <= 0 || total < (long long)wgs * conv3p_min_items() || total >= (1ll << 22)) return DS_OK;
+  if ((long long)4 * (a0.H + 2) * (a0.W + 2) * 16 >= (1ll << 31)) return DS_OK;       // the DMA's 32-bit lane offsets stay inside one (sample, chunk)
+  Conv3hArgs a = a0;
+  conv3p_fill_args(a);
+  int rc;
+  if (!a.res1) rc = launch_conv3p_w<false, false, 0, 4, false, true>(a, wgs, s);
+  else rc = a.res2 ? launch_conv3p_w<false, false, 2, 4, false, true>(a, wgs, s) : launch_conv3p_w<false, false, 1, 4, false, true>(a, wgs, s);
+  if (rc == DS_OK) *launched = true;
+  return rc;
+}
 
 int conv3p_try_launch(const Conv3hArgs& a, hipStream_t s, bool* launched) {
   *launched = false;

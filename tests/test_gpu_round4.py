@@ -40,6 +40,17 @@ def test_persistent_convolution_is_bit_identical_to_the_one_tile_kernel():
     assert p.stdout.count(" ok") >= 10
 
 
+def test_persistent_image_input_convolution_is_bit_identical_to_the_one_shot_kernel():
+    """ds_conv3p.hip with pre-split image input (the 256-channel level of config 2: producers issue DMA only) against ds_conv3h.hip's
+    image-input kernel (DS_CONV_PC_IMG=0, child process): config 2's level-2 shape with and without residual, two residuals, uneven
+    item counts, a launch below the persistent kernel's minimum -- outputs, tile statistics, output maxima bit for bit; fp64 to 2e-6."""
+    env = {k: v for k, v in os.environ.items() if k not in ("DS_CONV_PC", "DS_CONV_PC_MIN", "DS_CONV_PC_IMG")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "conv3p_img_check.py")], cwd=ROOT, env=env, capture_output=True,
+                       text=True, timeout=900)
+    assert p.returncode == 0 and "ALL OK" in p.stdout, p.stdout[-3000:] + p.stderr[-2000:]
+    assert p.stdout.count(" ok") >= 6
+
+
 def test_sixteen_byte_patch_loads_are_bit_identical_to_the_one_pixel_staging_plan():
     """ds_conv3h.hip's VEC staging plan (units of 2 channels x 4 pixels fetched by 16-byte loads, table rows through LDS) against its
     one-pixel items (DS_CONV_VEC=0, child process), DS_CONV_PC=0 in both arms: 18 launch shapes -- one and two channel tiles, ragged
