@@ -262,7 +262,7 @@ def dominant_kernel_roofline(module, args, dev, reps=40):
     ms = e0.elapsed_time(e1) / reps
     n = len(launches)
     kname, peak = {
-        "fp16x3": ("k_conv3h<PLAIN> / k_conv3p (ds_conv2d_h3 / ds_conv2d_h3_img, 3x3, fp32 via 3 fp16 MFMA products; the level-0 fused-loader launches as persistent producer / consumer workgroups"
+        "fp16x3": ("k_conv3p / k_conv3h<PLAIN> (ds_conv2d_h3 / ds_conv2d_h3_img, 3x3, fp32 via 3 fp16 MFMA products; all launches but the input layer as persistent producer / consumer workgroups"
                    + (", norm+SiLU in the loader or pre-split image input, tile statistics in the epilogue)" if fused else ")"), BF16_PEAK_TFLOPS / 3.0),
         "bf16x6": ("k_conv6<PLAIN> (ds_conv2d_x6, 3x3, fp32 via 6 bf16 MFMA products)", BF16_PEAK_TFLOPS / 6.0),
         "fp32": ("k_conv<3,PLAIN> (ds_conv2d 3x3, exact-fp32 MFMA)", MFMA_F32_PEAK_TFLOPS)}[net.conv_precision]
