@@ -36,7 +36,8 @@ def _worker(rank, world, port, nsamples, q):
     from diffsci_amd.parallel import shard_rows
     lo, _ = shard_rows(nsamples, world, rank)
     assert _StandIn.seen == (lo * 16, nsamples * 16) and m.noise_shard is None
-    q.put((rank, out.clone(), local.clone()))
+    q.put((rank, out.numpy().copy(), local.numpy().copy()))     # plain bytes: a tensor travels as a shared-memory handle the parent must
+                                                                # open while this process is still alive (an EOFError under load, once)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -59,6 +60,7 @@ def test_two_rank_shard_and_gather(nsamples):
         assert p.exitcode == 0
     want = _StandIn().propagate_white_noise(global_white_noise(nsamples, [1, 4, 4], 7), nsteps=3)
     for rank, full, local in got:
+        full, local = torch.from_numpy(full), torch.from_numpy(local)
         assert torch.equal(full, want)
         lo, hi = shard_rows(nsamples, 2, rank)
         assert torch.equal(local, want[lo:hi])

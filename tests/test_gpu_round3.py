@@ -563,7 +563,7 @@ def _two_rank_worker(rank, world, port, nsamples, q):
         for integrator in ("heun", "karras"):
             torch.manual_seed(11)                                     # every rank holds the same generator state
             out[integrator] = sample_sharded(module, nsamples, [1, 32, 32], nsteps=4, seed=7, integrator=integrator).cpu()
-        q.put((rank, out))
+        q.put((rank, {k: v.numpy().copy() for k, v in out.items()}))      # plain bytes (a tensor's shared-memory handle must be opened while this process lives)
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -603,7 +603,7 @@ def test_two_ranks_on_one_gpu_reproduce_the_single_process_batch(M, dev, nsample
     assert sorted(r for r, _ in got) == [0, 1]
     for _, out in got:
         for integrator in ("heun", "karras"):
-            assert torch.equal(out[integrator], want[integrator]), integrator
+            assert torch.equal(torch.from_numpy(out[integrator]), want[integrator]), integrator
     assert not torch.equal(want["heun"], want["karras"])
 
 
