@@ -75,6 +75,9 @@ __device__ __forceinline__ void bar_counted(int young) {
 #undef DS_VMCNT_CASE
 
 struct Item { int cot, b, y0, x0, tile; };
+#ifndef DS_PC_SPREAD
+#define DS_PC_SPREAD 1                               // 0: the whole store phase in the item's first chunk pair (measurement builds)
+#endif
 #ifndef DS_PC_IMG_CDMA
 #define DS_PC_IMG_CDMA 0                             // image input: 1 = the consumers issue the weight DMA there too (measurement builds)
 #endif
@@ -729,7 +732,12 @@ __global__ __launch_bounds__(256 + 64 * NPW, NPW == 4 ? 2 : 3) void k_conv3p(con
     //  and (E,2), activations in (E,0) and (O,0) -- measured WORSE (profiles/r04_pc_stamps.log, v7: 81.1 -> 81.1 samples/s against
     //  +1.6 % for this one): with both chunks' 48 loads issued in consecutive steps next to the residual loads and stores the wave
     //  runs into its 64 outstanding vector-memory operations and the loads' issue stalls.]
-    auto chunk_pair = [&](auto base_tag, Frag& Fa, Frag& Fb, bool head, bool last_of_item, int it) __attribute__((always_inline)) {
+    // head / second: the item's first / second chunk pair.  The previous item's store phase -- four batches of stores, residual
+    // loads, statistics -- runs on the producers one batch per (E,1) / (O,1) step of these TWO pairs (DS_PC_SPREAD; every item has
+    // at least two): a batch costs its wave 1,000-2,000 cycles, and with all four in the first pair's steps (E,1) .. (O,1) that
+    // pair took 19,400 cycles against 12,200 for the others (profiles/r04_pc_smooth_schedule.log)
+    constexpr bool SPREAD = DS_PC_SPREAD != 0;
+    auto chunk_pair = [&](auto base_tag, Frag& Fa, Frag& Fb, bool head, bool second, bool last_of_item, int it) __attribute__((always_inline)) {
       constexpr int B = decltype(base_tag)::value;
       constexpr int E0 = (B + 0) & 3, E1 = (B + 1) & 3, E2 = (B + 2) & 3;          // ring slots of chunk E's slabs
       constexpr int O0 = (B + 3) & 3, O1 = (B + 4) & 3, O2 = (B + 5) & 3;          // ... of chunk O's
@@ -787,6 +795,9 @@ __global__ __launch_bounds__(256 + 64 * NPW, NPW == 4 ? 2 : 3) void k_conv3p(con
           young += store_batch(RA, 0);
           young += res_prefetch(RB, 1);
         }
+        if constexpr (SPREAD) {
+          if (second) { young += store_batch(RA, 2); young += res_prefetch(RB, 3); }
+        }
       }
       if (stamp < 48) PSTAMP(stamp);
       ++stamp;
@@ -800,9 +811,11 @@ __global__ __launch_bounds__(256 + 64 * NPW, NPW == 4 ? 2 : 3) void k_conv3p(con
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (!IMG) activate_first_slots(halo, xrB, tagB, trowB, tscB, pk, 0);      // chunk E + 2 (fetched in (E, 0), rows parked in (E, 1))
         __builtin_amdgcn_sched_barrier(0);
-        if (head) {
-          young += store_batch(RB, 1);
-          young += res_prefetch(RA, 2);
+        if constexpr (!SPREAD) {
+          if (head) {
+            young += store_batch(RB, 1);
+            young += res_prefetch(RA, 2);
+          }
         }
       }
       if (stamp < 48) PSTAMP(stamp);
@@ -821,9 +834,11 @@ __global__ __launch_bounds__(256 + 64 * NPW, NPW == 4 ? 2 : 3) void k_conv3p(con
         if constexpr (!IMG) young += fetch_beside_last_slot(halo, xrA, prowA, tagA, trowA, tscA, xrB, tagB, trowB, tscB, pk, 0);       // chunk O + 2 | chunk E + 2's last slot
         __builtin_amdgcn_sched_barrier(0);
         PSTAMP_FINE(2);
-        if (head) {
-          young += store_batch(RA, 2);
-          young += res_prefetch(RB, 3);
+        if constexpr (!SPREAD) {
+          if (head) {
+            young += store_batch(RA, 2);
+            young += res_prefetch(RB, 3);
+          }
         }
         if (last_of_item && it + 1 < n_items) bs_fetch(item_of(it + 1), bsb, bss);
       }
@@ -844,9 +859,14 @@ __global__ __launch_bounds__(256 + 64 * NPW, NPW == 4 ? 2 : 3) void k_conv3p(con
           rows_park(prowA, 1);                        // chunk O + 2's table rows: read by its activation from (O, 2) on
         }
         PSTAMP_FINE(6);
-        if (head) {
-          young += store_batch(RB, 3);
-          if (want_amax) commit_amax_asm();
+        if constexpr (SPREAD) {
+          if (head) { young += store_batch(RB, 1); young += res_prefetch(RA, 2); }
+          if (second) { young += store_batch(RB, 3); if (want_amax) commit_amax_asm(); }
+        } else {
+          if (head) {
+            young += store_batch(RB, 3);
+            if (want_amax) commit_amax_asm();
+          }
         }
       }
       if (stamp < 48) PSTAMP(stamp);
@@ -861,7 +881,7 @@ __global__ __launch_bounds__(256 + 64 * NPW, NPW == 4 ? 2 : 3) void k_conv3p(con
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (!IMG) activate_first_slots(halo, xrA, tagA, trowA, tscA, pk, 1);      // chunk O + 2 (fetched in (O, 0), rows parked in (O, 1))
         __builtin_amdgcn_sched_barrier(0);
-        if (head && stats && wv == 4) store_stats();  // the four waves' batch-3 partials are behind the barrier of (O, 1)
+        if ((SPREAD ? second : head) && stats && wv == 4) store_stats();  // the four waves' batch-3 partials are behind the barrier of (O, 1)
         if (last_of_item && it + 1 < n_items) bs_commit(bsb, bss, unscale_of(item_of(it + 1)), (it + 1) & 1);
       }
       if (stamp < 48) PSTAMP(stamp);
@@ -921,9 +941,9 @@ __global__ __launch_bounds__(256 + 64 * NPW, NPW == 4 ? 2 : 3) void k_conv3p(con
     const int ncp = n_chunks >> 1;                    // even (the launcher's rule): fragment sets and ring slots are back in place after an item
     for (int it = 0; it < n_items; ++it) {
       for (int cp = 0; cp < ncp; cp += 2) {
-        chunk_pair(std::integral_constant<int, 0>{}, F0, F1, cp == 0 && it > 0, false, it);
-        if constexpr (NPW == 4) chunk_pair(std::integral_constant<int, 6>{}, F1, F0, false, cp + 2 == ncp, it);
-        else chunk_pair(std::integral_constant<int, 6>{}, F0, F1, false, cp + 2 == ncp, it);
+        chunk_pair(std::integral_constant<int, 0>{}, F0, F1, cp == 0 && it > 0, false, false, it);
+        if constexpr (NPW == 4) chunk_pair(std::integral_constant<int, 6>{}, F1, F0, false, cp == 0 && it > 0, cp + 2 == ncp, it);
+        else chunk_pair(std::integral_constant<int, 6>{}, F0, F1, false, cp == 0 && it > 0, cp + 2 == ncp, it);
       }
     }
     // ---- drain: the last item's store phase (its own barriers, nothing staged, nothing multiplied) ----
