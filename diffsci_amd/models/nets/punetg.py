@@ -1071,7 +1071,9 @@ class PUNetG(torch.nn.Module):
                 # the input's channels are too far apart in magnitude for one exponent per sample (precision.escalate_input):
                 # exact-fp32 kernel, no tile statistics (the first block normalises standalone)
                 hs = None
-                h = ops.conv(x, pk[(id(self.convin), "exact")], bias=self.convin.bias, out=ws.take((B, cfg.model_channels, H, W), dev))
+                # (circular= : a periodic network with exact_input_layer set by hand must raise -- the exact-fp32 kernel zero-pads)
+                h = ops.conv(x, pk[(id(self.convin), "exact")], bias=self.convin.bias, circular=self.circular,
+                             out=ws.take((B, cfg.model_channels, H, W), dev))
             else:
                 first = self.downward_blocks[0][0] if (ndown and len(self.downward_blocks[0])) else (bottom[0] if bottom else None)
                 hs = stats_for(first, cfg.model_channels, H, W)

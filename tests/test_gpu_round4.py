@@ -62,6 +62,16 @@ def test_sixteen_byte_patch_loads_are_bit_identical_to_the_one_pixel_staging_pla
     assert p.stdout.count(" ok") >= 18
 
 
+def test_exact_input_layer_on_a_periodic_network_raises(M, dev):
+    """the exact-fp32 input layer zero-pads; a periodic network that has it switched on by hand must raise, not compute
+    with the wrong padding (precision.escalate_input itself refuses periodic networks)."""
+    net = M.PUNetG(M.PUNetGConfig(model_channels=8, convolution_type="circular")).to(dev).eval()
+    net.exact_input_layer = True
+    x, t = torch.randn(2, 1, 16, 16, device=dev), torch.rand(2, device=dev)
+    with pytest.raises(NotImplementedError, match="periodic padding"):
+        net(x, t)
+
+
 def test_lightning_checkpoint_samples_like_the_reference(M, dev):
     """karrasmodule.py:410-429: a .ckpt in Lightning's layout, written from a reference module by make_golden.py, loaded through
     the mirrored classmethod; four Heun steps from the recorded noise against what the reference sampled from those weights."""
