@@ -62,6 +62,20 @@ def test_sixteen_byte_patch_loads_are_bit_identical_to_the_one_pixel_staging_pla
     assert p.stdout.count(" ok") >= 18
 
 
+def test_round_four_kernels_change_no_output_bit_of_the_headline_workload(tmp_path):
+    """PUNetG-64 on [64,1,128,128], 4-step Heun through the captured plan and one eager evaluation: with every switch of the round off
+    (one-shot kernels, one-pixel staging: the round-3 code paths) and with the defaults (persistent kernels on all three levels, 16-byte
+    patch loads) the results are bit-identical, and replays are reproducible in both (tools/pc_determinism.py)."""
+    ref = str(tmp_path / "ref.pt")
+    tool = os.path.join(ROOT, "tools", "pc_determinism.py")
+    base = {k: v for k, v in os.environ.items() if not k.startswith("DS_CONV_")}
+    p = subprocess.run([sys.executable, tool, "--save", ref], cwd=ROOT, env=dict(base, DS_CONV_PC="0", DS_CONV_VEC="0", DS_CONV_TWO_EARLY="0"),
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    p = subprocess.run([sys.executable, tool, "--compare", ref], cwd=ROOT, env=base, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "identical to the saved run: True" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
+
+
 def test_exact_input_layer_on_a_periodic_network_raises(M, dev):
     """the exact-fp32 input layer zero-pads; a periodic network that has it switched on by hand must raise, not compute
     with the wrong padding (precision.escalate_input itself refuses periodic networks)."""
