@@ -75,6 +75,9 @@ __device__ __forceinline__ void bar_counted(int young) {
 #undef DS_VMCNT_CASE
 
 struct Item { int cot, b, y0, x0, tile; };
+#ifndef DS_PC_FETCH_LATE
+#define DS_PC_FETCH_LATE 0
+#endif
 #ifndef DS_PC_SPREAD
 #define DS_PC_SPREAD 1                               // 0: the whole store phase in the item's first chunk pair (measurement builds)
 #endif
@@ -492,6 +495,21 @@ __global__ __launch_bounds__(256 + 64 * NPW, NPW == 4 ? 2 : 3) void k_conv3p(con
   // the loads of chunk n beside the vector work of the LAST slot of chunk o (whose other slots were activated a step earlier)
   auto fetch_beside_last_slot = [&](auto halo_tag, float (&xn)[XI][8], f32x4& prown, unsigned& tagn, int& trown, float& tscn,
                                     float (&xo)[XI][8], unsigned tago, int trowo, float tsco, Packed& pk, int bufo) __attribute__((always_inline)) {
+#if DS_PC_FETCH_LATE == 1   // measurement builds: the vector work first, the loads behind it (+3.5 %, profiles/r04_pc_smooth_schedule.log) ...
+    activate_item(halo_tag, xo, tago, trowo, tsco, pk, XI - 1, bufo);
+    __builtin_amdgcn_sched_barrier(0);
+    fetch_begin(tagn, trown, tscn);
+    rows_fetch(prown, trown);
+#pragma unroll
+    for (int i = 0; i < XI; ++i) fetch_item(halo_tag, xn, i);
+#elif DS_PC_FETCH_LATE == 2   // ... or every load in front of it
+    fetch_begin(tagn, trown, tscn);
+    rows_fetch(prown, trown);
+#pragma unroll
+    for (int i = 0; i < XI; ++i) fetch_item(halo_tag, xn, i);
+    __builtin_amdgcn_sched_barrier(0);
+    activate_item(halo_tag, xo, tago, trowo, tsco, pk, XI - 1, bufo);
+#else
     fetch_begin(tagn, trown, tscn);
     rows_fetch(prown, trown);
 #pragma unroll
@@ -500,6 +518,7 @@ __global__ __launch_bounds__(256 + 64 * NPW, NPW == 4 ? 2 : 3) void k_conv3p(con
     activate_item(halo_tag, xo, tago, trowo, tsco, pk, XI - 1, bufo);
     __builtin_amdgcn_sched_barrier(0);
     fetch_item(halo_tag, xn, XI - 1);
+#endif
     return fetch_count(halo_tag);
   };
   auto store_x = [&](auto halo_tag, const Packed& pk, unsigned tag, int buf) __attribute__((always_inline)) {
