@@ -20,6 +20,16 @@
 // loads, stores).  LDS: two X images, a 4-slot weight ring, 4 x 16 KiB accumulator tiles, statistics partials, two bias / shift
 // rows = 160,032 B.
 //
+//
+// As shipped at the end of round 4 (second session; every step bit-identical to ds_conv3h.hip):
+//   * staging by 16-byte loads (VEC: a unit = 2 channels x 4 pixels, the fused norm's table rows through LDS pad vectors), the two
+//     kinds of producer wave in their own instantiation of the loop;
+//   * the CONSUMERS issue the weight slabs' DMA at the head of their step (DS_PC_CDMA): a DMA costs its wave 150-200 cycles to issue,
+//     the consumers wait for the producers at every barrier anyway, and the producers then have no cross-wave vector-memory wait at all;
+//   * the producers' vector work in slot-thirds, one per step, the previous item's store phase one batch per (E,1) / (O,1) step of the
+//     item's first two chunk pairs (DS_PC_SPREAD);
+//   * IMG: pre-split image input (the 256-channel level) -- the producers issue DMA only (image patches in front of the weight slab).
+//
 // Shapes it takes (the launcher falls back to ds_conv3h.hip otherwise): plain load, 8 x 32 pixel tiles that tile the plane
 // exactly, Cout and Cin multiples of 64, and enough items to give every CU several.
 #include "ds_conv3h_args.h"
