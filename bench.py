@@ -499,7 +499,7 @@ def adm_conv_roofline(net, B, S, dev, reps=6):
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
     ach, peak = flops / (ms * 1e-3) / 1e12, BF16_PEAK_TFLOPS / 3.0
-    return {"bound": "mfma", "kernel": "k_conv3h<PLAIN> (ds_conv2d_h3: conv2 of every ADM residual block, folded norm + SiLU loader where the network folds)",
+    return {"bound": "mfma", "kernel": "k_conv3p / k_conv3h<PLAIN> (ds_conv2d_h3: conv2 of every ADM residual block, folded norm + SiLU loader where the network folds; the persistent form wherever the shape is its own)",
             "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
             "launches": len(launches), "avg_launch_ms": round(ms / len(launches), 4)}
 
