@@ -1062,13 +1062,15 @@ int launch_conv3p(Conv3hArgs a, int wgs, hipStream_t s) {
 // DS_CONV_PC: 0 = never, 1 = the fused-loader launches with one channel tile, 2 (default since the consumers issue the weight DMA and the
 // producers' schedule is smooth: +3.4 % end to end for mode 1 and +1.2 % more for mode 2 on config 2, same-box A/B,
 // profiles/r04_pc_ab_bench.log) = also in place of the two-channel-tile kernel, 3 = raw-input launches too.
-// DS_CONV_PC_MIN: fewest items per workgroup (default 4).
+// DS_CONV_PC_MIN: fewest items per workgroup (default 1 since the second session of round 4: at one or two items per workgroup the
+// persistent kernel is equal to 21 % faster than the one-shot kernels -- profiles/r04_pc_min_items.log, batch 8 / 16 / 32 of
+// config 2's shapes; it was 4 for the first session's kernel).
 int conv3p_mode() {
   static const int v = [] { const char* e = getenv("DS_CONV_PC"); return e ? atoi(e) : 2; }();
   return v;
 }
 int conv3p_min_items() {
-  static const int v = [] { const char* e = getenv("DS_CONV_PC_MIN"); const int n = e ? atoi(e) : 4; return n < 1 ? 1 : n; }();
+  static const int v = [] { const char* e = getenv("DS_CONV_PC_MIN"); const int n = e ? atoi(e) : 1; return n < 1 ? 1 : n; }();
   return v;
 }
 int conv3p_cus() {

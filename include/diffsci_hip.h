@@ -31,7 +31,7 @@
  * fused loader); DS_CONV_WAVES16=8 = eight waves for the 16x16x32 form with the fused loader (default 4); DS_ATTN_T =
  * rescaling threshold of ds_attention_h3's online softmax (default 8); DS_CONV_PC = 0|1|2|3 = which launches of ds_conv2d_h3 take the
  * persistent producer / consumer form (ds_conv3p.hip: 0 none, 1 fused-loader launches with one channel tile, 2 (default) also those
- * with several, 3 raw-input launches too; bit-identical results), DS_CONV_PC_MIN = fewest items per workgroup for it (default 4),
+ * with several, 3 raw-input launches too; bit-identical results), DS_CONV_PC_MIN = fewest items per workgroup for it (default 1),
  * DS_CONV_PC_IMG=0 = ds_conv2d_h3_img stays on the one-shot kernel, DS_CONV_PC_SKEW = mask of the persistent kernel's start-up stagger
  * (default 0), DS_CONV_PC_PRIO = s_setprio level of its producer waves (default 0), DS_CONV_PC_WAVES=8 = eight producer waves (the
  * one-pixel staging plan only); DS_CONV_VEC=0 = one-pixel staging items instead of the 16-byte patch loads (both kernels),
