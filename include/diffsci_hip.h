@@ -36,7 +36,8 @@
  * (default 0), DS_CONV_PC_PRIO = s_setprio level of its producer waves (default 0), DS_CONV_PC_WAVES=8 = eight producer waves (the
  * one-pixel staging plan only); DS_CONV_VEC=0 = one-pixel staging items instead of the 16-byte patch loads (both kernels),
  * DS_CONV_TWO=0|1|2 / DS_CONV_TWO_MIN / DS_CONV_TWO_EARLY=0 = the two-channel-tile one-shot kernel: off | two tiles | every even
- * count; its smallest grid; waves 0-3 staging after the step's matrix instructions like waves 4-7.
+ * count; its smallest grid; waves 0-3 staging after the step's matrix instructions like waves 4-7; DS_DIRECT_VEC=0 = ds_conv2d_direct's
+ * general kernel on whole 64-column tiles too.
  */
 #ifndef DIFFSCI_HIP_H
 #define DIFFSCI_HIP_H

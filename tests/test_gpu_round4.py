@@ -76,6 +76,16 @@ def test_round_four_kernels_change_no_output_bit_of_the_headline_workload(tmp_pa
     assert p.returncode == 0 and "identical to the saved run: True" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
 
 
+def test_output_layer_convolution_with_sixteen_byte_loads_is_bit_identical():
+    """ds_conv2d_direct on whole 64-column tiles (16-byte patch loads, the next chunk's loads in front of this chunk's arithmetic)
+    against the general kernel (DS_DIRECT_VEC=0, child process): the output layers of configs 2, 3 and 5, small periodic and
+    ragged-height cases -- bit for bit, and against fp64 (tools/direct_vec_check.py)."""
+    env = {k: v for k, v in os.environ.items() if k != "DS_DIRECT_VEC"}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "direct_vec_check.py")], cwd=ROOT, env=env, capture_output=True,
+                       text=True, timeout=900)
+    assert p.returncode == 0 and "ALL OK" in p.stdout, p.stdout[-3000:] + p.stderr[-2000:]
+
+
 def test_exact_input_layer_on_a_periodic_network_raises(M, dev):
     """the exact-fp32 input layer zero-pads; a periodic network that has it switched on by hand must raise, not compute
     with the wrong padding (precision.escalate_input itself refuses periodic networks)."""
